@@ -1,0 +1,295 @@
+/*
+ * voidin_abi.h — C ABI of libvoidin_hip.so, the MI355X (gfx950) implementation of
+ * voidin's GPU-driven visibility path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ / torch
+ * types.  Every entry point names the reference interface it replaces; paths are relative
+ * to the reference checkout (pudnax/voidin v0.69.0).
+ *
+ * Conventions
+ *   - every function returns VD_OK (0) or a negative VdStatus; nothing aborts or throws
+ *     across the boundary (the reference panics — crates/bvh/src/blas.rs:114-116 — we do not);
+ *   - `*_dev` variants take DEVICE pointers (hipMalloc'd on the ctx's device) and enqueue
+ *     on the ctx's stream without synchronising; the plain variants take HOST pointers,
+ *     stage through ctx-owned device buffers and return after the result is in host memory;
+ *   - the caller owns every in/out buffer; device scratch belongs to the VdCtx;
+ *   - a VdCtx is thread-compatible, not thread-safe (the reference's `World` is
+ *     RefCell-based and single-threaded: crates/components/src/world.rs:81-84).
+ */
+#ifndef VOIDIN_ABI_H
+#define VOIDIN_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* Data contract. All little-endian, f32/u32/i32, #[repr(C)].      */
+/* ------------------------------------------------------------------------------------ */
+
+/* D1  crates/components/src/shared.rs:67-75, shaders/shared.wgsl:53-59 — 144 B */
+typedef struct VdInstance {
+    float    transform[16];      /* mat4, column-major: transform[4*c + r]          */
+    float    inv_transform[16];  /* mat4, column-major                              */
+    uint32_t mesh;               /* MeshId                                          */
+    uint32_t material;           /* MaterialId                                      */
+    uint32_t junk[2];
+} VdInstance;
+
+/* D2  crates/components/src/shared.rs:29-39, shaders/shared.wgsl:43-51 — 48 B */
+typedef struct VdMeshInfo {
+    float    min[3];
+    uint32_t index_count;
+    float    max[3];
+    uint32_t base_index;
+    int32_t  vertex_offset;
+    uint32_t bvh_index;
+    uint32_t junk[2];
+} VdMeshInfo;
+
+/* D3  crates/components/src/lib.rs:99-107, shaders/shared.wgsl:69-75 — 20 B */
+typedef struct VdDrawIndexedIndirect {
+    uint32_t vertex_count;       /* = MeshInfo.index_count                          */
+    uint32_t instance_count;     /* 1 visible, 0 culled                             */
+    uint32_t base_index;
+    int32_t  vertex_offset;
+    uint32_t base_instance;      /* = instance index (visibility.wgsl:33 reads it)  */
+} VdDrawIndexedIndirect;
+
+/* D4  crates/components/src/camera.rs:13-27, shaders/shared.wgsl:13-24 — 320 B */
+typedef struct VdCameraUniform {
+    float view_position[4];
+    float projection[16];
+    float view[16];
+    float clip_to_world[16];
+    float prev_world_to_clip[16];
+    float frustum[4];
+    float zfar;
+    float znear;
+    float jitter[2];
+    float prev_jitter[2];
+    float _padding[2];
+} VdCameraUniform;
+
+/* D5  crates/bvh/src/blas.rs:10-17, shaders/utils/bvh.wgsl:11-16 — 32 B.
+ * count > 0: leaf over triangles [left_first, left_first+count) of the reordered index
+ * buffer; count == 0: interior, children at node ids left_first and left_first+1.      */
+typedef struct VdBvhNode {
+    float    min[3];
+    uint32_t left_first;
+    float    max[3];
+    uint32_t count;
+} VdBvhNode;
+
+/* D6  crates/bvh/src/tlas.rs:7-14, shaders/utils/bvh.wgsl:4-9 — 32 B.
+ * left_right = left | right << 16 (0 => leaf); instance_idx = u32::MAX for interior.    */
+typedef struct VdTlasNode {
+    float    min[3];
+    uint32_t left_right;
+    float    max[3];
+    uint32_t instance_idx;
+} VdTlasNode;
+
+/* Extended TLAS node for more than VD_TLAS_MAX_INSTANCES instances:
+ * the reference packs two 16-bit ids into left_right, so it cannot address n > 32768.
+ * Same build rule, children kept as two full u32. NOT a reference layout.               */
+typedef struct VdTlasNodeWide {
+    float    min[3];
+    uint32_t left;               /* 0 and right==0 => leaf                           */
+    float    max[3];
+    uint32_t right;
+    uint32_t instance_idx;
+    uint32_t _pad[3];
+} VdTlasNodeWide;
+
+/* Ray + hit records of the batch traversal entry point (the reference traces one ray per
+ * fragment: shaders/utils/intersections.wgsl:3-11, shaders/utils/bvh.wgsl:18-28).        */
+typedef struct VdRay {
+    float eye[3];
+    float _pad0;
+    float dir[3];
+    float _pad1;
+} VdRay;
+
+typedef struct VdHit {
+    float    dist;               /* MAX_DIST (1e30) on miss                          */
+    uint32_t hit;                /* 0 / 1                                            */
+    uint32_t instance;           /* instance whose BLAS produced the closest hit     */
+    uint32_t triangle;           /* mesh-local triangle slot in the reordered buffer */
+} VdHit;
+
+#define VD_MAX_DIST 1e30f
+#define VD_TLAS_MAX_INSTANCES 32768u
+
+#if defined(__cplusplus)
+static_assert(sizeof(VdInstance) == 144, "Instance is 144 B (shared.rs:67-75)");
+static_assert(sizeof(VdMeshInfo) == 48, "MeshInfo is 48 B (shared.rs:29-39)");
+static_assert(sizeof(VdDrawIndexedIndirect) == 20, "DrawIndexedIndirect is 20 B (lib.rs:99-107)");
+static_assert(sizeof(VdCameraUniform) == 320, "CameraUniform is 320 B (camera.rs:13-27)");
+static_assert(sizeof(VdBvhNode) == 32, "BvhNode is 32 B (blas.rs:10-17)");
+static_assert(sizeof(VdTlasNode) == 32, "TlasNode is 32 B (tlas.rs:7-14)");
+static_assert(sizeof(VdTlasNodeWide) == 48, "wide TLAS node is 48 B");
+static_assert(sizeof(VdRay) == 32 && sizeof(VdHit) == 16, "ray/hit records");
+#else
+_Static_assert(sizeof(VdInstance) == 144, "Instance is 144 B");
+_Static_assert(sizeof(VdMeshInfo) == 48, "MeshInfo is 48 B");
+_Static_assert(sizeof(VdDrawIndexedIndirect) == 20, "DrawIndexedIndirect is 20 B");
+_Static_assert(sizeof(VdCameraUniform) == 320, "CameraUniform is 320 B");
+_Static_assert(sizeof(VdBvhNode) == 32, "BvhNode is 32 B");
+_Static_assert(sizeof(VdTlasNode) == 32, "TlasNode is 32 B");
+_Static_assert(sizeof(VdTlasNodeWide) == 48, "wide TLAS node is 48 B");
+_Static_assert(sizeof(VdRay) == 32 && sizeof(VdHit) == 16, "ray/hit records");
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* Status codes                                                                          */
+/* ------------------------------------------------------------------------------------ */
+typedef enum VdStatus {
+    VD_OK = 0,
+    VD_ERR_INVALID_ARG = -1,     /* null pointer, zero/oversized count, bad capacity     */
+    VD_ERR_HIP = -2,             /* HIP runtime error; text in vd_last_error             */
+    VD_ERR_DEGENERATE = -3,      /* BVH input the reference builder crashes on
+                                    (all 21 split candidates rejected: blas.rs:137-140)  */
+    VD_ERR_TLAS_OVERFLOW = -4,   /* n > 32768 in the 16-bit reference TLAS layout
+                                    (tlas.rs:71)                                         */
+    VD_ERR_NO_DEVICE = -5,       /* no gfx950 device / extension built for another arch  */
+    VD_ERR_STACK_OVERFLOW = -6,  /* traversal stack exceeded (reference has no check:
+                                    shaders/utils/stack.wgsl:1-20)                       */
+    VD_ERR_OOM = -7
+} VdStatus;
+
+typedef struct VdCtx VdCtx;
+
+/* ------------------------------------------------------------------------------------ */
+/* Context                                                                               */
+/* ------------------------------------------------------------------------------------ */
+/* Replaces the wgpu device/queue pair the passes pull from `World`
+ * (crates/app/src/app.rs:108-118). One HIP stream per ctx.                              */
+int         vd_ctx_create(int device, VdCtx** out_ctx);
+int         vd_ctx_destroy(VdCtx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. the host framework's current stream).
+ * Passing NULL restores the ctx-owned stream.                                           */
+int         vd_ctx_set_stream(VdCtx* ctx, void* hip_stream);
+int         vd_ctx_synchronize(VdCtx* ctx);
+const char* vd_last_error(const VdCtx* ctx);
+const char* vd_version(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* Cull + emit                                                      */
+/* ------------------------------------------------------------------------------------ */
+/* C1/C2 — replaces the `emit_draws` compute dispatch recorded by EmitDraws::record
+ * (crates/app/src/pass/visibility.rs:233-254; shaders/emit_draws.wgsl:13-64).
+ * Writes out[0..n_inst): every slot, culled ones with instance_count = 0.
+ * mesh ids >= n_mesh are clamped to n_mesh-1 (the reference leaves this to Vulkan robust
+ * buffer access, i.e. undefined).                                                       */
+int vd_cull_emit(VdCtx* ctx, const VdCameraUniform* camera,
+                 const VdMeshInfo* meshes, uint32_t n_mesh,
+                 const VdInstance* instances, uint32_t n_inst,
+                 VdDrawIndexedIndirect* out);
+int vd_cull_emit_dev(VdCtx* ctx, const VdCameraUniform* camera /* host */,
+                     const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                     const VdInstance* d_instances, uint32_t n_inst,
+                     VdDrawIndexedIndirect* d_out);
+
+/* C1+C3 fused — cull and emit only the survivors, in ascending instance order:
+ *   S = [i : emit_draws(i).instance_count == 1];  out[k] = emit_draws(S[k]);  *count = |S|.
+ * base_instance keeps the original instance index, so shaders/visibility.wgsl:33 is
+ * unchanged.  If pad_tail != 0, out[count..n_inst) is filled with zeroed commands
+ * (instance_count = 0) so that the unchanged
+ * `multi_draw_indexed_indirect(buf, 0, N)` consumer (visibility.rs:188-192) stays valid;
+ * with pad_tail == 0 only out[0..count) is written (for multi_draw_indexed_indirect_count).
+ * `out` must hold n_inst commands either way.                                           */
+int vd_cull_compact(VdCtx* ctx, const VdCameraUniform* camera,
+                    const VdMeshInfo* meshes, uint32_t n_mesh,
+                    const VdInstance* instances, uint32_t n_inst,
+                    VdDrawIndexedIndirect* out, uint32_t* out_count, int pad_tail);
+int vd_cull_compact_dev(VdCtx* ctx, const VdCameraUniform* camera /* host */,
+                        const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                        const VdInstance* d_instances, uint32_t n_inst,
+                        VdDrawIndexedIndirect* d_out, uint32_t* d_out_count, int pad_tail);
+
+/* C3 alone — ordered compaction of an existing emit_draws output (same definition).     */
+int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t n,
+                         VdDrawIndexedIndirect* d_out, uint32_t* d_out_count);
+
+/* ------------------------------------------------------------------------------------ */
+/* BLAS build                                                       */
+/* ------------------------------------------------------------------------------------ */
+/* Replaces `BvhBuilder::new(vertices, indices).build()` (crates/bvh/src/blas.rs:51-103),
+ * called from MeshPool::add (crates/pools/src/mesh/mod.rs:320-321).
+ *   verts_xyz      n_vert * 3 floats
+ *   indices_inout  n_tri * 3 u32; permuted in place exactly as blas.rs:95-100 does
+ *   out_nodes      capacity node_cap (>= 2*n_tri as the reference allocates, blas.rs:52)
+ *   out_n_nodes    number of nodes used (`nodes.truncate(pool)`, blas.rs:93); node 1 is
+ *                  the reference's never-used all-zero slot
+ * VD_ERR_DEGENERATE where the reference would crash.                 */
+int vd_bvh_build(VdCtx* ctx, const float* verts_xyz, uint32_t n_vert,
+                 uint32_t* indices_inout, uint32_t n_tri,
+                 VdBvhNode* out_nodes, uint32_t node_cap, uint32_t* out_n_nodes);
+int vd_bvh_build_dev(VdCtx* ctx, const float* d_verts_xyz, uint32_t n_vert,
+                     uint32_t* d_indices_inout, uint32_t n_tri,
+                     VdBvhNode* d_out_nodes, uint32_t node_cap, uint32_t* out_n_nodes /* host */);
+
+/* ------------------------------------------------------------------------------------ */
+/* TLAS build / refit                                               */
+/* ------------------------------------------------------------------------------------ */
+/* Replaces `Tlas::build(&mut self, &[Instance], &[MeshInfo])`
+ * (crates/bvh/src/tlas.rs:31-105), called from MeshPool::generate_tlas
+ * (crates/pools/src/mesh/mod.rs:279-286). out_nodes holds 2*n+1 nodes.
+ * n > 32768 => VD_ERR_TLAS_OVERFLOW (use the *_wide variant).                           */
+int vd_tlas_build(VdCtx* ctx, const VdInstance* instances, uint32_t n,
+                  const VdMeshInfo* meshes, uint32_t n_mesh, VdTlasNode* out_nodes);
+int vd_tlas_build_dev(VdCtx* ctx, const VdInstance* d_instances, uint32_t n,
+                      const VdMeshInfo* d_meshes, uint32_t n_mesh, VdTlasNode* d_out_nodes);
+int vd_tlas_build_wide(VdCtx* ctx, const VdInstance* instances, uint32_t n,
+                       const VdMeshInfo* meshes, uint32_t n_mesh, VdTlasNodeWide* out_nodes);
+int vd_tlas_build_wide_dev(VdCtx* ctx, const VdInstance* d_instances, uint32_t n,
+                           const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                           VdTlasNodeWide* d_out_nodes);
+
+/* T3 refit (NEW, not in the reference): keep the topology in nodes_inout, recompute leaf
+ * boxes (tlas.rs:34-54) and interior boxes bottom-up (ascending k = n+1..2n, then
+ * nodes[0] = nodes[2n]).  refit(build(x), x) == build(x) bit for bit.                   */
+int vd_tlas_refit(VdCtx* ctx, const VdInstance* instances, uint32_t n,
+                  const VdMeshInfo* meshes, uint32_t n_mesh, VdTlasNode* nodes_inout);
+int vd_tlas_refit_dev(VdCtx* ctx, const VdInstance* d_instances, uint32_t n,
+                      const VdMeshInfo* d_meshes, uint32_t n_mesh, VdTlasNode* d_nodes_inout);
+int vd_tlas_refit_wide_dev(VdCtx* ctx, const VdInstance* d_instances, uint32_t n,
+                           const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                           VdTlasNodeWide* d_nodes_inout);
+
+/* ------------------------------------------------------------------------------------ */
+/* Traversal                                                           */
+/* ------------------------------------------------------------------------------------ */
+/* The scene the trace bind group exposes (crates/app/src/app.rs:255-287): six storage
+ * buffers.  All device pointers for *_dev, all host pointers otherwise.                 */
+typedef struct VdTraceScene {
+    const VdTlasNode* tlas_nodes;   uint32_t n_tlas_nodes;
+    const VdInstance* instances;    uint32_t n_instances;
+    const VdMeshInfo* meshes;       uint32_t n_meshes;
+    const VdBvhNode*  bvh_nodes;    uint32_t n_bvh_nodes;
+    const float*      vertices;     uint32_t n_vertices;   /* xyz triples            */
+    const uint32_t*   indices;      uint32_t n_indices;    /* reordered, all meshes  */
+} VdTraceScene;
+
+/* Replaces `traverse_tlas(ray)` (shaders/utils/bvh.wgsl:89-123) for a batch of rays.
+ * out[i].dist matches the WGSL result within 1e-5 relative; the traversal stack is 64
+ * deep (reference: 24, unchecked) and overflow is reported as VD_ERR_STACK_OVERFLOW.    */
+int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t n_rays,
+             VdHit* out);
+int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene /* struct on host, pointers on device */,
+                 const VdRay* d_rays, uint32_t n_rays, VdHit* d_out);
+
+/* ------------------------------------------------------------------------------------ */
+/* Instrumentation (replaces the wgpu_profiler scopes: visibility.rs:50,243-245)         */
+/* ------------------------------------------------------------------------------------ */
+/* Milliseconds the GPU spent in the most recent call's kernels, measured with HIP events
+ * on the ctx's stream (synchronises). Negative if nothing was recorded.                 */
+float vd_last_gpu_ms(VdCtx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOIDIN_ABI_H */

@@ -1,0 +1,143 @@
+"""ctypes view of include/voidin_abi.h: numpy dtypes for the POD wire structs and the loader
+for libvoidin_hip.so.
+
+The struct layouts restate SURVEY.md §8a D1-D6 (reference: crates/components/src/shared.rs:29-75,
+crates/components/src/lib.rs:99-107, crates/components/src/camera.rs:13-27,
+crates/bvh/src/blas.rs:10-17, crates/bvh/src/tlas.rs:7-14).
+
+There is NO CPU fallback: `load()` raises if the HIP library is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvoidin_hip.so")
+
+# --- wire structs ---------------------------------------------------------------------
+INSTANCE = np.dtype([("transform", "<f4", (16,)), ("inv_transform", "<f4", (16,)),
+                     ("mesh", "<u4"), ("material", "<u4"), ("junk", "<u4", (2,))])
+MESH_INFO = np.dtype([("min", "<f4", (3,)), ("index_count", "<u4"), ("max", "<f4", (3,)),
+                      ("base_index", "<u4"), ("vertex_offset", "<i4"), ("bvh_index", "<u4"),
+                      ("junk", "<u4", (2,))])
+DRAW = np.dtype([("vertex_count", "<u4"), ("instance_count", "<u4"), ("base_index", "<u4"),
+                 ("vertex_offset", "<i4"), ("base_instance", "<u4")])
+CAMERA = np.dtype([("view_position", "<f4", (4,)), ("projection", "<f4", (16,)),
+                   ("view", "<f4", (16,)), ("clip_to_world", "<f4", (16,)),
+                   ("prev_world_to_clip", "<f4", (16,)), ("frustum", "<f4", (4,)),
+                   ("zfar", "<f4"), ("znear", "<f4"), ("jitter", "<f4", (2,)),
+                   ("prev_jitter", "<f4", (2,)), ("_padding", "<f4", (2,))])
+BVH_NODE = np.dtype([("min", "<f4", (3,)), ("left_first", "<u4"), ("max", "<f4", (3,)),
+                     ("count", "<u4")])
+TLAS_NODE = np.dtype([("min", "<f4", (3,)), ("left_right", "<u4"), ("max", "<f4", (3,)),
+                      ("instance_idx", "<u4")])
+TLAS_NODE_WIDE = np.dtype([("min", "<f4", (3,)), ("left", "<u4"), ("max", "<f4", (3,)),
+                           ("right", "<u4"), ("instance_idx", "<u4"), ("_pad", "<u4", (3,))])
+RAY = np.dtype([("eye", "<f4", (3,)), ("_pad0", "<f4"), ("dir", "<f4", (3,)), ("_pad1", "<f4")])
+HIT = np.dtype([("dist", "<f4"), ("hit", "<u4"), ("instance", "<u4"), ("triangle", "<u4")])
+
+assert INSTANCE.itemsize == 144 and MESH_INFO.itemsize == 48 and DRAW.itemsize == 20
+assert CAMERA.itemsize == 320 and BVH_NODE.itemsize == 32 and TLAS_NODE.itemsize == 32
+assert TLAS_NODE_WIDE.itemsize == 48 and RAY.itemsize == 32 and HIT.itemsize == 16
+
+MAX_DIST = np.float32(1e30)
+TLAS_MAX_INSTANCES = 32768
+
+VD_OK = 0
+VD_ERR_INVALID_ARG = -1
+VD_ERR_HIP = -2
+VD_ERR_DEGENERATE = -3
+VD_ERR_TLAS_OVERFLOW = -4
+VD_ERR_NO_DEVICE = -5
+VD_ERR_STACK_OVERFLOW = -6
+VD_ERR_OOM = -7
+
+STATUS_NAMES = {0: "VD_OK", -1: "VD_ERR_INVALID_ARG", -2: "VD_ERR_HIP", -3: "VD_ERR_DEGENERATE",
+                -4: "VD_ERR_TLAS_OVERFLOW", -5: "VD_ERR_NO_DEVICE", -6: "VD_ERR_STACK_OVERFLOW",
+                -7: "VD_ERR_OOM"}
+
+
+class TraceScene(C.Structure):
+    """VdTraceScene (include/voidin_abi.h) — the six storage buffers of the trace bind group
+    (reference: crates/app/src/app.rs:255-287)."""
+    _fields_ = [("tlas_nodes", C.c_void_p), ("n_tlas_nodes", C.c_uint32),
+                ("instances", C.c_void_p), ("n_instances", C.c_uint32),
+                ("meshes", C.c_void_p), ("n_meshes", C.c_uint32),
+                ("bvh_nodes", C.c_void_p), ("n_bvh_nodes", C.c_uint32),
+                ("vertices", C.c_void_p), ("n_vertices", C.c_uint32),
+                ("indices", C.c_void_p), ("n_indices", C.c_uint32)]
+
+
+_P = C.c_void_p
+_U = C.c_uint32
+_I = C.c_int
+
+# name -> (restype, argtypes); every symbol include/voidin_abi.h declares
+PROTOTYPES = {
+    "vd_ctx_create": (_I, [_I, C.POINTER(_P)]),
+    "vd_ctx_destroy": (_I, [_P]),
+    "vd_ctx_set_stream": (_I, [_P, _P]),
+    "vd_ctx_synchronize": (_I, [_P]),
+    "vd_last_error": (C.c_char_p, [_P]),
+    "vd_version": (C.c_char_p, []),
+    "vd_cull_emit": (_I, [_P, _P, _P, _U, _P, _U, _P]),
+    "vd_cull_emit_dev": (_I, [_P, _P, _P, _U, _P, _U, _P]),
+    "vd_cull_compact": (_I, [_P, _P, _P, _U, _P, _U, _P, _P, _I]),
+    "vd_cull_compact_dev": (_I, [_P, _P, _P, _U, _P, _U, _P, _P, _I]),
+    "vd_compact_draws_dev": (_I, [_P, _P, _U, _P, _P]),
+    "vd_bvh_build": (_I, [_P, _P, _U, _P, _U, _P, _U, _P]),
+    "vd_bvh_build_dev": (_I, [_P, _P, _U, _P, _U, _P, _U, _P]),
+    "vd_tlas_build": (_I, [_P, _P, _U, _P, _U, _P]),
+    "vd_tlas_build_dev": (_I, [_P, _P, _U, _P, _U, _P]),
+    "vd_tlas_build_wide": (_I, [_P, _P, _U, _P, _U, _P]),
+    "vd_tlas_build_wide_dev": (_I, [_P, _P, _U, _P, _U, _P]),
+    "vd_tlas_refit": (_I, [_P, _P, _U, _P, _U, _P]),
+    "vd_tlas_refit_dev": (_I, [_P, _P, _U, _P, _U, _P]),
+    "vd_tlas_refit_wide_dev": (_I, [_P, _P, _U, _P, _U, _P]),
+    "vd_trace": (_I, [_P, C.POINTER(TraceScene), _P, _U, _P]),
+    "vd_trace_dev": (_I, [_P, C.POINTER(TraceScene), _P, _U, _P]),
+    "vd_last_gpu_ms": (C.c_float, [_P]),
+}
+
+_lib = None
+
+
+class VoidinHipMissing(RuntimeError):
+    pass
+
+
+def load(path: str | None = None) -> C.CDLL:
+    """dlopen libvoidin_hip.so and bind every prototype.  Raises (never falls back) when the
+    library or any declared symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise VoidinHipMissing(
+            f"{p} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C voidin_amd/csrc`; there is no CPU fallback")
+    lib = C.CDLL(p)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def ptr(a) -> int:
+    """Raw address of a numpy array / torch tensor / int."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    raise TypeError(type(a))
