@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the visibility hot path on MI355X.
+
+A "step" = one pass of cull + emit + ordered compaction (vd_cull_compact_shard_dev) over one
+batch of synthetic instances already resident in HBM.  Workload at N=1 = BASELINE.json
+configs[2]: 10M synthetic AABB instances (BASELINE.md §3 distribution), 16 MeshInfo, the
+model.rs camera.  N>1: weak scaling — every rank owns a 10M-instance shard of an N*10M scene,
+culls + compacts it with global base_instance values, then the compacted draw lists are
+exchanged (counts all-gather + one-shot direct all-gather over RCCL/xGMI) inside the step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
+kernel: cull_compact_kernel, HBM-bound) and `cpu_baseline` (the oracle's restatement of the
+cull timed on this box's host cores; a reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--instances", type=int, default=10_000_000, help="instances per GPU")
+    ap.add_argument("--dist", choices=["baseline", "small"], default="baseline",
+                    help="baseline = BASELINE.md §3 (S in [0.25,4]); small = S in [0.02,0.6] (more culled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--extra", action="store_true", help="also time emit_draws (uncompacted) and BVH build")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from voidin_amd import abi, synth
+    from voidin_amd import dist as vdist
+    from voidin_amd.runtime import Context
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if distributed else 0)
+    ctx = Context(dev.index)  # raises if the HIP extension or a gfx950 GPU is missing
+
+    n = args.instances
+    n_total = n * world
+    first = rank * n
+    kw = dict(scale_range=(0.25, 4.0)) if args.dist == "baseline" else dict(scale_range=(0.02, 0.6), extent=600.0)
+    cam = synth.camera_uniform()
+    meshes = synth.mesh_infos()
+    t0 = time.time()
+    inst = synth.instances(n, seed=synth.SEED_BASE + 3, offset=first, with_inverse=False, **kw)
+    t_gen = time.time() - t0
+
+    d_m, d_i = ctx.upload(meshes), ctx.upload(inst)
+    d_out = ctx.empty(n * 20)
+    d_cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+    d_all = ctx.empty(n_total * 20) if distributed else None
+
+    def step():
+        ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)
+        if distributed:
+            counts = vdist.allgather_counts(d_cnt[:1])
+            vdist.allgather_draws(d_out, counts, d_all)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    if distributed:
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    ms_per_step = wall * 1e3 / args.steps
+    count = int(d_cnt[0].item())
+
+    # dominant kernel alone (memset + cull_compact_kernel), HIP events on the launch stream
+    barrier()
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record()
+    for _ in range(args.steps):
+        ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)
+    k1.record()
+    torch.cuda.synchronize()
+    kernel_ms = k0.elapsed_time(k1) / args.steps
+    vis = count / n
+    alg_bytes = n * (144.0 + 20.0 * vis)          # 144 B read + 20 B per survivor
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    verified = None
+    cpu = None
+    if rank == 0:
+        from oracle import ref  # checker + cpu_baseline leg only
+        if not args.no_verify:
+            want = ref.cull_emit(cam, meshes, inst, threads=os.cpu_count() or 1)
+            want["base_instance"] += np.uint32(first)
+            wc, wn = ref.compact(want)
+            got = d_out.cpu().numpy()[: count * 20]
+            verified = bool(wn == count and got.tobytes() == wc[:wn].tobytes())
+        if not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            m = min(n, 10_000_000)
+            reps1 = 3
+            t = time.perf_counter()
+            for _ in range(reps1):
+                ref.cull_emit(cam, meshes, inst[:m], threads=1)
+            t1 = (time.perf_counter() - t) / reps1
+            repsN = 10
+            t = time.perf_counter()
+            for _ in range(repsN):
+                d = ref.cull_emit(cam, meshes, inst[:m], threads=cores)
+            tN = (time.perf_counter() - t) / repsN
+            t = time.perf_counter()
+            ref.compact(d)
+            tc = time.perf_counter() - t
+            cpu = {"value": round(m / (tN + tc) / 1e6, 2), "unit": "M instances culled+compacted/s", "cores": cores,
+                   "kind": "port",
+                   "sample": f"{m} instances of the same workload; cull on {cores} threads x{repsN} + serial compaction; "
+                             f"1-thread cull: {m / t1 / 1e6:.2f} M inst/s"}
+
+    extra = {}
+    if args.extra and rank == 0:
+        d_emit = ctx.empty(n * 20)
+        for _ in range(3):
+            ctx.cull_emit_dev(cam, d_m, len(meshes), d_i, n, d_emit)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            ctx.cull_emit_dev(cam, d_m, len(meshes), d_i, n, d_emit)
+        e1.record()
+        torch.cuda.synchronize()
+        ems = e0.elapsed_time(e1) / args.steps
+        extra["emit_draws_uncompacted"] = {"ms": round(ems, 4), "M_inst_per_s": round(n / ems / 1e3, 1),
+                                           "GBps": round(n * 164.0 / ems / 1e6, 1)}
+
+    if rank == 0:
+        value = n_total / (ms_per_step * 1e-3) / 1e6
+        line = {
+            "metric": "M instances culled+compacted/sec",
+            "value": round(value, 1),
+            "unit": "M instances/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "fps_equivalent": round(1e3 / ms_per_step, 1),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: 10M synthetic AABB instances, cull + prefix-sum compaction "
+                                   "(BASELINE.md §3 distribution, model.rs camera)",
+                       "instances_per_gpu": n, "instances_total": n_total, "n_meshes": int(len(meshes)),
+                       "visible_fraction": round(vis, 4), "distribution": args.dist,
+                       "parallelism": f"instance-shard x{world}" + (" + draw-list all-gather (RCCL)" if distributed else ""),
+                       "verified_bit_exact_vs_oracle": verified, "input_gen_s": round(t_gen, 1)},
+            "roofline": {"bound": "hbm", "kernel": "cull_compact_kernel", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "cpu_baseline": cpu,
+        }
+        if extra:
+            line["extra"] = extra
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

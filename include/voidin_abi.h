@@ -210,6 +210,18 @@ int vd_cull_compact_dev(VdCtx* ctx, const VdCameraUniform* camera /* host */,
                         const VdInstance* d_instances, uint32_t n_inst,
                         VdDrawIndexedIndirect* d_out, uint32_t* d_out_count, int pad_tail);
 
+/* Shard variants (NEW): the instance array is a contiguous shard
+ * [first_instance, first_instance + n_inst) of a larger scene; base_instance is written as the
+ * GLOBAL index so that shards concatenated in rank order equal the single-GPU result.      */
+int vd_cull_emit_shard_dev(VdCtx* ctx, const VdCameraUniform* camera /* host */,
+                           const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                           const VdInstance* d_instances, uint32_t n_inst, uint32_t first_instance,
+                           VdDrawIndexedIndirect* d_out);
+int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera /* host */,
+                              const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                              const VdInstance* d_instances, uint32_t n_inst, uint32_t first_instance,
+                              VdDrawIndexedIndirect* d_out, uint32_t* d_out_count, int pad_tail);
+
 /* C3 alone — ordered compaction of an existing emit_draws output (same definition).     */
 int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t n,
                          VdDrawIndexedIndirect* d_out, uint32_t* d_out_count);

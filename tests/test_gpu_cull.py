@@ -1,0 +1,144 @@
+"""Parity of the HIP cull / emit / compaction path against the CPU oracle, through the C ABI.
+Bit-exact (integer/index output): memcmp of the command buffers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from voidin_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["cull_model_wide.npz", "cull_model_small.npz", "cull_jitter_wide.npz", "cull_jitter_small.npz"]
+
+
+def run_dev(ctx, cam, meshes, inst, pad_tail=False):
+    import torch
+    n = len(inst)
+    d_m, d_i = ctx.upload(meshes), ctx.upload(inst)
+    d_emit = ctx.empty(n * 20)
+    d_comp = ctx.empty(n * 20)
+    d_comp.fill_(0xAB)
+    d_cnt = torch.zeros(4, dtype=torch.int32, device=ctx.torch_device)
+    ctx.cull_emit_dev(cam, d_m, len(meshes), d_i, n, d_emit)
+    ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_comp, d_cnt, pad_tail)
+    torch.cuda.synchronize()
+    emit = d_emit.cpu().numpy()[: n * 20].view(abi.DRAW)
+    cnt = int(d_cnt[0].item()) & 0xFFFFFFFF
+    comp = d_comp.cpu().numpy()[: n * 20].view(abi.DRAW)
+    return emit, comp, cnt
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_fixtures(ctx, name):
+    g = golden(name)
+    emit, comp, cnt = run_dev(ctx, g["camera"], g["meshes"], g["instances"])
+    assert emit.tobytes() == g["draws"].tobytes()
+    assert cnt == int(g["count"])
+    assert comp[:cnt].tobytes() == g["compact"].tobytes()
+    # host-pointer entry points give the same bytes
+    assert ctx.cull_emit(g["camera"], g["meshes"], g["instances"]).tobytes() == g["draws"].tobytes()
+    c2, n2 = ctx.cull_compact(g["camera"], g["meshes"], g["instances"])
+    assert n2 == cnt and c2[:n2].tobytes() == g["compact"].tobytes()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4097, 100_000])
+@pytest.mark.parametrize("dist", ["wide", "small"])
+def test_ragged_sizes_bit_exact(ctx, oracle, n, dist):
+    # BASELINE config 2 (100k) and every tile-boundary size around 64 / 256 / 2048
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    kw = dict(scale_range=(0.25, 4.0)) if dist == "wide" else dict(scale_range=(0.01, 0.3), extent=400.0)
+    inst = synth.instances(n, seed=synth.SEED_BASE + 2, **kw)
+    want = oracle.cull_emit(cam, meshes, inst)
+    emit, comp, cnt = run_dev(ctx, cam, meshes, inst, pad_tail=True)
+    assert emit.tobytes() == want.tobytes()
+    wc, wn = oracle.compact(want, pad_tail=True)
+    assert cnt == wn and comp.tobytes() == wc.tobytes()
+
+
+def test_empty_input(ctx):
+    import torch
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    d_m = ctx.upload(meshes)
+    d_cnt = torch.full((4,), 7, dtype=torch.int32, device=ctx.torch_device)
+    ctx.cull_emit_dev(cam, d_m, len(meshes), None, 0, None)
+    ctx.cull_compact_dev(cam, d_m, len(meshes), None, 0, None, d_cnt)
+    torch.cuda.synchronize()
+    assert int(d_cnt[0].item()) == 0
+    out, cnt = ctx.cull_compact(cam, meshes, np.zeros(0, abi.INSTANCE))
+    assert cnt == 0 and len(out) == 0
+
+
+def test_invalid_arguments_return_codes(ctx):
+    cam = synth.camera_uniform()
+    lib, h = ctx.lib, ctx.h
+    assert lib.vd_cull_emit_dev(h, None, None, 0, None, 5, None) == abi.VD_ERR_INVALID_ARG
+    assert b"vd_cull_emit" in lib.vd_last_error(h)
+    assert lib.vd_cull_compact_dev(h, cam.ctypes.data, None, 0, None, 5, None, None, 0) == abi.VD_ERR_INVALID_ARG
+
+
+def test_nan_and_out_of_range_mesh(ctx, oracle):
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    inst = synth.instances(300, scale_range=(0.01, 0.3), extent=400.0)
+    inst["mesh"][3] = 1000
+    inst["mesh"][77] = 0xFFFFFFFF
+    inst["transform"][5] = np.nan
+    inst["transform"][9][12] = np.inf
+    inst["transform"][11] = 0.0
+    want = oracle.cull_emit(cam, meshes, inst)
+    emit, comp, cnt = run_dev(ctx, cam, meshes, inst)
+    assert emit.tobytes() == want.tobytes()
+    wc, wn = oracle.compact(want)
+    assert cnt == wn and comp[:cnt].tobytes() == wc[:wn].tobytes()
+
+
+def test_compact_is_filter_of_emit_and_standalone_compaction(ctx):
+    """C3 is a pure function of C1's output: fused == vd_compact_draws_dev(emit)."""
+    import torch
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    n = 300_001
+    inst = synth.instances(n, scale_range=(0.02, 0.6), extent=600.0)
+    emit, comp, cnt = run_dev(ctx, cam, meshes, inst)
+    keep = emit["instance_count"] == 1
+    assert cnt == keep.sum() and comp[:cnt].tobytes() == emit[keep].tobytes()
+    d_in = ctx.upload(emit)
+    d_out = ctx.empty(n * 20)
+    d_cnt = torch.zeros(4, dtype=torch.int32, device=ctx.torch_device)
+    ctx.compact_draws_dev(d_in, n, d_out, d_cnt)
+    torch.cuda.synchronize()
+    assert int(d_cnt[0].item()) == cnt
+    assert d_out.cpu().numpy()[: cnt * 20].tobytes() == comp[:cnt].tobytes()
+
+
+def test_deterministic_across_runs(ctx):
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    inst = synth.instances(500_000, scale_range=(0.02, 0.6), extent=600.0)
+    a = run_dev(ctx, cam, meshes, inst)
+    b = run_dev(ctx, cam, meshes, inst)
+    assert a[2] == b[2] and a[0].tobytes() == b[0].tobytes() and a[1][: a[2]].tobytes() == b[1][: b[2]].tobytes()
+
+
+def test_full_size_10m_properties(ctx, oracle):
+    """BASELINE config 3: 10M instances.  The oracle finishes this in seconds, so the survivor
+    set is compared bit-exact, plus the size-independent properties (sorted survivor indices,
+    compact == filter(emit), count consistency)."""
+    import torch
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    n = 10_000_000
+    inst = synth.instances(n, seed=synth.SEED_BASE + 3, with_inverse=False)
+    d_m, d_i = ctx.upload(meshes), ctx.upload(inst)
+    d_emit, d_comp = ctx.empty(n * 20), ctx.empty(n * 20)
+    d_cnt = torch.zeros(4, dtype=torch.int32, device=ctx.torch_device)
+    ctx.cull_emit_dev(cam, d_m, len(meshes), d_i, n, d_emit)
+    ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_comp, d_cnt)
+    torch.cuda.synchronize()
+    cnt = int(d_cnt[0].item())
+    emit = d_emit.cpu().numpy()[: n * 20].view(abi.DRAW)
+    comp = d_comp.cpu().numpy()[: cnt * 20].view(abi.DRAW)
+    keep = emit["instance_count"] == 1
+    assert cnt == keep.sum()
+    assert (np.diff(comp["base_instance"].astype(np.int64)) > 0).all()
+    assert comp.tobytes() == emit[keep].tobytes()
+    want = oracle.cull_emit(cam, meshes, inst, threads=8)
+    assert emit.tobytes() == want.tobytes()

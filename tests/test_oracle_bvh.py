@@ -1,0 +1,171 @@
+"""Oracle pinning for BLAS / TLAS / traversal: C oracle == numpy restatement == golden fixtures,
+plus the structural properties SURVEY.md §8a lists (B1-B8, T1-T4, R1-R2)."""
+import numpy as np
+import pytest
+
+from conftest import fields_equal, golden
+from oracle import np_restate as npr
+from voidin_amd import abi, synth
+
+BLAS = ["blas_plane.npz", "blas_sphere_1_1.npz", "blas_sphere_1_10.npz", "blas_soup64.npz", "blas_knot_2k.npz"]
+
+
+@pytest.mark.parametrize("name", BLAS)
+def test_blas_c_oracle_matches_golden(oracle, name):
+    g = golden(name)
+    nodes, idx = oracle.bvh_build(g["vertices"], g["indices"])
+    assert fields_equal(nodes, g["nodes"]) and np.array_equal(idx, g["indices_out"])
+
+
+@pytest.mark.parametrize("name", ["blas_sphere_1_1.npz", "blas_soup64.npz"])
+def test_blas_numpy_matches_golden(name):
+    g = golden(name)
+    nodes, idx = npr.bvh_build(g["vertices"], g["indices"])
+    assert fields_equal(nodes, g["nodes"]) and np.array_equal(idx, g["indices_out"])
+
+
+def check_tree(nodes, verts, idx):
+    """B1/B2/B6 invariants: node 1 unused, DFS pre-order pair allocation, leaves <= 3 tris
+    covering [0,T) exactly once in order, bounds = vertex bounds of the subtree."""
+    tri = verts[idx.reshape(-1, 3)]
+    tmin, tmax = tri.min(axis=1), tri.max(axis=1)
+    assert not nodes[1:2].view(np.uint8).any()
+    pool, covered = [2], [0]
+
+    def rec(k):
+        n = nodes[k]
+        if n["count"] > 0:
+            assert n["count"] <= 3 and n["left_first"] == covered[0]
+            lo, hi = int(n["left_first"]), int(n["left_first"] + n["count"])
+            covered[0] = hi
+            return lo, hi
+        assert n["left_first"] == pool[0]
+        pool[0] += 2
+        l = int(n["left_first"])
+        a = rec(l)
+        b = rec(l + 1)
+        assert a[1] == b[0]
+        for c, (lo, hi) in ((l, a), (l + 1, b)):
+            assert np.array_equal(nodes[c]["min"], tmin[lo:hi].min(axis=0))
+            assert np.array_equal(nodes[c]["max"], tmax[lo:hi].max(axis=0))
+        return a[0], b[1]
+
+    import sys
+    sys.setrecursionlimit(100000)
+    lo, hi = rec(0)
+    assert (lo, hi) == (0, len(tri)) and pool[0] == len(nodes)
+
+
+@pytest.mark.parametrize("name", BLAS)
+def test_blas_structure(name):
+    g = golden(name)
+    check_tree(g["nodes"], g["vertices"], g["indices_out"])
+    # the permuted index buffer is a permutation of the input triangles
+    a = np.sort(g["indices"].reshape(-1, 3).view([("", np.uint32)] * 3).ravel())
+    b = np.sort(g["indices_out"].reshape(-1, 3).view([("", np.uint32)] * 3).ravel())
+    assert np.array_equal(a, b)
+
+
+def test_partition_shuffle_unexamined_element(oracle):
+    # blas.rs:168-182: the element where i == e meet is never tested and lands on the right
+    keys = np.array([0.1, 0.2, 0.3, 0.4], np.float32)
+    piv, ids = oracle.partition_shuffle(keys, np.arange(4), 0, 4, 1.0)  # all "true"
+    assert piv == 3 and list(ids) == [0, 1, 2, 3]
+    piv, ids = oracle.partition_shuffle(keys, np.arange(4), 0, 4, 0.0)  # all "false"
+    assert piv == 0
+
+
+def test_blas_degenerate_input_is_an_error(oracle):
+    # >= 4 triangles with identical centroids: the reference crashes
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    idx = np.tile(np.array([0, 1, 2], np.uint32), 5)
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.bvh_build(v, idx)
+    assert e.value.code == abi.VD_ERR_DEGENERATE
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 40, 300])
+def test_tlas_c_oracle_matches_golden(oracle, n):
+    g = golden(f"tlas_{n}.npz")
+    nodes = oracle.tlas_build(g["instances"], g["meshes"])
+    assert fields_equal(nodes, g["nodes"])
+    # T2: all 2N+1 slots used; node 2N (copied to 0) merges the true root 2N-1 with itself
+    assert nodes[0]["left_right"] == (2 * n - 1) | ((2 * n - 1) << 16)
+    assert fields_equal(nodes[0:1], nodes[2 * n:2 * n + 1])
+    # T3: refit(build(x), x) == build(x)
+    assert oracle.tlas_refit(g["instances"], g["meshes"], nodes).tobytes() == nodes.tobytes()
+    wide = oracle.tlas_build(g["instances"], g["meshes"], wide=True)
+    assert np.array_equal(wide["left"] + (wide["right"] << 16), nodes["left_right"])
+    assert np.array_equal(wide["min"], nodes["min"]) and np.array_equal(wide["max"], nodes["max"])
+
+
+def test_tlas_numpy_matches_golden():
+    g = golden("tlas_40.npz")
+    assert fields_equal(npr.tlas_nodes(g["instances"], g["meshes"]), g["nodes"])
+
+
+def test_tlas_leaf_seeded_with_object_space_box():
+    # tlas.rs:39: the fold is seeded with [mesh.min, mesh.max] (object space) — bug-compatible
+    g = golden("tlas_5.npz")
+    inst, meshes, nodes = g["instances"], g["meshes"], g["nodes"]
+    for i in range(5):
+        m = meshes[inst["mesh"][i]]
+        assert (nodes["min"][i + 1] <= m["min"]).all() and (nodes["max"][i + 1] >= m["max"]).all()
+
+
+def test_tlas_overflow_guard(oracle):
+    # tlas.rs:71 packs 16-bit ids: n > 32768 cannot be represented
+    inst = np.zeros(abi.TLAS_MAX_INSTANCES + 1, abi.INSTANCE)
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.tlas_build(inst, synth.mesh_infos())
+    assert e.value.code == abi.VD_ERR_TLAS_OVERFLOW
+
+
+def test_trace_c_oracle_matches_golden(oracle):
+    g = golden("trace_40.npz")
+    h, max_stack = oracle.trace((g["tlas"], g["instances"], g["meshes"], g["bvh_nodes"], g["vertices"], g["indices"]), g["rays"])
+    assert np.array_equal(h["hit"], g["hit"]) and np.array_equal(h["dist"], g["dist"])
+    assert max_stack <= 24  # the reference's unchecked stack (stack.wgsl:1) suffices here
+    assert (h["dist"][h["hit"] == 0] == np.float32(1e30)).all()
+
+
+def test_trace_brute_force_agrees(oracle):
+    """Closest hit over ALL triangles (no BVH) equals the traversal result: no truly-hit leaf
+    is pruned."""
+    g = golden("trace_40.npz")
+    inst, meshes, V, I = g["instances"], g["meshes"], g["vertices"].reshape(-1, 3), g["indices"]
+    rays = g["rays"][::7]
+    want = g["dist"][::7]
+    best = np.full(len(rays), 1e30)
+    for i in range(len(inst)):
+        m = meshes[inst["mesh"][i]]
+        M = inst["inv_transform"][i].reshape(4, 4).astype(np.float64).T
+        tri = V[int(m["vertex_offset"]) + I[int(m["base_index"]):int(m["base_index"]) + int(m["index_count"])].reshape(-1, 3)].astype(np.float64)
+        e = (M @ np.concatenate([rays["eye"].astype(np.float64), np.ones((len(rays), 1))], 1).T).T[:, :3]
+        d = (M @ np.concatenate([rays["dir"].astype(np.float64), np.zeros((len(rays), 1))], 1).T).T[:, :3]
+        e1, e2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+        for r in range(len(rays)):
+            u_ = np.cross(d[r], e2)
+            det = (e1 * u_).sum(1)
+            ok = det >= 1e-10
+            inv = np.where(ok, 1.0 / np.where(ok, det, 1), 0)
+            o = e[r] - tri[:, 0]
+            u = inv * (o * u_).sum(1)
+            vv = np.cross(o, e1)
+            v = inv * (d[r] * vv).sum(1)
+            t = inv * (e2 * vv).sum(1)
+            ok &= (u >= 0) & (u <= 1) & (v >= 0) & (u + v <= 1) & (t > 0)
+            if ok.any():
+                best[r] = min(best[r], t[ok].min())
+    hit = want < 1e29
+    assert np.array_equal(hit, best < 1e29) or (np.abs(best[hit] - want[hit]) / want[hit]).max() < 1e-4
+    assert np.allclose(best[hit], want[hit], rtol=1e-4)
+
+
+def test_rust_cpu_traversal_variant(oracle):
+    # R2 (blas.rs:247-295): two-sided, divides by dir; agrees with R1 on front-facing hits
+    g = golden("blas_soup64.npz")
+    cam = synth.camera_uniform(eye=(0, 0, 15), pitch_deg=0)  # bvh_cpu.rs:134
+    rays = synth.primary_rays(cam, 48, 48)
+    d = oracle.traverse_iter(g["nodes"], g["vertices"], g["indices_out"], rays)
+    assert (d >= 0).sum() > 20 and d[d >= 0].min() > 5.0

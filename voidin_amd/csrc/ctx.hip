@@ -1,0 +1,94 @@
+// ctx.hip — context, scratch arenas and instrumentation of libvoidin_hip.so.
+// Replaces the wgpu device/queue pair the reference passes pull from `World`
+// (crates/app/src/app.rs:108-118) and the wgpu_profiler scopes (visibility.rs:50,243-245).
+#include "vd_common.hpp"
+
+#include <new>
+
+int vd_ensure(VdCtx* ctx, void** buf, size_t* cur, size_t need) {
+    if (need <= *cur && *buf) return VD_OK;
+    size_t cap = *cur ? *cur : (size_t)1 << 16;
+    while (cap < need) cap *= 2;
+    if (*buf) {
+        VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        VD_HIP_CHECK(ctx, hipFree(*buf));
+        *buf = nullptr;
+        *cur = 0;
+    }
+    hipError_t e = hipMalloc(buf, cap);
+    if (e != hipSuccess) {
+        snprintf(ctx->err, sizeof(ctx->err), "hipMalloc(%zu) -> %s", cap, hipGetErrorString(e));
+        *buf = nullptr;
+        return e == hipErrorOutOfMemory ? VD_ERR_OOM : VD_ERR_HIP;
+    }
+    *cur = cap;
+    return VD_OK;
+}
+
+extern "C" {
+
+const char* vd_version(void) { return "voidin_hip 0.1.0 (gfx950)"; }
+
+int vd_ctx_create(int device, VdCtx** out_ctx) {
+    if (!out_ctx) return VD_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return VD_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return VD_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VD_ERR_NO_DEVICE;  // code objects are gfx950-only
+    VdCtx* ctx = new (std::nothrow) VdCtx();
+    if (!ctx) return VD_ERR_OOM;
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->host_pinned), 64 * sizeof(uint32_t)) != hipSuccess) {
+        vd_ctx_destroy(ctx);
+        return VD_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out_ctx = ctx;
+    return VD_OK;
+}
+
+int vd_ctx_destroy(VdCtx* ctx) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->stage_in) (void)hipFree(ctx->stage_in);
+    if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+    if (ctx->stage_aux) (void)hipFree(ctx->stage_aux);
+    if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return VD_OK;
+}
+
+int vd_ctx_set_stream(VdCtx* ctx, void* hip_stream) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return VD_OK;
+}
+
+int vd_ctx_synchronize(VdCtx* ctx) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VD_OK;
+}
+
+const char* vd_last_error(const VdCtx* ctx) { return ctx ? ctx->err : "null ctx"; }
+
+float vd_last_gpu_ms(VdCtx* ctx) {
+    if (!ctx || !ctx->timed) return -1.0f;
+    if (hipEventSynchronize(ctx->ev_stop) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+// vd_common.hpp — shared host/device plumbing of libvoidin_hip.so (gfx950 only).
+//
+// Strict fp32 everywhere: the library is compiled with -ffp-contract=off so that a*b+c is
+// never fused (rustc / the reference never contract), with hipcc's default
+// correctly-rounded f32 divide/sqrt and f32 denormals kept.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/voidin_abi.h"
+
+struct VdCtx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;      // stream in use (own or caller's)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    char err[512] = {0};
+    int num_cus = 256;
+
+    // grow-only device scratch arenas
+    void* scratch = nullptr;     size_t scratch_bytes = 0;     // general purpose
+    void* stage_in = nullptr;    size_t stage_in_bytes = 0;    // host-pointer API staging
+    void* stage_out = nullptr;   size_t stage_out_bytes = 0;
+    void* stage_aux = nullptr;   size_t stage_aux_bytes = 0;
+    uint32_t* host_pinned = nullptr;                           // 64 u32 of pinned host memory
+};
+
+#define VD_HIP_CHECK(ctx, call)                                                              \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__,   \
+                     #call, hipGetErrorString(e_));                                          \
+            return VD_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define VD_FAIL(ctx, code, msg)                                          \
+    do {                                                                 \
+        snprintf((ctx)->err, sizeof((ctx)->err), "%s", (msg));           \
+        return (code);                                                   \
+    } while (0)
+
+// Grow-only arena helper. Never called between a kernel's enqueue and its completion on the
+// same buffer without a stream sync (callers sync before growing).
+int vd_ensure(VdCtx* ctx, void** buf, size_t* cur, size_t need);
+
+static inline void vd_time_begin(VdCtx* ctx) {
+    (void)hipEventRecord(ctx->ev_start, ctx->stream);
+}
+static inline void vd_time_end(VdCtx* ctx) {
+    (void)hipEventRecord(ctx->ev_stop, ctx->stream);
+    ctx->timed = true;
+}
+
+#ifdef __HIPCC__
+// ---- device helpers ------------------------------------------------------------------
+
+// Total-order float key (-0 < +0): bounds reductions are order-independent and bit-exact
+// against the oracle (Rust leaves min(-0,+0) unspecified: SURVEY.md §8a B5).
+__device__ __forceinline__ int vd_key(float f) {
+    int i = __float_as_int(f);
+    return i ^ ((i >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float vd_unkey(int k) {
+    return __int_as_float(k ^ ((k >> 31) & 0x7fffffff));
+}
+__device__ __forceinline__ float vd_min_to(float a, float b) { return vd_key(b) < vd_key(a) ? b : a; }
+__device__ __forceinline__ float vd_max_to(float a, float b) { return vd_key(b) > vd_key(a) ? b : a; }
+
+// crates/bvh/src/intersection.rs:16-19
+__device__ __forceinline__ float vd_area(float dx, float dy, float dz) {
+    return (dx * dy + dx * dz + dy * dz) * 2.0f;
+}
+
+__device__ __forceinline__ unsigned vd_lane() { return __lane_id(); }
+
+// count of set bits of `mask` strictly below this lane
+__device__ __forceinline__ unsigned vd_mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// Compiler-level ordering for same-wave LDS exchange (DS ops of one wave execute in order).
+__device__ __forceinline__ void vd_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+typedef unsigned long long vd_u64;
+#define VD_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// ---- single-pass ordered scan across workgroups ("decoupled look-back") ----------------
+// tile_state[t] is one naturally aligned 8-byte {status:32 | value:32} granule written by ONE
+// agent-scope store and polled by agent-scope loads (write-through / L1-bypassing on gfx950),
+// so the data is its own flag and no fence is needed.  Words are zeroed by a
+// hipMemsetAsync ahead of every launch.  Tickets come from an atomic counter, so every
+// predecessor of a running tile is itself running or finished: no residency assumption.
+enum : unsigned { VD_TILE_INVALID = 0u, VD_TILE_AGGREGATE = 1u, VD_TILE_INCLUSIVE = 2u };
+
+__device__ __forceinline__ vd_u64 vd_tile_pack(unsigned status, unsigned value) {
+    return ((vd_u64)status << 32) | value;
+}
+
+// Called by ONE full wave of the workgroup. Returns the exclusive prefix of tile `t`
+// (sum of `total` over tiles < t) in every lane, after publishing this tile's state.
+__device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned t, unsigned total) {
+    const unsigned lane = vd_lane();
+    if (t == 0) {
+        if (lane == 0) __hip_atomic_store(&tile_state[0], vd_tile_pack(VD_TILE_INCLUSIVE, total), VD_RLX_AGENT);
+        return 0u;
+    }
+    if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(VD_TILE_AGGREGATE, total), VD_RLX_AGENT);
+    unsigned exclusive = 0u;
+    int look = (int)t - 1;
+    for (;;) {
+        const int idx = look - (int)lane;
+        vd_u64 s = vd_tile_pack(VD_TILE_INCLUSIVE, 0u);   // virtual tiles before 0
+        if (idx >= 0) {
+            s = __hip_atomic_load(&tile_state[idx], VD_RLX_AGENT);
+            while ((unsigned)(s >> 32) == VD_TILE_INVALID) {
+                __builtin_amdgcn_s_sleep(1);
+                s = __hip_atomic_load(&tile_state[idx], VD_RLX_AGENT);
+            }
+        }
+        const unsigned status = (unsigned)(s >> 32);
+        const unsigned value = (unsigned)s;
+        const unsigned long long incl = __ballot(status == VD_TILE_INCLUSIVE);
+        // lanes at or before the first INCLUSIVE one (closest predecessors first) contribute
+        const unsigned first = incl ? (unsigned)__builtin_ctzll(incl) : 63u;
+        unsigned v = lane <= first ? value : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        exclusive += v;
+        if (incl) break;
+        look -= 64;
+    }
+    if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(VD_TILE_INCLUSIVE, exclusive + total), VD_RLX_AGENT);
+    return exclusive;
+}
+#endif  // __HIPCC__

@@ -1,0 +1,242 @@
+"""Host-side mirror of the reference's pass-graph / builder API over the C ABI.
+
+Names follow the reference:
+  EmitDraws.record      <- crates/app/src/pass/visibility.rs:233-254 (`impl Pass for EmitDraws`)
+  BvhBuilder(...).build <- crates/bvh/src/blas.rs:51-103
+  Tlas.build            <- crates/bvh/src/tlas.rs:31-85
+  traverse_tlas         <- shaders/utils/bvh.wgsl:89-123
+
+torch is plumbing only (device memory + streams); all compute is in libvoidin_hip.so.
+There is no CPU fallback: constructing a Context without the HIP library or a gfx950 GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class VoidinError(RuntimeError):
+    def __init__(self, code: int, msg: str = ""):
+        super().__init__(f"{abi.STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def _as_u8_tensor(arr: np.ndarray, device):
+    import torch
+    a = np.ascontiguousarray(arr)
+    return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device)
+
+
+def to_numpy(t, dtype: np.dtype) -> np.ndarray:
+    """uint8 device tensor -> structured numpy array."""
+    return t.detach().cpu().numpy().view(dtype)
+
+
+class Context:
+    """One VdCtx bound to a device and (by default) torch's current HIP stream."""
+
+    def __init__(self, device: int = 0, use_torch_stream: bool = True):
+        self.lib = abi.load()
+        h = C.c_void_p()
+        rc = self.lib.vd_ctx_create(device, C.byref(h))
+        if rc != abi.VD_OK:
+            raise VoidinError(rc, "vd_ctx_create failed (need a gfx950 GPU; there is no CPU fallback)")
+        self.h = h
+        self.device = device
+        if use_torch_stream:
+            import torch
+            self.torch_device = torch.device("cuda", device)
+            self.set_stream(torch.cuda.current_stream(self.torch_device).cuda_stream)
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _chk(self, rc: int):
+        if rc != abi.VD_OK:
+            raise VoidinError(rc, self.lib.vd_last_error(self.h).decode())
+
+    def set_stream(self, hip_stream: int | None):
+        self._chk(self.lib.vd_ctx_set_stream(self.h, hip_stream))
+
+    def synchronize(self):
+        self._chk(self.lib.vd_ctx_synchronize(self.h))
+
+    def last_gpu_ms(self) -> float:
+        return float(self.lib.vd_last_gpu_ms(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vd_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, arr: np.ndarray):
+        return _as_u8_tensor(arr, self.torch_device)
+
+    def empty(self, nbytes: int):
+        import torch
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.torch_device)
+
+    # -- cull / emit (device pointers) ------------------------------------------------------
+    def cull_emit_dev(self, camera: np.ndarray, d_meshes, n_mesh, d_inst, n_inst, d_out, first_instance=0):
+        cam = np.ascontiguousarray(camera, dtype=abi.CAMERA)
+        self._chk(self.lib.vd_cull_emit_shard_dev(self.h, cam.ctypes.data, abi.ptr(d_meshes), n_mesh,
+                                                  abi.ptr(d_inst), n_inst, first_instance, abi.ptr(d_out)))
+
+    def cull_compact_dev(self, camera: np.ndarray, d_meshes, n_mesh, d_inst, n_inst, d_out, d_count,
+                         pad_tail: bool = False, first_instance=0):
+        cam = np.ascontiguousarray(camera, dtype=abi.CAMERA)
+        self._chk(self.lib.vd_cull_compact_shard_dev(self.h, cam.ctypes.data, abi.ptr(d_meshes), n_mesh,
+                                                     abi.ptr(d_inst), n_inst, first_instance, abi.ptr(d_out),
+                                                     abi.ptr(d_count), int(pad_tail)))
+
+    def compact_draws_dev(self, d_in, n, d_out, d_count):
+        self._chk(self.lib.vd_compact_draws_dev(self.h, abi.ptr(d_in), n, abi.ptr(d_out), abi.ptr(d_count)))
+
+    # -- cull / emit (host arrays) ----------------------------------------------------------
+    def cull_emit(self, camera, meshes, instances) -> np.ndarray:
+        cam = np.ascontiguousarray(camera, dtype=abi.CAMERA)
+        meshes = np.ascontiguousarray(meshes, dtype=abi.MESH_INFO)
+        instances = np.ascontiguousarray(instances, dtype=abi.INSTANCE)
+        out = np.zeros(len(instances), dtype=abi.DRAW)
+        self._chk(self.lib.vd_cull_emit(self.h, cam.ctypes.data, meshes.ctypes.data, len(meshes),
+                                        instances.ctypes.data, len(instances), out.ctypes.data))
+        return out
+
+    def cull_compact(self, camera, meshes, instances, pad_tail=False):
+        cam = np.ascontiguousarray(camera, dtype=abi.CAMERA)
+        meshes = np.ascontiguousarray(meshes, dtype=abi.MESH_INFO)
+        instances = np.ascontiguousarray(instances, dtype=abi.INSTANCE)
+        out = np.zeros(len(instances), dtype=abi.DRAW)
+        out.view(np.uint8)[:] = 0xAB  # poison: only [0,count) (or everything with pad_tail) is defined
+        cnt = C.c_uint32(0)
+        self._chk(self.lib.vd_cull_compact(self.h, cam.ctypes.data, meshes.ctypes.data, len(meshes),
+                                           instances.ctypes.data, len(instances), out.ctypes.data,
+                                           C.addressof(cnt), int(pad_tail)))
+        return out, cnt.value
+
+    # -- BLAS -------------------------------------------------------------------------------
+    def bvh_build(self, verts, indices):
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        idx = np.array(indices, dtype=np.uint32).reshape(-1).copy()
+        n_tri = len(idx) // 3
+        nodes = np.zeros(max(2 * n_tri, 2), dtype=abi.BVH_NODE)
+        n_nodes = C.c_uint32(0)
+        self._chk(self.lib.vd_bvh_build(self.h, verts.ctypes.data, len(verts), idx.ctypes.data, n_tri,
+                                        nodes.ctypes.data, len(nodes), C.addressof(n_nodes)))
+        return nodes[:n_nodes.value].copy(), idx
+
+    def bvh_build_dev(self, d_verts, n_vert, d_indices, n_tri, d_nodes, node_cap) -> int:
+        n_nodes = C.c_uint32(0)
+        self._chk(self.lib.vd_bvh_build_dev(self.h, abi.ptr(d_verts), n_vert, abi.ptr(d_indices), n_tri,
+                                            abi.ptr(d_nodes), node_cap, C.addressof(n_nodes)))
+        return n_nodes.value
+
+    # -- TLAS -------------------------------------------------------------------------------
+    def tlas_build(self, instances, meshes, wide=False) -> np.ndarray:
+        instances = np.ascontiguousarray(instances, dtype=abi.INSTANCE)
+        meshes = np.ascontiguousarray(meshes, dtype=abi.MESH_INFO)
+        out = np.zeros(2 * len(instances) + 1, dtype=abi.TLAS_NODE_WIDE if wide else abi.TLAS_NODE)
+        fn = self.lib.vd_tlas_build_wide if wide else self.lib.vd_tlas_build
+        self._chk(fn(self.h, instances.ctypes.data, len(instances), meshes.ctypes.data, len(meshes),
+                     out.ctypes.data))
+        return out
+
+    def tlas_refit(self, instances, meshes, nodes) -> np.ndarray:
+        instances = np.ascontiguousarray(instances, dtype=abi.INSTANCE)
+        meshes = np.ascontiguousarray(meshes, dtype=abi.MESH_INFO)
+        nodes = np.array(nodes, dtype=abi.TLAS_NODE, copy=True)
+        self._chk(self.lib.vd_tlas_refit(self.h, instances.ctypes.data, len(instances), meshes.ctypes.data,
+                                         len(meshes), nodes.ctypes.data))
+        return nodes
+
+    def tlas_build_dev(self, d_inst, n, d_meshes, n_mesh, d_nodes, wide=False):
+        fn = self.lib.vd_tlas_build_wide_dev if wide else self.lib.vd_tlas_build_dev
+        self._chk(fn(self.h, abi.ptr(d_inst), n, abi.ptr(d_meshes), n_mesh, abi.ptr(d_nodes)))
+
+    def tlas_refit_dev(self, d_inst, n, d_meshes, n_mesh, d_nodes, wide=False):
+        fn = self.lib.vd_tlas_refit_wide_dev if wide else self.lib.vd_tlas_refit_dev
+        self._chk(fn(self.h, abi.ptr(d_inst), n, abi.ptr(d_meshes), n_mesh, abi.ptr(d_nodes)))
+
+    # -- traversal ----------------------------------------------------------------------------
+    def trace(self, scene_arrays, rays) -> np.ndarray:
+        """scene_arrays = (tlas_nodes, instances, meshes, bvh_nodes, vertices, indices), host."""
+        dts = [abi.TLAS_NODE, abi.INSTANCE, abi.MESH_INFO, abi.BVH_NODE, np.float32, np.uint32]
+        arrs = [np.ascontiguousarray(a, dtype=d).reshape(-1) for a, d in zip(scene_arrays, dts)]
+        s = abi.TraceScene()
+        s.tlas_nodes, s.n_tlas_nodes = arrs[0].ctypes.data, len(arrs[0])
+        s.instances, s.n_instances = arrs[1].ctypes.data, len(arrs[1])
+        s.meshes, s.n_meshes = arrs[2].ctypes.data, len(arrs[2])
+        s.bvh_nodes, s.n_bvh_nodes = arrs[3].ctypes.data, len(arrs[3])
+        s.vertices, s.n_vertices = arrs[4].ctypes.data, len(arrs[4]) // 3
+        s.indices, s.n_indices = arrs[5].ctypes.data, len(arrs[5])
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY)
+        out = np.zeros(len(rays), dtype=abi.HIT)
+        self._chk(self.lib.vd_trace(self.h, C.byref(s), rays.ctypes.data, len(rays), out.ctypes.data))
+        return out
+
+
+# ------------------------------------------------------------------------------------------
+# Reference-shaped façade
+# ------------------------------------------------------------------------------------------
+class EmitDraws:
+    """`impl Pass for EmitDraws` (visibility.rs:230-255): record() leaves draw_cmd_buffer[0..N)
+    valid on the ctx's stream before the consumer (Geometry::record) runs on the same stream."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def record(self, camera, mesh_info_buf, n_mesh, instances_buf, n_inst, draw_cmd_buffer):
+        self.ctx.cull_emit_dev(camera, mesh_info_buf, n_mesh, instances_buf, n_inst, draw_cmd_buffer)
+
+    def record_compacted(self, camera, mesh_info_buf, n_mesh, instances_buf, n_inst, draw_cmd_buffer,
+                         draw_count_buf, pad_tail=False):
+        self.ctx.cull_compact_dev(camera, mesh_info_buf, n_mesh, instances_buf, n_inst, draw_cmd_buffer,
+                                  draw_count_buf, pad_tail)
+
+
+class Bvh:
+    def __init__(self, nodes: np.ndarray):
+        self.nodes = nodes
+
+
+class BvhBuilder:
+    """BvhBuilder::new(vertices, indices).build() (blas.rs:51-103).  `indices` is permuted in
+    place, as the reference does to the caller's slice."""
+
+    def __init__(self, ctx: Context, vertices: np.ndarray, indices: np.ndarray):
+        self.ctx, self.vertices, self.indices = ctx, vertices, indices
+        self.num_bins = 8
+
+    def set_bin_number(self, num_bins: int):
+        self.num_bins = num_bins  # stored and ignored, exactly like blas.rs:64-67 vs :136
+        return self
+
+    def build(self) -> Bvh:
+        nodes, idx = self.ctx.bvh_build(self.vertices, self.indices)
+        self.indices.reshape(-1)[:] = idx
+        return Bvh(nodes)
+
+
+class Tlas:
+    """Tlas::empty() / Tlas::build(&mut self, instances, meshes) (tlas.rs:27-85)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.nodes = np.zeros(0, dtype=abi.TLAS_NODE)
+
+    @classmethod
+    def empty(cls, ctx: Context):
+        return cls(ctx)
+
+    def build(self, instances, meshes):
+        self.nodes = self.ctx.tlas_build(instances, meshes)
+
+    def refit(self, instances, meshes):
+        self.nodes = self.ctx.tlas_refit(instances, meshes, self.nodes)

@@ -137,36 +137,48 @@ def _quat_to_mat(q):
     return R
 
 
+def _instances_chunk(out, c0, m, n_mesh, seed, extent, centre, lo, hi, offset, with_inverse):
+    u = np.stack([uniform01(seed, s, m, offset + c0) for s in range(10)], axis=1)
+    t = (u[:, 0:3] - 0.5) * extent + np.asarray(centre)
+    # Shoemake uniform quaternion
+    r1, r2 = np.sqrt(1 - u[:, 3]), np.sqrt(u[:, 3])
+    a1, a2 = 2 * math.pi * u[:, 4], 2 * math.pi * u[:, 5]
+    q = np.stack([r1 * np.sin(a1), r1 * np.cos(a1), r2 * np.sin(a2), r2 * np.cos(a2)], axis=1)
+    R = _quat_to_mat(q)
+    S = np.exp(lo + (hi - lo) * u[:, 6:9])
+    M = np.zeros((m, 4, 4))  # M[i][col][row]
+    for j in range(3):
+        M[:, j, 0:3] = R[:, :, j] * S[:, j:j + 1]
+    M[:, 3, 0:3] = t
+    M[:, 3, 3] = 1.0
+    rec = np.zeros(m, dtype=abi.INSTANCE)
+    rec["transform"] = M.reshape(m, 16).astype(np.float32)
+    if with_inverse:
+        # Instance::new: inv_transform = transform.inverse() (shared.rs:93) — an input
+        Mi = np.linalg.inv(np.transpose(rec["transform"].reshape(m, 4, 4).astype(np.float64), (0, 2, 1)))
+        rec["inv_transform"] = np.transpose(Mi, (0, 2, 1)).reshape(m, 16).astype(np.float32)
+    rec["mesh"] = np.minimum((u[:, 9] * n_mesh).astype(np.uint32), n_mesh - 1)
+    rec["material"] = 1  # MaterialId::default (shared.rs:55-58)
+    out[c0:c0 + m] = rec
+
+
 def instances(n: int, n_mesh: int = 16, seed: int = SEED_BASE + 2, extent: float = 2000.0,
               centre=(0.0, 0.0, 0.0), scale_range=(0.25, 4.0), offset: int = 0,
-              with_inverse: bool = True, chunk: int = 1 << 20) -> np.ndarray:
+              with_inverse: bool = True, chunk: int = 1 << 17, workers: int = 8) -> np.ndarray:
     """n instances `transform = T·R·S` (T uniform in an extent³ cube, R from a uniform unit
     quaternion, S log-uniform per axis), mesh id uniform.  Element i depends only on
     (seed, offset+i), so shards of one cloud can be generated independently."""
     out = np.zeros(n, dtype=abi.INSTANCE)
     lo, hi = math.log(scale_range[0]), math.log(scale_range[1])
-    for c0 in range(0, n, chunk):
-        m = min(chunk, n - c0)
-        u = np.stack([uniform01(seed, s, m, offset + c0) for s in range(10)], axis=1)
-        t = (u[:, 0:3] - 0.5) * extent + np.asarray(centre)
-        # Shoemake uniform quaternion
-        r1, r2 = np.sqrt(1 - u[:, 3]), np.sqrt(u[:, 3])
-        a1, a2 = 2 * math.pi * u[:, 4], 2 * math.pi * u[:, 5]
-        q = np.stack([r1 * np.sin(a1), r1 * np.cos(a1), r2 * np.sin(a2), r2 * np.cos(a2)], axis=1)
-        R = _quat_to_mat(q)
-        S = np.exp(lo + (hi - lo) * u[:, 6:9])
-        M = np.zeros((m, 4, 4))  # M[i][col][row]
-        for j in range(3):
-            M[:, j, 0:3] = R[:, :, j] * S[:, j:j + 1]
-        M[:, 3, 0:3] = t
-        M[:, 3, 3] = 1.0
-        out["transform"][c0:c0 + m] = M.reshape(m, 16).astype(np.float32)
-        if with_inverse:
-            # Instance::new: inv_transform = transform.inverse() (shared.rs:93) — an input
-            Mi = np.linalg.inv(np.transpose(out["transform"][c0:c0 + m].reshape(m, 4, 4).astype(np.float64), (0, 2, 1)))
-            out["inv_transform"][c0:c0 + m] = np.transpose(Mi, (0, 2, 1)).reshape(m, 16).astype(np.float32)
-        out["mesh"][c0:c0 + m] = np.minimum((u[:, 9] * n_mesh).astype(np.uint32), n_mesh - 1)
-        out["material"][c0:c0 + m] = 1  # MaterialId::default (shared.rs:55-58)
+    jobs = [(c0, min(chunk, n - c0)) for c0 in range(0, n, chunk)]
+    args = (n_mesh, seed, extent, centre, lo, hi, offset, with_inverse)
+    if len(jobs) <= 1 or workers <= 1:
+        for c0, m in jobs:
+            _instances_chunk(out, c0, m, *args)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(lambda j: _instances_chunk(out, j[0], j[1], *args), jobs))
     return out
 
 
