@@ -169,9 +169,10 @@ typedef struct VdCtx VdCtx;
  * (crates/app/src/app.rs:108-118). One HIP stream per ctx.                              */
 int         vd_ctx_create(int device, VdCtx** out_ctx);
 int         vd_ctx_destroy(VdCtx* ctx);
-/* Run on a caller-owned hipStream_t (e.g. the host framework's current stream).
- * Passing NULL restores the ctx-owned stream.                                           */
+/* Run on a caller-owned hipStream_t (e.g. the host framework's current stream); NULL is
+ * the HIP default stream.  vd_ctx_reset_stream goes back to the ctx-owned stream.       */
 int         vd_ctx_set_stream(VdCtx* ctx, void* hip_stream);
+int         vd_ctx_reset_stream(VdCtx* ctx);
 int         vd_ctx_synchronize(VdCtx* ctx);
 const char* vd_last_error(const VdCtx* ctx);
 const char* vd_version(void);

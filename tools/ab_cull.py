@@ -1,0 +1,62 @@
+"""A/B the cull_compact kernel variants in ONE process (interleaved rounds, median + min).
+Usage (on a GPU box): python tools/ab_cull.py [--variants 0,1,2,...] [--n 10000000] [--dist baseline|small]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from voidin_amd import abi, synth  # noqa: E402
+from voidin_amd.runtime import Context  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8,9,10")
+ap.add_argument("--n", type=int, default=10_000_000)
+ap.add_argument("--dist", default="baseline")
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--iters", type=int, default=20)
+args = ap.parse_args()
+
+ctx = Context(0)
+lib = ctx.lib
+lib.vd_debug_set_cull_variant.restype = C.c_int
+lib.vd_debug_set_cull_variant.argtypes = [C.c_void_p, C.c_int]
+cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+kw = dict(scale_range=(0.25, 4.0)) if args.dist == "baseline" else dict(scale_range=(0.02, 0.6), extent=600.0)
+inst = synth.instances(args.n, seed=synth.SEED_BASE + 3, with_inverse=False, **kw)
+n = args.n
+d_m, d_i = ctx.upload(meshes), ctx.upload(inst)
+d_out = ctx.empty(n * 20)
+d_cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+variants = [int(v) for v in args.variants.split(",")]
+ref_bytes = None
+times = {v: [] for v in variants}
+for rnd in range(args.rounds):
+    for v in variants:
+        lib.vd_debug_set_cull_variant(ctx.h, v)
+        for _ in range(2):
+            ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt)
+        torch.cuda.synchronize()
+        if rnd == 0:
+            cnt = int(d_cnt[0].item())
+            b = d_out[: cnt * 20].cpu().numpy().tobytes()
+            if ref_bytes is None and v < 100:
+                ref_bytes, ref_cnt = b, cnt
+            ok = (cnt == ref_cnt and b == ref_bytes) if v < 100 else "n/a (probe)"
+            print(f"variant {v}: count {cnt} matches variant {variants[0]}: {ok}", flush=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt)
+        e1.record()
+        torch.cuda.synchronize()
+        times[v].append(e0.elapsed_time(e1) / args.iters)
+vis = ref_cnt / n
+alg = n * (144 + 20 * vis)
+print(f"n={n} visible={vis:.4f} algorithmic bytes={alg/1e9:.3f} GB")
+for v in variants:
+    t = np.array(times[v])
+    print(f"variant {v:2d}: median {np.median(t)*1e3:8.1f} us  min {t.min()*1e3:8.1f} us  -> {alg/np.median(t)/1e6:7.1f} GB/s ({alg/np.median(t)/1e6/8000*100:.1f}% of 8 TB/s)")

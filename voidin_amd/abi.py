@@ -80,6 +80,7 @@ PROTOTYPES = {
     "vd_ctx_create": (_I, [_I, C.POINTER(_P)]),
     "vd_ctx_destroy": (_I, [_P]),
     "vd_ctx_set_stream": (_I, [_P, _P]),
+    "vd_ctx_reset_stream": (_I, [_P]),
     "vd_ctx_synchronize": (_I, [_P]),
     "vd_last_error": (C.c_char_p, [_P]),
     "vd_version": (C.c_char_p, []),

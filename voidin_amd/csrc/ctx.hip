@@ -4,6 +4,7 @@
 #include "vd_common.hpp"
 
 #include <new>
+#include <stdlib.h>
 
 int vd_ensure(VdCtx* ctx, void** buf, size_t* cur, size_t need) {
     if (need <= *cur && *buf) return VD_OK;
@@ -48,6 +49,7 @@ int vd_ctx_create(int device, VdCtx** out_ctx) {
         return VD_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (const char* v = getenv("VD_CULL_VARIANT")) ctx->cull_variant = atoi(v);
     *out_ctx = ctx;
     return VD_OK;
 }
@@ -71,7 +73,14 @@ int vd_ctx_destroy(VdCtx* ctx) {
 int vd_ctx_set_stream(VdCtx* ctx, void* hip_stream) {
     if (!ctx) return VD_ERR_INVALID_ARG;
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);   // NULL = the HIP default stream
+    return VD_OK;
+}
+
+int vd_ctx_reset_stream(VdCtx* ctx) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
     return VD_OK;
 }
 
@@ -82,6 +91,13 @@ int vd_ctx_synchronize(VdCtx* ctx) {
 }
 
 const char* vd_last_error(const VdCtx* ctx) { return ctx ? ctx->err : "null ctx"; }
+
+// Tuning hook (not part of the reference boundary): pick the cull_compact kernel variant.
+int vd_debug_set_cull_variant(VdCtx* ctx, int variant) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    ctx->cull_variant = variant;
+    return VD_OK;
+}
 
 float vd_last_gpu_ms(VdCtx* ctx) {
     if (!ctx || !ctx->timed) return -1.0f;

@@ -20,6 +20,7 @@ struct VdCtx {
     bool timed = false;
     char err[512] = {0};
     int num_cus = 256;
+    int cull_variant = 0;               // kernel variant for A/B tuning (env VD_CULL_VARIANT)
 
     // grow-only device scratch arenas
     void* scratch = nullptr;     size_t scratch_bytes = 0;     // general purpose
