@@ -1,0 +1,105 @@
+"""Parity of the HIP TLAS build / refit and traversal against the CPU oracle, through the C ABI.
+Node layouts are bit-exact; hit distances within 1e-5 relative (north_star tolerance)."""
+import numpy as np
+import pytest
+
+from conftest import fields_equal, golden
+from voidin_amd import abi, synth
+from voidin_amd.runtime import VoidinError
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-5
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 40, 300])
+def test_tlas_build_matches_golden(ctx, n):
+    g = golden(f"tlas_{n}.npz")
+    nodes = ctx.tlas_build(g["instances"], g["meshes"])
+    assert fields_equal(nodes, g["nodes"])
+    # T3: refit(build(x), x) == build(x), bit for bit
+    assert ctx.tlas_refit(g["instances"], g["meshes"], nodes).tobytes() == nodes.tobytes()
+
+
+@pytest.mark.parametrize("n", [1000, 4097])
+def test_tlas_build_seeded_vs_oracle(ctx, oracle, n):
+    meshes = synth.mesh_infos()
+    inst = synth.instances(n, seed=synth.SEED_BASE + 6, extent=300.0)
+    want = oracle.tlas_build(inst, meshes)
+    got = ctx.tlas_build(inst, meshes)
+    assert fields_equal(got, want)
+    wide = ctx.tlas_build(inst, meshes, wide=True)
+    assert np.array_equal(wide["left"] + (wide["right"] << 16), want["left_right"])
+    assert np.array_equal(wide["min"], want["min"]) and np.array_equal(wide["instance_idx"], want["instance_idx"])
+
+
+def test_tlas_refit_after_motion(ctx, oracle):
+    """compute_update-style motion (rotz(theta) * transform on 10 % of the instances,
+    shaders/compute_update.wgsl:12-28), then refit == oracle refit == same-topology recompute."""
+    meshes = synth.mesh_infos()
+    n = 2000
+    inst = synth.instances(n, seed=synth.SEED_BASE + 7, extent=200.0)
+    nodes = ctx.tlas_build(inst, meshes)
+    th = np.float32(0.3)
+    c, s = np.cos(th), np.sin(th)
+    rot = np.array([[c, s, 0, 0], [-s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)  # column-major [col][row]
+    moved = inst.copy()
+    for i in range(0, n, 10):
+        T = moved["transform"][i].reshape(4, 4)
+        moved["transform"][i] = (T @ rot.T.T).reshape(16) if False else np.einsum("kr,ck->cr", rot, T).reshape(16)
+    got = ctx.tlas_refit(moved, meshes, nodes)
+    want = oracle.tlas_refit(moved, meshes, nodes)
+    assert got.tobytes() == want.tobytes()
+    assert np.array_equal(got["left_right"], nodes["left_right"])          # topology untouched
+    assert not np.array_equal(got["min"], nodes["min"])                    # boxes did move
+    # every interior box is the union of its children
+    for k in range(n + 1, 2 * n + 1):
+        l, r = int(got["left_right"][k] & 0xFFFF), int(got["left_right"][k] >> 16)
+        assert np.array_equal(got["min"][k], np.minimum(got["min"][l], got["min"][r]))
+        assert np.array_equal(got["max"][k], np.maximum(got["max"][l], got["max"][r]))
+
+
+def test_tlas_overflow_and_bad_args(ctx):
+    meshes = synth.mesh_infos()
+    inst = np.zeros(abi.TLAS_MAX_INSTANCES + 1, abi.INSTANCE)
+    with pytest.raises(VoidinError) as e:
+        ctx.tlas_build(inst, meshes)
+    assert e.value.code == abi.VD_ERR_TLAS_OVERFLOW
+    assert ctx.lib.vd_tlas_build(ctx.h, None, 0, None, 0, None) == abi.VD_ERR_INVALID_ARG
+
+
+def test_trace_matches_golden(ctx):
+    g = golden("trace_40.npz")
+    scene = (g["tlas"], g["instances"], g["meshes"], g["bvh_nodes"], g["vertices"], g["indices"])
+    h = ctx.trace(scene, g["rays"])
+    assert np.array_equal(h["hit"], g["hit"])
+    hit = g["hit"] == 1
+    assert np.all(np.abs(h["dist"][hit] - g["dist"][hit]) <= REL_TOL * np.abs(g["dist"][hit]))
+    assert (h["dist"][~hit] == np.float32(1e30)).all()
+
+
+def test_trace_seeded_scene_vs_oracle(ctx, oracle):
+    """bvh_gpu.rs-shaped scene: a few meshes, many instances, 256x256 primary rays."""
+    meshes_src = [synth.uv_sphere(1.0, 4), synth.knot_mesh(96, 24), synth.triangle_soup(64)]
+    V, I, B = [], [], []
+    infos = np.zeros(len(meshes_src), dtype=abi.MESH_INFO)
+    vo = bo = no = 0
+    for k, (v, i) in enumerate(meshes_src):
+        nodes, idx = oracle.bvh_build(v, i)
+        infos[k]["min"], infos[k]["max"] = synth.mesh_bounds(v)
+        infos[k]["index_count"], infos[k]["base_index"] = len(idx), bo
+        infos[k]["vertex_offset"], infos[k]["bvh_index"] = vo, no
+        V.append(v); I.append(idx); B.append(nodes)
+        vo += len(v); bo += len(idx); no += len(nodes)
+    V, I, B = np.concatenate(V), np.concatenate(I), np.concatenate(B)
+    inst = synth.instances(500, n_mesh=3, seed=synth.SEED_BASE + 8, extent=60.0, scale_range=(0.5, 3.0))
+    tl = ctx.tlas_build(inst, infos)
+    assert fields_equal(tl, oracle.tlas_build(inst, infos))
+    cam = synth.camera_uniform(eye=(0, 2.5, 45), pitch_deg=0)
+    rays = synth.primary_rays(cam, 256, 256)
+    scene = (tl, inst, infos, B, V, I)
+    want, max_stack = oracle.trace(scene, rays, threads=8)
+    got = ctx.trace(scene, rays)
+    assert np.array_equal(got["hit"], want["hit"]) and want["hit"].sum() > 1000
+    hit = want["hit"] == 1
+    assert np.all(np.abs(got["dist"][hit] - want["dist"][hit]) <= REL_TOL * np.abs(want["dist"][hit]))
+    assert max_stack <= 64

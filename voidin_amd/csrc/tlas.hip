@@ -1,0 +1,358 @@
+// tlas.hip — TLAS leaf boxes, exact agglomerative build and refit on gfx950.
+//
+// Replaces Tlas::build (reference: crates/bvh/src/tlas.rs:31-105), called once per scene from
+// MeshPool::generate_tlas (crates/pools/src/mesh/mod.rs:279-286), and adds refit (SURVEY.md
+// §8a T3, not in the reference).
+//
+//  * leaf boxes (tlas.rs:34-54): one lane per instance, 8 transformed corners folded with the
+//    object-space mesh box as seed (bug-compatible), total-order min/max;
+//  * build (tlas.rs:56-84): the reference is a sequential chain of ~2.5 N `find_best_match`
+//    scans whose tie-breaking depends on the slot order, so the chain itself cannot be
+//    reordered.  One 1024-lane workgroup runs the chain; each scan is data-parallel over the
+//    active slots, which are kept as a compacted SoA (six float arrays + node ids) so a scan is
+//    a pure stream of 24 B per slot; the argmin is a 64-bit {area bits, slot} key reduced by
+//    wave shuffles + LDS, which reproduces "strict <, first slot wins";
+//  * refit: leaves recomputed, interior boxes by a bottom-up walk with per-node arrival counters
+//    (agent-scope release/acquire around the counter; boxes re-read L1-bypassing).
+#include "vd_common.hpp"
+
+namespace {
+
+constexpr int kBuildThreads = 1024;
+
+struct Box { float mn[3], mx[3]; };
+
+// tlas.rs:35-44.  glam Mat4::transform_point3: ((X*p.x + Y*p.y) + Z*p.z) + W, no FMA.
+__device__ __forceinline__ Box leaf_box(const VdInstance* __restrict__ inst, const VdMeshInfo* __restrict__ meshes,
+                                        unsigned n_mesh, unsigned i) {
+    const float4* t4 = reinterpret_cast<const float4*>(inst + i);
+    const float4 X = t4[0], Y = t4[1], Z = t4[2], W = t4[3];
+    const unsigned mesh_id = reinterpret_cast<const unsigned*>(inst + i)[32];
+    const VdMeshInfo* m = meshes + min(mesh_id, n_mesh - 1u);
+    const float b[2][3] = {{m->min[0], m->min[1], m->min[2]}, {m->max[0], m->max[1], m->max[2]}};
+    Box r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.mn[k] = b[0][k]; r.mx[k] = b[1][k]; }   // fold seed: object-space box
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float px = b[(c & 1) == 0][0], py = b[(c & 2) == 0][1], pz = b[(c & 4) == 0][2];
+        const float p[3] = {((X.x * px + Y.x * py) + Z.x * pz) + W.x, ((X.y * px + Y.y * py) + Z.y * pz) + W.y,
+                            ((X.z * px + Y.z * py) + Z.z * pz) + W.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r.mn[k] = vd_min_to(r.mn[k], p[k]); r.mx[k] = vd_max_to(r.mx[k], p[k]); }
+    }
+    return r;
+}
+
+template <typename Node> __device__ __forceinline__ void node_set_children(Node& n, unsigned l, unsigned r);
+template <> __device__ __forceinline__ void node_set_children<VdTlasNode>(VdTlasNode& n, unsigned l, unsigned r) {
+    n.left_right = l + (r << 16);   // tlas.rs:71
+}
+template <> __device__ __forceinline__ void node_set_children<VdTlasNodeWide>(VdTlasNodeWide& n, unsigned l, unsigned r) {
+    n.left = l; n.right = r; n._pad[0] = n._pad[1] = n._pad[2] = 0u;
+}
+template <typename Node> __device__ __forceinline__ void node_get_children(const Node& n, unsigned& l, unsigned& r);
+template <> __device__ __forceinline__ void node_get_children<VdTlasNode>(const VdTlasNode& n, unsigned& l, unsigned& r) {
+    l = n.left_right & 0xffffu; r = n.left_right >> 16;
+}
+template <> __device__ __forceinline__ void node_get_children<VdTlasNodeWide>(const VdTlasNodeWide& n, unsigned& l, unsigned& r) {
+    l = n.left; r = n.right;
+}
+
+// Leaves for build: nodes[i+1] = {box, leaf, instance i}; slot arrays seeded in slot order.
+template <typename Node>
+__global__ __launch_bounds__(256) void tlas_leaves_kernel(const VdInstance* __restrict__ inst, unsigned n,
+                                                          const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
+                                                          Node* __restrict__ nodes, float* __restrict__ slot_box /* [6][cap] or null */,
+                                                          unsigned* __restrict__ slot_node, unsigned cap, int refit) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const unsigned src = refit ? nodes[i + 1].instance_idx : i;
+    const Box b = leaf_box(inst, meshes, n_mesh, src);
+    Node nd = nodes[i + 1];
+    if (!refit) {
+        node_set_children(nd, 0u, 0u);
+        nd.instance_idx = i;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { nd.min[k] = b.mn[k]; nd.max[k] = b.mx[k]; }
+    nodes[i + 1] = nd;
+    if (slot_box) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { slot_box[k * cap + i] = b.mn[k]; slot_box[(3 + k) * cap + i] = b.mx[k]; }
+        slot_node[i] = i + 1;
+    }
+}
+
+// {area, slot} -> unsigned-comparable key; areas of real boxes are >= +0, the monotone map also
+// orders garbage (negative / NaN-free) input the way `<` does.
+__device__ __forceinline__ vd_u64 match_key(float area, unsigned slot) {
+    const unsigned k = (unsigned)vd_key(area + 0.0f) ^ 0x80000000u;
+    return ((vd_u64)k << 32) | slot;
+}
+
+__device__ __forceinline__ vd_u64 wave_min_u64(vd_u64 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, off), hi = __shfl_xor((unsigned)(v >> 32), off);
+        const vd_u64 o = ((vd_u64)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// tlas.rs:87-105 over the compacted slot arrays; every thread returns the same slot.
+__device__ __forceinline__ unsigned find_best_match(const float* sb, unsigned cap, unsigned cnt,
+                                                    unsigned target, vd_u64* s_red, unsigned* s_res) {
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    vd_u64 best = ~0ull;
+    if (target < cap) {
+        const float t0 = sb[target], t1 = sb[cap + target], t2 = sb[2 * cap + target];
+        const float t3 = sb[3 * cap + target], t4 = sb[4 * cap + target], t5 = sb[5 * cap + target];
+        for (unsigned i = tid; i < cnt; i += kBuildThreads) {
+            const float dx = vd_max_to(t3, sb[3 * cap + i]) - vd_min_to(t0, sb[i]);
+            const float dy = vd_max_to(t4, sb[4 * cap + i]) - vd_min_to(t1, sb[cap + i]);
+            const float dz = vd_max_to(t5, sb[5 * cap + i]) - vd_min_to(t2, sb[2 * cap + i]);
+            const float area = vd_area(dx, dy, dz);
+            if (i != target && area < 1e30f) {          // `surface_area < smallest` from 1e30, NaN never passes
+                const vd_u64 k = match_key(area, i);
+                best = k < best ? k : best;
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) s_red[wave] = best;
+    __syncthreads();
+    if (wave == 0) {
+        vd_u64 v = lane < (kBuildThreads / 64) ? s_red[lane] : ~0ull;
+        v = wave_min_u64(v);
+        if (lane == 0) *s_res = v == ~0ull ? target : (unsigned)v;
+    }
+    __syncthreads();
+    return *s_res;
+}
+
+// tlas.rs:56-84 — one workgroup runs the whole chain.
+template <typename Node>
+__global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restrict__ nodes, unsigned n,
+                                                                   float* sb, unsigned* slot_node,
+                                                                   unsigned cap) {
+    __shared__ vd_u64 s_red[kBuildThreads / 64];
+    __shared__ unsigned s_res;
+    unsigned cnt = n, used = n + 1, a = 0;
+    unsigned b = find_best_match(sb, cap, cnt, a, s_red, &s_res);
+    while (cnt > 0) {
+        const unsigned c = find_best_match(sb, cap, cnt, b, s_red, &s_res);
+        if (a == c) {
+            if (threadIdx.x == 0) {
+                const unsigned idx_a = slot_node[a], idx_b = slot_node[b];
+                Node nd;
+                float u[6];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    u[k] = vd_min_to(sb[k * cap + a], sb[k * cap + b]);
+                    u[3 + k] = vd_max_to(sb[(3 + k) * cap + a], sb[(3 + k) * cap + b]);
+                    nd.min[k] = u[k];
+                    nd.max[k] = u[3 + k];
+                }
+                node_set_children(nd, idx_a, idx_b);
+                nd.instance_idx = 0xffffffffu;
+                nodes[used] = nd;
+                // node_indices[a] = nodes_used; node_indices[b] = node_indices[cnt - 1]  (in this order)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sb[k * cap + a] = u[k];
+                slot_node[a] = used;
+                const unsigned last = cnt - 1;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sb[k * cap + b] = sb[k * cap + last];
+                slot_node[b] = slot_node[last];
+            }
+            used += 1;
+            cnt -= 1;
+            __syncthreads();
+            b = find_best_match(sb, cap, cnt, a, s_red, &s_res);
+        } else {
+            a = b;
+            b = c;
+        }
+    }
+    if (threadIdx.x == 0) nodes[0] = nodes[slot_node[a]];   // tlas.rs:84
+}
+
+// ---- refit -------------------------------------------------------------------------------
+template <typename Node>
+__global__ __launch_bounds__(256) void tlas_parents_kernel(const Node* __restrict__ nodes, unsigned n,
+                                                           unsigned* __restrict__ parent, unsigned* __restrict__ arrivals) {
+    const unsigned k = blockIdx.x * 256u + threadIdx.x + n + 1u;   // interior nodes n+1 .. 2n
+    if (k > 2u * n) return;
+    unsigned l, r;
+    node_get_children(nodes[k], l, r);
+    parent[l] = k;
+    parent[r] = k;
+    arrivals[k] = 0u;
+}
+
+template <typename Node>
+__global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigned n, const unsigned* __restrict__ parent,
+                                                            unsigned* arrivals) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    unsigned k = parent[i + 1];
+    // publish this leaf's box (written by the leaves kernel in an earlier launch: already visible)
+    while (k != 0u) {
+        unsigned l, r;
+        node_get_children(nodes[k], l, r);
+        const unsigned need = l == r ? 1u : 2u;          // node 2n merges the true root with itself
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ROCm 7.2 can drop the fence's own wait
+        const unsigned seen = __hip_atomic_fetch_add(&arrivals[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen + 1u < need) return;                    // sibling subtree not finished yet
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float mn[3], mx[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float lmn = __hip_atomic_load(&nodes[l].min[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float rmn = __hip_atomic_load(&nodes[r].min[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float lmx = __hip_atomic_load(&nodes[l].max[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float rmx = __hip_atomic_load(&nodes[r].max[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mn[c] = vd_min_to(lmn, rmn);
+            mx[c] = vd_max_to(lmx, rmx);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            __hip_atomic_store(&nodes[k].min[c], mn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&nodes[k].max[c], mx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (k == 2u * n) return;
+        k = parent[k];
+    }
+}
+
+template <typename Node>
+__global__ void tlas_root_copy_kernel(Node* nodes, unsigned n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) nodes[0] = nodes[2u * n];
+}
+
+template <typename Node>
+int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                    Node* d_nodes) {
+    // scratch: 6 float slot arrays + slot node ids, capacity n
+    const size_t cap = n;
+    const size_t need = cap * 7 * 4 + 256;
+    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
+    if (rc) return rc;
+    float* sb = reinterpret_cast<float*>(ctx->scratch);
+    unsigned* slot_node = reinterpret_cast<unsigned*>(sb + 6 * cap);
+    vd_time_begin(ctx);
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_nodes, 0, sizeof(Node) * (2 * (size_t)n + 1), ctx->stream));   // TlasNode::default()
+    hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
+                       n_mesh, d_nodes, sb, slot_node, (unsigned)cap, 0);
+    hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
+                       (unsigned)cap);
+    vd_time_end(ctx);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    return VD_OK;
+}
+
+template <typename Node>
+int tlas_refit_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                    Node* d_nodes) {
+    const size_t total = 2 * (size_t)n + 1;
+    const size_t need = total * 8 + 256;
+    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
+    if (rc) return rc;
+    unsigned* parent = reinterpret_cast<unsigned*>(ctx->scratch);
+    unsigned* arrivals = parent + total;
+    vd_time_begin(ctx);
+    VD_HIP_CHECK(ctx, hipMemsetAsync(parent, 0, total * 8, ctx->stream));
+    hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
+                       n_mesh, d_nodes, (float*)nullptr, (unsigned*)nullptr, 0u, 1);
+    hipLaunchKernelGGL((tlas_parents_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_nodes, n, parent, arrivals);
+    hipLaunchKernelGGL((tlas_refit_up_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_nodes, n, parent, arrivals);
+    hipLaunchKernelGGL((tlas_root_copy_kernel<Node>), dim3(1), dim3(64), 0, ctx->stream, d_nodes, n);
+    vd_time_end(ctx);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    return VD_OK;
+}
+
+int check_args(VdCtx* ctx, const void* inst, uint32_t n, const void* meshes, uint32_t n_mesh, const void* nodes, bool wide) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!inst || !meshes || !nodes || n == 0 || n_mesh == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_tlas_*: null pointer or zero count");
+    if (!wide && n > VD_TLAS_MAX_INSTANCES)
+        VD_FAIL(ctx, VD_ERR_TLAS_OVERFLOW, "vd_tlas_*: n > 32768 does not fit the 16-bit left_right packing (tlas.rs:71); use the _wide variant");
+    if (n > 0x3fffffffu) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_tlas_*: n too large");
+    return VD_OK;
+}
+
+// host-pointer wrapper: stage instances + meshes in, nodes out
+template <typename Node, typename Fn>
+int tlas_host(VdCtx* ctx, const VdInstance* inst, uint32_t n, const VdMeshInfo* meshes, uint32_t n_mesh, Node* nodes,
+              bool upload_nodes, Fn fn) {
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t nb = sizeof(Node) * (2 * (size_t)n + 1);
+    int rc = vd_ensure(ctx, &ctx->stage_in, &ctx->stage_in_bytes, (size_t)n * sizeof(VdInstance));
+    if (rc) return rc;
+    rc = vd_ensure(ctx, &ctx->stage_aux, &ctx->stage_aux_bytes, (size_t)n_mesh * sizeof(VdMeshInfo) + 16);
+    if (rc) return rc;
+    rc = vd_ensure(ctx, &ctx->stage_out, &ctx->stage_out_bytes, nb);
+    if (rc) return rc;
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->stage_in, inst, (size_t)n * sizeof(VdInstance), hipMemcpyHostToDevice, ctx->stream));
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->stage_aux, meshes, (size_t)n_mesh * sizeof(VdMeshInfo), hipMemcpyHostToDevice, ctx->stream));
+    if (upload_nodes) VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->stage_out, nodes, nb, hipMemcpyHostToDevice, ctx->stream));
+    rc = fn(reinterpret_cast<const VdInstance*>(ctx->stage_in), reinterpret_cast<const VdMeshInfo*>(ctx->stage_aux),
+            reinterpret_cast<Node*>(ctx->stage_out));
+    if (rc) return rc;
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(nodes, ctx->stage_out, nb, hipMemcpyDeviceToHost, ctx->stream));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vd_tlas_build_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                      VdTlasNode* d_nodes) {
+    int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, false);
+    return rc ? rc : tlas_build_impl<VdTlasNode>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
+}
+int vd_tlas_build_wide_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                           VdTlasNodeWide* d_nodes) {
+    int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, true);
+    return rc ? rc : tlas_build_impl<VdTlasNodeWide>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
+}
+int vd_tlas_refit_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                      VdTlasNode* d_nodes) {
+    int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, false);
+    return rc ? rc : tlas_refit_impl<VdTlasNode>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
+}
+int vd_tlas_refit_wide_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                           VdTlasNodeWide* d_nodes) {
+    int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, true);
+    return rc ? rc : tlas_refit_impl<VdTlasNodeWide>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
+}
+
+int vd_tlas_build(VdCtx* ctx, const VdInstance* inst, uint32_t n, const VdMeshInfo* meshes, uint32_t n_mesh, VdTlasNode* nodes) {
+    int rc = check_args(ctx, inst, n, meshes, n_mesh, nodes, false);
+    if (rc) return rc;
+    return tlas_host<VdTlasNode>(ctx, inst, n, meshes, n_mesh, nodes, false, [&](const VdInstance* di, const VdMeshInfo* dm, VdTlasNode* dn) {
+        return tlas_build_impl<VdTlasNode>(ctx, di, n, dm, n_mesh, dn);
+    });
+}
+int vd_tlas_build_wide(VdCtx* ctx, const VdInstance* inst, uint32_t n, const VdMeshInfo* meshes, uint32_t n_mesh,
+                       VdTlasNodeWide* nodes) {
+    int rc = check_args(ctx, inst, n, meshes, n_mesh, nodes, true);
+    if (rc) return rc;
+    return tlas_host<VdTlasNodeWide>(ctx, inst, n, meshes, n_mesh, nodes, false, [&](const VdInstance* di, const VdMeshInfo* dm, VdTlasNodeWide* dn) {
+        return tlas_build_impl<VdTlasNodeWide>(ctx, di, n, dm, n_mesh, dn);
+    });
+}
+int vd_tlas_refit(VdCtx* ctx, const VdInstance* inst, uint32_t n, const VdMeshInfo* meshes, uint32_t n_mesh, VdTlasNode* nodes) {
+    int rc = check_args(ctx, inst, n, meshes, n_mesh, nodes, false);
+    if (rc) return rc;
+    return tlas_host<VdTlasNode>(ctx, inst, n, meshes, n_mesh, nodes, true, [&](const VdInstance* di, const VdMeshInfo* dm, VdTlasNode* dn) {
+        return tlas_refit_impl<VdTlasNode>(ctx, di, n, dm, n_mesh, dn);
+    });
+}
+
+}  // extern "C"

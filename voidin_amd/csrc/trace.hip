@@ -1,0 +1,217 @@
+// trace.hip — batch TLAS -> instance -> BLAS ray traversal on gfx950.
+//
+// Replaces `traverse_tlas(ray)` (reference: shaders/utils/bvh.wgsl:89-123) and its callees
+// `instance_intersect` (bvh.wgsl:78-87), `traverse_bvh` (bvh.wgsl:35-76), `fetch_vertex`
+// (bvh.wgsl:30-33), `intersect_aabb` / `intersect_trig` (shaders/utils/intersections.wgsl:13-45).
+// One lane per ray; the arithmetic order is the WGSL source order with no FMA, so hit distances
+// are reproduced to the bit on the oracle's evaluation model (tolerance in tests: 1e-5).
+// The reference's 24-entry stack is unchecked (shaders/utils/stack.wgsl:1-20); here the stack is
+// 64 deep per traversal level and overflow is reported, not ignored.
+#include "vd_common.hpp"
+
+namespace {
+
+constexpr int kStack = 64;
+constexpr float kMaxDist = 1e30f;
+
+struct Ray { float ex, ey, ez, dx, dy, dz, ix, iy, iz; };
+
+__device__ __forceinline__ float min3(float a, float b, float c) { return fminf(a, fminf(b, c)); }   // math.wgsl:19-21
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }   // math.wgsl:23-25
+
+// intersections.wgsl:13-23
+__device__ __forceinline__ float intersect_aabb(const Ray& r, const float* mn, const float* mx, float t) {
+    const float ax = (mn[0] - r.ex) * r.ix, ay = (mn[1] - r.ey) * r.iy, az = (mn[2] - r.ez) * r.iz;
+    const float bx = (mx[0] - r.ex) * r.ix, by = (mx[1] - r.ey) * r.iy, bz = (mx[2] - r.ez) * r.iz;
+    const float tmax = min3(fmaxf(ax, bx), fmaxf(ay, by), fmaxf(az, bz));
+    const float tmin = max3(fminf(ax, bx), fminf(ay, by), fminf(az, bz));
+    return (tmax >= tmin && tmin < t && tmax > 0.0f) ? tmin : kMaxDist;
+}
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+
+// intersections.wgsl:25-45 (Moeller-Trumbore, backface cull det < 1e-10)
+__device__ __forceinline__ bool intersect_trig(const Ray& r, const float* v0, const float* v1, const float* v2, float& hit) {
+    const float e1x = v1[0] - v0[0], e1y = v1[1] - v0[1], e1z = v1[2] - v0[2];
+    const float e2x = v2[0] - v0[0], e2y = v2[1] - v0[1], e2z = v2[2] - v0[2];
+    // cross(dir, edge2)
+    const float ux = r.dy * e2z - e2y * r.dz, uy = r.dz * e2x - e2z * r.dx, uz = r.dx * e2y - e2x * r.dy;
+    const float det = dot3(e1x, e1y, e1z, ux, uy, uz);
+    if (det < 1e-10f) return false;
+    const float inv_det = 1.0f / det;
+    const float ox = r.ex - v0[0], oy = r.ey - v0[1], oz = r.ez - v0[2];
+    const float u = inv_det * dot3(ox, oy, oz, ux, uy, uz);
+    if (u < 0.0f || 1.0f < u) return false;
+    // cross(orig, edge1)
+    const float vx = oy * e1z - e1y * oz, vy = oz * e1x - e1z * ox, vz = ox * e1y - e1x * oy;
+    const float v = inv_det * dot3(r.dx, r.dy, r.dz, vx, vy, vz);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float t = inv_det * dot3(e2x, e2y, e2z, vx, vy, vz);
+    if (t > 0.0f && t < hit) {
+        hit = t;
+        return true;
+    }
+    return false;
+}
+
+struct Scene {
+    const VdTlasNode* tlas; const VdInstance* inst; const VdMeshInfo* meshes; const VdBvhNode* bvh;
+    const float* verts; const unsigned* indices; unsigned n_meshes;
+};
+
+__global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restrict__ rays, unsigned n_rays,
+                                                   VdHit* __restrict__ out, unsigned* __restrict__ overflow) {
+    const unsigned i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n_rays) return;
+    unsigned tstack[kStack], bstack[kStack];
+    Ray ray;
+    {
+        const float4 a = reinterpret_cast<const float4*>(rays + i)[0], b = reinterpret_cast<const float4*>(rays + i)[1];
+        ray.ex = a.x; ray.ey = a.y; ray.ez = a.z; ray.dx = b.x; ray.dy = b.y; ray.dz = b.z;
+        ray.ix = 1.0f / ray.dx; ray.iy = 1.0f / ray.dy; ray.iz = 1.0f / ray.dz;   // ray_new: inv_dir = 1. / dir
+    }
+    VdHit res; res.dist = kMaxDist; res.hit = 0u; res.instance = 0xffffffffu; res.triangle = 0xffffffffu;
+    bool ovf = false;
+    unsigned thead = 0;
+    tstack[thead++] = 0u;
+    while (thead > 0u) {                                           // bvh.wgsl:94
+        const VdTlasNode node = s.tlas[tstack[--thead]];
+        if (node.left_right == 0u) {                               // leaf: instance_intersect (bvh.wgsl:78-87)
+            const VdInstance* I = s.inst + node.instance_idx;
+            const unsigned mesh_id = min(I->mesh, s.n_meshes - 1u);
+            const VdMeshInfo mesh = s.meshes[mesh_id];
+            const float* M = I->inv_transform;
+            Ray nr;
+            nr.ex = ((M[0] * ray.ex + M[4] * ray.ey) + M[8] * ray.ez) + M[12] * 1.0f;
+            nr.ey = ((M[1] * ray.ex + M[5] * ray.ey) + M[9] * ray.ez) + M[13] * 1.0f;
+            nr.ez = ((M[2] * ray.ex + M[6] * ray.ey) + M[10] * ray.ez) + M[14] * 1.0f;
+            nr.dx = ((M[0] * ray.dx + M[4] * ray.dy) + M[8] * ray.dz) + M[12] * 0.0f;
+            nr.dy = ((M[1] * ray.dx + M[5] * ray.dy) + M[9] * ray.dz) + M[13] * 0.0f;
+            nr.dz = ((M[2] * ray.dx + M[6] * ray.dy) + M[10] * ray.dz) + M[14] * 0.0f;
+            nr.ix = 1.0f / nr.dx; nr.iy = 1.0f / nr.dy; nr.iz = 1.0f / nr.dz;
+            // traverse_bvh (bvh.wgsl:35-76)
+            unsigned bhead = 0;
+            bstack[bhead++] = mesh.bvh_index;
+            float hit = res.dist;
+            while (bhead > 0u) {
+                const VdBvhNode bn = s.bvh[bstack[--bhead]];
+                if (bn.count > 0u) {
+                    for (unsigned k = 0; k < bn.count; ++k) {
+                        const unsigned idx = bn.left_first + k;
+                        const unsigned i0 = (unsigned)mesh.vertex_offset + s.indices[mesh.base_index + 3u * idx + 0u];
+                        const unsigned i1 = (unsigned)mesh.vertex_offset + s.indices[mesh.base_index + 3u * idx + 1u];
+                        const unsigned i2 = (unsigned)mesh.vertex_offset + s.indices[mesh.base_index + 3u * idx + 2u];
+                        const float* v0 = s.verts + 3u * (size_t)i0;
+                        const float* v1 = s.verts + 3u * (size_t)i1;
+                        const float* v2 = s.verts + 3u * (size_t)i2;
+                        const float a0[3] = {v0[0], v0[1], v0[2]}, a1[3] = {v1[0], v1[1], v1[2]}, a2[3] = {v2[0], v2[1], v2[2]};
+                        if (intersect_trig(nr, a0, a1, a2, hit)) {
+                            res.dist = hit; res.hit = 1u; res.instance = node.instance_idx; res.triangle = idx;
+                        }
+                    }
+                } else {
+                    unsigned min_index = mesh.bvh_index + bn.left_first;
+                    unsigned max_index = mesh.bvh_index + bn.left_first + 1u;
+                    const VdBvhNode c0 = s.bvh[min_index], c1 = s.bvh[max_index];
+                    float min_dist = intersect_aabb(nr, c0.min, c0.max, hit);
+                    float max_dist = intersect_aabb(nr, c1.min, c1.max, hit);
+                    if (min_dist > max_dist) {
+                        const unsigned ti = min_index; min_index = max_index; max_index = ti;
+                        const float tf = min_dist; min_dist = max_dist; max_dist = tf;
+                    }
+                    if (min_dist >= hit) continue;
+                    if (bhead + 2u > (unsigned)kStack) { ovf = true; break; }
+                    if (max_dist <= hit) bstack[bhead++] = max_index;
+                    bstack[bhead++] = min_index;
+                }
+            }
+        } else {
+            unsigned min_index = node.left_right & 0xffffu;
+            unsigned max_index = node.left_right >> 16u;
+            const VdTlasNode c0 = s.tlas[min_index], c1 = s.tlas[max_index];
+            float min_dist = intersect_aabb(ray, c0.min, c0.max, res.dist);
+            float max_dist = intersect_aabb(ray, c1.min, c1.max, res.dist);
+            if (min_dist > max_dist) {
+                const unsigned ti = min_index; min_index = max_index; max_index = ti;
+                const float tf = min_dist; min_dist = max_dist; max_dist = tf;
+            }
+            if (min_dist >= res.dist) continue;
+            if (thead + 2u > (unsigned)kStack) { ovf = true; break; }
+            if (max_dist < res.dist) tstack[thead++] = max_index;
+            tstack[thead++] = min_index;
+        }
+    }
+    if (ovf) atomicOr(overflow, 1u);
+    out[i] = res;
+}
+
+int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out) {
+    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256);
+    if (rc) return rc;
+    unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);
+    Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes};
+    vd_time_begin(ctx);
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(trace_kernel, dim3((n_rays + 63) / 64), dim3(64), 0, ctx->stream, s, d_rays, n_rays, d_out, d_flag);
+    vd_time_end(ctx);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->host_pinned[0]) VD_FAIL(ctx, VD_ERR_STACK_OVERFLOW, "vd_trace: traversal stack (64) exceeded");
+    return VD_OK;
+}
+
+bool scene_ok(const VdTraceScene* s) {
+    return s && s->tlas_nodes && s->instances && s->meshes && s->bvh_nodes && s->vertices && s->indices && s->n_meshes &&
+           s->n_tlas_nodes && s->n_instances;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!scene_ok(d_scene)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: incomplete scene");
+    if (n_rays == 0) return VD_OK;
+    if (!d_rays || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: null rays/out");
+    return launch_trace(ctx, d_scene, d_rays, n_rays, d_out);
+}
+
+int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t n_rays, VdHit* out) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!scene_ok(scene)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: incomplete scene");
+    if (n_rays == 0) return VD_OK;
+    if (!rays || !out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: null rays/out");
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // one staging arena, sub-allocated at 256-B boundaries
+    const size_t sz[8] = {(size_t)scene->n_tlas_nodes * sizeof(VdTlasNode), (size_t)scene->n_instances * sizeof(VdInstance),
+                          (size_t)scene->n_meshes * sizeof(VdMeshInfo), (size_t)scene->n_bvh_nodes * sizeof(VdBvhNode),
+                          (size_t)scene->n_vertices * 12, (size_t)scene->n_indices * 4, (size_t)n_rays * sizeof(VdRay),
+                          (size_t)n_rays * sizeof(VdHit)};
+    const void* src[7] = {scene->tlas_nodes, scene->instances, scene->meshes, scene->bvh_nodes, scene->vertices, scene->indices, rays};
+    size_t off[8], total = 0;
+    for (int k = 0; k < 8; ++k) { off[k] = total; total += (sz[k] + 255) & ~(size_t)255; }
+    int rc = vd_ensure(ctx, &ctx->stage_in, &ctx->stage_in_bytes, total);
+    if (rc) return rc;
+    char* base = reinterpret_cast<char*>(ctx->stage_in);
+    for (int k = 0; k < 7; ++k)
+        if (sz[k]) VD_HIP_CHECK(ctx, hipMemcpyAsync(base + off[k], src[k], sz[k], hipMemcpyHostToDevice, ctx->stream));
+    VdTraceScene d = *scene;
+    d.tlas_nodes = reinterpret_cast<const VdTlasNode*>(base + off[0]);
+    d.instances = reinterpret_cast<const VdInstance*>(base + off[1]);
+    d.meshes = reinterpret_cast<const VdMeshInfo*>(base + off[2]);
+    d.bvh_nodes = reinterpret_cast<const VdBvhNode*>(base + off[3]);
+    d.vertices = reinterpret_cast<const float*>(base + off[4]);
+    d.indices = reinterpret_cast<const uint32_t*>(base + off[5]);
+    VdHit* d_out = reinterpret_cast<VdHit*>(base + off[7]);
+    rc = launch_trace(ctx, &d, reinterpret_cast<const VdRay*>(base + off[6]), n_rays, d_out);
+    if (rc) return rc;
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, sz[7], hipMemcpyDeviceToHost, ctx->stream));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VD_OK;
+}
+
+}  // extern "C"
