@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvoidin_hip.so")
+LIB_PATH = os.environ.get("VOIDIN_HIP_LIB") or os.path.join(_HERE, "csrc", "libvoidin_hip.so")
 
 # --- wire structs ---------------------------------------------------------------------
 INSTANCE = np.dtype([("transform", "<f4", (16,)), ("inv_transform", "<f4", (16,)),

@@ -30,7 +30,13 @@
 
 namespace {
 
-constexpr int kSmallMax = 512;          // largest segment built by one wave out of LDS
+#ifndef VD_SMALL_MAX
+#define VD_SMALL_MAX 512
+#endif
+#ifndef VD_LANE_MAX
+#define VD_LANE_MAX 16
+#endif
+constexpr int kSmallMax = VD_SMALL_MAX;  // largest segment built by one wave out of LDS
 constexpr int kChunks = kSmallMax / 64;
 constexpr int kCand = 21;               // 3 axes x 7 planes (blas.rs:144-145; `bins` hard-coded to 8)
 constexpr int kBig = 0x7fffffff;
@@ -159,229 +165,388 @@ __device__ __forceinline__ vd_u64 wave_min_u64(vd_u64 v) {
 }
 
 // =============================================================================================
-// Phase B: one wave builds the subtree of one small segment in DFS order out of LDS.
+// Phase B: one wave builds the subtree of one small segment in DFS order, entirely out of LDS.
 // =============================================================================================
+// Per-wave LDS image of a subtree of N <= kSmallMax triangles, addressed by LOCAL element id
+// e in [0, N): centroids and box keys stay put, only the 2-byte permutation moves.
 struct SmallRoot { unsigned start, count, top_node, pad; };
 
 struct WaveLds {
-    u32x4 pay[2][kSmallMax];                // arrangement ping-pong: {id, cx, cy, cz}
-    u32x4 u_pay[kCand + 1];
-    int bin_min[3][8][3], bin_max[3][8][3];
+    float cent[3][kSmallMax];
+    int box[6][kSmallMax];                        // order-preserving keys: min xyz, max xyz
+    unsigned gid[kSmallMax];                      // local element -> triangle id
+    unsigned stack[kSmallMax];                    // pending right children: node | start << 10 | count << 20
     float pos[kCand + 3];
-    unsigned ttot[kCand + 1], u_p[kCand + 1];
+    unsigned ttot[kCand + 3];
+    unsigned short perm[2][kSmallMax];            // arrangement ping-pong (position -> local element)
     unsigned short falsepos[kSmallMax + 2];
     unsigned short truepos[kSmallMax + 2];
+    unsigned short u_e[kCand + 3];
+    unsigned short u_p[kCand + 3];
 };
 
-// One closed-form shuffle of segment [s, s+n) with predicate centroid[axis] < pos: reads
-// pay[src], writes pay[src^1].  Returns Ttot and u's payload / predicate uniformly.
+// One closed-form shuffle of segment [s, s+n) with predicate cent[axis] < pos: reads perm[src],
+// writes perm[src^1].  NCH = number of 64-position chunks compiled in (1 = the n <= 64 fast path).
+template <int NCH>
 __device__ __forceinline__ void wave_shuffle(WaveLds& L, int src, unsigned s, unsigned n, int axis, float pos,
-                                             unsigned& out_ttot, u32x4& out_u, unsigned& out_up) {
+                                             unsigned& out_ttot, unsigned& out_ue, unsigned& out_up) {
     const unsigned lane = vd_lane();
-    const unsigned n_chunks = (n + 63u) >> 6;
-    unsigned long long masks[kChunks];
+    const unsigned short* pin = L.perm[src] + s;
+    unsigned short* pout = L.perm[src ^ 1] + s;
+    const float* cen = L.cent[axis];
+    unsigned long long masks[NCH];
+    unsigned short el[NCH];
     unsigned ttot = 0;
 #pragma unroll
-    for (int ch = 0; ch < kChunks; ++ch) {
-        masks[ch] = 0ull;
-        if ((unsigned)ch < n_chunks) {
-            const unsigned x = ch * 64u + lane;
-            bool p = false;
-            if (x < n) p = pay_c(L.pay[src][s + x], axis) < pos;
-            masks[ch] = __ballot(p);
-            ttot += (unsigned)__popcll(masks[ch]);
-        }
+    for (int ch = 0; ch < NCH; ++ch) {
+        const unsigned x = ch * 64u + lane;
+        bool p = false;
+        el[ch] = 0;
+        if (x < n) { el[ch] = pin[x]; p = cen[el[ch]] < pos; }
+        masks[ch] = __ballot(p);
+        ttot += (unsigned)__popcll(masks[ch]);
     }
     const unsigned ftot = n - ttot;
-    // rank -> position: falsepos[j] = j-th false from the left, truepos[j] = j-th true from the right (1-based)
     unsigned run = 0;
 #pragma unroll
-    for (int ch = 0; ch < kChunks; ++ch) {
-        if ((unsigned)ch < n_chunks) {
-            const unsigned x = ch * 64u + lane;
-            if (x < n) {
-                const bool p = (masks[ch] >> lane) & 1ull;
-                const unsigned tl = run + vd_mbcnt(masks[ch]);
-                if (p) L.truepos[ttot - tl] = (unsigned short)x;        // T + 1 = ttot - tl - 1 + 1
-                else L.falsepos[x - tl + 1u] = (unsigned short)x;       // F + 1
-            }
-            run += (unsigned)__popcll(masks[ch]);
+    for (int ch = 0; ch < NCH; ++ch) {
+        const unsigned x = ch * 64u + lane;
+        if (x < n) {
+            const bool p = (masks[ch] >> lane) & 1ull;
+            const unsigned tl = run + vd_mbcnt(masks[ch]);
+            if (p) L.truepos[ttot - tl] = (unsigned short)x;        // (T+1)-th true from the right
+            else L.falsepos[x - tl + 1u] = (unsigned short)x;       // (F+1)-th false from the left
         }
+        run += (unsigned)__popcll(masks[ch]);
     }
     vd_wave_lds_sync();
     run = 0;
-    u32x4 uv = {0u, 0u, 0u, 0u};
-    unsigned up = 0;
+    unsigned ue = 0, up = 0;
 #pragma unroll
-    for (int ch = 0; ch < kChunks; ++ch) {
-        if ((unsigned)ch < n_chunks) {
-            const unsigned x = ch * 64u + lane;
-            bool is_u = false;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            bool p = false;
-            if (x < n) {
-                p = (masks[ch] >> lane) & 1ull;
-                const unsigned tl = run + vd_mbcnt(masks[ch]);
-                const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
-                const int tF = F == 0u ? (int)n : (F <= ttot ? (int)L.truepos[F] : -1);
-                const bool left = (int)x < tF;
-                const unsigned fj = (T + 1u <= ftot) ? (unsigned)L.falsepos[T + 1u] : n;
-                const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
-                is_u = fetch == n - 1u;
-                unsigned dest;
-                if (is_u) dest = ttot - (p ? 1u : 0u);
-                else if (left) dest = p ? x : (unsigned)tF - 1u;
-                else dest = p ? fj : x - 1u;
-                v = L.pay[src][s + x];
-                L.pay[src ^ 1][s + dest] = v;
-            }
-            const unsigned long long um = __ballot(is_u);
-            if (um) {
-                const int ul = __builtin_ctzll(um);
-                uv.x = __shfl(v.x, ul); uv.y = __shfl(v.y, ul); uv.z = __shfl(v.z, ul); uv.w = __shfl(v.w, ul);
-                up = __shfl(p ? 1u : 0u, ul);
-            }
-            run += (unsigned)__popcll(masks[ch]);
+    for (int ch = 0; ch < NCH; ++ch) {
+        const unsigned x = ch * 64u + lane;
+        bool is_u = false, p = false;
+        if (x < n) {
+            p = (masks[ch] >> lane) & 1ull;
+            const unsigned tl = run + vd_mbcnt(masks[ch]);
+            const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
+            const int tF = F == 0u ? (int)n : (F <= ttot ? (int)L.truepos[F] : -1);
+            const bool left = (int)x < tF;
+            const unsigned fj = (T + 1u <= ftot) ? (unsigned)L.falsepos[T + 1u] : n;
+            const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
+            is_u = fetch == n - 1u;
+            unsigned dest;
+            if (is_u) dest = ttot - (p ? 1u : 0u);
+            else if (left) dest = p ? x : (unsigned)tF - 1u;
+            else dest = p ? fj : x - 1u;
+            pout[dest] = el[ch];
         }
+        const unsigned long long um = __ballot(is_u);
+        if (um) {
+            const int ul = __builtin_ctzll(um);
+            ue = __shfl((unsigned)el[ch], ul);
+            up = __shfl(p ? 1u : 0u, ul);
+        }
+        run += (unsigned)__popcll(masks[ch]);
     }
     vd_wave_lds_sync();
-    out_ttot = ttot; out_u = uv; out_up = up;
+    out_ttot = ttot; out_ue = ue; out_up = up;
 }
 
-constexpr int kSmallWaves = 2;   // waves (= subtrees) per workgroup: 2 x ~20 KB of LDS
+__device__ __forceinline__ void wave_shuffle_any(WaveLds& L, int src, unsigned s, unsigned n, int axis, float pos,
+                                                 unsigned& tt, unsigned& ue, unsigned& up) {
+    if (n <= 64u) wave_shuffle<1>(L, src, s, n, axis, pos, tt, ue, up);
+    else if (kChunks >= 2 && n <= 128u) wave_shuffle<(kChunks >= 2 ? 2 : 1)>(L, src, s, n, axis, pos, tt, ue, up);
+    else if (kChunks >= 4 && n <= 256u) wave_shuffle<(kChunks >= 4 ? 4 : 1)>(L, src, s, n, axis, pos, tt, ue, up);
+    else wave_shuffle<kChunks>(L, src, s, n, axis, pos, tt, ue, up);
+}
+
+constexpr int kLaneMax = VD_LANE_MAX;   // nodes up to this size are built one-per-lane (literal sequential algorithm)
+constexpr int kQueue = kSmallMax / 4;   // a BFS level holds at most N/4 splittable nodes
+
+struct WaveQueues {                      // BFS frontiers: entry = node | start << 10 | count << 20
+    unsigned big[2][kQueue], small[2][kQueue];
+};
+
+// blas.rs:135-166 run literally by ONE lane on its own node [s, s+n) (n <= kLaneMax).  Returns
+// the stale pivot (relative) or 0xffffffff when every candidate is rejected; writes the children
+// box keys (left min/max, right min/max).
+__device__ __forceinline__ unsigned lane_partition(WaveLds& L, unsigned short* perm, unsigned s, unsigned n, int (&ck)[12]) {
+    int kmn[3] = {kBig, kBig, kBig}, kmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
+    for (unsigned i = 0; i < n; ++i) {
+        const unsigned e = perm[s + i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int key = vd_key(L.cent[k][e]); kmn[k] = min(kmn[k], key); kmx[k] = max(kmx[k], key); }
+    }
+    float cbmin[3], cbmax[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(kmn[k]); cbmax[k] = box_hi(kmx[k]); }
+    float best_cost = 3.40282347e+38f, best_pos = 0.0f;
+    int best_axis = -1;
+    unsigned best_piv = 0;
+    for (int c = 0; c <= kCand; ++c) {
+        int axis; float pos;
+        if (c < kCand) { axis = c / 7; pos = cand_pos(cbmin, cbmax, c); }
+        else { if (best_axis < 0) return 0xffffffffu; axis = best_axis; pos = best_pos; }
+        // partition_shuffle (blas.rs:168-182)
+        int i = 0, e = (int)n - 1;
+        const float* cen = L.cent[axis];
+        while (i < e) {
+            const unsigned short a = perm[s + i];
+            if (cen[a] < pos) { i += 1; }
+            else { const unsigned short b = perm[s + e]; perm[s + i] = b; perm[s + e] = a; e -= 1; }
+        }
+        const unsigned piv = c < kCand ? (unsigned)i : best_piv;   // final pass: the stale pivot splits the children
+        int k12[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) k12[q] = (q % 6) < 3 ? kBig : -kBig - 1;
+        for (unsigned x = 0; x < n; ++x) {
+            const unsigned el = perm[s + x];
+            const int o = x < piv ? 0 : 6;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { k12[o + q] = min(k12[o + q], L.box[q][el]); k12[o + 3 + q] = max(k12[o + 3 + q], L.box[3 + q][el]); }
+        }
+        if (c == kCand) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) ck[q] = k12[q];
+            break;
+        }
+        const float a1 = vd_area(box_hi(k12[3]) - box_lo(k12[0]), box_hi(k12[4]) - box_lo(k12[1]), box_hi(k12[5]) - box_lo(k12[2]));
+        const float a2 = vd_area(box_hi(k12[9]) - box_lo(k12[6]), box_hi(k12[10]) - box_lo(k12[7]), box_hi(k12[11]) - box_lo(k12[8]));
+        const float cost = a1 * (float)piv + a2 * (float)(n - piv);
+        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_pos = pos; best_piv = piv; }
+    }
+    return best_piv;
+}
+
+constexpr int kSmallWaves = 1;   // subtrees per workgroup
 __global__ __launch_bounds__(64 * kSmallWaves) void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
-                                                         const u32x4* __restrict__ payload, const TriBox* __restrict__ boxes,
-                                                         TmpNode* __restrict__ subnodes, unsigned* __restrict__ sub_interior,
-                                                         unsigned* __restrict__ final_ids, unsigned* __restrict__ stack_mem,
-                                                         unsigned* __restrict__ err) {
+                                                                      const u32x4* __restrict__ payload, const TriBox* __restrict__ boxes,
+                                                                      TmpNode* __restrict__ subnodes, unsigned short* __restrict__ submap,
+                                                                      unsigned* __restrict__ sub_interior,
+                                                                      unsigned* __restrict__ final_ids, unsigned* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lane = vd_lane();
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveLds& L = *reinterpret_cast<WaveLds*>(smem + wave * sizeof(WaveLds));
+    char* wbase = smem + wave * (sizeof(WaveLds) + sizeof(WaveQueues));
+    WaveLds& L = *reinterpret_cast<WaveLds*>(wbase);
+    WaveQueues& Q = *reinterpret_cast<WaveQueues*>(wbase + sizeof(WaveLds));
     const unsigned root_i = blockIdx.x * (unsigned)kSmallWaves + wave;
     if (root_i >= *n_roots_p) return;
     const SmallRoot root = roots[root_i];
     const unsigned base = root.start, N = root.count;
-    TmpNode* nodes = subnodes + 2u * (size_t)base;   // disjoint region per root: < 2*N nodes
-    unsigned* stack = stack_mem + base;              // disjoint region per root: depth < N
+    TmpNode* nodes = subnodes + 2u * (size_t)base;   // disjoint region per root: < 2*N nodes, creation order
+    unsigned short* nmap = submap + 2u * (size_t)base;
 
-    for (unsigned x = lane; x < N; x += 64u) L.pay[0][x] = payload[base + x];
+    for (unsigned x = lane; x < N; x += 64u) {
+        const u32x4 v = payload[base + x];
+        const TriBox bx = boxes[v.x];
+        L.gid[x] = v.x;
+        L.perm[0][x] = (unsigned short)x;
+        L.perm[1][x] = (unsigned short)x;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            L.cent[k][x] = pay_c(v, k);
+            L.box[k][x] = vd_key(bx.mn[k]);
+            L.box[3 + k][x] = vd_key(bx.mx[k]);
+        }
+    }
     vd_wave_lds_sync();
-    int cur = 0;
-    unsigned pool = 0, n_interior = 0, sp = 0;
-    // current node: id (kNone = the subtree root, which lives in the top tree), rel start, count
-    unsigned node_id = kNone, s = 0, n = N;
-    for (;;) {
-        if (n <= 3u) {
-            if (lane == 0) nodes[node_id].left_first = base + s;        // leaf: blas.rs:106-109
-        } else {
-            // ---- centroid bounds (blas.rs:142) and the 21 planes ----
+
+    // Both perm buffers always hold the same arrangement OUTSIDE of a node being processed: a
+    // wave-wide node ping-pongs its own segment an even number of times (22), a lane-serial node
+    // works in place on buffer 0 and the segment is mirrored afterwards.
+    unsigned pool = 0, n_interior = 0;
+    unsigned root_left = kNone;            // creation id of the root's children pair
+    unsigned n_big = 0, n_small = 0;
+    int qi = 0;
+    {   // the root entry: node field unused (root_pending flags it); s = 0, n = N
+        const unsigned ent = 1023u | (N << 20);
+        if (N > (unsigned)kLaneMax) { if (lane == 0) Q.big[0][0] = ent; n_big = 1; }
+        else { if (lane == 0) Q.small[0][0] = ent; n_small = 1; }
+    }
+    vd_wave_lds_sync();
+    bool root_pending = true;
+
+    while (n_big + n_small > 0u) {
+        unsigned nb_next = 0, ns_next = 0;
+        // ---------------- wave-wide nodes, one after the other ----------------
+        for (unsigned bi = 0; bi < n_big; ++bi) {
+            const unsigned ent = Q.big[qi][bi];
+            const unsigned node_id = ent & 1023u, s = (ent >> 10) & 1023u, n = ent >> 20;
+            const bool is_root = root_pending;
+            int cur = 0;
             int kmn[3] = {kBig, kBig, kBig}, kmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
             for (unsigned x = lane; x < n; x += 64u) {
-                const u32x4 v = L.pay[cur][s + x];
+                const unsigned e = L.perm[cur][s + x];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int key = vd_key(pay_c(v, k));
-                    kmn[k] = min(kmn[k], key); kmx[k] = max(kmx[k], key);
-                }
+                for (int k = 0; k < 3; ++k) { const int key = vd_key(L.cent[k][e]); kmn[k] = min(kmn[k], key); kmx[k] = max(kmx[k], key); }
             }
             float cbmin[3], cbmax[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(wave_min_i(kmn[k])); cbmax[k] = box_hi(wave_max_i(kmx[k])); }
             if (lane < (unsigned)kCand) L.pos[lane] = cand_pos(cbmin, cbmax, (int)lane);
-            for (unsigned i = lane; i < 72u; i += 64u) { (&L.bin_min[0][0][0])[i] = kBig; (&L.bin_max[0][0][0])[i] = -kBig - 1; }
             vd_wave_lds_sync();
-            // ---- 21 trial shuffles (blas.rs:144-147) ----
-            for (int c = 0; c < kCand; ++c) {
-                unsigned tt, up; u32x4 uv;
-                wave_shuffle(L, cur, s, n, c / 7, L.pos[c], tt, uv, up);
+            for (int c = 0; c < kCand; ++c) {                              // blas.rs:144-147
+                unsigned tt, ue, up;
+                wave_shuffle_any(L, cur, s, n, c / 7, L.pos[c], tt, ue, up);
                 cur ^= 1;
-                if (lane == 0) { L.u_pay[c] = uv; L.u_p[c] = up; L.ttot[c] = tt; }
+                if (lane == 0) { L.u_e[c] = (unsigned short)ue; L.u_p[c] = (unsigned short)up; L.ttot[c] = tt; }
             }
             vd_wave_lds_sync();
-            // ---- binning pass over the non-u elements ----
-            for (unsigned x = lane; x < n; x += 64u) {
-                const u32x4 v = L.pay[cur][s + x];
-                bool is_u = false;
-                for (int c = 0; c < kCand; ++c) is_u |= L.u_pay[c].x == v.x;
-                if (is_u) continue;
-                const TriBox bx = boxes[v.x];
+            // evaluate (blas.rs:149-161): lane = 3*c + part owns a third of candidate c's elements;
+            // left = examined trues = {e : p_c(e) and e != u_c}, right = the rest (incl. u_c)
+            vd_u64 key = ~0ull;
+            {
+                const unsigned c = lane / 3u, part = lane - c * 3u;
+                int k12[12];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const float ce = pay_c(v, a);
-                    int b = 0;
+                for (int i = 0; i < 12; ++i) k12[i] = (i % 6) < 3 ? kBig : -kBig - 1;
+                if (c < (unsigned)kCand) {
+                    const float* cen = L.cent[c / 7u];
+                    const float pos = L.pos[c];
+                    const unsigned ue = L.u_e[c];
+                    for (unsigned i = part; i < n; i += 3u) {
+                        const unsigned e = L.perm[cur][s + i];
+                        const int o = (cen[e] < pos && e != ue) ? 0 : 6;
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) b += !(ce < L.pos[a * 7 + k]);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        atomicMin(&L.bin_min[a][b][q], vd_key(bx.mn[q]));
-                        atomicMax(&L.bin_max[a][b][q], vd_key(bx.mx[q]));
+                        for (int q = 0; q < 3; ++q) { k12[o + q] = min(k12[o + q], L.box[q][e]); k12[o + 3 + q] = max(k12[o + 3 + q], L.box[3 + q][e]); }
                     }
                 }
-            }
-            vd_wave_lds_sync();
-            // ---- evaluate: lane c owns candidate c (blas.rs:149-161) ----
-            vd_u64 key = ~0ull;
-            if (lane < (unsigned)kCand) {
-                const int c = (int)lane, a = c / 7, k = c % 7 + 1;
-                EvalIn in{&L.bin_min[a][0][0], &L.bin_max[a][0][0], L.u_pay, boxes, kCand, L.u_pay[c].x};
-                const unsigned n1 = L.ttot[c] - L.u_p[c];
-                key = cost_key(eval_candidate(in, a, k, L.pos[c], n1, n), (unsigned)c);
-            }
-            key = wave_min_u64(key);
-            if (key == ~0ull) {                                          // every candidate rejected: SURVEY.md §8a B7
-                if (lane == 0) atomicOr(err, ERR_DEGENERATE);
-                return;
-            }
-            const int best = (int)(unsigned)key;
-            const unsigned Lst = L.ttot[best] - L.u_p[best];             // stale optimal_pivot (blas.rs:159,165)
-            // ---- final re-shuffle with the best plane, result discarded (blas.rs:164) ----
-            {
-                unsigned tt, up; u32x4 uv;
-                wave_shuffle(L, cur, s, n, best / 7, L.pos[best], tt, uv, up);
-                cur ^= 1;
-            }
-            // ---- children boxes from the actual arrangement (blas.rs:115-123) ----
-            int lmn[3] = {kBig, kBig, kBig}, lmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
-            int rmn[3] = {kBig, kBig, kBig}, rmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
-            for (unsigned x = lane; x < n; x += 64u) {
-                const TriBox bx = boxes[L.pay[cur][s + x].x];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int lo = vd_key(bx.mn[q]), hi = vd_key(bx.mx[q]);
-                    if (x < Lst) { lmn[q] = min(lmn[q], lo); lmx[q] = max(lmx[q], hi); }
-                    else { rmn[q] = min(rmn[q], lo); rmx[q] = max(rmx[q], hi); }
+                for (int i = 0; i < 12; ++i) {
+                    const int a1 = __shfl(k12[i], (int)(c * 3u + 1u)), a2 = __shfl(k12[i], (int)(c * 3u + 2u));
+                    k12[i] = (i % 6) < 3 ? min(k12[i], min(a1, a2)) : max(k12[i], max(a1, a2));
+                }
+                if (c < (unsigned)kCand && part == 0u) {
+                    const unsigned n1 = L.ttot[c] - L.u_p[c];
+                    const float a1 = vd_area(box_hi(k12[3]) - box_lo(k12[0]), box_hi(k12[4]) - box_lo(k12[1]), box_hi(k12[5]) - box_lo(k12[2]));
+                    const float a2 = vd_area(box_hi(k12[9]) - box_lo(k12[6]), box_hi(k12[10]) - box_lo(k12[7]), box_hi(k12[11]) - box_lo(k12[8]));
+                    key = cost_key(a1 * (float)n1 + a2 * (float)(n - n1), c);
                 }
             }
-            TmpNode ln, rn;
+            key = wave_min_u64(key);
+            if (key == ~0ull) { if (lane == 0) atomicOr(err, ERR_DEGENERATE); return; }
+            const int best = (int)(unsigned)key;
+            const unsigned Lst = L.ttot[best] - L.u_p[best];             // stale optimal_pivot (blas.rs:159,165)
+            {
+                unsigned tt, ue, up;                                     // blas.rs:164
+                wave_shuffle_any(L, cur, s, n, best / 7, L.pos[best], tt, ue, up);
+                cur ^= 1;                                                // 22 flips: back in buffer 0
+            }
+            int k12[12];                                                 // children boxes (blas.rs:115-123)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                ln.mn[q] = box_lo(wave_min_i(lmn[q])); ln.mx[q] = box_hi(wave_max_i(lmx[q]));
-                rn.mn[q] = box_lo(wave_min_i(rmn[q])); rn.mx[q] = box_hi(wave_max_i(rmx[q]));
+            for (int i = 0; i < 12; ++i) k12[i] = (i % 6) < 3 ? kBig : -kBig - 1;
+            for (unsigned x = lane; x < n; x += 64u) {
+                const unsigned short e = L.perm[0][s + x];
+                L.perm[1][s + x] = e;                                    // keep both buffers in step
+                const int o = x < Lst ? 0 : 6;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { k12[o + q] = min(k12[o + q], L.box[q][e]); k12[o + 3 + q] = max(k12[o + 3 + q], L.box[3 + q][e]); }
             }
-            const unsigned pair = pool;                                   // blas.rs:110-112, local numbering
+#pragma unroll
+            for (int i = 0; i < 12; ++i) k12[i] = (i % 6) < 3 ? wave_min_i(k12[i]) : wave_max_i(k12[i]);
+            const unsigned pair = pool;
             pool += 2; n_interior += 1;
+            const unsigned cn[2] = {Lst, n - Lst}, cs[2] = {s, s + Lst};
             if (lane == 0) {
-                // children keep (rel start, count) until they are visited
-                ln.left_first = s; ln.count = Lst;
-                rn.left_first = s + Lst; rn.count = n - Lst;
+                TmpNode ln, rn;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    ln.mn[q] = box_lo(k12[q]); ln.mx[q] = box_hi(k12[3 + q]);
+                    rn.mn[q] = box_lo(k12[6 + q]); rn.mx[q] = box_hi(k12[9 + q]);
+                }
+                ln.left_first = base + cs[0]; ln.count = cn[0];          // leaf form; interior nodes are patched when split
+                rn.left_first = base + cs[1]; rn.count = cn[1];
                 nodes[pair] = ln; nodes[pair + 1] = rn;
-                if (node_id != kNone) { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }   // blas.rs:112,127
-                stack[sp] = pair + 1u;                                    // right after the whole left subtree
+                if (!is_root) { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }   // creation-order link
             }
-            sp += 1;
-            node_id = pair; n = Lst;                                      // descend left (s unchanged)
-            continue;
+            if (is_root) { root_left = pair; root_pending = false; }
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                if (cn[side] > 3u) {
+                    const unsigned e2 = (pair + side) | (cs[side] << 10) | (cn[side] << 20);
+                    if (cn[side] > (unsigned)kLaneMax) { if (lane == 0) Q.big[qi ^ 1][nb_next] = e2; nb_next += 1; }
+                    else { if (lane == 0) Q.small[qi ^ 1][ns_next] = e2; ns_next += 1; }
+                }
+            }
+            vd_wave_lds_sync();
         }
-        // pop
-        if (sp == 0u) break;
-        sp -= 1;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        node_id = __builtin_amdgcn_readfirstlane(stack[sp]);
-        s = __builtin_amdgcn_readfirstlane(nodes[node_id].left_first);
-        n = __builtin_amdgcn_readfirstlane(nodes[node_id].count);
+        // ---------------- lane-serial nodes, 64 at a time ----------------
+        for (unsigned b0 = 0; b0 < n_small; b0 += 64u) {
+            const bool active = b0 + lane < n_small;
+            unsigned node_id = 0, s = 0, n = 0, piv = 0;
+            int ck[12];
+            const bool is_root = root_pending;
+            if (active) {
+                const unsigned ent = Q.small[qi][b0 + lane];
+                node_id = ent & 1023u; s = (ent >> 10) & 1023u; n = ent >> 20;
+                piv = lane_partition(L, L.perm[0], s, n, ck);
+                for (unsigned x = 0; x < n; ++x) L.perm[1][s + x] = L.perm[0][s + x];
+            }
+            const bool bad = active && piv == 0xffffffffu;
+            if (__ballot(bad)) { if (lane == 0) atomicOr(err, ERR_DEGENERATE); return; }
+            const unsigned long long am = __ballot(active);
+            const unsigned pair = pool + 2u * vd_mbcnt(am);
+            pool += 2u * (unsigned)__popcll(am);
+            n_interior += (unsigned)__popcll(am);
+            if (active) {
+                TmpNode ln, rn;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    ln.mn[q] = box_lo(ck[q]); ln.mx[q] = box_hi(ck[3 + q]);
+                    rn.mn[q] = box_lo(ck[6 + q]); rn.mx[q] = box_hi(ck[9 + q]);
+                }
+                ln.left_first = base + s; ln.count = piv;
+                rn.left_first = base + s + piv; rn.count = n - piv;
+                nodes[pair] = ln; nodes[pair + 1] = rn;
+                if (!is_root) { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }
+            }
+            if (is_root) { root_left = __shfl(pair, 0); root_pending = false; }
+            // children > 3 go to the next small frontier (they are <= kLaneMax)
+            const bool pl = active && piv > 3u, pr = active && (n - piv) > 3u;
+            const unsigned long long ml = __ballot(pl), mr = __ballot(pr);
+            if (pl) Q.small[qi ^ 1][ns_next + vd_mbcnt(ml)] = pair | (s << 10) | (piv << 20);
+            ns_next += (unsigned)__popcll(ml);
+            if (pr) Q.small[qi ^ 1][ns_next + vd_mbcnt(mr)] = (pair + 1u) | ((s + piv) << 10) | ((n - piv) << 20);
+            ns_next += (unsigned)__popcll(mr);
+            vd_wave_lds_sync();
+        }
+        n_big = nb_next; n_small = ns_next; qi ^= 1;
+        vd_wave_lds_sync();
     }
-    for (unsigned x = lane; x < N; x += 64u) final_ids[base + x] = L.pay[cur][x].x;
+
+    // ---- restore the reference's DFS pre-order numbering (blas.rs:110-112,125-126) ----
+    // creation order is breadth-first: children have larger ids than their parent.  I[j] =
+    // interior nodes in j's subtree; rank r(j) = interior nodes before j in pre-order (the subtree
+    // root has rank 0 and owns local pair 0).  Work arrays alias the (now dead) box keys.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    unsigned short* I = reinterpret_cast<unsigned short*>(&L.box[0][0]);          // [2N]
+    unsigned short* R = I + 2 * kSmallMax;                                          // [2N]
+    unsigned short* LC = R + 2 * kSmallMax;                                         // [2N] left child pair (creation id), 0xffff = leaf
+    const unsigned n_nodes = pool;
+    for (unsigned j = lane; j < n_nodes; j += 64u) {
+        const TmpNode t = nodes[j];
+        LC[j] = t.count == 0u ? (unsigned short)t.left_first : (unsigned short)0xffffu;
+        I[j] = 0;
+    }
+    vd_wave_lds_sync();
+    if (lane == 0) {
+        for (int j = (int)n_nodes - 1; j >= 0; --j)
+            if (LC[j] != 0xffffu) I[j] = (unsigned short)(1u + I[LC[j]] + I[LC[j] + 1u]);
+        // forward: parents first
+        if (root_left != kNone) { R[root_left] = 1; R[root_left + 1u] = (unsigned short)(1u + I[root_left]); }
+        for (unsigned j = 0; j < n_nodes; ++j)
+            if (LC[j] != 0xffffu) { const unsigned l = LC[j]; R[l] = (unsigned short)(R[j] + 1u); R[l + 1u] = (unsigned short)(R[j] + 1u + I[l]); }
+    }
+    vd_wave_lds_sync();
+    // new local index of node j = 2 * r(parent) + side; parent's rank = R[left sibling] - 1
+    for (unsigned j = lane; j < n_nodes; j += 64u) {
+        const unsigned rl = R[j & ~1u];                    // rank of the left sibling = r(parent) + 1
+        nmap[j] = (unsigned short)(2u * (rl - 1u) + (j & 1u));
+        if (LC[j] != 0xffffu) nodes[j].left_first = 2u * R[j];   // interior: its own pair in DFS numbering
+    }
+    for (unsigned x = lane; x < N; x += 64u) final_ids[base + x] = L.gid[L.perm[0][x]];
     if (lane == 0) sub_interior[root_i] = n_interior;
 }
 
@@ -768,10 +933,12 @@ __global__ void c_top_kernel(const TopNode* top, const TopOut* tout, unsigned n_
 }
 
 __global__ __launch_bounds__(256) void c_sub_kernel(const SmallRoot* roots, const unsigned* sub_interior, const unsigned* root_pair,
-                                                    unsigned n_roots, const TmpNode* subnodes, VdBvhNode* out) {
+                                                    unsigned n_roots, const TmpNode* subnodes, const unsigned short* submap,
+                                                    VdBvhNode* out) {
     const unsigned r = blockIdx.x;
     if (r >= n_roots) return;
     const TmpNode* src = subnodes + 2u * (size_t)roots[r].start;
+    const unsigned short* nmap = submap + 2u * (size_t)roots[r].start;
     const unsigned n_nodes = 2u * sub_interior[r], off = root_pair[r];
     for (unsigned j = threadIdx.x; j < n_nodes; j += 256u) {
         const TmpNode t = src[j];
@@ -779,7 +946,7 @@ __global__ __launch_bounds__(256) void c_sub_kernel(const SmallRoot* roots, cons
         for (int q = 0; q < 3; ++q) { n.min[q] = t.mn[q]; n.max[q] = t.mx[q]; }
         n.count = t.count;
         n.left_first = t.count == 0u ? t.left_first + off : t.left_first;   // interior: local pair -> final pair
-        out[off + j] = n;
+        out[off + nmap[j]] = n;
     }
 }
 
@@ -841,7 +1008,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     auto layout = [&](Arena& a, bool) {
         struct P { u32x4 *pay0, *pay1; TriBox* boxes; unsigned *tmp, *falsepos, *truepos, *final_ids, *stack, *idx_copy;
                    unsigned char* is_u; Seg *seg0, *seg1; unsigned *item_seg, *item_cnt, *item_pre; TopNode* top; SmallRoot* small;
-                   unsigned* sub_interior; TmpNode* subnodes; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair; } p;
+                   unsigned* sub_interior; TmpNode* subnodes; unsigned short* submap; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair; } p;
         p.pay0 = a.take<u32x4>(T); p.pay1 = a.take<u32x4>(T); p.boxes = a.take<TriBox>(T);
         p.tmp = a.take<unsigned>(T); p.falsepos = a.take<unsigned>(T); p.truepos = a.take<unsigned>(T);
         p.final_ids = a.take<unsigned>(T); p.stack = a.take<unsigned>(T); p.idx_copy = a.take<unsigned>(3 * T);
@@ -849,7 +1016,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         p.seg0 = a.take<Seg>(seg_cap); p.seg1 = a.take<Seg>(seg_cap);
         p.item_seg = a.take<unsigned>(item_cap); p.item_cnt = a.take<unsigned>(item_cap); p.item_pre = a.take<unsigned>(item_cap + 1);
         p.top = a.take<TopNode>(top_cap); p.small = a.take<SmallRoot>(small_cap); p.sub_interior = a.take<unsigned>(small_cap);
-        p.subnodes = a.take<TmpNode>(2 * T + 2); p.ctl = a.take<LevelCtl>(1); p.root_keys = a.take<int>(8);
+        p.subnodes = a.take<TmpNode>(2 * T + 2); p.submap = a.take<unsigned short>(2 * T + 2); p.ctl = a.take<LevelCtl>(1); p.root_keys = a.take<int>(8);
         p.tout = a.take<TopOut>(top_cap); p.root_pair = a.take<unsigned>(small_cap);
         return p;
     };
@@ -923,8 +1090,8 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     // ---- phase B ----
     const unsigned n_small = h_ctl.n_small, n_top = h_ctl.n_top;
     if (n_small) {
-        hipLaunchKernelGGL(blas_small_kernel, dim3((n_small + kSmallWaves - 1) / kSmallWaves), dim3(64 * kSmallWaves), kSmallWaves * sizeof(WaveLds), st, P.small, &P.ctl->n_small, P.pay0,
-                           P.boxes, P.subnodes, P.sub_interior, P.final_ids, P.stack, &P.ctl->err);
+        hipLaunchKernelGGL(blas_small_kernel, dim3((n_small + kSmallWaves - 1) / kSmallWaves), dim3(64 * kSmallWaves), kSmallWaves * (sizeof(WaveLds) + sizeof(WaveQueues)), st, P.small, &P.ctl->n_small, P.pay0,
+                           P.boxes, P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err);
     }
     // ---- phase C: DFS numbering of the top tree on the host ----
     std::vector<TopNode> h_top(n_top);
@@ -966,7 +1133,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     if (n_small) VD_HIP_CHECK(ctx, hipMemcpyAsync(P.root_pair, h_root_pair.data(), 4 * (size_t)n_small, hipMemcpyHostToDevice, st));
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_out, 0, sizeof(VdBvhNode) * 2, st));   // node 1 stays all-zero (blas.rs:52,90)
     hipLaunchKernelGGL(c_top_kernel, dim3((n_top + 63) / 64), dim3(64), 0, st, P.top, P.tout, n_top, d_out);
-    if (n_small) hipLaunchKernelGGL(c_sub_kernel, dim3(n_small), dim3(256), 0, st, P.small, P.sub_interior, P.root_pair, n_small, P.subnodes, d_out);
+    if (n_small) hipLaunchKernelGGL(c_sub_kernel, dim3(n_small), dim3(256), 0, st, P.small, P.sub_interior, P.root_pair, n_small, P.subnodes, P.submap, d_out);
     hipLaunchKernelGGL(c_ids_big_leaves_kernel, dim3((n_top + 63) / 64), dim3(64), 0, st, P.top, n_top, P.pay0, P.final_ids);
     hipLaunchKernelGGL(c_permute_kernel, dim3(tri_blocks), dim3(256), 0, st, P.final_ids, P.idx_copy, d_idx, n_tri);
     vd_time_end(ctx);
