@@ -35,7 +35,9 @@ def main():
                     help="baseline = BASELINE.md §3 (S in [0.25,4]); small = S in [0.02,0.6] (more culled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--extra", action="store_true", help="also time emit_draws (uncompacted) and BVH build")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (emit_draws, BVH build, TLAS)")
+    ap.add_argument("--bvh-u", type=int, default=2048, help="knot mesh resolution: 2*u*v triangles (default 8.4M)")
+    ap.add_argument("--bvh-v", type=int, default=2048)
     args = ap.parse_args()
 
     import numpy as np
@@ -103,15 +105,14 @@ def main():
     ms_per_step = wall * 1e3 / args.steps
     count = int(d_cnt[0].item())
 
-    # dominant kernel alone (memset + cull_compact_kernel), HIP events on the launch stream
+    # dominant kernel alone: HIP events recorded by the library on the launch stream right around
+    # cull_compact_kernel (vd_last_gpu_ms), averaged over the same number of launches
     barrier()
-    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    k0.record()
+    k_ms = []
     for _ in range(args.steps):
         ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)
-    k1.record()
-    torch.cuda.synchronize()
-    kernel_ms = k0.elapsed_time(k1) / args.steps
+        k_ms.append(ctx.last_gpu_ms())
+    kernel_ms = sum(k_ms) / len(k_ms)
     vis = count / n
     alg_bytes = n * (144.0 + 20.0 * vis)          # 144 B read + 20 B per survivor
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -148,7 +149,7 @@ def main():
                              f"1-thread cull: {m / t1 / 1e6:.2f} M inst/s"}
 
     extra = {}
-    if args.extra and rank == 0:
+    if not args.no_extra and rank == 0:
         d_emit = ctx.empty(n * 20)
         for _ in range(3):
             ctx.cull_emit_dev(cam, d_m, len(meshes), d_i, n, d_emit)
@@ -161,8 +162,57 @@ def main():
         torch.cuda.synchronize()
         ems = e0.elapsed_time(e1) / args.steps
         extra["emit_draws_uncompacted"] = {"ms": round(ems, 4), "M_inst_per_s": round(n / ems / 1e3, 1),
-                                           "GBps": round(n * 164.0 / ems / 1e6, 1)}
+                                           "GBps": round(n * 164.0 / ems / 1e6, 1),
+                                           "frac_of_8TBps": round(n * 164.0 / ems / 1e6 / HBM_PEAK_GBS, 4)}
+        del d_emit
+        # --- BASELINE config 5: SAH BVH build of a dragon-like 8M-tri mesh, TLAS build/refit ---
+        from oracle import ref
+        v, idx = synth.knot_mesh(args.bvh_u, args.bvh_v)
+        n_tri = len(idx) // 3
+        d_v = ctx.upload(v)
+        d_n = ctx.empty(2 * n_tri * 32)
+        best = None
+        for r in range(3):
+            d_idx = ctx.upload(idx)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            n_nodes = ctx.bvh_build_dev(d_v, len(v), d_idx, n_tri, d_n, 2 * n_tri)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            best = dt if best is None or (r and dt < best) else best
+        # CPU baseline + parity on a bounded sample of the same mesh family
+        sv, sidx = synth.knot_mesh(512, 256)            # 262k triangles
+        t = time.perf_counter()
+        wn, wi = ref.bvh_build(sv, sidx)
+        t_cpu = time.perf_counter() - t
+        gn, gi = ctx.bvh_build(sv, sidx)
+        bvh_ok = bool(len(gn) == len(wn) and gn.tobytes() == wn.tobytes() and np.array_equal(gi, wi))
+        extra["bvh_build"] = {"metric": "SAH BVH build Mprims/s", "value": round(n_tri / best / 1e6, 1), "n_tris": n_tri,
+                              "ms": round(best * 1e3, 2), "nodes": int(n_nodes),
+                              "cpu_baseline": {"value": round(len(sidx) // 3 / t_cpu / 1e6, 3), "unit": "Mprims/s", "cores": 1,
+                                               "kind": "port", "sample": f"{len(sidx)//3}-tri knot mesh, oracle vd_ref_bvh_build"},
+                              "sample_bit_exact_vs_oracle": bvh_ok}
+        del d_v, d_n, d_idx
+        n_tl = 32768
+        tinst = synth.instances(n_tl, seed=synth.SEED_BASE + 6, extent=300.0)
+        d_ti = ctx.upload(tinst)
+        d_t = ctx.empty((2 * n_tl + 1) * 32)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        ctx.tlas_build_dev(d_ti, n_tl, d_m, len(meshes), d_t)
+        torch.cuda.synchronize(); t_build = time.perf_counter() - t
+        for _ in range(3):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            ctx.tlas_refit_dev(d_ti, n_tl, d_m, len(meshes), d_t)
+            torch.cuda.synchronize(); t_refit = time.perf_counter() - t
+        extra["tlas"] = {"n_instances": n_tl, "build_ms": round(t_build * 1e3, 1), "refit_ms": round(t_refit * 1e3, 3)}
 
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_cull_pmc.json")
+    if rank == 0 and os.path.exists(pmc_path) and n == 10_000_000 and args.dist == "baseline":
+        # HBM bytes per cull_compact launch from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+        # passes of this same command (profiles/README.md); gfx950: FETCH_SIZE counts 64 B per 128-B request
+        pmc = json.load(open(pmc_path))
+        traffic = int((2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024)
     if rank == 0:
         value = n_total / (ms_per_step * 1e-3) / 1e6
         line = {
@@ -187,7 +237,7 @@ def main():
                        "verified_bit_exact_vs_oracle": verified, "input_gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": "cull_compact_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel_ms": round(kernel_ms, 4),
+                         "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
             "cpu_baseline": cpu,
         }

@@ -1,0 +1,238 @@
+// voidin.hpp — C++ host-side mirror of the reference's builder / pass API over the C ABI
+// (include/voidin_abi.h).  The reference's host code is Rust; this image has no Rust toolchain,
+// so the host side above the boundary is written in C++ with the reference's names, argument
+// meaning and error behaviour.  Header-only; link with libvoidin_hip.so.
+//
+//   voidin::BvhBuilder(vertices, indices).build() -> Bvh{nodes}      crates/bvh/src/blas.rs:51-103
+//   voidin::Tlas::empty(); tlas.build(instances, meshes); tlas.nodes   crates/bvh/src/tlas.rs:27-85
+//   voidin::pass::EmitDraws::record(world, encoder, resources)         crates/app/src/pass/visibility.rs:230-255
+//   voidin::MeshPool::add(mesh) / generate_tlas(instances)             crates/pools/src/mesh/mod.rs:279-351
+//   voidin::InstancePool::add(instances)                               crates/pools/src/instance.rs:67-79
+//
+// Error behaviour: the Rust constructors return color_eyre::Result and the builder panics on
+// degenerate input; here every failure is a voidin::Error (exception) carrying the VdStatus and
+// vd_last_error text — nothing aborts.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "voidin_abi.h"
+
+namespace voidin {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+// glam types as the wire structs use them
+struct Vec3 { float x, y, z; };
+struct UVec3 { uint32_t x, y, z; };
+using Instance = VdInstance;
+using MeshInfo = VdMeshInfo;
+using DrawIndexedIndirect = VdDrawIndexedIndirect;
+using CameraUniform = VdCameraUniform;
+using BvhNode = VdBvhNode;
+using TlasNode = VdTlasNode;
+
+// Owns the VdCtx (the reference's wgpu device/queue pair inside `World`: app.rs:108-118).
+class Gpu {
+   public:
+    explicit Gpu(int device = 0) {
+        int rc = vd_ctx_create(device, &ctx_);
+        if (rc != VD_OK) throw Error(rc, "vd_ctx_create failed: no gfx950 device (there is no CPU fallback)");
+    }
+    ~Gpu() { if (ctx_) vd_ctx_destroy(ctx_); }
+    Gpu(const Gpu&) = delete;
+    Gpu& operator=(const Gpu&) = delete;
+    VdCtx* ctx() const { return ctx_; }
+    void check(int rc) const { if (rc != VD_OK) throw Error(rc, vd_last_error(ctx_)); }
+    void set_stream(void* hip_stream) { check(vd_ctx_set_stream(ctx_, hip_stream)); }
+    void synchronize() { check(vd_ctx_synchronize(ctx_)); }
+
+   private:
+    VdCtx* ctx_ = nullptr;
+};
+
+// ---- crates/bvh ---------------------------------------------------------------------------
+struct Bvh {
+    std::vector<BvhNode> nodes;   // `pub nodes: Vec<BvhNode>` (blas.rs:206-208)
+};
+
+// BvhBuilder::new(&[Vec3], &mut [UVec3]) — borrows both slices; build() permutes `indices` in
+// place exactly as blas.rs:95-100 does.
+class BvhBuilder {
+   public:
+    BvhBuilder(const Gpu& gpu, const Vec3* vertices, size_t n_vertices, UVec3* indices, size_t n_triangles)
+        : gpu_(gpu), vertices_(vertices), n_vertices_(n_vertices), indices_(indices), n_triangles_(n_triangles) {}
+    // stored and ignored, like the reference (blas.rs:64-67 vs the hard-coded `let bins = 8` at :136)
+    BvhBuilder& set_bin_number(size_t num_bins) { num_bins_ = num_bins; return *this; }
+    Bvh build() {
+        Bvh bvh;
+        bvh.nodes.resize(2 * n_triangles_ > 2 ? 2 * n_triangles_ : 2);   // `vec![BvhNode::default(); indices.len() * 2]`
+        uint32_t n_nodes = 0;
+        gpu_.check(vd_bvh_build(gpu_.ctx(), &vertices_->x, (uint32_t)n_vertices_, &indices_->x, (uint32_t)n_triangles_,
+                                bvh.nodes.data(), (uint32_t)bvh.nodes.size(), &n_nodes));
+        bvh.nodes.resize(n_nodes);                                       // `self.nodes.truncate(new_node_index)`
+        return bvh;
+    }
+
+   private:
+    const Gpu& gpu_;
+    const Vec3* vertices_; size_t n_vertices_;
+    UVec3* indices_; size_t n_triangles_;
+    size_t num_bins_ = 8;
+};
+
+class Tlas {
+   public:
+    std::vector<TlasNode> nodes;   // `pub nodes: Vec<TlasNode>` (tlas.rs:22-24)
+    static Tlas empty() { return Tlas(); }
+    // Tlas::build(&mut self, &[Instance], &[MeshInfo]) (tlas.rs:31)
+    void build(const Gpu& gpu, const Instance* instances, size_t n, const MeshInfo* meshes, size_t n_mesh) {
+        nodes.assign(2 * n + 1, TlasNode{});
+        gpu.check(vd_tlas_build(gpu.ctx(), instances, (uint32_t)n, meshes, (uint32_t)n_mesh, nodes.data()));
+    }
+    // NEW: same topology, boxes recomputed
+    void refit(const Gpu& gpu, const Instance* instances, size_t n, const MeshInfo* meshes, size_t n_mesh) {
+        if (nodes.size() != 2 * n + 1) throw Error(VD_ERR_INVALID_ARG, "Tlas::refit: node count does not match instance count");
+        gpu.check(vd_tlas_refit(gpu.ctx(), instances, (uint32_t)n, meshes, (uint32_t)n_mesh, nodes.data()));
+    }
+};
+
+// ---- crates/pools (CPU-side bookkeeping only; GPU buffers stay with the renderer) --------------
+struct MeshRef {
+    const Vec3* vertices; size_t n_vertices;
+    uint32_t* indices; size_t n_indices;          // permuted by add(), like `mesh.indices` in mesh/mod.rs:320-321
+};
+
+class MeshPool {
+   public:
+    std::vector<Vec3> vertices;
+    std::vector<uint32_t> indices;
+    std::vector<BvhNode> bvh_nodes;
+    std::vector<MeshInfo> mesh_info_cpu;
+    Tlas tlas = Tlas::empty();
+
+    explicit MeshPool(const Gpu& gpu) : gpu_(gpu) {}
+
+    // MeshPool::add (mesh/mod.rs:309-351): build the BLAS, append to the concatenated buffers,
+    // record {min,max,index_count,base_index,vertex_offset,bvh_index}
+    uint32_t add(MeshRef mesh) {
+        const uint32_t vertex_offset = (uint32_t)vertices.size();
+        vertices.insert(vertices.end(), mesh.vertices, mesh.vertices + mesh.n_vertices);
+        Bvh bvh = BvhBuilder(gpu_, mesh.vertices, mesh.n_vertices, reinterpret_cast<UVec3*>(mesh.indices), mesh.n_indices / 3).build();
+        const uint32_t bvh_index = (uint32_t)bvh_nodes.size();
+        bvh_nodes.insert(bvh_nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
+        const uint32_t base_index = (uint32_t)indices.size();
+        indices.insert(indices.end(), mesh.indices, mesh.indices + mesh.n_indices);
+        MeshInfo info{};
+        // calculate_bounds (mesh/mod.rs:22-27): fold from (+inf, -inf)
+        float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        for (size_t i = 0; i < mesh.n_vertices; ++i) {
+            const float p[3] = {mesh.vertices[i].x, mesh.vertices[i].y, mesh.vertices[i].z};
+            for (int k = 0; k < 3; ++k) { mn[k] = p[k] < mn[k] ? p[k] : mn[k]; mx[k] = p[k] > mx[k] ? p[k] : mx[k]; }
+        }
+        std::memcpy(info.min, mn, 12); std::memcpy(info.max, mx, 12);
+        info.index_count = (uint32_t)mesh.n_indices;
+        info.base_index = base_index;
+        info.vertex_offset = (int32_t)vertex_offset;
+        info.bvh_index = bvh_index;
+        mesh_info_cpu.push_back(info);
+        return (uint32_t)mesh_info_cpu.size() - 1;     // MeshId
+    }
+
+    // MeshPool::generate_tlas (mesh/mod.rs:279-286)
+    void generate_tlas(const std::vector<Instance>& instances) {
+        if (instances.empty()) return;
+        tlas.build(gpu_, instances.data(), instances.size(), mesh_info_cpu.data(), mesh_info_cpu.size());
+    }
+
+    VdTraceScene trace_scene(const std::vector<Instance>& instances) const {
+        VdTraceScene s{};
+        s.tlas_nodes = tlas.nodes.data(); s.n_tlas_nodes = (uint32_t)tlas.nodes.size();
+        s.instances = instances.data(); s.n_instances = (uint32_t)instances.size();
+        s.meshes = mesh_info_cpu.data(); s.n_meshes = (uint32_t)mesh_info_cpu.size();
+        s.bvh_nodes = bvh_nodes.data(); s.n_bvh_nodes = (uint32_t)bvh_nodes.size();
+        s.vertices = &vertices.data()->x; s.n_vertices = (uint32_t)vertices.size();
+        s.indices = indices.data(); s.n_indices = (uint32_t)indices.size();
+        return s;
+    }
+
+   private:
+    const Gpu& gpu_;
+};
+
+class InstancePool {
+   public:
+    std::vector<Instance> instances_data;            // instance.rs:9
+    // InstancePool::add (instance.rs:67-79): returns the ids of the appended instances
+    std::vector<uint32_t> add(const Instance* instances, size_t n) {
+        const uint32_t first = (uint32_t)instances_data.size();
+        instances_data.insert(instances_data.end(), instances, instances + n);
+        std::vector<uint32_t> ids(n);
+        for (size_t i = 0; i < n; ++i) ids[i] = first + (uint32_t)i;
+        return ids;
+    }
+    uint32_t count() const { return (uint32_t)instances_data.size(); }
+    void clear() { instances_data.clear(); }
+};
+
+// ---- crates/app/src/pass ------------------------------------------------------------------------
+// The reference's `World` is a TypeId -> resource map (components/src/world.rs:81-162); the pass
+// pulls CameraUniformBinding, MeshPool, InstancePool from it.  Here `World` carries exactly those
+// device-side resources.
+struct World {
+    const CameraUniform* camera;                      // host copy of the 320-byte uniform (camera.rs:13-27)
+    const MeshInfo* d_mesh_info; uint32_t n_meshes;   // device buffer (MeshPool::mesh_info)
+    const Instance* d_instances; uint32_t n_instances;// device buffer (InstancePool::instances)
+};
+
+struct ProfilerCommandEncoder {                       // app.rs:660-703: here just the stream the pass records on
+    void* hip_stream = nullptr;
+};
+
+namespace pass {
+
+// trait Pass { type Resources<'a>; fn record(&self, &World, &mut ProfilerCommandEncoder, Self::Resources<'_>); }
+// (crates/app/src/pass/mod.rs:9-18)
+struct EmitDrawsResource {                            // visibility.rs:225-228
+    DrawIndexedIndirect* draw_cmd_buffer;             // device buffer, draw_cmd_buffer.len() == n_instances (app.rs:242-246)
+    uint32_t* draw_count = nullptr;                   // device u32; non-null => compacted emission
+    bool pad_tail = false;
+};
+
+class EmitDraws {
+   public:
+    explicit EmitDraws(Gpu& gpu) : gpu_(gpu) {}       // EmitDraws::new(&World) -> Result<Self> (visibility.rs:200-222)
+    // Leaves draw_cmd_buffer[0..N) valid on the encoder's stream before the consumer
+    // (Geometry::record, visibility.rs:151-193) runs on the same stream.
+    void record(const World& world, ProfilerCommandEncoder& encoder, EmitDrawsResource resources) const {
+        gpu_.set_stream(encoder.hip_stream);
+        if (resources.draw_count)
+            gpu_.check(vd_cull_compact_dev(gpu_.ctx(), world.camera, world.d_mesh_info, world.n_meshes, world.d_instances,
+                                           world.n_instances, resources.draw_cmd_buffer, resources.draw_count,
+                                           resources.pad_tail ? 1 : 0));
+        else
+            gpu_.check(vd_cull_emit_dev(gpu_.ctx(), world.camera, world.d_mesh_info, world.n_meshes, world.d_instances,
+                                        world.n_instances, resources.draw_cmd_buffer));
+    }
+
+   private:
+    Gpu& gpu_;
+};
+
+}  // namespace pass
+
+// `traverse_tlas(ray)` for a batch (shaders/utils/bvh.wgsl:89-123)
+inline std::vector<VdHit> traverse_tlas(const Gpu& gpu, const VdTraceScene& scene, const std::vector<VdRay>& rays) {
+    std::vector<VdHit> out(rays.size());
+    gpu.check(vd_trace(gpu.ctx(), &scene, rays.data(), (uint32_t)rays.size(), out.data()));
+    return out;
+}
+
+}  // namespace voidin

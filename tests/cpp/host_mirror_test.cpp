@@ -1,0 +1,137 @@
+// host_mirror_test.cpp — drives the path through the C++ mirror of the reference API
+// (include/voidin.hpp) the way the reference's own call sites do, and checks every result
+// against the CPU oracle (tests may link it; the product does not).
+//   MeshPool::add -> BvhBuilder::new(..).build()         crates/pools/src/mesh/mod.rs:309-351
+//   MeshPool::generate_tlas -> Tlas::build               crates/pools/src/mesh/mod.rs:279-286
+//   EmitDraws::record                                    crates/app/src/pass/visibility.rs:233-254
+//   traverse_tlas                                        shaders/utils/bvh.wgsl:89-123
+// Build: hipcc --offload-arch=gfx950 -I include tests/cpp/host_mirror_test.cpp -L... -lvoidin_hip -lvd_oracle
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/voidin.hpp"
+#include "../../oracle/vd_oracle.h"
+
+#define REQUIRE(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+static uint64_t rng_state = 0x5EED0042ull;
+static float frand() {   // splitmix64 -> [0,1)
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+int main() {
+    voidin::Gpu gpu(0);
+    voidin::MeshPool pool(gpu);
+
+    // make_plane_mesh(1,1) (crates/pools/src/mesh/plane.rs:5-38) and a bvh_cpu.rs-style soup
+    std::vector<voidin::Vec3> plane_v = {{-.5f, 0, -.5f}, {-.5f, 0, .5f}, {.5f, 0, .5f}, {.5f, 0, -.5f}};
+    std::vector<uint32_t> plane_i = {0, 1, 2, 0, 2, 3};
+    std::vector<voidin::Vec3> soup_v; std::vector<uint32_t> soup_i;
+    for (int t = 0; t < 900; ++t) {
+        voidin::Vec3 b{frand() * 9 - 5, frand() * 9 - 5, frand() * 9};
+        soup_v.push_back(b);
+        soup_v.push_back({b.x + frand(), b.y + frand(), b.z + frand()});
+        soup_v.push_back({b.x + frand(), b.y + frand(), b.z + frand()});
+        for (int k = 0; k < 3; ++k) soup_i.push_back(3 * t + k);
+    }
+    // oracle BLAS on copies (the builder permutes the caller's indices)
+    std::vector<uint32_t> ref_i = soup_i;
+    std::vector<VdBvhNode> ref_nodes(2 * 900);
+    uint32_t ref_n = 0;
+    REQUIRE(vd_ref_bvh_build(&soup_v[0].x, (uint32_t)soup_v.size(), ref_i.data(), 900, ref_nodes.data(), 1800, &ref_n) == VD_OK);
+
+    const uint32_t plane_id = pool.add({plane_v.data(), plane_v.size(), plane_i.data(), plane_i.size()});
+    const uint32_t soup_id = pool.add({soup_v.data(), soup_v.size(), soup_i.data(), soup_i.size()});
+    REQUIRE(plane_id == 0 && soup_id == 1);
+    REQUIRE(pool.mesh_info_cpu[1].bvh_index == 2 && pool.mesh_info_cpu[1].base_index == 6 && pool.mesh_info_cpu[1].vertex_offset == 4);
+    REQUIRE(pool.bvh_nodes.size() == 2 + ref_n);
+    REQUIRE(std::memcmp(pool.bvh_nodes.data() + 2, ref_nodes.data(), ref_n * sizeof(VdBvhNode)) == 0);
+    REQUIRE(soup_i == ref_i);
+
+    // instances: translate + uniform scale, Instance::new computes inv_transform (shared.rs:90-98)
+    voidin::InstancePool ipool;
+    std::vector<voidin::Instance> inst(300);
+    for (size_t i = 0; i < inst.size(); ++i) {
+        std::memset(&inst[i], 0, sizeof(inst[i]));
+        const float s = 0.5f + 2.0f * frand(), tx = frand() * 80 - 40, ty = frand() * 80 - 40, tz = frand() * 80 - 40;
+        float* T = inst[i].transform; float* I = inst[i].inv_transform;
+        T[0] = T[5] = T[10] = s; T[15] = 1; T[12] = tx; T[13] = ty; T[14] = tz;
+        I[0] = I[5] = I[10] = 1.0f / s; I[15] = 1; I[12] = -tx / s; I[13] = -ty / s; I[14] = -tz / s;
+        inst[i].mesh = (i % 3) ? 1 : 0; inst[i].material = 1;
+    }
+    ipool.add(inst.data(), inst.size());
+    pool.generate_tlas(ipool.instances_data);
+    std::vector<VdTlasNode> ref_tlas(2 * inst.size() + 1);
+    REQUIRE(vd_ref_tlas_build(inst.data(), (uint32_t)inst.size(), pool.mesh_info_cpu.data(), 2, ref_tlas.data()) == VD_OK);
+    REQUIRE(std::memcmp(ref_tlas.data(), pool.tlas.nodes.data(), ref_tlas.size() * sizeof(VdTlasNode)) == 0);
+
+    // rays through the scene
+    std::vector<VdRay> rays(4096);
+    for (auto& r : rays) {
+        std::memset(&r, 0, sizeof(r));
+        r.eye[0] = frand() * 20 - 10; r.eye[1] = frand() * 20 - 10; r.eye[2] = 90;
+        float d[3] = {frand() - .5f, frand() - .5f, -1.0f - frand()};
+        const float l = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        for (int k = 0; k < 3; ++k) r.dir[k] = d[k] / l;
+    }
+    const VdTraceScene scene = pool.trace_scene(ipool.instances_data);
+    std::vector<VdHit> hits = voidin::traverse_tlas(gpu, scene, rays);
+    std::vector<VdHit> ref_hits(rays.size());
+    uint32_t max_stack = 0;
+    REQUIRE(vd_ref_trace(&scene, rays.data(), (uint32_t)rays.size(), ref_hits.data(), &max_stack, 1) == VD_OK);
+    size_t n_hit = 0;
+    for (size_t i = 0; i < rays.size(); ++i) {
+        REQUIRE(hits[i].hit == ref_hits[i].hit);
+        if (hits[i].hit) { ++n_hit; REQUIRE(std::fabs(hits[i].dist - ref_hits[i].dist) <= 1e-5f * std::fabs(ref_hits[i].dist)); }
+    }
+    REQUIRE(n_hit > 10);
+
+    // EmitDraws::record on device buffers, then the consumer-side contract: draw_cmd_buffer[0..N) valid
+    VdCameraUniform cam; std::memset(&cam, 0, sizeof(cam));
+    for (int k = 0; k < 4; ++k) cam.view[5 * k] = 1.0f;       // identity view
+    cam.view[14] = -60.0f;                                    // camera at z = +60 looking down -Z
+    cam.frustum[0] = 0.7808688f; cam.frustum[1] = -0.6246950f; cam.frustum[2] = 0.7071068f; cam.frustum[3] = -0.7071068f;
+    cam.zfar = INFINITY; cam.znear = 0.001f;
+    voidin::Instance* d_inst; voidin::MeshInfo* d_mesh; voidin::DrawIndexedIndirect* d_draw; uint32_t* d_count;
+    REQUIRE(hipMalloc(&d_inst, inst.size() * sizeof(voidin::Instance)) == hipSuccess);
+    REQUIRE(hipMalloc(&d_mesh, 2 * sizeof(voidin::MeshInfo)) == hipSuccess);
+    REQUIRE(hipMalloc(&d_draw, inst.size() * sizeof(voidin::DrawIndexedIndirect)) == hipSuccess);
+    REQUIRE(hipMalloc(&d_count, 16) == hipSuccess);
+    REQUIRE(hipMemcpy(d_inst, inst.data(), inst.size() * sizeof(voidin::Instance), hipMemcpyHostToDevice) == hipSuccess);
+    REQUIRE(hipMemcpy(d_mesh, pool.mesh_info_cpu.data(), 2 * sizeof(voidin::MeshInfo), hipMemcpyHostToDevice) == hipSuccess);
+    hipStream_t stream; REQUIRE(hipStreamCreate(&stream) == hipSuccess);
+    voidin::World world{&cam, d_mesh, 2, d_inst, (uint32_t)inst.size()};
+    voidin::ProfilerCommandEncoder encoder{stream};
+    voidin::pass::EmitDraws emit_draws(gpu);
+    emit_draws.record(world, encoder, {d_draw});
+    std::vector<voidin::DrawIndexedIndirect> draws(inst.size()), ref_draws(inst.size());
+    REQUIRE(hipMemcpyAsync(draws.data(), d_draw, draws.size() * sizeof(draws[0]), hipMemcpyDeviceToHost, stream) == hipSuccess);
+    REQUIRE(hipStreamSynchronize(stream) == hipSuccess);
+    REQUIRE(vd_ref_cull_emit(&cam, pool.mesh_info_cpu.data(), 2, inst.data(), (uint32_t)inst.size(), ref_draws.data(), 1) == VD_OK);
+    REQUIRE(std::memcmp(draws.data(), ref_draws.data(), draws.size() * sizeof(draws[0])) == 0);
+    // compacted emission
+    emit_draws.record(world, encoder, {d_draw, d_count, true});
+    uint32_t count = 0, ref_count = 0;
+    REQUIRE(hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, stream) == hipSuccess);
+    REQUIRE(hipMemcpyAsync(draws.data(), d_draw, draws.size() * sizeof(draws[0]), hipMemcpyDeviceToHost, stream) == hipSuccess);
+    REQUIRE(hipStreamSynchronize(stream) == hipSuccess);
+    std::vector<voidin::DrawIndexedIndirect> ref_comp(inst.size());
+    REQUIRE(vd_ref_compact(ref_draws.data(), (uint32_t)inst.size(), ref_comp.data(), &ref_count, 1) == VD_OK);
+    REQUIRE(count == ref_count && std::memcmp(draws.data(), ref_comp.data(), draws.size() * sizeof(draws[0])) == 0);
+
+    // error behaviour: degenerate input is an error code, not a crash (blas.rs:137-140 would panic)
+    std::vector<voidin::Vec3> tv = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}};
+    std::vector<uint32_t> ti; for (int k = 0; k < 5; ++k) { ti.push_back(0); ti.push_back(1); ti.push_back(2); }
+    bool threw = false;
+    try { voidin::BvhBuilder(gpu, tv.data(), 3, reinterpret_cast<voidin::UVec3*>(ti.data()), 5).build(); }
+    catch (const voidin::Error& e) { threw = e.code == VD_ERR_DEGENERATE; }
+    REQUIRE(threw);
+    std::printf("host_mirror_test OK: %zu hits, %u of %zu instances visible\n", n_hit, count, inst.size());
+    return 0;
+}

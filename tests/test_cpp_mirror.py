@@ -1,0 +1,34 @@
+"""The C++ host-side mirror of the reference API (include/voidin.hpp) compiles against the C ABI
+(CPU check) and, on a GPU box, drives the whole path bit-exact against the oracle."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+SRC = os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")
+
+
+def build():
+    from oracle import ref
+    ref.load()
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), SRC,
+           "-L", os.path.join(ROOT, "voidin_amd", "csrc"), "-lvoidin_hip", "-L", os.path.join(ROOT, "oracle"), "-lvd_oracle",
+           f"-Wl,-rpath,{os.path.join(ROOT, 'voidin_amd', 'csrc')}", f"-Wl,-rpath,{os.path.join(ROOT, 'oracle')}", "-o", EXE]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=300)
+
+
+def test_mirror_header_compiles_and_links():
+    build()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_mirror_drives_the_path_bit_exact():
+    if not os.path.exists(EXE):
+        build()
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host_mirror_test OK" in out.stdout

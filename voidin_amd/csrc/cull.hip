@@ -668,6 +668,7 @@ int scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned** ticket, vd_u64** state
     VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need16, ctx->stream));
     *ticket = reinterpret_cast<unsigned*>(ctx->scratch);
     *states = reinterpret_cast<vd_u64*>(reinterpret_cast<char*>(ctx->scratch) + 16);
+    vd_time_begin(ctx);   // vd_last_gpu_ms brackets the scan kernel itself, not the state memset
     return VD_OK;
 }
 
@@ -718,7 +719,6 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
     if (!d_instances || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_compact: null instances/out");
     int variant = ctx->cull_variant;
     unsigned* ticket; vd_u64* states;
-    vd_time_begin(ctx);
     int rc = VD_OK;
 #define VD_LAUNCH_COMPACT(R, L, O)                                                                              \
     do {                                                                                                         \
@@ -798,11 +798,11 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
         }
     }
 #undef VD_LAUNCH_COMPACT
+    vd_time_end(ctx);
     if (pad_tail) {
         unsigned blocks = (unsigned)ctx->num_cus * 4u;
         hipLaunchKernelGGL(pad_tail_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_out, d_out_count, n_inst);
     }
-    vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;
 }
@@ -818,7 +818,6 @@ int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t
     if (!d_in || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_compact_draws: null in/out");
     const unsigned n_tiles = (n + kCompactTile - 1) / kCompactTile;
     unsigned* ticket; vd_u64* states;
-    vd_time_begin(ctx);
     int rc = scan_scratch(ctx, n_tiles, &ticket, &states);
     if (rc) return rc;
     hipLaunchKernelGGL(compact_draws_kernel, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, d_in, n, d_out, d_out_count,
