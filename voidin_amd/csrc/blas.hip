@@ -34,7 +34,7 @@ namespace {
 #define VD_SMALL_MAX 512
 #endif
 #ifndef VD_LANE_MAX
-#define VD_LANE_MAX 16
+#define VD_LANE_MAX 8
 #endif
 constexpr int kSmallMax = VD_SMALL_MAX;  // largest segment built by one wave out of LDS
 constexpr int kChunks = kSmallMax / 64;
@@ -171,18 +171,21 @@ __device__ __forceinline__ vd_u64 wave_min_u64(vd_u64 v) {
 // e in [0, N): centroids and box keys stay put, only the 2-byte permutation moves.
 struct SmallRoot { unsigned start, count, top_node, pad; };
 
+constexpr int kSubWaves = 4;                       // waves of the workgroup that shares one subtree image
+struct WaveScratch {                              // per-wave: the node this wave is splitting
+    float pos[kCand + 3];
+    unsigned ttot[kCand + 3];
+    unsigned short u_e[kCand + 3];
+    unsigned short u_p[kCand + 3];
+};
 struct WaveLds {
     float cent[3][kSmallMax];
     int box[6][kSmallMax];                        // order-preserving keys: min xyz, max xyz
     unsigned gid[kSmallMax];                      // local element -> triangle id
-    unsigned stack[kSmallMax];                    // pending right children: node | start << 10 | count << 20
-    float pos[kCand + 3];
-    unsigned ttot[kCand + 3];
     unsigned short perm[2][kSmallMax];            // arrangement ping-pong (position -> local element)
-    unsigned short falsepos[kSmallMax + 2];
-    unsigned short truepos[kSmallMax + 2];
-    unsigned short u_e[kCand + 3];
-    unsigned short u_p[kCand + 3];
+    unsigned short falsepos[kSmallMax + 2];       // indexed by ABSOLUTE position s + j: segments are disjoint,
+    unsigned short truepos[kSmallMax + 2];        // so waves working on different nodes never collide
+    WaveScratch w[kSubWaves];
 };
 
 // One closed-form shuffle of segment [s, s+n) with predicate cent[axis] < pos: reads perm[src],
@@ -214,8 +217,8 @@ __device__ __forceinline__ void wave_shuffle(WaveLds& L, int src, unsigned s, un
         if (x < n) {
             const bool p = (masks[ch] >> lane) & 1ull;
             const unsigned tl = run + vd_mbcnt(masks[ch]);
-            if (p) L.truepos[ttot - tl] = (unsigned short)x;        // (T+1)-th true from the right
-            else L.falsepos[x - tl + 1u] = (unsigned short)x;       // (F+1)-th false from the left
+            if (p) L.truepos[s + ttot - tl] = (unsigned short)x;        // (T+1)-th true from the right
+            else L.falsepos[s + x - tl + 1u] = (unsigned short)x;       // (F+1)-th false from the left
         }
         run += (unsigned)__popcll(masks[ch]);
     }
@@ -230,9 +233,9 @@ __device__ __forceinline__ void wave_shuffle(WaveLds& L, int src, unsigned s, un
             p = (masks[ch] >> lane) & 1ull;
             const unsigned tl = run + vd_mbcnt(masks[ch]);
             const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
-            const int tF = F == 0u ? (int)n : (F <= ttot ? (int)L.truepos[F] : -1);
+            const int tF = F == 0u ? (int)n : (F <= ttot ? (int)L.truepos[s + F] : -1);
             const bool left = (int)x < tF;
-            const unsigned fj = (T + 1u <= ftot) ? (unsigned)L.falsepos[T + 1u] : n;
+            const unsigned fj = (T + 1u <= ftot) ? (unsigned)L.falsepos[s + T + 1u] : n;
             const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
             is_u = fetch == n - 1u;
             unsigned dest;
@@ -261,22 +264,52 @@ __device__ __forceinline__ void wave_shuffle_any(WaveLds& L, int src, unsigned s
     else wave_shuffle<kChunks>(L, src, s, n, axis, pos, tt, ue, up);
 }
 
+#ifndef VD_BLAS_ABL
+#define VD_BLAS_ABL 0
+#endif
 constexpr int kLaneMax = VD_LANE_MAX;   // nodes up to this size are built one-per-lane (literal sequential algorithm)
 constexpr int kQueue = kSmallMax / 4;   // a BFS level holds at most N/4 splittable nodes
 
-struct WaveQueues {                      // BFS frontiers: entry = node | start << 10 | count << 20
-    unsigned big[2][kQueue], small[2][kQueue];
+struct WaveQueues {                      // entry = node | start << 10 | count << 20
+    unsigned big[2][kQueue];             // BFS frontier of the wave-wide nodes
+    unsigned small[kQueue];              // every node <= kLaneMax spawned by a wave-wide node
+    unsigned lane_stack[2][64 * kSubWaves];   // per-lane DFS stack (<= kLaneMax/4 - 1 = 1 pending sibling)
+    unsigned pool;                       // next free node pair
+    unsigned n_big_cnt[2], n_small, root_left, bad;   // n_big_cnt[q] counts the entries pushed into big[q]
 };
 
-// blas.rs:135-166 run literally by ONE lane on its own node [s, s+n) (n <= kLaneMax).  Returns
-// the stale pivot (relative) or 0xffffffff when every candidate is rejected; writes the children
-// box keys (left min/max, right min/max).
+// blas.rs:135-166 run literally by ONE lane on its own node [s, s+n), n <= 8, entirely in
+// registers: the node's elements sit in 8 fixed register slots (centroids + box keys, static
+// indexing), the arrangement is a packed word of 4-bit slot ids, and partition_shuffle
+// (blas.rs:168-182) is simulated on that word with the predicates as an 8-bit mask.  Returns the
+// stale pivot (relative) or 0xffffffff when every candidate is rejected; writes the children box
+// keys (left min/max, right min/max) and the final arrangement back to `perm`.
+static_assert(kLaneMax <= 8, "the register-resident lane path holds at most 8 elements");
 __device__ __forceinline__ unsigned lane_partition(WaveLds& L, unsigned short* perm, unsigned s, unsigned n, int (&ck)[12]) {
-    int kmn[3] = {kBig, kBig, kBig}, kmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
-    for (unsigned i = 0; i < n; ++i) {
-        const unsigned e = perm[s + i];
+    unsigned el[8];
+    float cx[8], cy[8], cz[8];
+    int bk[6][8];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { const int key = vd_key(L.cent[k][e]); kmn[k] = min(kmn[k], key); kmx[k] = max(kmx[k], key); }
+    for (int j = 0; j < 8; ++j) {
+        el[j] = 0; cx[j] = cy[j] = cz[j] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) bk[q][j] = q < 3 ? kBig : -kBig - 1;
+        if ((unsigned)j < n) {
+            el[j] = perm[s + j];
+            cx[j] = L.cent[0][el[j]]; cy[j] = L.cent[1][el[j]]; cz[j] = L.cent[2][el[j]];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) bk[q][j] = L.box[q][el[j]];
+        }
+    }
+    int kmn[3] = {kBig, kBig, kBig}, kmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if ((unsigned)j < n) {
+            const int k0 = vd_key(cx[j]), k1 = vd_key(cy[j]), k2 = vd_key(cz[j]);
+            kmn[0] = min(kmn[0], k0); kmx[0] = max(kmx[0], k0);
+            kmn[1] = min(kmn[1], k1); kmx[1] = max(kmx[1], k1);
+            kmn[2] = min(kmn[2], k2); kmx[2] = max(kmx[2], k2);
+        }
     }
     float cbmin[3], cbmax[3];
 #pragma unroll
@@ -284,27 +317,45 @@ __device__ __forceinline__ unsigned lane_partition(WaveLds& L, unsigned short* p
     float best_cost = 3.40282347e+38f, best_pos = 0.0f;
     int best_axis = -1;
     unsigned best_piv = 0;
+    unsigned arr = 0x76543210u;           // position x holds slot (arr >> 4x) & 15
     for (int c = 0; c <= kCand; ++c) {
         int axis; float pos;
         if (c < kCand) { axis = c / 7; pos = cand_pos(cbmin, cbmax, c); }
         else { if (best_axis < 0) return 0xffffffffu; axis = best_axis; pos = best_pos; }
-        // partition_shuffle (blas.rs:168-182)
-        int i = 0, e = (int)n - 1;
-        const float* cen = L.cent[axis];
-        while (i < e) {
-            const unsigned short a = perm[s + i];
-            if (cen[a] < pos) { i += 1; }
-            else { const unsigned short b = perm[s + e]; perm[s + i] = b; perm[s + e] = a; e -= 1; }
+        unsigned pmask = 0;               // predicate per slot
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float ce = axis == 0 ? cx[j] : (axis == 1 ? cy[j] : cz[j]);
+            pmask |= (ce < pos ? 1u : 0u) << j;
         }
-        const unsigned piv = c < kCand ? (unsigned)i : best_piv;   // final pass: the stale pivot splits the children
+        // partition_shuffle (blas.rs:168-182) on the packed arrangement
+        unsigned i = 0, e = n - 1u;
+        while (i < e) {
+            const unsigned a = (arr >> (4u * i)) & 15u;
+            if ((pmask >> a) & 1u) { i += 1u; }
+            else {
+                const unsigned bb = (arr >> (4u * e)) & 15u, x = a ^ bb;
+                arr ^= (x << (4u * i)) | (x << (4u * e));
+                e -= 1u;
+            }
+        }
+        const unsigned piv = c < kCand ? i : best_piv;   // final pass: the stale pivot splits the children
+        unsigned leftmask = 0;            // slots at positions < piv
+        for (unsigned x = 0; x < piv; ++x) leftmask |= 1u << ((arr >> (4u * x)) & 15u);
         int k12[12];
 #pragma unroll
         for (int q = 0; q < 12; ++q) k12[q] = (q % 6) < 3 ? kBig : -kBig - 1;
-        for (unsigned x = 0; x < n; ++x) {
-            const unsigned el = perm[s + x];
-            const int o = x < piv ? 0 : 6;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { k12[o + q] = min(k12[o + q], L.box[q][el]); k12[o + 3 + q] = max(k12[o + 3 + q], L.box[3 + q][el]); }
+        for (int j = 0; j < 8; ++j) {
+            const bool valid = (unsigned)j < n, inl = (leftmask >> j) & 1u;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int lo = bk[q][j], hi = bk[3 + q][j];
+                k12[q] = min(k12[q], (valid && inl) ? lo : kBig);
+                k12[3 + q] = max(k12[3 + q], (valid && inl) ? hi : -kBig - 1);
+                k12[6 + q] = min(k12[6 + q], (valid && !inl) ? lo : kBig);
+                k12[9 + q] = max(k12[9 + q], (valid && !inl) ? hi : -kBig - 1);
+            }
         }
         if (c == kCand) {
 #pragma unroll
@@ -316,29 +367,38 @@ __device__ __forceinline__ unsigned lane_partition(WaveLds& L, unsigned short* p
         const float cost = a1 * (float)piv + a2 * (float)(n - piv);
         if (cost < best_cost) { best_cost = cost; best_axis = axis; best_pos = pos; best_piv = piv; }
     }
+    // write the final arrangement back
+    for (unsigned x = 0; x < n; ++x) {
+        const unsigned slot = (arr >> (4u * x)) & 15u;
+        unsigned v = el[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) v = slot == (unsigned)j ? el[j] : v;
+        perm[s + x] = (unsigned short)v;
+    }
     return best_piv;
 }
 
-constexpr int kSmallWaves = 1;   // subtrees per workgroup
-__global__ __launch_bounds__(64 * kSmallWaves) void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
-                                                                      const u32x4* __restrict__ payload, const TriBox* __restrict__ boxes,
-                                                                      TmpNode* __restrict__ subnodes, unsigned short* __restrict__ submap,
-                                                                      unsigned* __restrict__ sub_interior,
-                                                                      unsigned* __restrict__ final_ids, unsigned* __restrict__ err) {
+__global__ __launch_bounds__(64 * kSubWaves, 4)
+void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
+                       const u32x4* __restrict__ payload, const TriBox* __restrict__ boxes,
+                       TmpNode* __restrict__ subnodes, unsigned short* __restrict__ submap,
+                       unsigned* __restrict__ sub_interior, unsigned* __restrict__ final_ids, unsigned* __restrict__ err,
+                       unsigned* __restrict__ dbg_cycles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned lane = vd_lane();
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    const unsigned tid = threadIdx.x, lane = vd_lane();
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char* wbase = smem + wave * (sizeof(WaveLds) + sizeof(WaveQueues));
-    WaveLds& L = *reinterpret_cast<WaveLds*>(wbase);
-    WaveQueues& Q = *reinterpret_cast<WaveQueues*>(wbase + sizeof(WaveLds));
-    const unsigned root_i = blockIdx.x * (unsigned)kSmallWaves + wave;
+    WaveLds& L = *reinterpret_cast<WaveLds*>(smem);
+    WaveQueues& Q = *reinterpret_cast<WaveQueues*>(smem + sizeof(WaveLds));
+    WaveScratch& W = L.w[wave];
+    const unsigned root_i = blockIdx.x;
     if (root_i >= *n_roots_p) return;
     const SmallRoot root = roots[root_i];
     const unsigned base = root.start, N = root.count;
     TmpNode* nodes = subnodes + 2u * (size_t)base;   // disjoint region per root: < 2*N nodes, creation order
     unsigned short* nmap = submap + 2u * (size_t)base;
 
-    for (unsigned x = lane; x < N; x += 64u) {
+    for (unsigned x = tid; x < N; x += 64u * kSubWaves) {
         const u32x4 v = payload[base + x];
         const TriBox bx = boxes[v.x];
         L.gid[x] = v.x;
@@ -351,30 +411,25 @@ __global__ __launch_bounds__(64 * kSmallWaves) void blas_small_kernel(const Smal
             L.box[3 + k][x] = vd_key(bx.mx[k]);
         }
     }
-    vd_wave_lds_sync();
-
-    // Both perm buffers always hold the same arrangement OUTSIDE of a node being processed: a
-    // wave-wide node ping-pongs its own segment an even number of times (22), a lane-serial node
-    // works in place on buffer 0 and the segment is mirrored afterwards.
-    unsigned pool = 0, n_interior = 0;
-    unsigned root_left = kNone;            // creation id of the root's children pair
-    unsigned n_big = 0, n_small = 0;
-    int qi = 0;
-    {   // the root entry: node field unused (root_pending flags it); s = 0, n = N
-        const unsigned ent = 1023u | (N << 20);
-        if (N > (unsigned)kLaneMax) { if (lane == 0) Q.big[0][0] = ent; n_big = 1; }
-        else { if (lane == 0) Q.small[0][0] = ent; n_small = 1; }
+    // Wave-wide nodes ping-pong their own segment between the two perm buffers an even number of
+    // times (22) and mirror the result, so both buffers agree outside the node being processed.
+    // The four waves split different nodes of one BFS level concurrently.  Nodes <= kLaneMax are
+    // collected and built afterwards, one whole sub-subtree per lane.
+    if (tid == 0) {
+        Q.pool = 0; Q.n_big_cnt[0] = 0; Q.n_big_cnt[1] = 0; Q.n_small = 0; Q.root_left = kNone; Q.bad = 0;
+        const unsigned ent = 1023u | (N << 20);     // the root entry: node field unused; s = 0, n = N
+        if (N > (unsigned)kLaneMax) Q.big[0][0] = ent; else { Q.small[0] = ent; Q.n_small = 1; }
     }
-    vd_wave_lds_sync();
-    bool root_pending = true;
+    __syncthreads();
+    unsigned n_big = N > (unsigned)kLaneMax ? 1u : 0u;
+    bool root_level = true;
+    int qi = 0;
 
-    while (n_big + n_small > 0u) {
-        unsigned nb_next = 0, ns_next = 0;
-        // ---------------- wave-wide nodes, one after the other ----------------
-        for (unsigned bi = 0; bi < n_big; ++bi) {
+    while (n_big > 0u) {
+        for (unsigned bi = wave; bi < (((VD_BLAS_ABL & 4) && !root_level) ? 0u : n_big); bi += kSubWaves) {
             const unsigned ent = Q.big[qi][bi];
             const unsigned node_id = ent & 1023u, s = (ent >> 10) & 1023u, n = ent >> 20;
-            const bool is_root = root_pending;
+            const bool is_root = root_level;
             int cur = 0;
             int kmn[3] = {kBig, kBig, kBig}, kmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
             for (unsigned x = lane; x < n; x += 64u) {
@@ -385,13 +440,13 @@ __global__ __launch_bounds__(64 * kSmallWaves) void blas_small_kernel(const Smal
             float cbmin[3], cbmax[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(wave_min_i(kmn[k])); cbmax[k] = box_hi(wave_max_i(kmx[k])); }
-            if (lane < (unsigned)kCand) L.pos[lane] = cand_pos(cbmin, cbmax, (int)lane);
+            if (lane < (unsigned)kCand) W.pos[lane] = cand_pos(cbmin, cbmax, (int)lane);
             vd_wave_lds_sync();
-            for (int c = 0; c < kCand; ++c) {                              // blas.rs:144-147
+            for (int c = 0; c < ((VD_BLAS_ABL & 8) ? 1 : kCand); ++c) {                              // blas.rs:144-147
                 unsigned tt, ue, up;
-                wave_shuffle_any(L, cur, s, n, c / 7, L.pos[c], tt, ue, up);
+                wave_shuffle_any(L, cur, s, n, c / 7, W.pos[c], tt, ue, up);
                 cur ^= 1;
-                if (lane == 0) { L.u_e[c] = (unsigned short)ue; L.u_p[c] = (unsigned short)up; L.ttot[c] = tt; }
+                if (lane == 0) { W.u_e[c] = (unsigned short)ue; W.u_p[c] = (unsigned short)up; W.ttot[c] = tt; }
             }
             vd_wave_lds_sync();
             // evaluate (blas.rs:149-161): lane = 3*c + part owns a third of candidate c's elements;
@@ -404,8 +459,8 @@ __global__ __launch_bounds__(64 * kSmallWaves) void blas_small_kernel(const Smal
                 for (int i = 0; i < 12; ++i) k12[i] = (i % 6) < 3 ? kBig : -kBig - 1;
                 if (c < (unsigned)kCand) {
                     const float* cen = L.cent[c / 7u];
-                    const float pos = L.pos[c];
-                    const unsigned ue = L.u_e[c];
+                    const float pos = W.pos[c];
+                    const unsigned ue = W.u_e[c];
                     for (unsigned i = part; i < n; i += 3u) {
                         const unsigned e = L.perm[cur][s + i];
                         const int o = (cen[e] < pos && e != ue) ? 0 : 6;
@@ -419,19 +474,19 @@ __global__ __launch_bounds__(64 * kSmallWaves) void blas_small_kernel(const Smal
                     k12[i] = (i % 6) < 3 ? min(k12[i], min(a1, a2)) : max(k12[i], max(a1, a2));
                 }
                 if (c < (unsigned)kCand && part == 0u) {
-                    const unsigned n1 = L.ttot[c] - L.u_p[c];
+                    const unsigned n1 = W.ttot[c] - W.u_p[c];
                     const float a1 = vd_area(box_hi(k12[3]) - box_lo(k12[0]), box_hi(k12[4]) - box_lo(k12[1]), box_hi(k12[5]) - box_lo(k12[2]));
                     const float a2 = vd_area(box_hi(k12[9]) - box_lo(k12[6]), box_hi(k12[10]) - box_lo(k12[7]), box_hi(k12[11]) - box_lo(k12[8]));
                     key = cost_key(a1 * (float)n1 + a2 * (float)(n - n1), c);
                 }
             }
             key = wave_min_u64(key);
-            if (key == ~0ull) { if (lane == 0) atomicOr(err, ERR_DEGENERATE); return; }
+            if (key == ~0ull) { if (lane == 0) Q.bad = 1; continue; }
             const int best = (int)(unsigned)key;
-            const unsigned Lst = L.ttot[best] - L.u_p[best];             // stale optimal_pivot (blas.rs:159,165)
+            const unsigned Lst = W.ttot[best] - W.u_p[best];             // stale optimal_pivot (blas.rs:159,165)
             {
                 unsigned tt, ue, up;                                     // blas.rs:164
-                wave_shuffle_any(L, cur, s, n, best / 7, L.pos[best], tt, ue, up);
+                wave_shuffle_any(L, cur, s, n, best / 7, W.pos[best], tt, ue, up);
                 cur ^= 1;                                                // 22 flips: back in buffer 0
             }
             int k12[12];                                                 // children boxes (blas.rs:115-123)
@@ -446,10 +501,9 @@ __global__ __launch_bounds__(64 * kSmallWaves) void blas_small_kernel(const Smal
             }
 #pragma unroll
             for (int i = 0; i < 12; ++i) k12[i] = (i % 6) < 3 ? wave_min_i(k12[i]) : wave_max_i(k12[i]);
-            const unsigned pair = pool;
-            pool += 2; n_interior += 1;
-            const unsigned cn[2] = {Lst, n - Lst}, cs[2] = {s, s + Lst};
             if (lane == 0) {
+                const unsigned pair = atomicAdd(&Q.pool, 2u);
+                const unsigned cn[2] = {Lst, n - Lst}, cs[2] = {s, s + Lst};
                 TmpNode ln, rn;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -459,38 +513,39 @@ __global__ __launch_bounds__(64 * kSmallWaves) void blas_small_kernel(const Smal
                 ln.left_first = base + cs[0]; ln.count = cn[0];          // leaf form; interior nodes are patched when split
                 rn.left_first = base + cs[1]; rn.count = cn[1];
                 nodes[pair] = ln; nodes[pair + 1] = rn;
-                if (!is_root) { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }   // creation-order link
-            }
-            if (is_root) { root_left = pair; root_pending = false; }
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                if (cn[side] > 3u) {
-                    const unsigned e2 = (pair + side) | (cs[side] << 10) | (cn[side] << 20);
-                    if (cn[side] > (unsigned)kLaneMax) { if (lane == 0) Q.big[qi ^ 1][nb_next] = e2; nb_next += 1; }
-                    else { if (lane == 0) Q.small[qi ^ 1][ns_next] = e2; ns_next += 1; }
+                if (is_root) Q.root_left = pair;
+                else { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }   // creation-order link
+                for (int side = 0; side < 2; ++side) {
+                    if (cn[side] > 3u) {
+                        const unsigned e2 = (pair + side) | (cs[side] << 10) | (cn[side] << 20);
+                        if (cn[side] > (unsigned)kLaneMax) Q.big[qi ^ 1][atomicAdd(&Q.n_big_cnt[qi ^ 1], 1u)] = e2;
+                        else Q.small[atomicAdd(&Q.n_small, 1u)] = e2;
+                    }
                 }
             }
-            vd_wave_lds_sync();
         }
-        // ---------------- lane-serial nodes, 64 at a time ----------------
-        for (unsigned b0 = 0; b0 < n_small; b0 += 64u) {
-            const bool active = b0 + lane < n_small;
-            unsigned node_id = 0, s = 0, n = 0, piv = 0;
-            int ck[12];
-            const bool is_root = root_pending;
-            if (active) {
-                const unsigned ent = Q.small[qi][b0 + lane];
-                node_id = ent & 1023u; s = (ent >> 10) & 1023u; n = ent >> 20;
-                piv = lane_partition(L, L.perm[0], s, n, ck);
-                for (unsigned x = 0; x < n; ++x) L.perm[1][s + x] = L.perm[0][s + x];
-            }
-            const bool bad = active && piv == 0xffffffffu;
-            if (__ballot(bad)) { if (lane == 0) atomicOr(err, ERR_DEGENERATE); return; }
-            const unsigned long long am = __ballot(active);
-            const unsigned pair = pool + 2u * vd_mbcnt(am);
-            pool += 2u * (unsigned)__popcll(am);
-            n_interior += (unsigned)__popcll(am);
-            if (active) {
+        __syncthreads();
+        n_big = Q.n_big_cnt[qi ^ 1];
+        if (tid == 0) Q.n_big_cnt[qi] = 0;     // big[qi] is the push target of the next level
+        root_level = false;
+        qi ^= 1;
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---------------- lane-serial phase: one whole sub-subtree (<= kLaneMax prims) per lane ----------------
+    const unsigned n_small = Q.n_small;
+    for (unsigned b0 = 0; b0 < ((VD_BLAS_ABL & 1) ? 0u : n_small); b0 += 64u * kSubWaves) {
+        if (b0 + tid < n_small) {
+            unsigned ent = Q.small[b0 + tid];
+            unsigned sp = 0;
+            bool is_root = N <= (unsigned)kLaneMax;      // then the single entry is the subtree root
+            for (;;) {
+                const unsigned node_id = ent & 1023u, s = (ent >> 10) & 1023u, n = ent >> 20;
+                int ck[12];
+                const unsigned piv = lane_partition(L, L.perm[0], s, n, ck);
+                if (piv == 0xffffffffu) { Q.bad = 1; break; }
+                const unsigned pair = atomicAdd(&Q.pool, 2u);
                 TmpNode ln, rn;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -500,38 +555,38 @@ __global__ __launch_bounds__(64 * kSmallWaves) void blas_small_kernel(const Smal
                 ln.left_first = base + s; ln.count = piv;
                 rn.left_first = base + s + piv; rn.count = n - piv;
                 nodes[pair] = ln; nodes[pair + 1] = rn;
-                if (!is_root) { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }
+                if (is_root) { Q.root_left = pair; is_root = false; }
+                else { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }
+                const bool gl = piv > 3u, gr = (n - piv) > 3u;
+                if (gl && gr) { Q.lane_stack[sp][tid] = (pair + 1u) | ((s + piv) << 10) | ((n - piv) << 20); sp += 1; }
+                if (gl) ent = pair | (s << 10) | (piv << 20);
+                else if (gr) ent = (pair + 1u) | ((s + piv) << 10) | ((n - piv) << 20);
+                else if (sp > 0u) { sp -= 1; ent = Q.lane_stack[sp][tid]; }
+                else break;
             }
-            if (is_root) { root_left = __shfl(pair, 0); root_pending = false; }
-            // children > 3 go to the next small frontier (they are <= kLaneMax)
-            const bool pl = active && piv > 3u, pr = active && (n - piv) > 3u;
-            const unsigned long long ml = __ballot(pl), mr = __ballot(pr);
-            if (pl) Q.small[qi ^ 1][ns_next + vd_mbcnt(ml)] = pair | (s << 10) | (piv << 20);
-            ns_next += (unsigned)__popcll(ml);
-            if (pr) Q.small[qi ^ 1][ns_next + vd_mbcnt(mr)] = (pair + 1u) | ((s + piv) << 10) | ((n - piv) << 20);
-            ns_next += (unsigned)__popcll(mr);
-            vd_wave_lds_sync();
         }
-        n_big = nb_next; n_small = ns_next; qi ^= 1;
-        vd_wave_lds_sync();
     }
+    __threadfence();     // node records written by all lanes are re-read below
+    __syncthreads();
+    if (Q.bad) { if (tid == 0) atomicOr(err, ERR_DEGENERATE); return; }
+    const unsigned pool = Q.pool, root_left = Q.root_left;
+    const unsigned n_interior = pool / 2u;
 
     // ---- restore the reference's DFS pre-order numbering (blas.rs:110-112,125-126) ----
-    // creation order is breadth-first: children have larger ids than their parent.  I[j] =
-    // interior nodes in j's subtree; rank r(j) = interior nodes before j in pre-order (the subtree
-    // root has rank 0 and owns local pair 0).  Work arrays alias the (now dead) box keys.
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    // creation order: children have larger ids than their parent.  I[j] = interior nodes in j's
+    // subtree; rank r(j) = interior nodes before j in pre-order (the subtree root has rank 0 and
+    // owns local pair 0).  Work arrays alias the (now dead) box keys.
     unsigned short* I = reinterpret_cast<unsigned short*>(&L.box[0][0]);          // [2N]
     unsigned short* R = I + 2 * kSmallMax;                                          // [2N]
     unsigned short* LC = R + 2 * kSmallMax;                                         // [2N] left child pair (creation id), 0xffff = leaf
     const unsigned n_nodes = pool;
-    for (unsigned j = lane; j < n_nodes; j += 64u) {
+    for (unsigned j = tid; j < n_nodes; j += 64u * kSubWaves) {
         const TmpNode t = nodes[j];
         LC[j] = t.count == 0u ? (unsigned short)t.left_first : (unsigned short)0xffffu;
         I[j] = 0;
     }
-    vd_wave_lds_sync();
-    if (lane == 0) {
+    __syncthreads();
+    if (tid == 0 && !(VD_BLAS_ABL & 2)) {
         for (int j = (int)n_nodes - 1; j >= 0; --j)
             if (LC[j] != 0xffffu) I[j] = (unsigned short)(1u + I[LC[j]] + I[LC[j] + 1u]);
         // forward: parents first
@@ -539,15 +594,18 @@ __global__ __launch_bounds__(64 * kSmallWaves) void blas_small_kernel(const Smal
         for (unsigned j = 0; j < n_nodes; ++j)
             if (LC[j] != 0xffffu) { const unsigned l = LC[j]; R[l] = (unsigned short)(R[j] + 1u); R[l + 1u] = (unsigned short)(R[j] + 1u + I[l]); }
     }
-    vd_wave_lds_sync();
+    __syncthreads();
     // new local index of node j = 2 * r(parent) + side; parent's rank = R[left sibling] - 1
-    for (unsigned j = lane; j < n_nodes; j += 64u) {
+    for (unsigned j = tid; j < n_nodes; j += 64u * kSubWaves) {
         const unsigned rl = R[j & ~1u];                    // rank of the left sibling = r(parent) + 1
         nmap[j] = (unsigned short)(2u * (rl - 1u) + (j & 1u));
         if (LC[j] != 0xffffu) nodes[j].left_first = 2u * R[j];   // interior: its own pair in DFS numbering
     }
-    for (unsigned x = lane; x < N; x += 64u) final_ids[base + x] = L.gid[L.perm[0][x]];
-    if (lane == 0) sub_interior[root_i] = n_interior;
+    for (unsigned x = tid; x < N; x += 64u * kSubWaves) final_ids[base + x] = L.gid[L.perm[0][x]];
+    if (tid == 0) {
+        sub_interior[root_i] = n_interior;
+        if (dbg_cycles) { dbg_cycles[2 * root_i] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin); dbg_cycles[2 * root_i + 1] = N; }
+    }
 }
 
 // =============================================================================================
@@ -1090,8 +1148,9 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     // ---- phase B ----
     const unsigned n_small = h_ctl.n_small, n_top = h_ctl.n_top;
     if (n_small) {
-        hipLaunchKernelGGL(blas_small_kernel, dim3((n_small + kSmallWaves - 1) / kSmallWaves), dim3(64 * kSmallWaves), kSmallWaves * (sizeof(WaveLds) + sizeof(WaveQueues)), st, P.small, &P.ctl->n_small, P.pay0,
-                           P.boxes, P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err);
+        hipLaunchKernelGGL(blas_small_kernel, dim3(n_small), dim3(64 * kSubWaves), sizeof(WaveLds) + sizeof(WaveQueues), st, P.small, &P.ctl->n_small, P.pay0,
+                           P.boxes, P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err, P.stack);
+        ctx->dbg_ptr = P.stack; ctx->dbg_count = 2 * n_small;
     }
     // ---- phase C: DFS numbering of the top tree on the host ----
     std::vector<TopNode> h_top(n_top);
@@ -1154,6 +1213,14 @@ int check_build_args(VdCtx* ctx, const void* verts, uint32_t n_vert, const void*
 }  // namespace
 
 extern "C" {
+
+// Tuning hook: per-subtree {cycles, prims} pairs of the last phase B run.
+int vd_debug_blas_cycles(VdCtx* ctx, uint32_t* out, uint32_t cap) {
+    if (!ctx || !ctx->dbg_ptr) return 0;
+    const uint32_t n = ctx->dbg_count < cap ? ctx->dbg_count : cap;
+    if (hipMemcpy(out, ctx->dbg_ptr, 4 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return (int)n;
+}
 
 int vd_bvh_build_dev(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32_t* d_idx, uint32_t n_tri, VdBvhNode* d_out,
                      uint32_t node_cap, uint32_t* out_n_nodes) {

@@ -200,11 +200,13 @@ __device__ __forceinline__ void slab_dma(char* slab, const VdInstance* __restric
     }
 }
 
-template <int ROUNDS, int LOAD, int OUT>
+// ABL (timing-only ablations, wrong results): bit 0 = skip the visibility math, bit 1 = skip the
+// survivor stores, bit 2 = skip ticket + look-back.
+template <int ROUNDS, int LOAD, int OUT, int ABL = 0>
 __global__ __launch_bounds__(kBlock, (LOAD == 0 || LOAD == 1) ? 3 : 4)
 void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
                          const VdInstance* __restrict__ inst, unsigned n_inst, VdDrawIndexedIndirect* __restrict__ out,
-                         unsigned* __restrict__ out_count, vd_u64* tile_state, unsigned* ticket_counter,
+                         unsigned* __restrict__ out_count, vd_u64* tile_state, vd_u64* ticket_counter,
                          unsigned n_tiles, unsigned first_instance) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kSlabsPerWave = LOAD == 2 ? 2 : (LOAD == 3 ? 0 : 1);
@@ -216,9 +218,10 @@ void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, 
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     char* slab = smem + wave * kWaveLds;
 
-    if (threadIdx.x == 0) s_misc[0] = atomicAdd(ticket_counter, 1u);
+    if (!(ABL & 4) && threadIdx.x == 0) s_misc[0] = vd_take_ticket(ticket_counter, n_tiles, &s_misc[1]);
     __syncthreads();
-    const unsigned tile = s_misc[0];
+    const unsigned tile = (ABL & 4) ? blockIdx.x : s_misc[0], epoch = s_misc[1];
+    __syncthreads();
     const size_t tile_first = (size_t)tile * (kBlock * ROUNDS);
     // wave-contiguous ranges keep the output order (wave, round, lane) == instance order
     const size_t wave_first = tile_first + (size_t)wave * (kWave * ROUNDS);
@@ -260,7 +263,8 @@ void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, 
         }
         const unsigned mid = min(li.mesh, n_mesh - 1u);
         const MeshRec m = load_mesh(meshes, mid);
-        const bool vis = lane < n_valid && is_visible(cam, m, li.T0, li.T1, li.T2, li.T3);
+        const bool vis = lane < n_valid && ((ABL & 1) ? (__float_as_uint(li.T0.x + li.T1.y + li.T2.z + li.T3.w + m.mnx) & 15u) != 0u
+                                                      : is_visible(cam, m, li.T0, li.T1, li.T2, li.T3));
         s_rec[r * kBlock + threadIdx.x] = mid | (vis ? 0x80000000u : 0u);
         wave_total += (unsigned)__popcll(__ballot(vis));
     }
@@ -271,7 +275,7 @@ void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, 
         unsigned tile_total = 0;
 #pragma unroll
         for (int w = 0; w < kWavesPerBlock; ++w) tile_total += s_misc[2 + w];
-        const unsigned excl = vd_lookback(tile_state, tile, tile_total);
+        const unsigned excl = (ABL & 4) ? tile * (unsigned)(kBlock * ROUNDS) : vd_lookback(tile_state, epoch, tile, tile_total);
         if (lane == 0) {
             s_misc[1] = excl;
             if (tile == n_tiles - 1u) *out_count = excl + tile_total;
@@ -280,6 +284,7 @@ void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, 
     __syncthreads();
     unsigned base = s_misc[1];
     for (unsigned w = 0; w < wave; ++w) base += s_misc[2 + w];
+    if (ABL & 2) { if (base == 0xffffffffu) out[0].vertex_count = wave_total; return; }
 
     char* stage = (LOAD == 3) ? slab : slab;   // slab memory is free again after the last round
 #pragma unroll 1
@@ -337,108 +342,6 @@ void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Persistent form of the fused kernel: a fixed grid of workgroups pulls tile tickets, and the
-// instance stream never stops — the first round of the NEXT tile is already in flight while this
-// tile waits in the look-back and writes its survivors.  `rounds` (64-instance rounds per wave
-// per tile) is a run-time knob so small inputs still spread over the chip.
-// ------------------------------------------------------------------------------------------
-template <bool NT_STORE>
-__global__ __launch_bounds__(kBlock, 3)
-void cull_compact_persistent_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
-                                    const VdInstance* __restrict__ inst, unsigned n_inst,
-                                    VdDrawIndexedIndirect* __restrict__ out, unsigned* __restrict__ out_count,
-                                    vd_u64* tile_state, unsigned* ticket_counter, unsigned n_tiles,
-                                    unsigned first_instance, unsigned rounds) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned* s_rec = reinterpret_cast<unsigned*>(smem + kWavesPerBlock * kSlabBytes);   // [rounds][kBlock]
-    // s_misc: [0],[1] ticket slots, [2] tile_excl, [4..7] / [8..11] wave totals by tile parity
-    unsigned* s_misc = s_rec + rounds * kBlock;
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    char* slab = smem + wave * kSlabBytes;
-    const unsigned tile_inst = kBlock * rounds, wave_inst = kWave * rounds;
-    auto valid_at = [&](size_t f) -> unsigned { return f < n_inst ? (unsigned)min((size_t)64, (size_t)n_inst - f) : 0u; };
-
-    if (threadIdx.x == 0) {
-        s_misc[0] = atomicAdd(ticket_counter, 1u);
-        s_misc[1] = atomicAdd(ticket_counter, 1u);
-    }
-    __syncthreads();
-    unsigned cur = s_misc[0], nxt = s_misc[1];
-    __syncthreads();
-    if (cur >= n_tiles) return;
-
-    u32x4 regs[kChunksPerLane];
-    {
-        const size_t wf = (size_t)cur * tile_inst + (size_t)wave * wave_inst;
-        slab_fill<true>(inst, wf, valid_at(wf), lane, regs);
-    }
-    for (unsigned it = 0;; ++it) {
-        const unsigned par = (it & 1u) * 4u;
-        if (threadIdx.x == 0) s_misc[it & 1u] = atomicAdd(ticket_counter, 1u);   // the ticket after nxt
-        const size_t wave_first = (size_t)cur * tile_inst + (size_t)wave * wave_inst;
-        const size_t next_wave_first = (size_t)nxt * tile_inst + (size_t)wave * wave_inst;
-        unsigned wave_total = 0;
-#pragma unroll 1
-        for (unsigned r = 0; r < rounds; ++r) {
-            const size_t first = wave_first + (size_t)r * kWave;
-            const unsigned n_valid = valid_at(first);
-            slab_store(slab, lane, regs);
-            if (r + 1 < rounds) slab_fill<true>(inst, first + kWave, valid_at(first + kWave), lane, regs);
-            else if (nxt < n_tiles) slab_fill<true>(inst, next_wave_first, valid_at(next_wave_first), lane, regs);
-            vd_wave_lds_sync();
-            const LaneInst li = slab_read(slab, lane);
-            vd_wave_lds_sync();
-            const unsigned mid = min(li.mesh, n_mesh - 1u);
-            const MeshRec m = load_mesh(meshes, mid);
-            const bool vis = lane < n_valid && is_visible(cam, m, li.T0, li.T1, li.T2, li.T3);
-            s_rec[r * kBlock + threadIdx.x] = mid | (vis ? 0x80000000u : 0u);
-            wave_total += (unsigned)__popcll(__ballot(vis));
-        }
-        if (lane == 0) s_misc[4 + par + wave] = wave_total;
-        __syncthreads();
-        const unsigned after = s_misc[it & 1u];
-        if (wave == 0) {
-            unsigned tile_total = 0;
-#pragma unroll
-            for (int w = 0; w < kWavesPerBlock; ++w) tile_total += s_misc[4 + par + w];
-            const unsigned excl = vd_lookback(tile_state, cur, tile_total);
-            if (lane == 0) {
-                s_misc[2] = excl;
-                if (cur == n_tiles - 1u) *out_count = excl + tile_total;
-            }
-        }
-        __syncthreads();
-        unsigned base = s_misc[2];
-        for (unsigned w = 0; w < wave; ++w) base += s_misc[4 + par + w];
-
-#pragma unroll 1
-        for (unsigned r = 0; r < rounds; ++r) {
-            const unsigned rec = s_rec[r * kBlock + threadIdx.x];
-            const bool vis = (rec >> 31) != 0u;
-            const unsigned long long mask = __ballot(vis);
-            if (vis) {
-                const unsigned mid = rec & 0x7fffffffu;
-                const uint4* mp = reinterpret_cast<const uint4*>(meshes + mid);
-                unsigned* o = reinterpret_cast<unsigned*>(out + (base + vd_mbcnt(mask)));
-                const unsigned v0 = mp[0].w, v2 = mp[1].w, v3 = (unsigned)meshes[mid].vertex_offset;
-                const unsigned v4 = first_instance + (unsigned)(wave_first + (size_t)r * kWave) + lane;
-                if (NT_STORE) {
-                    __builtin_nontemporal_store(v0, o + 0); __builtin_nontemporal_store(1u, o + 1);
-                    __builtin_nontemporal_store(v2, o + 2); __builtin_nontemporal_store(v3, o + 3);
-                    __builtin_nontemporal_store(v4, o + 4);
-                } else {
-                    o[0] = v0; o[1] = 1u; o[2] = v2; o[3] = v3; o[4] = v4;
-                }
-            }
-            base += (unsigned)__popcll(mask);
-        }
-        cur = nxt;
-        nxt = after;
-        if (cur >= n_tiles) break;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Second-generation fused kernel: stage only what the cull reads.  CH = 16-B chunks staged per
 // instance: 9 = whole record, 5 = transform (chunks 0-3) + the chunk holding mesh id (chunk 8);
 // the skipped chunks share 128-B lines with the staged ones, so HBM traffic is unchanged but
@@ -484,7 +387,7 @@ template <int ROUNDS, int CH, int PF, int MINW>
 __global__ __launch_bounds__(kBlock, MINW)
 void cull_compact2_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
                           const VdInstance* __restrict__ inst, unsigned n_inst, VdDrawIndexedIndirect* __restrict__ out,
-                          unsigned* __restrict__ out_count, vd_u64* tile_state, unsigned* ticket_counter,
+                          unsigned* __restrict__ out_count, vd_u64* tile_state, vd_u64* ticket_counter,
                           unsigned n_tiles, unsigned first_instance) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kWaveLds = kWave * CH * 16;
@@ -493,9 +396,10 @@ void cull_compact2_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes,
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     char* slab = smem + wave * kWaveLds;
 
-    if (threadIdx.x == 0) s_misc[0] = atomicAdd(ticket_counter, 1u);
+    if (threadIdx.x == 0) s_misc[0] = vd_take_ticket(ticket_counter, n_tiles, &s_misc[1]);
     __syncthreads();
-    const unsigned tile = s_misc[0];
+    const unsigned tile = s_misc[0], epoch = s_misc[1];
+    __syncthreads();
     const size_t wave_first = (size_t)tile * (kBlock * ROUNDS) + (size_t)wave * (kWave * ROUNDS);
     auto valid_at = [&](size_t f) -> unsigned { return f < n_inst ? (unsigned)min((size_t)64, (size_t)n_inst - f) : 0u; };
 
@@ -525,7 +429,7 @@ void cull_compact2_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes,
         unsigned tile_total = 0;
 #pragma unroll
         for (int w = 0; w < kWavesPerBlock; ++w) tile_total += s_misc[2 + w];
-        const unsigned excl = vd_lookback(tile_state, tile, tile_total);
+        const unsigned excl = vd_lookback(tile_state, epoch, tile, tile_total);
         if (lane == 0) {
             s_misc[1] = excl;
             if (tile == n_tiles - 1u) *out_count = excl + tile_total;
@@ -547,6 +451,70 @@ void cull_compact2_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes,
             o[0] = mp[0].w;                         // index_count
             o[1] = 1u;
             o[2] = mp[1].w;                         // base_index
+            o[3] = (unsigned)meshes[mid].vertex_offset;
+            o[4] = first_instance + (unsigned)(wave_first + (size_t)r * kWave) + lane;
+        }
+        base += (unsigned)__popcll(mask);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-tile form: every wave is its own tile (64*ROUNDS instances), draws its own ticket and
+// runs its own look-back, so a workgroup never synchronises: no barrier bubbles at tile ends.
+// ------------------------------------------------------------------------------------------
+template <int ROUNDS, int MINW>
+__global__ __launch_bounds__(kBlock, MINW)
+void cull_compact_wave_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
+                              const VdInstance* __restrict__ inst, unsigned n_inst, VdDrawIndexedIndirect* __restrict__ out,
+                              unsigned* __restrict__ out_count, vd_u64* tile_state, vd_u64* ticket_counter,
+                              unsigned n_tiles, unsigned first_instance) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kWaveLds = kSlabBytes + ROUNDS * kWave * 4;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* slab = smem + wave * kWaveLds;
+    unsigned* s_rec = reinterpret_cast<unsigned*>(slab + kSlabBytes);   // [ROUNDS][64]
+
+    if (blockIdx.x * (unsigned)kWavesPerBlock + wave >= n_tiles) return;   // exactly n_tiles tickets are drawn
+    unsigned tile = 0, epoch = 0;
+    if (lane == 0) tile = vd_take_ticket(ticket_counter, n_tiles, &epoch);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    epoch = __builtin_amdgcn_readfirstlane(epoch);
+    const size_t wave_first = (size_t)tile * (kWave * ROUNDS);
+    auto valid_at = [&](size_t f) -> unsigned { return f < n_inst ? (unsigned)min((size_t)64, (size_t)n_inst - f) : 0u; };
+
+    unsigned wave_total = 0;
+    u32x4 regs[kChunksPerLane];
+    slab_fill<true>(inst, wave_first, valid_at(wave_first), lane, regs);
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS; ++r) {
+        const size_t first = wave_first + (size_t)r * kWave;
+        const unsigned n_valid = valid_at(first);
+        slab_store(slab, lane, regs);
+        if (r + 1 < ROUNDS) slab_fill<true>(inst, first + kWave, valid_at(first + kWave), lane, regs);
+        vd_wave_lds_sync();
+        const LaneInst li = slab_read(slab, lane);
+        vd_wave_lds_sync();
+        const unsigned mid = min(li.mesh, n_mesh - 1u);
+        const MeshRec m = load_mesh(meshes, mid);
+        const bool vis = lane < n_valid && is_visible(cam, m, li.T0, li.T1, li.T2, li.T3);
+        s_rec[r * kWave + lane] = mid | (vis ? 0x80000000u : 0u);
+        wave_total += (unsigned)__popcll(__ballot(vis));
+    }
+    unsigned base = vd_lookback(tile_state, epoch, tile, wave_total);
+    if (tile == n_tiles - 1u && lane == 0) *out_count = base + wave_total;
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS; ++r) {
+        const unsigned rec = s_rec[r * kWave + lane];
+        const bool vis = (rec >> 31) != 0u;
+        const unsigned long long mask = __ballot(vis);
+        if (vis) {
+            const unsigned mid = rec & 0x7fffffffu;
+            const uint4* mp = reinterpret_cast<const uint4*>(meshes + mid);
+            unsigned* o = reinterpret_cast<unsigned*>(out + (base + vd_mbcnt(mask)));
+            o[0] = mp[0].w;
+            o[1] = 1u;
+            o[2] = mp[1].w;
             o[3] = (unsigned)meshes[mid].vertex_offset;
             o[4] = first_instance + (unsigned)(wave_first + (size_t)r * kWave) + lane;
         }
@@ -604,12 +572,12 @@ constexpr int kCompactTile = kBlock * kCompactPerThread;
 __global__ __launch_bounds__(kBlock) void compact_draws_kernel(const VdDrawIndexedIndirect* __restrict__ in, unsigned n,
                                                                VdDrawIndexedIndirect* __restrict__ out,
                                                                unsigned* __restrict__ out_count, vd_u64* tile_state,
-                                                               unsigned* ticket_counter, unsigned n_tiles) {
-    __shared__ unsigned s_ticket, s_wave_total[kWavesPerBlock], s_tile_excl;
+                                                               vd_u64* ticket_counter, unsigned n_tiles) {
+    __shared__ unsigned s_ticket, s_epoch, s_wave_total[kWavesPerBlock], s_tile_excl;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket_counter, 1u);
+    if (threadIdx.x == 0) s_ticket = vd_take_ticket(ticket_counter, n_tiles, &s_epoch);
     __syncthreads();
-    const unsigned tile = s_ticket;
+    const unsigned tile = s_ticket, epoch = s_epoch;
     const size_t wave_first = (size_t)tile * kCompactTile + (size_t)wave * (kWave * kCompactPerThread);
     unsigned long long masks[kCompactPerThread];
     unsigned wave_total = 0;
@@ -627,7 +595,7 @@ __global__ __launch_bounds__(kBlock) void compact_draws_kernel(const VdDrawIndex
         unsigned tile_total = 0;
 #pragma unroll
         for (int w = 0; w < kWavesPerBlock; ++w) tile_total += s_wave_total[w];
-        const unsigned excl = vd_lookback(tile_state, tile, tile_total);
+        const unsigned excl = vd_lookback(tile_state, epoch, tile, tile_total);
         if (lane == 0) {
             s_tile_excl = excl;
             if (tile == n_tiles - 1u) *out_count = excl + tile_total;
@@ -659,16 +627,19 @@ CullCamera make_cam(const VdCameraUniform* c) {
     return k;
 }
 
-// scratch layout for the scans: [0,16) ticket counter (+pad), [16, 16+8*n_tiles) tile states
-int scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned** ticket, vd_u64** states) {
-    const size_t need = 16 + (size_t)n_tiles * 8;
-    const size_t need16 = (need + 15) & ~(size_t)15;
-    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need16);
-    if (rc) return rc;
-    VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->scratch, 0, need16, ctx->stream));
-    *ticket = reinterpret_cast<unsigned*>(ctx->scratch);
-    *states = reinterpret_cast<vd_u64*>(reinterpret_cast<char*>(ctx->scratch) + 16);
-    vd_time_begin(ctx);   // vd_last_gpu_ms brackets the scan kernel itself, not the state memset
+// scan state: [0,16) 64-bit ticket word {epoch | ticket} (+pad), [16, 16+8*n_tiles) tile granules.
+// Zeroed once when (re)allocated; afterwards the epoch tags make per-launch clearing unnecessary.
+int scan_scratch(VdCtx* ctx, unsigned n_tiles, vd_u64** ticket, vd_u64** states) {
+    const size_t need = (16 + (size_t)n_tiles * 8 + 15) & ~(size_t)15;
+    const bool periodic = (++ctx->scan_launches & ((1ull << 28) - 1)) == 0;   // epoch field is 30 bits: never let it lap
+    if (need > ctx->scan_state_bytes || !ctx->scan_state || periodic) {
+        int rc = vd_ensure(ctx, &ctx->scan_state, &ctx->scan_state_bytes, need);
+        if (rc) return rc;
+        VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->scan_state, 0, ctx->scan_state_bytes, ctx->stream));
+    }
+    *ticket = reinterpret_cast<vd_u64*>(ctx->scan_state);
+    *states = reinterpret_cast<vd_u64*>(reinterpret_cast<char*>(ctx->scan_state) + 16);
+    vd_time_begin(ctx);   // vd_last_gpu_ms brackets the scan kernel itself
     return VD_OK;
 }
 
@@ -718,8 +689,17 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
     }
     if (!d_instances || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_compact: null instances/out");
     int variant = ctx->cull_variant;
-    unsigned* ticket; vd_u64* states;
+    vd_u64* ticket; vd_u64* states;
     int rc = VD_OK;
+#define VD_LAUNCH_ABL(A)                                                                                          \
+    do {                                                                                                         \
+        const unsigned n_tiles = (n_inst + kBlock * 32 - 1) / (kBlock * 32);                                     \
+        rc = scan_scratch(ctx, n_tiles, &ticket, &states);                                                       \
+        if (rc) return rc;                                                                                       \
+        hipLaunchKernelGGL((cull_compact_kernel<32, 0, 0, A>), dim3(n_tiles), dim3(kBlock),                      \
+                           (compact_lds_bytes<32, 0, 0>()), ctx->stream, make_cam(camera), d_meshes, n_mesh,     \
+                           d_instances, n_inst, d_out, d_out_count, states, ticket, n_tiles, first_instance);    \
+    } while (0)
 #define VD_LAUNCH_COMPACT(R, L, O)                                                                              \
     do {                                                                                                         \
         const unsigned n_tiles = (n_inst + kBlock * (R) - 1) / (kBlock * (R));                                   \
@@ -772,21 +752,26 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
         case 39: VD_LAUNCH_C2(8, 5, 1, 4); break;
         case 40: VD_LAUNCH_C2(16, 9, 0, 4); break;
         case 41: VD_LAUNCH_C2(16, 9, 0, 6); break;
-        case 20: case 21: case 22: case 23: case 24: case 25: {
-            const unsigned rounds = variant == 20 || variant == 23 ? 4u : (variant == 21 || variant == 24 ? 8u : 16u);
-            const unsigned n_tiles = (n_inst + kBlock * rounds - 1) / (kBlock * rounds);
-            rc = scan_scratch(ctx, n_tiles, &ticket, &states);
-            if (rc) return rc;
-            const unsigned grid = min(n_tiles, (unsigned)ctx->num_cus * 3u);
-            const unsigned lds = kWavesPerBlock * kSlabBytes + rounds * kBlock * 4 + 64;
-            if (variant <= 22)
-                hipLaunchKernelGGL((cull_compact_persistent_kernel<false>), dim3(grid), dim3(kBlock), lds, ctx->stream, make_cam(camera),
-                                   d_meshes, n_mesh, d_instances, n_inst, d_out, d_out_count, states, ticket, n_tiles, first_instance, rounds);
-            else
-                hipLaunchKernelGGL((cull_compact_persistent_kernel<true>), dim3(grid), dim3(kBlock), lds, ctx->stream, make_cam(camera),
-                                   d_meshes, n_mesh, d_instances, n_inst, d_out, d_out_count, states, ticket, n_tiles, first_instance, rounds);
-            break;
-        }
+#define VD_LAUNCH_WAVE(R, MW)                                                                                    \
+    do {                                                                                                         \
+        const unsigned n_tiles = (n_inst + kWave * (R) - 1) / (kWave * (R));                                     \
+        rc = scan_scratch(ctx, n_tiles, &ticket, &states);                                                       \
+        if (rc) return rc;                                                                                       \
+        hipLaunchKernelGGL((cull_compact_wave_kernel<R, MW>), dim3((n_tiles + 3) / 4), dim3(kBlock),             \
+                           kWavesPerBlock * (kSlabBytes + (R) * kWave * 4), ctx->stream, make_cam(camera),       \
+                           d_meshes, n_mesh, d_instances, n_inst, d_out, d_out_count, states, ticket, n_tiles,   \
+                           first_instance);                                                                      \
+    } while (0)
+        case 60: VD_LAUNCH_WAVE(8, 3); break;
+        case 61: VD_LAUNCH_WAVE(16, 3); break;
+        case 62: VD_LAUNCH_WAVE(32, 3); break;
+        case 63: VD_LAUNCH_WAVE(64, 3); break;
+        case 64: VD_LAUNCH_WAVE(16, 4); break;
+        case 50: VD_LAUNCH_ABL(1); break;
+        case 51: VD_LAUNCH_ABL(2); break;
+        case 52: VD_LAUNCH_ABL(4); break;
+        case 53: VD_LAUNCH_ABL(7); break;
+        case 54: VD_LAUNCH_ABL(3); break;
         case 100: case 101: case 102: case 103: {
             const unsigned rounds = 8, per_block = kBlock * rounds;
             const unsigned blocks = n_inst / per_block;
@@ -817,7 +802,7 @@ int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t
     }
     if (!d_in || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_compact_draws: null in/out");
     const unsigned n_tiles = (n + kCompactTile - 1) / kCompactTile;
-    unsigned* ticket; vd_u64* states;
+    vd_u64* ticket; vd_u64* states;
     int rc = scan_scratch(ctx, n_tiles, &ticket, &states);
     if (rc) return rc;
     hipLaunchKernelGGL(compact_draws_kernel, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, d_in, n, d_out, d_out_count,

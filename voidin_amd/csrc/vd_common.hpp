@@ -24,6 +24,9 @@ struct VdCtx {
 
     // grow-only device scratch arenas
     void* scratch = nullptr;     size_t scratch_bytes = 0;     // general purpose
+    void* scan_state = nullptr;  size_t scan_state_bytes = 0;  // look-back granules + ticket word (epoch-tagged)
+    unsigned long long scan_launches = 0;
+    void* dbg_ptr = nullptr; unsigned dbg_count = 0;   // tuning hooks
     void* stage_in = nullptr;    size_t stage_in_bytes = 0;    // host-pointer API staging
     void* stage_out = nullptr;   size_t stage_out_bytes = 0;
     void* stage_aux = nullptr;   size_t stage_aux_bytes = 0;
@@ -96,39 +99,63 @@ typedef unsigned long long vd_u64;
 #define VD_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 // ---- single-pass ordered scan across workgroups ("decoupled look-back") ----------------
-// tile_state[t] is one naturally aligned 8-byte {status:32 | value:32} granule written by ONE
-// agent-scope store and polled by agent-scope loads (write-through / L1-bypassing on gfx950),
-// so the data is its own flag and no fence is needed.  Words are zeroed by a
-// hipMemsetAsync ahead of every launch.  Tickets come from an atomic counter, so every
+// tile_state[t] is one naturally aligned 8-byte {epoch:30 | status:2 | value:32} granule written
+// by ONE agent-scope store and polled by agent-scope loads (write-through / L1-bypassing on
+// gfx950), so the data is its own flag and no fence is needed.  A granule whose epoch is not the
+// launch's epoch is INVALID, so nothing has to be zeroed between launches: the 64-bit ticket
+// word {epoch:32 | next ticket:32} hands out both, and the workgroup that draws the last ticket
+// re-arms it for the next launch ({epoch + 1, 0}).  Tickets come from an atomic counter, so every
 // predecessor of a running tile is itself running or finished: no residency assumption.
-enum : unsigned { VD_TILE_INVALID = 0u, VD_TILE_AGGREGATE = 1u, VD_TILE_INCLUSIVE = 2u };
+enum : unsigned { VD_TILE_AGGREGATE = 1u, VD_TILE_INCLUSIVE = 2u };
 
-__device__ __forceinline__ vd_u64 vd_tile_pack(unsigned status, unsigned value) {
-    return ((vd_u64)status << 32) | value;
+__device__ __forceinline__ vd_u64 vd_tile_pack(unsigned epoch, unsigned status, unsigned value) {
+    return ((vd_u64)(epoch & 0x3fffffffu) << 34) | ((vd_u64)status << 32) | value;
+}
+
+// ONE lane: draw a ticket.  Returns the ticket; *epoch = this launch's epoch.
+__device__ __forceinline__ unsigned vd_take_ticket(vd_u64* ticket_word, unsigned n_tiles, unsigned* epoch) {
+    const vd_u64 t = __hip_atomic_fetch_add(ticket_word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned ticket = (unsigned)t, ep = (unsigned)(t >> 32);
+    *epoch = ep;
+    if (ticket == n_tiles - 1u)   // every ticket of this launch is out: re-arm for the next one
+        __hip_atomic_store(ticket_word, (vd_u64)(ep + 1u) << 32, VD_RLX_AGENT);
+    return ticket;
 }
 
 // Called by ONE full wave of the workgroup. Returns the exclusive prefix of tile `t`
 // (sum of `total` over tiles < t) in every lane, after publishing this tile's state.
-__device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned t, unsigned total) {
+__device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned epoch, unsigned t, unsigned total) {
     const unsigned lane = vd_lane();
+    const unsigned ep = epoch & 0x3fffffffu;
     if (t == 0) {
-        if (lane == 0) __hip_atomic_store(&tile_state[0], vd_tile_pack(VD_TILE_INCLUSIVE, total), VD_RLX_AGENT);
+        if (lane == 0) __hip_atomic_store(&tile_state[0], vd_tile_pack(ep, VD_TILE_INCLUSIVE, total), VD_RLX_AGENT);
         return 0u;
     }
-    if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(VD_TILE_AGGREGATE, total), VD_RLX_AGENT);
+    if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_AGGREGATE, total), VD_RLX_AGENT);
     unsigned exclusive = 0u;
     int look = (int)t - 1;
+    {   // tiles finish roughly in ticket order: wait for the immediate predecessor with ONE lane
+        // (one 8-byte poll per iteration instead of a 64-granule window), then sweep the window
+        vd_u64 s0 = 0;
+        if (lane == 0) {
+            s0 = __hip_atomic_load(&tile_state[look], VD_RLX_AGENT);
+            while ((unsigned)(s0 >> 34) != ep || ((unsigned)(s0 >> 32) & 3u) == 0u) {
+                __builtin_amdgcn_s_sleep(8);
+                s0 = __hip_atomic_load(&tile_state[look], VD_RLX_AGENT);
+            }
+        }
+    }
     for (;;) {
         const int idx = look - (int)lane;
-        vd_u64 s = vd_tile_pack(VD_TILE_INCLUSIVE, 0u);   // virtual tiles before 0
+        vd_u64 s = vd_tile_pack(ep, VD_TILE_INCLUSIVE, 0u);   // virtual tiles before 0
         if (idx >= 0) {
             s = __hip_atomic_load(&tile_state[idx], VD_RLX_AGENT);
-            while ((unsigned)(s >> 32) == VD_TILE_INVALID) {
+            while ((unsigned)(s >> 34) != ep || ((unsigned)(s >> 32) & 3u) == 0u) {   // not written in this launch yet
                 __builtin_amdgcn_s_sleep(1);
                 s = __hip_atomic_load(&tile_state[idx], VD_RLX_AGENT);
             }
         }
-        const unsigned status = (unsigned)(s >> 32);
+        const unsigned status = (unsigned)(s >> 32) & 3u;
         const unsigned value = (unsigned)s;
         const unsigned long long incl = __ballot(status == VD_TILE_INCLUSIVE);
         // lanes at or before the first INCLUSIVE one (closest predecessors first) contribute
@@ -140,7 +167,7 @@ __device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned t, 
         if (incl) break;
         look -= 64;
     }
-    if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(VD_TILE_INCLUSIVE, exclusive + total), VD_RLX_AGENT);
+    if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_INCLUSIVE, exclusive + total), VD_RLX_AGENT);
     return exclusive;
 }
 #endif  // __HIPCC__
