@@ -627,22 +627,6 @@ CullCamera make_cam(const VdCameraUniform* c) {
     return k;
 }
 
-// scan state: [0,16) 64-bit ticket word {epoch | ticket} (+pad), [16, 16+8*n_tiles) tile granules.
-// Zeroed once when (re)allocated; afterwards the epoch tags make per-launch clearing unnecessary.
-int scan_scratch(VdCtx* ctx, unsigned n_tiles, vd_u64** ticket, vd_u64** states) {
-    const size_t need = (16 + (size_t)n_tiles * 8 + 15) & ~(size_t)15;
-    const bool periodic = (++ctx->scan_launches & ((1ull << 28) - 1)) == 0;   // epoch field is 30 bits: never let it lap
-    if (need > ctx->scan_state_bytes || !ctx->scan_state || periodic) {
-        int rc = vd_ensure(ctx, &ctx->scan_state, &ctx->scan_state_bytes, need);
-        if (rc) return rc;
-        VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->scan_state, 0, ctx->scan_state_bytes, ctx->stream));
-    }
-    *ticket = reinterpret_cast<vd_u64*>(ctx->scan_state);
-    *states = reinterpret_cast<vd_u64*>(reinterpret_cast<char*>(ctx->scan_state) + 16);
-    vd_time_begin(ctx);   // vd_last_gpu_ms brackets the scan kernel itself
-    return VD_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -694,7 +678,7 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
 #define VD_LAUNCH_ABL(A)                                                                                          \
     do {                                                                                                         \
         const unsigned n_tiles = (n_inst + kBlock * 32 - 1) / (kBlock * 32);                                     \
-        rc = scan_scratch(ctx, n_tiles, &ticket, &states);                                                       \
+        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);                                                       \
         if (rc) return rc;                                                                                       \
         hipLaunchKernelGGL((cull_compact_kernel<32, 0, 0, A>), dim3(n_tiles), dim3(kBlock),                      \
                            (compact_lds_bytes<32, 0, 0>()), ctx->stream, make_cam(camera), d_meshes, n_mesh,     \
@@ -703,7 +687,7 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
 #define VD_LAUNCH_COMPACT(R, L, O)                                                                              \
     do {                                                                                                         \
         const unsigned n_tiles = (n_inst + kBlock * (R) - 1) / (kBlock * (R));                                   \
-        rc = scan_scratch(ctx, n_tiles, &ticket, &states);                                                       \
+        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);                                                       \
         if (rc) return rc;                                                                                       \
         hipLaunchKernelGGL((cull_compact_kernel<R, L, O>), dim3(n_tiles), dim3(kBlock),                          \
                            (compact_lds_bytes<R, L, O>()), ctx->stream, make_cam(camera), d_meshes, n_mesh,      \
@@ -733,7 +717,7 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
 #define VD_LAUNCH_C2(R, CH, PF, MW)                                                                              \
     do {                                                                                                         \
         const unsigned n_tiles = (n_inst + kBlock * (R) - 1) / (kBlock * (R));                                   \
-        rc = scan_scratch(ctx, n_tiles, &ticket, &states);                                                       \
+        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);                                                       \
         if (rc) return rc;                                                                                       \
         hipLaunchKernelGGL((cull_compact2_kernel<R, CH, PF, MW>), dim3(n_tiles), dim3(kBlock),                   \
                            kWavesPerBlock * kWave * (CH) * 16 + (R) * kBlock * 4 + 32, ctx->stream,              \
@@ -755,7 +739,7 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
 #define VD_LAUNCH_WAVE(R, MW)                                                                                    \
     do {                                                                                                         \
         const unsigned n_tiles = (n_inst + kWave * (R) - 1) / (kWave * (R));                                     \
-        rc = scan_scratch(ctx, n_tiles, &ticket, &states);                                                       \
+        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);                                                       \
         if (rc) return rc;                                                                                       \
         hipLaunchKernelGGL((cull_compact_wave_kernel<R, MW>), dim3((n_tiles + 3) / 4), dim3(kBlock),             \
                            kWavesPerBlock * (kSlabBytes + (R) * kWave * 4), ctx->stream, make_cam(camera),       \
@@ -803,7 +787,7 @@ int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t
     if (!d_in || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_compact_draws: null in/out");
     const unsigned n_tiles = (n + kCompactTile - 1) / kCompactTile;
     vd_u64* ticket; vd_u64* states;
-    int rc = scan_scratch(ctx, n_tiles, &ticket, &states);
+    int rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);
     if (rc) return rc;
     hipLaunchKernelGGL(compact_draws_kernel, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, d_in, n, d_out, d_out_count,
                        states, ticket, n_tiles);

@@ -52,6 +52,9 @@ struct VdCtx {
 // Grow-only arena helper. Never called between a kernel's enqueue and its completion on the
 // same buffer without a stream sync (callers sync before growing).
 int vd_ensure(VdCtx* ctx, void** buf, size_t* cur, size_t need);
+// Look-back scan state for n_tiles tiles: *ticket = 64-bit {epoch | ticket} word, *states = granules.
+// Zeroed once when (re)allocated; the epoch tags make per-launch clearing unnecessary.
+int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer);
 
 static inline void vd_time_begin(VdCtx* ctx) {
     (void)hipEventRecord(ctx->ev_start, ctx->stream);
@@ -124,11 +127,12 @@ __device__ __forceinline__ unsigned vd_take_ticket(vd_u64* ticket_word, unsigned
 
 // Called by ONE full wave of the workgroup. Returns the exclusive prefix of tile `t`
 // (sum of `total` over tiles < t) in every lane, after publishing this tile's state.
-__device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned epoch, unsigned t, unsigned total) {
+// `first` marks the first tile of a segment (segmented scan): its prefix restarts at 0.
+__device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned epoch, unsigned t, unsigned total, bool first = false) {
     const unsigned lane = vd_lane();
     const unsigned ep = epoch & 0x3fffffffu;
-    if (t == 0) {
-        if (lane == 0) __hip_atomic_store(&tile_state[0], vd_tile_pack(ep, VD_TILE_INCLUSIVE, total), VD_RLX_AGENT);
+    if (t == 0 || first) {
+        if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_INCLUSIVE, total), VD_RLX_AGENT);
         return 0u;
     }
     if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_AGGREGATE, total), VD_RLX_AGENT);
