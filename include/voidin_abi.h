@@ -296,6 +296,21 @@ int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene /* struct on host, poin
                  const VdRay* d_rays, uint32_t n_rays, VdHit* d_out);
 
 /* ------------------------------------------------------------------------------------ */
+/* Instance animation  (SURVEY.md §8f N2 — the upstream mutator of the cull / TLAS input)  */
+/* ------------------------------------------------------------------------------------ */
+/* Replaces the `update` compute pass (shaders/compute_update.wgsl:10-28, recorded by
+ * ComputeUpdate::record, crates/app/src/pass/compute_update.rs:51-73): for every listed
+ * instance id, transform = rotz(speed * dt) * transform with speed = 2*sin(time*0.5), negated
+ * when transform[3][2] <= -15.  sin/cos are evaluated once on the host (libm, f32) for the
+ * two possible angles, so the device work is plain mul/add and matches the oracle bit for bit
+ * (WGSL leaves sin/cos precision to the driver).
+ * fix_inverse != 0 additionally keeps inv_transform consistent (inv' = inv * rotz(-angle));
+ * the reference leaves it stale.                                   */
+int vd_compute_update_dev(VdCtx* ctx, const uint32_t* d_indices, uint32_t n_indices,
+                          VdInstance* d_instances, uint32_t n_instances, float time, float dt,
+                          int fix_inverse);
+
+/* ------------------------------------------------------------------------------------ */
 /* Instrumentation (replaces the wgpu_profiler scopes: visibility.rs:50,243-245)         */
 /* ------------------------------------------------------------------------------------ */
 /* Milliseconds the GPU spent in the most recent call's kernels, measured with HIP events

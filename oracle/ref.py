@@ -42,6 +42,7 @@ def load() -> C.CDLL:
             "vd_ref_tlas_refit_wide": (_I, [_P, _U, _P, _U, _P]),
             "vd_ref_trace": (_I, [C.POINTER(abi.TraceScene), _P, _U, _P, _P, _I]),
             "vd_ref_traverse_iter": (_I, [_P, _U, _P, _P, _P, _U, _P]),
+            "vd_ref_compute_update": (_I, [_P, _U, _P, _U, C.c_float, C.c_float, _I]),
             "vd_ref_version": (C.c_char_p, []),
         }
         for name, (res, args) in protos.items():
@@ -82,6 +83,13 @@ def cull_margins(camera, meshes, instances):
     _chk(load().vd_ref_cull_margins(camera.ctypes.data, meshes.ctypes.data, len(meshes),
                                     instances.ctypes.data, n, mx.ctypes.data, my.ctypes.data, r.ctypes.data))
     return mx, my, r
+
+
+def compute_update(indices, instances, time, dt, fix_inverse=False):
+    indices = _c(indices, np.uint32)
+    inst = np.array(instances, dtype=abi.INSTANCE, copy=True)
+    _chk(load().vd_ref_compute_update(indices.ctypes.data, len(indices), inst.ctypes.data, len(inst), float(time), float(dt), int(fix_inverse)))
+    return inst
 
 
 def compact(draws, pad_tail=False):

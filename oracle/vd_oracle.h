@@ -66,6 +66,10 @@ int vd_ref_traverse_iter(const VdBvhNode* nodes, uint32_t n_nodes, const float* 
                          const uint32_t* indices, const VdRay* rays, uint32_t n_rays,
                          float* out_dist);
 
+/* shaders/compute_update.wgsl:10-28 (+ fix-forward of inv_transform) */
+int vd_ref_compute_update(const uint32_t* indices, uint32_t n_indices, VdInstance* instances,
+                          uint32_t n_instances, float time, float dt, int fix_inverse);
+
 const char* vd_ref_version(void);
 
 #ifdef __cplusplus

@@ -150,4 +150,37 @@ int vd_ref_compact(const VdDrawIndexedIndirect* in, uint32_t n, VdDrawIndexedInd
     return VD_OK;
 }
 
+/* shaders/compute_update.wgsl:10-28.  rotz = from_rotation_z(angle) (utils/math.wgsl:55-63):
+ * columns (c, s, 0, 0), (-s, c, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1); product column j =
+ * ((R.c0*T[j].x + R.c1*T[j].y) + R.c2*T[j].z) + R.c3*T[j].w (spec decision C2'). */
+static void mat_mul_cm(const float* A, const float* B, float* out) { /* out = A * B, column-major */
+    float r[16];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i)
+            r[4 * j + i] = ((A[i] * B[4 * j] + A[4 + i] * B[4 * j + 1]) + A[8 + i] * B[4 * j + 2]) + A[12 + i] * B[4 * j + 3];
+    memcpy(out, r, sizeof(r));
+}
+
+int vd_ref_compute_update(const uint32_t* indices, uint32_t n_indices, VdInstance* instances,
+                          uint32_t n_instances, float time, float dt, int fix_inverse) {
+    if ((n_indices && !indices) || !instances) return VD_ERR_INVALID_ARG;
+    const float speed0 = 2.0f * sinf(time * 0.5f);
+    for (uint32_t k = 0; k < n_indices; ++k) {
+        const uint32_t idx = indices[k];
+        if (idx >= n_instances) continue;               /* robust-buffer-access: out of range is dropped */
+        float* T = instances[idx].transform;
+        float speed = speed0;
+        if (T[14] > -15.0f) speed *= 1.0f; else speed *= -1.0f;   /* transform[3][2] */
+        const float ang = speed * dt;
+        const float c = cosf(ang), s = sinf(ang);
+        const float R[16] = {c, s, 0, 0, -s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        mat_mul_cm(R, T, T);
+        if (fix_inverse) {
+            const float Ri[16] = {c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};   /* rotz(-ang) */
+            mat_mul_cm(instances[idx].inv_transform, Ri, instances[idx].inv_transform);
+        }
+    }
+    return VD_OK;
+}
+
 const char* vd_ref_version(void) { return "vd_oracle 0.1 (voidin v0.69.0 restatement; parity unpinned)"; }

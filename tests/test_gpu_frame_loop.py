@@ -1,0 +1,76 @@
+"""the dynamic-scene frame loop — compute_update (instance animation) ->
+TLAS refit -> cull + compaction — against the oracle running the same steps."""
+import numpy as np
+import pytest
+
+from conftest import fields_equal
+from voidin_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_compute_update_matches_oracle(ctx, oracle):
+    import torch
+    inst = synth.instances(5000, seed=synth.SEED_BASE + 9, extent=60.0)
+    ids = np.arange(0, 5000, 3, dtype=np.uint32)
+    ids[5] = 999_999          # out of range: dropped
+    d_i, d_ids = ctx.upload(inst), ctx.upload(ids)
+    for fix in (False, True):
+        want = oracle.compute_update(ids, inst, 1.7, 0.016, fix)
+        d_i = ctx.upload(inst)
+        ctx.compute_update_dev(d_ids, len(ids), d_i, len(inst), 1.7, 0.016, fix)
+        torch.cuda.synchronize()
+        got = d_i.cpu().numpy().view(abi.INSTANCE)
+        assert got.tobytes() == want.tobytes()
+    # untouched instances are untouched; with fix_inverse the pair stays an inverse
+    mask = np.ones(5000, bool); mask[ids[ids < 5000]] = False
+    assert got[mask].tobytes() == inst[mask].tobytes()
+    T = got["transform"][0].reshape(4, 4).astype(np.float64).T
+    Ti = got["inv_transform"][0].reshape(4, 4).astype(np.float64).T
+    assert np.abs(T @ Ti - np.eye(4)).max() < 1e-3
+
+
+def test_frame_loop_animation_refit_cull(ctx, oracle):
+    import torch
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    n = 3000
+    inst = synth.instances(n, seed=synth.SEED_BASE + 11, extent=80.0, scale_range=(0.02, 0.4))
+    ids = np.arange(0, n, 2, dtype=np.uint32)
+    nodes = ctx.tlas_build(inst, meshes)
+    d_m, d_i, d_ids = ctx.upload(meshes), ctx.upload(inst), ctx.upload(ids)
+    d_t = ctx.upload(nodes)
+    d_out, d_cnt = ctx.empty(n * 20), torch.zeros(4, dtype=torch.int32, device="cuda")
+    ref_inst, ref_nodes = inst.copy(), nodes.copy()
+    for frame in range(4):
+        t, dt = 0.3 + 0.016 * frame, 0.016
+        ctx.compute_update_dev(d_ids, len(ids), d_i, n, t, dt, True)
+        ctx.tlas_refit_dev(d_i, n, d_m, len(meshes), d_t)
+        ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt)
+        torch.cuda.synchronize()
+        ref_inst = oracle.compute_update(ids, ref_inst, t, dt, True)
+        ref_nodes = oracle.tlas_refit(ref_inst, meshes, ref_nodes)
+        want, wn = oracle.compact(oracle.cull_emit(cam, meshes, ref_inst))
+        cnt = int(d_cnt[0].item())
+        assert d_i.cpu().numpy().view(abi.INSTANCE).tobytes() == ref_inst.tobytes()
+        assert fields_equal(d_t.cpu().numpy()[: (2 * n + 1) * 32].view(abi.TLAS_NODE), ref_nodes)
+        assert cnt == wn and d_out.cpu().numpy()[: cnt * 20].tobytes() == want[:wn].tobytes()
+
+
+def test_tlas_wide_64k_refit_is_idempotent(ctx):
+    """BASELINE config 5: 64k-instance TLAS in the explicitly-named wide layout (the reference's
+    16-bit packing stops at 32768: tlas.rs:71).  refit(build(x), x) == build(x)."""
+    import torch
+    meshes = synth.mesh_infos()
+    n = 65536
+    inst = synth.instances(n, seed=synth.SEED_BASE + 12, extent=1500.0, with_inverse=False)
+    d_i, d_m = ctx.upload(inst), ctx.upload(meshes)
+    d_t = ctx.empty((2 * n + 1) * 48)
+    ctx.tlas_build_dev(d_i, n, d_m, len(meshes), d_t, wide=True)
+    torch.cuda.synchronize()
+    a = d_t.cpu().numpy()[: (2 * n + 1) * 48].copy()
+    ctx.tlas_refit_dev(d_i, n, d_m, len(meshes), d_t, wide=True)
+    torch.cuda.synchronize()
+    b = d_t.cpu().numpy()[: (2 * n + 1) * 48]
+    assert a.tobytes() == b.tobytes()
+    w = a.view(abi.TLAS_NODE_WIDE)
+    assert w["left"][0] == 2 * n - 1 and w["right"][0] == 2 * n - 1 and (w["instance_idx"][1:n + 1] == np.arange(n)).all()

@@ -16,6 +16,8 @@
 //     tiles, so instances are read exactly once and only survivors are written.
 #include "vd_common.hpp"
 
+#include <math.h>
+
 namespace {
 
 constexpr int kWave = 64;
@@ -618,6 +620,47 @@ __global__ __launch_bounds__(kBlock) void compact_draws_kernel(const VdDrawIndex
     }
 }
 
+// compute_update.wgsl:10-28 — one lane per listed instance; (c,s) for both signs come from the host.
+struct RotZ { float c_pos, s_pos, c_neg, s_neg; };
+__device__ __forceinline__ void mat_mul_cm(const float* A, const float* B, float* out) {
+    float r[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            r[4 * j + i] = ((A[i] * B[4 * j] + A[4 + i] * B[4 * j + 1]) + A[8 + i] * B[4 * j + 2]) + A[12 + i] * B[4 * j + 3];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) out[k] = r[k];
+}
+__global__ __launch_bounds__(64) void compute_update_kernel(const unsigned* __restrict__ indices, unsigned n_indices,
+                                                            VdInstance* __restrict__ inst, unsigned n_inst, RotZ rz, int fix_inverse) {
+    const unsigned k = blockIdx.x * 64u + threadIdx.x;
+    if (k >= n_indices) return;
+    const unsigned idx = indices[k];
+    if (idx >= n_inst) return;
+    float T[16];
+    float4* t4 = reinterpret_cast<float4*>(inst[idx].transform);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float4 v = t4[j]; T[4 * j] = v.x; T[4 * j + 1] = v.y; T[4 * j + 2] = v.z; T[4 * j + 3] = v.w; }
+    const bool pos = T[14] > -15.0f;                       // transform[3][2]
+    const float c = pos ? rz.c_pos : rz.c_neg, s = pos ? rz.s_pos : rz.s_neg;
+    const float R[16] = {c, s, 0.0f, 0.0f, -s, c, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+    float O[16];
+    mat_mul_cm(R, T, O);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t4[j] = make_float4(O[4 * j], O[4 * j + 1], O[4 * j + 2], O[4 * j + 3]);
+    if (fix_inverse) {
+        float4* i4 = reinterpret_cast<float4*>(inst[idx].inv_transform);
+        float I[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float4 v = i4[j]; I[4 * j] = v.x; I[4 * j + 1] = v.y; I[4 * j + 2] = v.z; I[4 * j + 3] = v.w; }
+        const float Ri[16] = {c, -s, 0.0f, 0.0f, s, c, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+        mat_mul_cm(I, Ri, O);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) i4[j] = make_float4(O[4 * j], O[4 * j + 1], O[4 * j + 2], O[4 * j + 3]);
+    }
+}
+
 CullCamera make_cam(const VdCameraUniform* c) {
     CullCamera k;
     memcpy(k.view, c->view, sizeof(k.view));
@@ -791,6 +834,22 @@ int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t
     if (rc) return rc;
     hipLaunchKernelGGL(compact_draws_kernel, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, d_in, n, d_out, d_out_count,
                        states, ticket, n_tiles);
+    vd_time_end(ctx);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    return VD_OK;
+}
+
+int vd_compute_update_dev(VdCtx* ctx, const uint32_t* d_indices, uint32_t n_indices, VdInstance* d_instances,
+                          uint32_t n_instances, float time, float dt, int fix_inverse) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (n_indices == 0) return VD_OK;
+    if (!d_indices || !d_instances) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_compute_update: null indices/instances");
+    const float speed = 2.0f * sinf(time * 0.5f);          // compute_update.wgsl:20
+    const float a_pos = (speed * 1.0f) * dt, a_neg = (speed * -1.0f) * dt;
+    RotZ rz{cosf(a_pos), sinf(a_pos), cosf(a_neg), sinf(a_neg)};
+    vd_time_begin(ctx);
+    hipLaunchKernelGGL(compute_update_kernel, dim3((n_indices + 63) / 64), dim3(64), 0, ctx->stream, d_indices, n_indices,
+                       d_instances, n_instances, rz, fix_inverse);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;

@@ -99,6 +99,10 @@ class Context:
     def compact_draws_dev(self, d_in, n, d_out, d_count):
         self._chk(self.lib.vd_compact_draws_dev(self.h, abi.ptr(d_in), n, abi.ptr(d_out), abi.ptr(d_count)))
 
+    def compute_update_dev(self, d_indices, n_indices, d_instances, n_instances, time, dt, fix_inverse=False):
+        self._chk(self.lib.vd_compute_update_dev(self.h, abi.ptr(d_indices), n_indices, abi.ptr(d_instances), n_instances,
+                                                 float(time), float(dt), int(fix_inverse)))
+
     # -- cull / emit (host arrays) ----------------------------------------------------------
     def cull_emit(self, camera, meshes, instances) -> np.ndarray:
         cam = np.ascontiguousarray(camera, dtype=abi.CAMERA)
