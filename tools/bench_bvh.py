@@ -71,3 +71,39 @@ for n in [1000, args.tlas]:
         t = time.time(); w = ref.tlas_build(inst, meshes); dt = time.time() - t
         got = d_t.cpu().numpy()[: (2 * n + 1) * 32].view(abi.TLAS_NODE)
         print(f"  oracle TLAS build {dt*1e3:.1f} ms; match {got.tobytes()==w.tobytes()}")
+
+# ---- traversal: bvh_gpu.rs-shaped scene (one big mesh + many instances), primary rays ----
+from oracle import ref as _ref  # noqa: E402  (bench tool: oracle used for the CPU leg only)
+tv, ti = synth.knot_mesh(512, 128)                        # 131k triangles
+nodes_b, idx_b = ctx.bvh_build(tv, ti)
+infos = np.zeros(1, dtype=abi.MESH_INFO)
+infos[0]["min"], infos[0]["max"] = synth.mesh_bounds(tv)
+infos[0]["index_count"] = len(idx_b)
+inst_t = synth.instances(2000, n_mesh=1, seed=synth.SEED_BASE + 8, extent=120.0, scale_range=(0.5, 2.0))
+tl = ctx.tlas_build(inst_t, infos)
+cam_t = synth.camera_uniform(eye=(0, 2.5, 90), pitch_deg=0)
+W = 1024
+rays = synth.primary_rays(cam_t, W, W)
+scene_np = (tl, inst_t, infos, nodes_b, tv, idx_b)
+d_arrs = [ctx.upload(np.ascontiguousarray(a)) for a in (tl, inst_t, infos, nodes_b, tv.reshape(-1), idx_b)]
+s = abi.TraceScene()
+s.tlas_nodes, s.n_tlas_nodes = d_arrs[0].data_ptr(), len(tl)
+s.instances, s.n_instances = d_arrs[1].data_ptr(), len(inst_t)
+s.meshes, s.n_meshes = d_arrs[2].data_ptr(), 1
+s.bvh_nodes, s.n_bvh_nodes = d_arrs[3].data_ptr(), len(nodes_b)
+s.vertices, s.n_vertices = d_arrs[4].data_ptr(), len(tv)
+s.indices, s.n_indices = d_arrs[5].data_ptr(), len(idx_b)
+import ctypes as C  # noqa: E402
+d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
+for r in range(3):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    rc = ctx.lib.vd_trace_dev(ctx.h, C.byref(s), d_rays.data_ptr(), len(rays), d_hits.data_ptr())
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    assert rc == 0, ctx.lib.vd_last_error(ctx.h)
+hits = d_hits.cpu().numpy()[: len(rays) * 16].view(abi.HIT)
+print(f"trace: {len(rays)} rays, {dt*1e3:.2f} ms = {len(rays)/dt/1e6:.1f} Mrays/s, hit fraction {hits['hit'].mean():.3f}", flush=True)
+if args.verify:
+    t = time.time(); want, ms = _ref.trace(scene_np, rays[::16], threads=os.cpu_count()); dtc = time.time() - t
+    sub = hits[::16]
+    ok = np.array_equal(sub["hit"], want["hit"]) and np.allclose(sub["dist"][want["hit"] == 1], want["dist"][want["hit"] == 1], rtol=1e-5, atol=0)
+    print(f"  oracle ({os.cpu_count()} threads) {len(rays)//16/dtc/1e6:.2f} Mrays/s; match {ok}; max stack {ms}")

@@ -103,33 +103,42 @@ __device__ __forceinline__ vd_u64 wave_min_u64(vd_u64 v) {
 
 // tlas.rs:87-105 over the compacted slot arrays; every thread returns the same slot.
 __device__ __forceinline__ unsigned find_best_match(const float* sb, unsigned cap, unsigned cnt,
-                                                    unsigned target, vd_u64* s_red, unsigned* s_res) {
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+                                                    unsigned target, vd_u64* s_red, unsigned call) {
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
     vd_u64 best = ~0ull;
     if (target < cap) {
         const float t0 = sb[target], t1 = sb[cap + target], t2 = sb[2 * cap + target];
         const float t3 = sb[3 * cap + target], t4 = sb[4 * cap + target], t5 = sb[5 * cap + target];
-        for (unsigned i = tid; i < cnt; i += kBuildThreads) {
-            const float dx = vd_max_to(t3, sb[3 * cap + i]) - vd_min_to(t0, sb[i]);
-            const float dy = vd_max_to(t4, sb[4 * cap + i]) - vd_min_to(t1, sb[cap + i]);
-            const float dz = vd_max_to(t5, sb[5 * cap + i]) - vd_min_to(t2, sb[2 * cap + i]);
-            const float area = vd_area(dx, dy, dz);
-            if (i != target && area < 1e30f) {          // `surface_area < smallest` from 1e30, NaN never passes
-                const vd_u64 k = match_key(area, i);
-                best = k < best ? k : best;
+        // four consecutive slots per lane per step: six independent 16-B loads in flight
+        for (unsigned i0 = tid * 4u; i0 < cnt; i0 += kBuildThreads * 4u) {
+            const float4 a0 = *reinterpret_cast<const float4*>(sb + i0), a1 = *reinterpret_cast<const float4*>(sb + cap + i0);
+            const float4 a2 = *reinterpret_cast<const float4*>(sb + 2 * cap + i0), a3 = *reinterpret_cast<const float4*>(sb + 3 * cap + i0);
+            const float4 a4 = *reinterpret_cast<const float4*>(sb + 4 * cap + i0), a5 = *reinterpret_cast<const float4*>(sb + 5 * cap + i0);
+            const float mn0[4] = {a0.x, a0.y, a0.z, a0.w}, mn1[4] = {a1.x, a1.y, a1.z, a1.w}, mn2[4] = {a2.x, a2.y, a2.z, a2.w};
+            const float mx0[4] = {a3.x, a3.y, a3.z, a3.w}, mx1[4] = {a4.x, a4.y, a4.z, a4.w}, mx2[4] = {a5.x, a5.y, a5.z, a5.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned i = i0 + k;
+                const float dx = vd_max_to(t3, mx0[k]) - vd_min_to(t0, mn0[k]);
+                const float dy = vd_max_to(t4, mx1[k]) - vd_min_to(t1, mn1[k]);
+                const float dz = vd_max_to(t5, mx2[k]) - vd_min_to(t2, mn2[k]);
+                const float area = vd_area(dx, dy, dz);
+                if (i < cnt && i != target && area < 1e30f) {   // `surface_area < smallest` from 1e30, NaN never passes
+                    const vd_u64 kk = match_key(area, i);
+                    best = kk < best ? kk : best;
+                }
             }
         }
     }
+    // one barrier per scan: waves fold their best key into a rotating LDS slot with a 64-bit atomic
+    // min; the slot two scans ahead is re-armed by thread 0 while nobody can be reading it
     best = wave_min_u64(best);
-    if (lane == 0) s_red[wave] = best;
+    vd_u64* slot = s_red + (call % 3u);
+    if (lane == 0 && best != ~0ull) atomicMin(slot, best);
+    if (tid == 0) s_red[(call + 1u) % 3u] = ~0ull;
     __syncthreads();
-    if (wave == 0) {
-        vd_u64 v = lane < (kBuildThreads / 64) ? s_red[lane] : ~0ull;
-        v = wave_min_u64(v);
-        if (lane == 0) *s_res = v == ~0ull ? target : (unsigned)v;
-    }
-    __syncthreads();
-    return *s_res;
+    const vd_u64 v = *slot;
+    return v == ~0ull ? target : (unsigned)v;
 }
 
 // tlas.rs:56-84 — one workgroup runs the whole chain.
@@ -137,12 +146,14 @@ template <typename Node>
 __global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restrict__ nodes, unsigned n,
                                                                    float* sb, unsigned* slot_node,
                                                                    unsigned cap) {
-    __shared__ vd_u64 s_red[kBuildThreads / 64];
-    __shared__ unsigned s_res;
+    __shared__ vd_u64 s_red[4];
+    if (threadIdx.x < 4) s_red[threadIdx.x] = ~0ull;
+    __syncthreads();
+    unsigned call = 0;
     unsigned cnt = n, used = n + 1, a = 0;
-    unsigned b = find_best_match(sb, cap, cnt, a, s_red, &s_res);
+    unsigned b = find_best_match(sb, cap, cnt, a, s_red, call++);
     while (cnt > 0) {
-        const unsigned c = find_best_match(sb, cap, cnt, b, s_red, &s_res);
+        const unsigned c = find_best_match(sb, cap, cnt, b, s_red, call++);
         if (a == c) {
             if (threadIdx.x == 0) {
                 const unsigned idx_a = slot_node[a], idx_b = slot_node[b];
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restr
             used += 1;
             cnt -= 1;
             __syncthreads();
-            b = find_best_match(sb, cap, cnt, a, s_red, &s_res);
+            b = find_best_match(sb, cap, cnt, a, s_red, call++);
         } else {
             a = b;
             b = c;
@@ -237,7 +248,7 @@ template <typename Node>
 int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                     Node* d_nodes) {
     // scratch: 6 float slot arrays + slot node ids, capacity n
-    const size_t cap = n;
+    const size_t cap = ((size_t)n + 7) & ~(size_t)3;   // multiple of 4 (+ slack): slot arrays are read 16 B at a time
     const size_t need = cap * 7 * 4 + 256;
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
     if (rc) return rc;
