@@ -784,8 +784,7 @@ __global__ __launch_bounds__(1024) void a_scan_kernel(Seg* segs, const LevelCtl*
 // round step 3: TL per position + rank -> position tables
 __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                       const u32x4* __restrict__ pay, int c, const unsigned* item_pre,
-                                                      unsigned* __restrict__ tmp, unsigned* __restrict__ falsepos,
-                                                      unsigned* __restrict__ truepos) {
+                                                      unsigned* __restrict__ falsepos, unsigned* __restrict__ truepos) {
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
@@ -807,7 +806,6 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
             const unsigned x = ic.rel0 + xr;
             const bool p = (masks[j] >> lane) & 1ull;
             const unsigned tl = run + vd_mbcnt(masks[j]);
-            tmp[s + x] = (tl << 1) | (p ? 1u : 0u);
             if (p) truepos[s + (ttot - tl - 1u)] = x;     // index T: (T+1)-th true from the right
             else falsepos[s + (x - tl)] = x;              // index F: (F+1)-th false from the left
         }
@@ -818,33 +816,48 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
 // round step 4: destinations, scatter, `u`
 __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                       const u32x4* __restrict__ src, u32x4* __restrict__ dst, int c,
-                                                      const unsigned* __restrict__ tmp, const unsigned* __restrict__ falsepos,
+                                                      const unsigned* item_pre, const unsigned* __restrict__ falsepos,
                                                       const unsigned* __restrict__ truepos, unsigned char* __restrict__ is_u_flag) {
+    __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
+    // predicates and TL are recomputed from the payload (cheaper than a per-position word through HBM)
+    unsigned long long masks[4]; u32x4 vals[4];
+    item_masks(sg, ic, src, c, masks, vals);
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned t = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t += (unsigned)__popcll(masks[j]);
+    if (lane == 0u) s_w[wave] = t;
+    __syncthreads();
+    unsigned run = item_pre[blockIdx.x] - item_pre[sg->item_first];
+    for (unsigned w = 0; w < wave; ++w) run += s_w[w];
     const unsigned n = sg->count, s = sg->start, ttot = sg->ttot_cur, ftot = n - ttot;
-    for (unsigned xr = threadIdx.x; xr < ic.n_here; xr += 256u) {
-        const unsigned x = ic.rel0 + xr;
-        const unsigned tp = tmp[s + x];
-        const bool p = tp & 1u;
-        const unsigned tl = tp >> 1;
-        const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
-        const long long tF = F == 0u ? (long long)n : (F <= ttot ? (long long)truepos[s + F - 1u] : -1ll);
-        const bool left = (long long)x < tF;
-        const unsigned fj = (T + 1u <= ftot) ? falsepos[s + T] : n;
-        const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
-        const bool is_u = fetch == n - 1u;
-        unsigned dest;
-        if (is_u) dest = ttot - (p ? 1u : 0u);
-        else if (left) dest = p ? x : (unsigned)tF - 1u;
-        else dest = p ? fj : x - 1u;
-        const u32x4 v = src[s + x];
-        dst[s + dest] = v;
-        if (is_u && c >= 0) {
-            Seg& w = segs[ic.seg];
-            w.u_pay[c] = v; w.u_p[c] = p ? 1u : 0u; w.ttot[c] = ttot;
-            is_u_flag[v.x] = 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned xr = wave * 256u + j * 64u + lane;
+        if (xr < ic.n_here) {
+            const unsigned x = ic.rel0 + xr;
+            const bool p = (masks[j] >> lane) & 1ull;
+            const unsigned tl = run + vd_mbcnt(masks[j]);
+            const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
+            const long long tF = F == 0u ? (long long)n : (F <= ttot ? (long long)truepos[s + F - 1u] : -1ll);
+            const bool left = (long long)x < tF;
+            const unsigned fj = (T + 1u <= ftot) ? falsepos[s + T] : n;
+            const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
+            const bool is_u = fetch == n - 1u;
+            unsigned dest;
+            if (is_u) dest = ttot - (p ? 1u : 0u);
+            else if (left) dest = p ? x : (unsigned)tF - 1u;
+            else dest = p ? fj : x - 1u;
+            dst[s + dest] = vals[j];
+            if (is_u && c >= 0) {
+                Seg& w = segs[ic.seg];
+                w.u_pay[c] = vals[j]; w.u_p[c] = p ? 1u : 0u; w.ttot[c] = ttot;
+                is_u_flag[vals[j].x] = 1;
+            }
         }
+        run += (unsigned)__popcll(masks[j]);
     }
 }
 
@@ -1124,9 +1137,9 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
             }
             hipLaunchKernelGGL(a_count_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_cnt);
             hipLaunchKernelGGL(a_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl, P.item_cnt, P.item_pre);
-            hipLaunchKernelGGL(a_ranks_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre, P.tmp,
+            hipLaunchKernelGGL(a_ranks_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre,
                                P.falsepos, P.truepos);
-            hipLaunchKernelGGL(a_apply_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, P.tmp,
+            hipLaunchKernelGGL(a_apply_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, P.item_pre,
                                P.falsepos, P.truepos, P.is_u);
             u32x4* t = src; src = dst; dst = t;
         }
