@@ -6,14 +6,14 @@ oracle produces — the script asserts that before writing.  Each .npz holds inp
 outputs only (no reference source text).  Parity stays "unpinned" in the sense of SURVEY.md §8c:
 these fixtures freeze OUR restatement, they are not outputs of the reference binary.
 
-Usage: python tools/make_golden.py
+Usage: python tests/golden/make_golden.py
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import np_restate as npr  # noqa: E402
 from oracle import ref  # noqa: E402

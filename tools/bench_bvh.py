@@ -16,7 +16,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--u", type=int, default=2048)
 ap.add_argument("--v", type=int, default=2048)
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--verify", action="store_true")
 ap.add_argument("--tlas", type=int, default=32768)
 args = ap.parse_args()
 
@@ -40,15 +39,7 @@ for r in range(args.reps + 1):
     print(f"  build {r}: {dt*1e3:.1f} ms  ({n_tri/dt/1e6:.1f} Mprims/s), nodes {n_nodes}, gpu_ms {ctx.last_gpu_ms():.1f}", flush=True)
 best = min(times)
 print(f"BLAS build: {n_tri} prims, best {best*1e3:.1f} ms = {n_tri/best/1e6:.1f} Mprims/s")
-if args.verify:
-    from oracle import ref
-    t = time.time()
-    wn, wi = ref.bvh_build(v, i)
-    dt = time.time() - t
-    nodes = d_n.cpu().numpy()[: n_nodes * 32].view(abi.BVH_NODE)
-    idx = d_i.cpu().numpy().view(np.uint32)[: 3 * n_tri]
-    ok = len(nodes) == len(wn) and all(np.array_equal(nodes[f], wn[f]) for f in wn.dtype.names) and np.array_equal(idx, wi)
-    print(f"oracle: {dt:.1f}s = {n_tri/dt/1e6:.3f} Mprims/s (1 core); bit-exact: {ok}")
+# (parity against the oracle lives in tests/test_gpu_blas.py and tests/perf_verify_bvh.py; this tool only times)
 
 # TLAS
 meshes = synth.mesh_infos()
@@ -66,14 +57,8 @@ for n in [1000, args.tlas]:
         ctx.tlas_refit_dev(d_inst, n, d_m, len(meshes), d_t)
         torch.cuda.synchronize(); dt = time.perf_counter() - t
     print(f"TLAS refit n={n}: {dt*1e3:.3f} ms (gpu {ctx.last_gpu_ms():.3f} ms)", flush=True)
-    if args.verify and n <= 4096:
-        from oracle import ref
-        t = time.time(); w = ref.tlas_build(inst, meshes); dt = time.time() - t
-        got = d_t.cpu().numpy()[: (2 * n + 1) * 32].view(abi.TLAS_NODE)
-        print(f"  oracle TLAS build {dt*1e3:.1f} ms; match {got.tobytes()==w.tobytes()}")
 
 # ---- traversal: bvh_gpu.rs-shaped scene (one big mesh + many instances), primary rays ----
-from oracle import ref as _ref  # noqa: E402  (bench tool: oracle used for the CPU leg only)
 tv, ti = synth.knot_mesh(512, 128)                        # 131k triangles
 nodes_b, idx_b = ctx.bvh_build(tv, ti)
 infos = np.zeros(1, dtype=abi.MESH_INFO)
@@ -102,8 +87,3 @@ for r in range(3):
     assert rc == 0, ctx.lib.vd_last_error(ctx.h)
 hits = d_hits.cpu().numpy()[: len(rays) * 16].view(abi.HIT)
 print(f"trace: {len(rays)} rays, {dt*1e3:.2f} ms = {len(rays)/dt/1e6:.1f} Mrays/s, hit fraction {hits['hit'].mean():.3f}", flush=True)
-if args.verify:
-    t = time.time(); want, ms = _ref.trace(scene_np, rays[::16], threads=os.cpu_count()); dtc = time.time() - t
-    sub = hits[::16]
-    ok = np.array_equal(sub["hit"], want["hit"]) and np.allclose(sub["dist"][want["hit"] == 1], want["dist"][want["hit"] == 1], rtol=1e-5, atol=0)
-    print(f"  oracle ({os.cpu_count()} threads) {len(rays)//16/dtc/1e6:.2f} Mrays/s; match {ok}; max stack {ms}")

@@ -299,14 +299,21 @@ void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, 
         const unsigned mid = rec & 0x7fffffffu;
         const uint4* mp = reinterpret_cast<const uint4*>(meshes + mid);
         const unsigned global_idx = first_instance + (unsigned)(wave_first + (size_t)r * kWave) + lane;
-        if constexpr (OUT == 0) {
+        if constexpr (OUT == 0 || OUT == 2) {
             if (vis) {
                 unsigned* o = reinterpret_cast<unsigned*>(out + (base + vd_mbcnt(mask)));
-                o[0] = mp[0].w;                         // index_count
-                o[1] = 1u;
-                o[2] = mp[1].w;                         // base_index
-                o[3] = (unsigned)meshes[mid].vertex_offset;
-                o[4] = global_idx;
+                const unsigned v0 = mp[0].w, v2 = mp[1].w, v3 = (unsigned)meshes[mid].vertex_offset;
+                if constexpr (OUT == 2) {
+                    __builtin_nontemporal_store(v0, o + 0); __builtin_nontemporal_store(1u, o + 1);
+                    __builtin_nontemporal_store(v2, o + 2); __builtin_nontemporal_store(v3, o + 3);
+                    __builtin_nontemporal_store(global_idx, o + 4);
+                } else {
+                    o[0] = v0;                              // index_count
+                    o[1] = 1u;
+                    o[2] = v2;                              // base_index
+                    o[3] = v3;
+                    o[4] = global_idx;
+                }
             }
         } else {
             // destination bytes [A, A + 20*cnt); LDS image starts at A's 16-B phase so that 16-B
@@ -757,6 +764,10 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
         case 10: VD_LAUNCH_COMPACT(16, 0, 1); break;
         case 11: VD_LAUNCH_COMPACT(16, 0, 0); break;
         case 12: VD_LAUNCH_COMPACT(32, 0, 0); break;
+        case 13: VD_LAUNCH_COMPACT(32, 0, 1); break;
+        case 14: VD_LAUNCH_COMPACT(32, 0, 2); break;
+        case 15: VD_LAUNCH_COMPACT(24, 0, 0); break;
+        case 16: VD_LAUNCH_COMPACT(48, 0, 0); break;
 #define VD_LAUNCH_C2(R, CH, PF, MW)                                                                              \
     do {                                                                                                         \
         const unsigned n_tiles = (n_inst + kBlock * (R) - 1) / (kBlock * (R));                                   \
