@@ -2,7 +2,7 @@
 
 Second, separately written restatement of the same reference lines as the C oracle
 (oracle/vd_oracle_*.c).  It exists to cross-check the C oracle HERE (tests/test_oracle_*.py)
-and to write the golden vectors under tests/golden/ (tools/make_golden.py).  It is slow
+and to write the golden vectors under tests/golden/ (tests/golden/make_golden.py).  It is slow
 (pure-Python loops for the order-dependent parts) and only used on small cases.
 numpy float32 element-wise add/mul/div/sqrt are IEEE-754 single operations without FMA
 contraction, which is the evaluation model SURVEY.md §8a C2' fixes.
