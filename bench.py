@@ -74,13 +74,17 @@ def main():
     d_m, d_i = ctx.upload(meshes), ctx.upload(inst)
     d_out = ctx.empty(n * 20)
     d_cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+    # N > 1: every rank ends the step with the ordered draw list of the WHOLE scene.  The exchange is
+    # one bit per instance (bitmask all-gather) + local expansion (voidin_amd/dist.py).
     d_all = ctx.empty(n_total * 20) if distributed else None
+    d_cnt_all = torch.zeros(4, dtype=torch.int32, device=dev) if distributed else None
+    sv = vdist.ShardedVisibility(ctx, n_total, d_m, len(meshes), d_i) if distributed else None
 
     def step():
-        ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)
         if distributed:
-            counts = vdist.allgather_counts(d_cnt[:1])
-            vdist.allgather_draws(d_out, counts, d_all)
+            sv.step(cam, d_all, d_cnt_all)
+        else:
+            ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)
 
     def barrier():
         if distributed:
@@ -103,6 +107,9 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     ms_per_step = wall * 1e3 / args.steps
+    if distributed:   # also run the local fused kernel once so the roofline / verification legs have its output
+        ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)
+        torch.cuda.synchronize()
     count = int(d_cnt[0].item())
 
     # dominant kernel alone: HIP events recorded by the library on the launch stream right around
@@ -127,6 +134,10 @@ def main():
             wc, wn = ref.compact(want)
             got = d_out.cpu().numpy()[: count * 20]
             verified = bool(wn == count and got.tobytes() == wc[:wn].tobytes())
+            if distributed:   # rank 0 owns the first shard: the head of the gathered list must be its compaction
+                head = d_all.cpu().numpy()[: count * 20]
+                total = int(d_cnt_all[0].item())
+                verified = bool(verified and head.tobytes() == wc[:wn].tobytes() and total >= count)
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             m = min(n, 10_000_000)
@@ -165,6 +176,21 @@ def main():
                                            "GBps": round(n * 164.0 / ems / 1e6, 1),
                                            "frac_of_8TBps": round(n * 164.0 / ems / 1e6 / HBM_PEAK_GBS, 4)}
         del d_emit
+        # the multi-GPU wire-format path on one GPU: cull -> bitmask, bitmask -> ordered draw list
+        sv1 = vdist.ShardedVisibility(ctx, n, d_m, len(meshes), d_i)
+        d_o2, d_c2 = ctx.empty(n * 20), torch.zeros(4, dtype=torch.int32, device=dev)
+        for _ in range(3):
+            sv1.step(cam, d_o2, d_c2)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            sv1.step(cam, d_o2, d_c2)
+        e1.record()
+        torch.cuda.synchronize()
+        same = bool(int(d_c2[0].item()) == count and torch.equal(d_o2[: count * 20], d_out[: count * 20]))
+        extra["mask_then_expand_1gpu"] = {"ms": round(e0.elapsed_time(e1) / args.steps, 4), "equals_fused": same}
+        del d_o2, sv1
         # --- BASELINE config 5: SAH BVH build of a dragon-like 8M-tri mesh, TLAS build/refit ---
         from oracle import ref
         v, idx = synth.knot_mesh(args.bvh_u, args.bvh_v)
@@ -233,7 +259,7 @@ def main():
                                    "(BASELINE.md §3 distribution, model.rs camera)",
                        "instances_per_gpu": n, "instances_total": n_total, "n_meshes": int(len(meshes)),
                        "visible_fraction": round(vis, 4), "distribution": args.dist,
-                       "parallelism": f"instance-shard x{world}" + (" + draw-list all-gather (RCCL)" if distributed else ""),
+                       "parallelism": f"instance-shard x{world}" + (" + visibility-bitmask all-gather (RCCL) + local expansion to the full draw list" if distributed else ""),
                        "verified_bit_exact_vs_oracle": verified, "input_gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": "cull_compact_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -64,8 +64,65 @@ def test_sharded_exchange_equals_single_rank(oracle, world, n):
 
 
 def test_shard_ranges_cover_everything():
-    for n in (0, 1, 7, 10_000_000):
+    for n in (0, 1, 7, 130, 10_000_000):
         for world in (1, 2, 3, 8):
             r = [vdist.shard_range(n, k, world) for k in range(world)]
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            s = vdist.shard_size(n, world)
+            assert all(hi - lo <= s for lo, hi in r)
+
+
+def _mask_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ref
+        cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+        lo, hi = vdist.shard_range(n, rank, world)
+        shard = synth.instances(hi - lo, seed=78, offset=lo, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+        vis = ref.cull_emit(cam, meshes, shard)["instance_count"].astype(np.uint8)
+        S, wps = vdist.shard_size(n, world), vdist.mask_words(vdist.shard_size(n, world))
+        bits = np.zeros(wps * 64, np.uint8)
+        bits[: hi - lo] = vis
+        words = np.packbits(bits.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.int64)   # what vd_cull_mask_dev writes
+        mask = torch.from_numpy(words.copy())
+        all_masks = torch.zeros(wps * world, dtype=torch.int64)
+        dist.all_gather_into_tensor(all_masks, mask)
+        ids = torch.zeros(S, dtype=torch.int32)
+        ids[: hi - lo] = torch.from_numpy(shard["mesh"].astype(np.int32))
+        all_ids = torch.zeros(S * world, dtype=torch.int32)
+        dist.all_gather_into_tensor(all_ids, ids)
+        q.put((rank, all_masks.numpy().tobytes(), all_ids.numpy().tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bitmask_exchange_reconstructs_the_scene(oracle):
+    """world-size-2 gloo run of the mask wire format: the gathered masks + replicated mesh ids
+    decode (here in numpy; on the GPU by vd_expand_mask_dev) to the single-rank compaction."""
+    world, n = 2, 20_003
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    inst = synth.instances(n, seed=78, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+    want, wn = oracle.compact(oracle.cull_emit(cam, meshes, inst))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mask_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    S, wps = vdist.shard_size(n, world), vdist.mask_words(vdist.shard_size(n, world))
+    for rank, mblob, iblob in res:
+        words = np.frombuffer(mblob, np.uint8)
+        bits = np.unpackbits(words, bitorder="little").reshape(world, wps * 64)
+        ids = np.frombuffer(iblob, np.int32).reshape(world, S)
+        surv = np.concatenate([r * S + np.nonzero(bits[r][:S])[0] for r in range(world)])
+        surv = surv[surv < n]
+        assert np.array_equal(surv, want["base_instance"][:wn])
+        mesh_of = np.concatenate([ids[r] for r in range(world)])
+        assert np.array_equal(meshes["index_count"][mesh_of[surv]], want["vertex_count"][:wn])

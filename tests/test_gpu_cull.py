@@ -142,3 +142,33 @@ def test_full_size_10m_properties(ctx, oracle):
     assert comp.tobytes() == emit[keep].tobytes()
     want = oracle.cull_emit(cam, meshes, inst, threads=8)
     assert emit.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("n,shards", [(1, 1), (100_000, 1), (100_001, 3), (1_000_000, 8), (130, 2)])
+def test_mask_wire_format_equals_fused_compaction(ctx, oracle, n, shards):
+    """Multi-GPU wire format on one GPU: cull every shard into its bitmask, concatenate the
+    shard masks as the all-gather would, expand -> identical to the fused single-pass list."""
+    import torch
+    from voidin_amd import dist as vdist
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    inst = synth.instances(n, seed=synth.SEED_BASE + 4, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+    want, wn = oracle.compact(oracle.cull_emit(cam, meshes, inst))
+    d_m = ctx.upload(meshes)
+    S = vdist.shard_size(n, shards)
+    wps = vdist.mask_words(S)
+    d_mask_all = torch.zeros(wps * shards, dtype=torch.int64, device="cuda")
+    ids = np.zeros(S * shards, np.uint32)
+    ids[:n] = inst["mesh"]
+    for r in range(shards):
+        lo, hi = vdist.shard_range(n, r, shards)
+        if hi > lo:
+            d_i = ctx.upload(inst[lo:hi])
+            ctx.cull_mask_dev(cam, d_m, len(meshes), d_i, hi - lo, d_mask_all[r * wps:])
+    d_ids = ctx.upload(ids)
+    d_out = ctx.empty(n * 20)
+    d_cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+    ctx.expand_mask_dev(d_mask_all, n, S, d_ids, d_m, len(meshes), d_out, d_cnt)
+    torch.cuda.synchronize()
+    cnt = int(d_cnt[0].item())
+    assert cnt == wn
+    assert d_out.cpu().numpy()[: cnt * 20].tobytes() == want[:wn].tobytes()

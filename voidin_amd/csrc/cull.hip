@@ -531,6 +531,127 @@ void cull_compact_wave_kernel(CullCamera cam, const VdMeshInfo* __restrict__ mes
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Multi-GPU wire format: cull -> one bit per instance; expand bits -> ordered draw list.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock, 3) void cull_mask_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes,
+                                                               unsigned n_mesh, const VdInstance* __restrict__ inst,
+                                                               unsigned n_inst, vd_u64* __restrict__ mask,
+                                                               unsigned n_wave_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    char* slab = smem + wave * kSlabBytes;
+    const unsigned waves_total = gridDim.x * kWavesPerBlock;
+    u32x4 regs[kChunksPerLane];
+    unsigned wt = blockIdx.x * kWavesPerBlock + wave;
+    if (wt < n_wave_tiles) {
+        const size_t f0 = (size_t)wt * kWave;
+        slab_fill<true>(inst, f0, min(64u, n_inst - (unsigned)f0), lane, regs);
+    }
+    for (; wt < n_wave_tiles; wt += waves_total) {
+        const size_t first = (size_t)wt * kWave;
+        const unsigned n_valid = min(64u, n_inst - (unsigned)first);
+        slab_store(slab, lane, regs);
+        const unsigned wn = wt + waves_total;
+        if (wn < n_wave_tiles) {
+            const size_t fn = (size_t)wn * kWave;
+            slab_fill<true>(inst, fn, min(64u, n_inst - (unsigned)fn), lane, regs);
+        }
+        vd_wave_lds_sync();
+        const LaneInst li = slab_read(slab, lane);
+        vd_wave_lds_sync();
+        const MeshRec m = load_mesh(meshes, min(li.mesh, n_mesh - 1u));
+        const bool vis = lane < n_valid && is_visible(cam, m, li.T0, li.T1, li.T2, li.T3);
+        const unsigned long long b = __ballot(vis);
+        if (lane == 0) mask[wt] = b;
+    }
+}
+
+constexpr int kExpandWords = 16;                     // mask words (64 instances each) per wave per tile
+
+// Tile t covers the mask words [t*64, t*64 + 64) (4 waves x 16 words).  Word w belongs to shard
+// w / wps and holds the instances shard*shard_size + 64*(w % wps) + bit.
+__global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned wps,
+                                                             unsigned shard_size, unsigned n_total,
+                                                             const unsigned* __restrict__ mesh_ids,
+                                                             const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
+                                                             VdDrawIndexedIndirect* __restrict__ out,
+                                                             unsigned* __restrict__ out_count, vd_u64* tile_state,
+                                                             vd_u64* ticket_counter, unsigned n_tiles) {
+    __shared__ unsigned s_ticket, s_epoch, s_wave_total[kWavesPerBlock], s_tile_excl;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_ticket = vd_take_ticket(ticket_counter, n_tiles, &s_epoch);
+    __syncthreads();
+    const unsigned tile = s_ticket, epoch = s_epoch;
+    const unsigned w0 = tile * (kWavesPerBlock * kExpandWords) + wave * kExpandWords;
+    // lane l < 16 loads word w0 + l; popcounts give the wave total
+    vd_u64 my_word = 0;
+    if (lane < (unsigned)kExpandWords && w0 + lane < n_words) my_word = mask[w0 + lane];
+    unsigned wave_total = (unsigned)__popcll(my_word);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) wave_total += __shfl_xor(wave_total, off);
+    wave_total = __shfl(wave_total, 0);
+    if (lane == 0) s_wave_total[wave] = wave_total;
+    __syncthreads();
+    if (wave == 0) {
+        unsigned tile_total = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) tile_total += s_wave_total[w];
+        const unsigned excl = vd_lookback(tile_state, epoch, tile, tile_total);
+        if (lane == 0) {
+            s_tile_excl = excl;
+            if (tile == n_tiles - 1u) *out_count = excl + tile_total;
+        }
+    }
+    __syncthreads();
+    unsigned base = s_tile_excl;
+    for (unsigned w = 0; w < wave; ++w) base += s_wave_total[w];
+    // survivors of one mask word are staged in LDS at the destination's 16-B phase and leave as
+    // 16-B-per-lane stores: this kernel is write-dominated (20 B out per 4 B in)
+    __shared__ __attribute__((aligned(16))) char s_stage[kWavesPerBlock][1312];
+    char* stage = s_stage[wave];
+#pragma unroll 1
+    for (int k = 0; k < kExpandWords; ++k) {
+        const unsigned w = w0 + k;
+        const unsigned lo = __shfl((unsigned)my_word, k), hi = __shfl((unsigned)(my_word >> 32), k);
+        const vd_u64 m = ((vd_u64)hi << 32) | lo;
+        if (m == 0ull) continue;
+        const unsigned cnt = (unsigned)__popcll(m);
+        char* gbase = reinterpret_cast<char*>(out + base);
+        const unsigned shift = (unsigned)(reinterpret_cast<uintptr_t>(gbase) & 15u);
+        if ((m >> lane) & 1ull) {
+            const unsigned shard = w / wps;
+            const unsigned inst_idx = shard * shard_size + 64u * (w - shard * wps) + lane;
+            const unsigned mid = min(mesh_ids[inst_idx], n_mesh - 1u);
+            const uint4* mp = reinterpret_cast<const uint4*>(meshes + mid);
+            unsigned* o = reinterpret_cast<unsigned*>(stage + shift + 20u * vd_mbcnt(m));
+            o[0] = mp[0].w;
+            o[1] = 1u;
+            o[2] = mp[1].w;
+            o[3] = (unsigned)meshes[mid].vertex_offset;
+            o[4] = inst_idx;
+        }
+        vd_wave_lds_sync();
+        const unsigned total = shift + 20u * cnt;
+        char* g16 = gbase - shift;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned b0 = (q * kWave + lane) * 16u;
+            if (b0 < total) {
+                if (b0 >= shift && b0 + 16u <= total) {
+                    *reinterpret_cast<u32x4*>(g16 + b0) = *reinterpret_cast<const u32x4*>(stage + b0);
+                } else {
+                    const unsigned lo_b = b0 > shift ? b0 : shift, hi_b = b0 + 16u < total ? b0 + 16u : total;
+                    for (unsigned b = lo_b; b < hi_b; b += 4u)
+                        *reinterpret_cast<unsigned*>(g16 + b) = *reinterpret_cast<const unsigned*>(stage + b);
+                }
+            }
+        }
+        vd_wave_lds_sync();
+        base += cnt;
+    }
+}
+
 // ---- tuning probes (debug variants >= 100): what a pure stream of the same shape reaches ----
 template <bool NT, bool WRITE>
 __global__ __launch_bounds__(kBlock) void probe_stream_kernel(const VdInstance* __restrict__ inst, unsigned n_inst,
@@ -826,6 +947,48 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
         unsigned blocks = (unsigned)ctx->num_cus * 4u;
         hipLaunchKernelGGL(pad_tail_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_out, d_out_count, n_inst);
     }
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    return VD_OK;
+}
+
+int vd_cull_mask_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                     const VdInstance* d_instances, uint32_t n_inst, uint64_t* d_mask) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!camera || !d_meshes || n_mesh == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_mask: null camera/meshes or n_mesh == 0");
+    if (n_inst == 0) return VD_OK;
+    if (!d_instances || !d_mask) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_mask: null instances/mask");
+    const unsigned n_wave_tiles = (n_inst + kWave - 1) / kWave;
+    unsigned blocks = (n_wave_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned cap = (unsigned)ctx->num_cus * 4u;
+    if (blocks > cap) blocks = cap;
+    vd_time_begin(ctx);
+    hipLaunchKernelGGL(cull_mask_kernel, dim3(blocks), dim3(kBlock), kWavesPerBlock * kSlabBytes, ctx->stream, make_cam(camera),
+                       d_meshes, n_mesh, d_instances, n_inst, reinterpret_cast<vd_u64*>(d_mask), n_wave_tiles);
+    vd_time_end(ctx);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    return VD_OK;
+}
+
+int vd_expand_mask_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_total, uint32_t shard_size, const uint32_t* d_mesh_ids,
+                       const VdMeshInfo* d_meshes, uint32_t n_mesh, VdDrawIndexedIndirect* d_out, uint32_t* d_out_count) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!d_out_count || !d_meshes || n_mesh == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_expand_mask: null count/meshes");
+    if (n_total == 0) {
+        VD_HIP_CHECK(ctx, hipMemsetAsync(d_out_count, 0, 4, ctx->stream));
+        return VD_OK;
+    }
+    if (!d_mask || !d_mesh_ids || !d_out || shard_size == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_expand_mask: null mask/ids/out or shard_size == 0");
+    const unsigned n_shards = (n_total + shard_size - 1) / shard_size;
+    const unsigned wps = (shard_size + 63u) / 64u;
+    const unsigned n_words = n_shards * wps;   // padding bits (beyond a shard's / the scene's end) are 0 by construction
+    const unsigned words_per_tile = kWavesPerBlock * kExpandWords;
+    const unsigned n_tiles = (n_words + words_per_tile - 1) / words_per_tile;
+    vd_u64* ticket; vd_u64* states;
+    int rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(expand_mask_kernel, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, reinterpret_cast<const vd_u64*>(d_mask), n_words,
+                       wps, shard_size, n_total, d_mesh_ids, d_meshes, n_mesh, d_out, d_out_count, states, ticket, n_tiles);
+    vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;
 }

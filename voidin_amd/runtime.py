@@ -96,6 +96,15 @@ class Context:
                                                      abi.ptr(d_inst), n_inst, first_instance, abi.ptr(d_out),
                                                      abi.ptr(d_count), int(pad_tail)))
 
+    def cull_mask_dev(self, camera: np.ndarray, d_meshes, n_mesh, d_inst, n_inst, d_mask):
+        cam = np.ascontiguousarray(camera, dtype=abi.CAMERA)
+        self._chk(self.lib.vd_cull_mask_dev(self.h, cam.ctypes.data, abi.ptr(d_meshes), n_mesh, abi.ptr(d_inst), n_inst,
+                                            abi.ptr(d_mask)))
+
+    def expand_mask_dev(self, d_mask, n_total, shard_size, d_mesh_ids, d_meshes, n_mesh, d_out, d_count):
+        self._chk(self.lib.vd_expand_mask_dev(self.h, abi.ptr(d_mask), n_total, shard_size, abi.ptr(d_mesh_ids),
+                                              abi.ptr(d_meshes), n_mesh, abi.ptr(d_out), abi.ptr(d_count)))
+
     def compact_draws_dev(self, d_in, n, d_out, d_count):
         self._chk(self.lib.vd_compact_draws_dev(self.h, abi.ptr(d_in), n, abi.ptr(d_out), abi.ptr(d_count)))
 
