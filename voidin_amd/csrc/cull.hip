@@ -31,6 +31,13 @@ constexpr int kChunksPerLane = kSlabBytes / (kWave * 16);  // 9
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// One 20-byte command written as dwordx4 + dword: global stores only need 4-byte alignment on gfx950.
+struct __attribute__((packed, aligned(4))) Draw5 { unsigned v[5]; };
+__device__ __forceinline__ void store_draw(VdDrawIndexedIndirect* dst, unsigned a, unsigned b, unsigned c, unsigned d, unsigned e) {
+    Draw5 t; t.v[0] = a; t.v[1] = b; t.v[2] = c; t.v[3] = d; t.v[4] = e;
+    *reinterpret_cast<Draw5*>(dst) = t;
+}
+
 struct CullCamera {   // the slice of CameraUniform the shader reads (shared.wgsl:13-24)
     float view[16];
     float frustum[4];
@@ -299,11 +306,13 @@ void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, 
         const unsigned mid = rec & 0x7fffffffu;
         const uint4* mp = reinterpret_cast<const uint4*>(meshes + mid);
         const unsigned global_idx = first_instance + (unsigned)(wave_first + (size_t)r * kWave) + lane;
-        if constexpr (OUT == 0 || OUT == 2) {
+        if constexpr (OUT == 0 || OUT == 2 || OUT == 3) {
             if (vis) {
                 unsigned* o = reinterpret_cast<unsigned*>(out + (base + vd_mbcnt(mask)));
                 const unsigned v0 = mp[0].w, v2 = mp[1].w, v3 = (unsigned)meshes[mid].vertex_offset;
-                if constexpr (OUT == 2) {
+                if constexpr (OUT == 3) {
+                    store_draw(out + (base + vd_mbcnt(mask)), v0, 1u, v2, v3, global_idx);   // dwordx4 + dword
+                } else if constexpr (OUT == 2) {
                     __builtin_nontemporal_store(v0, o + 0); __builtin_nontemporal_store(1u, o + 1);
                     __builtin_nontemporal_store(v2, o + 2); __builtin_nontemporal_store(v3, o + 3);
                     __builtin_nontemporal_store(global_idx, o + 4);
@@ -579,8 +588,15 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
                                                              unsigned* __restrict__ out_count, vd_u64* tile_state,
                                                              vd_u64* ticket_counter, unsigned n_tiles) {
     __shared__ unsigned s_ticket, s_epoch, s_wave_total[kWavesPerBlock], s_tile_excl;
+    constexpr unsigned kTab = 512;                        // mesh tables up to this size are served from LDS
+    __shared__ unsigned s_tab[kTab][3];                   // {index_count, base_index, vertex_offset}
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_ticket = vd_take_ticket(ticket_counter, n_tiles, &s_epoch);
+    const bool tab = n_mesh <= kTab;
+    if (tab)
+        for (unsigned i = threadIdx.x; i < n_mesh; i += kBlock) {
+            s_tab[i][0] = meshes[i].index_count; s_tab[i][1] = meshes[i].base_index; s_tab[i][2] = (unsigned)meshes[i].vertex_offset;
+        }
     __syncthreads();
     const unsigned tile = s_ticket, epoch = s_epoch;
     const unsigned w0 = tile * (kWavesPerBlock * kExpandWords) + wave * kExpandWords;
@@ -606,11 +622,20 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
     __syncthreads();
     unsigned base = s_tile_excl;
     for (unsigned w = 0; w < wave; ++w) base += s_wave_total[w];
+    // all sixteen mesh-id loads of this lane are issued up front (independent, 4 B coalesced)
+    unsigned mids[kExpandWords];
+#pragma unroll
+    for (int k = 0; k < kExpandWords; ++k) {
+        const unsigned w = w0 + k;
+        const unsigned shard = w / wps;
+        const unsigned inst_idx = shard * shard_size + 64u * (w - shard * wps) + lane;
+        mids[k] = (w < n_words && inst_idx < n_total) ? mesh_ids[inst_idx] : 0u;
+    }
     // survivors of one mask word are staged in LDS at the destination's 16-B phase and leave as
-    // 16-B-per-lane stores: this kernel is write-dominated (20 B out per 4 B in)
+    // 16-B-per-lane stores (this kernel is write-dominated: 20 B out per 4 B in)
     __shared__ __attribute__((aligned(16))) char s_stage[kWavesPerBlock][1312];
     char* stage = s_stage[wave];
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < kExpandWords; ++k) {
         const unsigned w = w0 + k;
         const unsigned lo = __shfl((unsigned)my_word, k), hi = __shfl((unsigned)(my_word >> 32), k);
@@ -622,13 +647,11 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
         if ((m >> lane) & 1ull) {
             const unsigned shard = w / wps;
             const unsigned inst_idx = shard * shard_size + 64u * (w - shard * wps) + lane;
-            const unsigned mid = min(mesh_ids[inst_idx], n_mesh - 1u);
-            const uint4* mp = reinterpret_cast<const uint4*>(meshes + mid);
+            const unsigned mid = min(mids[k], n_mesh - 1u);
             unsigned* o = reinterpret_cast<unsigned*>(stage + shift + 20u * vd_mbcnt(m));
-            o[0] = mp[0].w;
+            if (tab) { o[0] = s_tab[mid][0]; o[2] = s_tab[mid][1]; o[3] = s_tab[mid][2]; }
+            else { o[0] = meshes[mid].index_count; o[2] = meshes[mid].base_index; o[3] = (unsigned)meshes[mid].vertex_offset; }
             o[1] = 1u;
-            o[2] = mp[1].w;
-            o[3] = (unsigned)meshes[mid].vertex_offset;
             o[4] = inst_idx;
         }
         vd_wave_lds_sync();
@@ -885,6 +908,7 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
         case 10: VD_LAUNCH_COMPACT(16, 0, 1); break;
         case 11: VD_LAUNCH_COMPACT(16, 0, 0); break;
         case 12: VD_LAUNCH_COMPACT(32, 0, 0); break;
+        case 17: VD_LAUNCH_COMPACT(32, 0, 3); break;
         case 13: VD_LAUNCH_COMPACT(32, 0, 1); break;
         case 14: VD_LAUNCH_COMPACT(32, 0, 2); break;
         case 15: VD_LAUNCH_COMPACT(24, 0, 0); break;
