@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kBlock, 3) void cull_mask_kernel(CullCamera cam, co
     }
 }
 
-constexpr int kExpandWords = 16;                     // mask words (64 instances each) per wave per tile
+constexpr int kExpandWords = 32;                     // mask words (64 instances each) per wave per tile
 
 // Tile t covers the mask words [t*64, t*64 + 64) (4 waves x 16 words).  Word w belongs to shard
 // w / wps and holds the instances shard*shard_size + 64*(w % wps) + bit.
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
     if (lane < (unsigned)kExpandWords && w0 + lane < n_words) my_word = mask[w0 + lane];
     unsigned wave_total = (unsigned)__popcll(my_word);
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) wave_total += __shfl_xor(wave_total, off);
+    for (int off = 32; off > 0; off >>= 1) wave_total += __shfl_xor(wave_total, off);
     wave_total = __shfl(wave_total, 0);
     if (lane == 0) s_wave_total[wave] = wave_total;
     __syncthreads();
