@@ -54,11 +54,19 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one rank per GPU over RCCL ("nccl" on ROCm).  VOIDIN_DIST_BACKEND=gloo lets the same code path be
+        # exercised with several ranks on ONE GPU (tests / debugging): ranks then share device 0.
+        backend = os.environ.get("VOIDIN_DIST_BACKEND", "nccl")
+        dev_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if distributed else 0)
+    dev = torch.device("cuda", dev_index)
     ctx = Context(dev.index)  # raises if the HIP extension or a gfx950 GPU is missing
 
     n = args.instances

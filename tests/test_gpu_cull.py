@@ -172,3 +172,24 @@ def test_mask_wire_format_equals_fused_compaction(ctx, oracle, n, shards):
     cnt = int(d_cnt[0].item())
     assert cnt == wn
     assert d_out.cpu().numpy()[: cnt * 20].tobytes() == want[:wn].tobytes()
+
+
+def test_large_mesh_table(ctx, oracle):
+    """700 MeshInfo records: exercises the non-LDS mesh-table path of vd_expand_mask_dev and the
+    gathers of the cull kernels."""
+    import torch
+    from voidin_amd import dist as vdist
+    cam = synth.camera_uniform()
+    meshes = synth.mesh_infos(700, seed=synth.SEED_BASE + 40)
+    n = 150_000
+    inst = synth.instances(n, n_mesh=700, seed=synth.SEED_BASE + 41, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+    want = oracle.cull_emit(cam, meshes, inst)
+    wc, wn = oracle.compact(want)
+    emit, comp, cnt = run_dev(ctx, cam, meshes, inst)
+    assert emit.tobytes() == want.tobytes() and cnt == wn and comp[:cnt].tobytes() == wc[:wn].tobytes()
+    d_m, d_i = ctx.upload(meshes), ctx.upload(inst)
+    sv = vdist.ShardedVisibility(ctx, n, d_m, len(meshes), d_i)
+    d_out, d_cnt = ctx.empty(n * 20), torch.zeros(4, dtype=torch.int32, device="cuda")
+    sv.step(cam, d_out, d_cnt)
+    torch.cuda.synchronize()
+    assert int(d_cnt[0].item()) == wn and d_out.cpu().numpy()[: wn * 20].tobytes() == wc[:wn].tobytes()
