@@ -123,10 +123,12 @@ def main():
     # dominant kernel alone: HIP events recorded by the library on the launch stream right around
     # cull_compact_kernel (vd_last_gpu_ms), averaged over the same number of launches
     barrier()
+    ctx.set_timing(True)
     k_ms = []
     for _ in range(args.steps):
         ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)
         k_ms.append(ctx.last_gpu_ms())
+    ctx.set_timing(False)
     kernel_ms = sum(k_ms) / len(k_ms)
     vis = count / n
     alg_bytes = n * (144.0 + 20.0 * vis)          # 144 B read + 20 B per survivor

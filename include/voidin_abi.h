@@ -330,8 +330,11 @@ int vd_compute_update_dev(VdCtx* ctx, const uint32_t* d_indices, uint32_t n_indi
 /* ------------------------------------------------------------------------------------ */
 /* Instrumentation (replaces the wgpu_profiler scopes: visibility.rs:50,243-245)         */
 /* ------------------------------------------------------------------------------------ */
-/* Milliseconds the GPU spent in the most recent call's kernels, measured with HIP events
- * on the ctx's stream (synchronises). Negative if nothing was recorded.                 */
+/* Opt-in kernel timing: with timing enabled every call brackets its kernels with a HIP event
+ * pair on the ctx's stream (costs a few microseconds of GPU idle per call, so it is off by
+ * default).  vd_last_gpu_ms returns the milliseconds of the most recent call's kernels
+ * (synchronises); negative if timing is off or nothing was recorded.                     */
+int   vd_ctx_set_timing(VdCtx* ctx, int enabled);
 float vd_last_gpu_ms(VdCtx* ctx);
 
 #ifdef __cplusplus

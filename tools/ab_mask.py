@@ -6,6 +6,7 @@ from voidin_amd import synth
 from voidin_amd import dist as vdist
 from voidin_amd.runtime import Context
 ctx = Context(0)
+ctx.set_timing(True)
 n = 10_000_000
 cam, meshes = synth.camera_uniform(), synth.mesh_infos()
 inst = synth.instances(n, seed=synth.SEED_BASE + 3, with_inverse=False)

@@ -20,6 +20,7 @@ ap.add_argument("--tlas", type=int, default=32768)
 args = ap.parse_args()
 
 ctx = Context(0)
+ctx.set_timing(True)
 t0 = time.time()
 v, i = synth.knot_mesh(args.u, args.v)
 n_tri = len(i) // 3

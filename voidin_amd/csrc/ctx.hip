@@ -114,6 +114,13 @@ int vd_debug_set_cull_variant(VdCtx* ctx, int variant) {
     return VD_OK;
 }
 
+int vd_ctx_set_timing(VdCtx* ctx, int enabled) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    ctx->timing_enabled = enabled != 0;
+    ctx->timed = false;
+    return VD_OK;
+}
+
 float vd_last_gpu_ms(VdCtx* ctx) {
     if (!ctx || !ctx->timed) return -1.0f;
     if (hipEventSynchronize(ctx->ev_stop) != hipSuccess) return -1.0f;

@@ -18,6 +18,7 @@ struct VdCtx {
     hipStream_t stream = nullptr;      // stream in use (own or caller's)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
+    bool timing_enabled = false;        // event pairs around kernels cost a few us of GPU idle each: opt-in
     char err[512] = {0};
     int num_cus = 256;
     int cull_variant = 0;               // kernel variant for A/B tuning (env VD_CULL_VARIANT)
@@ -57,9 +58,10 @@ int vd_ensure(VdCtx* ctx, void** buf, size_t* cur, size_t need);
 int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer);
 
 static inline void vd_time_begin(VdCtx* ctx) {
-    (void)hipEventRecord(ctx->ev_start, ctx->stream);
+    if (ctx->timing_enabled) (void)hipEventRecord(ctx->ev_start, ctx->stream);
 }
 static inline void vd_time_end(VdCtx* ctx) {
+    if (!ctx->timing_enabled) { ctx->timed = false; return; }
     (void)hipEventRecord(ctx->ev_stop, ctx->stream);
     ctx->timed = true;
 }

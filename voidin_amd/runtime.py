@@ -62,6 +62,9 @@ class Context:
     def synchronize(self):
         self._chk(self.lib.vd_ctx_synchronize(self.h))
 
+    def set_timing(self, enabled: bool):
+        self._chk(self.lib.vd_ctx_set_timing(self.h, int(enabled)))
+
     def last_gpu_ms(self) -> float:
         return float(self.lib.vd_last_gpu_ms(self.h))
 
