@@ -631,43 +631,53 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
         const unsigned inst_idx = shard * shard_size + 64u * (w - shard * wps) + lane;
         mids[k] = (w < n_words && inst_idx < n_total) ? mesh_ids[inst_idx] : 0u;
     }
-    // survivors of one mask word are staged in LDS at the destination's 16-B phase and leave as
-    // 16-B-per-lane stores (this kernel is write-dominated: 20 B out per 4 B in)
-    __shared__ __attribute__((aligned(16))) char s_stage[kWavesPerBlock][1312];
+    // survivors of kGroup mask words are staged in LDS at the destination's 16-B phase and leave as
+    // 16-B-per-lane stores in one contiguous run (this kernel is write-dominated: 20 B out per 4 B in)
+    constexpr int kGroup = 4;
+    constexpr int kStageBytes = kGroup * 1280 + 32;
+    __shared__ __attribute__((aligned(16))) char s_stage[kWavesPerBlock][kStageBytes];
     char* stage = s_stage[wave];
 #pragma unroll
-    for (int k = 0; k < kExpandWords; ++k) {
-        const unsigned w = w0 + k;
-        const unsigned lo = __shfl((unsigned)my_word, k), hi = __shfl((unsigned)(my_word >> 32), k);
-        const vd_u64 m = ((vd_u64)hi << 32) | lo;
-        if (m == 0ull) continue;
-        const unsigned cnt = (unsigned)__popcll(m);
+    for (int g = 0; g < kExpandWords / kGroup; ++g) {
+        vd_u64 m[kGroup];
+        unsigned cnt = 0;
+#pragma unroll
+        for (int q = 0; q < kGroup; ++q) {
+            const int k = g * kGroup + q;
+            const unsigned lo = __shfl((unsigned)my_word, k), hi = __shfl((unsigned)(my_word >> 32), k);
+            m[q] = ((vd_u64)hi << 32) | lo;
+            cnt += (unsigned)__popcll(m[q]);
+        }
+        if (cnt == 0u) continue;
         char* gbase = reinterpret_cast<char*>(out + base);
         const unsigned shift = (unsigned)(reinterpret_cast<uintptr_t>(gbase) & 15u);
-        if ((m >> lane) & 1ull) {
-            const unsigned shard = w / wps;
-            const unsigned inst_idx = shard * shard_size + 64u * (w - shard * wps) + lane;
-            const unsigned mid = min(mids[k], n_mesh - 1u);
-            unsigned* o = reinterpret_cast<unsigned*>(stage + shift + 20u * vd_mbcnt(m));
-            if (tab) { o[0] = s_tab[mid][0]; o[2] = s_tab[mid][1]; o[3] = s_tab[mid][2]; }
-            else { o[0] = meshes[mid].index_count; o[2] = meshes[mid].base_index; o[3] = (unsigned)meshes[mid].vertex_offset; }
-            o[1] = 1u;
-            o[4] = inst_idx;
+        unsigned run = 0;
+#pragma unroll
+        for (int q = 0; q < kGroup; ++q) {
+            const int k = g * kGroup + q;
+            if ((m[q] >> lane) & 1ull) {
+                const unsigned w = w0 + k;
+                const unsigned shard = w / wps;
+                const unsigned inst_idx = shard * shard_size + 64u * (w - shard * wps) + lane;
+                const unsigned mid = min(mids[k], n_mesh - 1u);
+                unsigned* o = reinterpret_cast<unsigned*>(stage + shift + 20u * (run + vd_mbcnt(m[q])));
+                if (tab) { o[0] = s_tab[mid][0]; o[2] = s_tab[mid][1]; o[3] = s_tab[mid][2]; }
+                else { o[0] = meshes[mid].index_count; o[2] = meshes[mid].base_index; o[3] = (unsigned)meshes[mid].vertex_offset; }
+                o[1] = 1u;
+                o[4] = inst_idx;
+            }
+            run += (unsigned)__popcll(m[q]);
         }
         vd_wave_lds_sync();
         const unsigned total = shift + 20u * cnt;
         char* g16 = gbase - shift;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const unsigned b0 = (q * kWave + lane) * 16u;
-            if (b0 < total) {
-                if (b0 >= shift && b0 + 16u <= total) {
-                    *reinterpret_cast<u32x4*>(g16 + b0) = *reinterpret_cast<const u32x4*>(stage + b0);
-                } else {
-                    const unsigned lo_b = b0 > shift ? b0 : shift, hi_b = b0 + 16u < total ? b0 + 16u : total;
-                    for (unsigned b = lo_b; b < hi_b; b += 4u)
-                        *reinterpret_cast<unsigned*>(g16 + b) = *reinterpret_cast<const unsigned*>(stage + b);
-                }
+        for (unsigned b0 = lane * 16u; b0 < total; b0 += kWave * 16u) {
+            if (b0 >= shift && b0 + 16u <= total) {
+                *reinterpret_cast<u32x4*>(g16 + b0) = *reinterpret_cast<const u32x4*>(stage + b0);
+            } else {
+                const unsigned lo_b = b0 > shift ? b0 : shift, hi_b = b0 + 16u < total ? b0 + 16u : total;
+                for (unsigned b = lo_b; b < hi_b; b += 4u)
+                    *reinterpret_cast<unsigned*>(g16 + b) = *reinterpret_cast<const unsigned*>(stage + b);
             }
         }
         vd_wave_lds_sync();
