@@ -120,18 +120,30 @@ def main():
         torch.cuda.synchronize()
     count = int(d_cnt[0].item())
 
-    # dominant kernel alone: HIP events recorded by the library on the launch stream right around
-    # cull_compact_kernel (vd_last_gpu_ms), averaged over the same number of launches
+    # Kernel-level timing: HIP events recorded by the library on the launch stream around each pass of
+    # vd_cull_compact (large inputs run two passes: cull -> bitmask + mesh id, then expansion).
     barrier()
     ctx.set_timing(True)
-    k_ms = []
+    k_all, k_cull, k_expand = [], [], []
     for _ in range(args.steps):
         ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)
-        k_ms.append(ctx.last_gpu_ms())
+        k_all.append(ctx.last_gpu_ms())
+        k_cull.append(ctx.last_gpu_ms_stage(0))
+        k_expand.append(ctx.last_gpu_ms_stage(1))
     ctx.set_timing(False)
-    kernel_ms = sum(k_ms) / len(k_ms)
+    step_kernel_ms = sum(k_all) / len(k_all)
+    split = min(k_cull) > 0
     vis = count / n
-    alg_bytes = n * (144.0 + 20.0 * vis)          # 144 B read + 20 B per survivor
+    step_bytes = n * (144.0 + 20.0 * vis)          # 144 B read + 20 B per survivor
+    if split:
+        id_bytes = 1 if len(meshes) <= 256 else (2 if len(meshes) <= 65536 else 4)
+        kernel_name = "cull_mask_kernel"
+        kernel_ms = sum(k_cull) / len(k_cull)
+        alg_bytes = n * (144.0 + 0.125 + id_bytes)  # 144 B instance read + 1 bit + the compact mesh id written
+        expand_ms = sum(k_expand) / len(k_expand)
+        expand_bytes = n * (0.125 + id_bytes) + count * 20.0
+    else:
+        kernel_name, kernel_ms, alg_bytes, expand_ms, expand_bytes = "cull_compact_kernel", step_kernel_ms, step_bytes, None, None
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
     verified = None
@@ -245,10 +257,11 @@ def main():
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_cull_pmc.json")
     if rank == 0 and os.path.exists(pmc_path) and n == 10_000_000 and args.dist == "baseline":
-        # HBM bytes per cull_compact launch from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+        # HBM bytes per launch of the dominant kernel from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
         # passes of this same command (profiles/README.md); gfx950: FETCH_SIZE counts 64 B per 128-B request
-        pmc = json.load(open(pmc_path))
-        traffic = int((2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024)
+        pmc = json.load(open(pmc_path)).get(kernel_name)
+        if pmc:
+            traffic = int((2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024)
     if rank == 0:
         value = n_total / (ms_per_step * 1e-3) / 1e6
         line = {
@@ -271,10 +284,17 @@ def main():
                        "visible_fraction": round(vis, 4), "distribution": args.dist,
                        "parallelism": f"instance-shard x{world}" + (" + visibility-bitmask all-gather (RCCL) + local expansion to the full draw list" if distributed else ""),
                        "verified_bit_exact_vs_oracle": verified, "input_gen_s": round(t_gen, 1)},
-            "roofline": {"bound": "hbm", "kernel": "cull_compact_kernel", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "second_kernel": None if not split else {
+                             "kernel": "expand_mask_kernel", "kernel_ms": round(expand_ms, 4),
+                             "algorithmic_bytes_per_launch": int(expand_bytes),
+                             "achieved": round(expand_bytes / (expand_ms * 1e-3) / 1e9, 1)},
+                         "step": {"kernels_ms": round(step_kernel_ms, 4), "algorithmic_bytes": int(step_bytes),
+                                  "achieved": round(step_bytes / (step_kernel_ms * 1e-3) / 1e9, 1),
+                                  "frac": round(step_bytes / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
             "cpu_baseline": cpu,
         }
         if extra:

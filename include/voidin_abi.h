@@ -336,6 +336,9 @@ int vd_compute_update_dev(VdCtx* ctx, const uint32_t* d_indices, uint32_t n_indi
  * (synchronises); negative if timing is off or nothing was recorded.                     */
 int   vd_ctx_set_timing(VdCtx* ctx, int enabled);
 float vd_last_gpu_ms(VdCtx* ctx);
+/* For calls that run two passes (vd_cull_compact* on large inputs: cull-to-bitmask, then
+ * expansion): milliseconds of pass `stage` (0 or 1); negative when the call had one pass.  */
+float vd_last_gpu_ms_stage(VdCtx* ctx, int stage);
 
 #ifdef __cplusplus
 }

@@ -17,11 +17,13 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o cull -- python
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o cull -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-extra > $O/pmc_write_stdout.log 2>&1
 python3 - <<'PY'
 import csv,glob,json
-out={}
+out={'note':'mean per launch; rocprofv3 --pmc, one counter per pass; units KB; gfx950 FETCH_SIZE = 1/2 of the bytes read by wide coalesced loads'}
 for d,c in [('pmc_fetch','FETCH_SIZE'),('pmc_write','WRITE_SIZE')]:
     for f in glob.glob(f'gpurun_out/round/{d}/*counter_collection.csv'):
-        v=[float(r['Counter_Value']) for r in csv.DictReader(open(f)) if 'cull_compact' in r['Kernel_Name'] and r['Counter_Name']==c]
-        out[c+'_KB']=sum(v)/len(v); out[c+'_launches']=len(v)
-out['note']='mean per cull_compact_kernel launch; rocprofv3 --pmc, one counter per pass; units KB; gfx950 FETCH_SIZE = 1/2 of bytes read by wide coalesced loads'
+        rows=list(csv.DictReader(open(f)))
+        for kern in ['cull_mask_kernel','expand_mask_kernel','cull_compact_kernel']:
+            v=[float(r['Counter_Value']) for r in rows if kern in r['Kernel_Name'] and r['Counter_Name']==c]
+            if v:
+                out.setdefault(kern,{})[c+'_KB']=sum(v)/len(v); out[kern][c+'_launches']=len(v)
 json.dump(out,open('gpurun_out/round/cull_pmc.json','w'),indent=1); print(out)
 PY

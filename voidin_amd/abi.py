@@ -107,6 +107,7 @@ PROTOTYPES = {
     "vd_compute_update_dev": (_I, [_P, _P, _U, _P, _U, C.c_float, C.c_float, _I]),
     "vd_ctx_set_timing": (_I, [_P, _I]),
     "vd_last_gpu_ms": (C.c_float, [_P]),
+    "vd_last_gpu_ms_stage": (C.c_float, [_P, _I]),
 }
 
 _lib = None

@@ -58,6 +58,7 @@ int vd_ctx_create(int device, VdCtx** out_ctx) {
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
+        hipEventCreate(&ctx->ev_mid) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->host_pinned), 64 * sizeof(uint32_t)) != hipSuccess) {
         vd_ctx_destroy(ctx);
         return VD_ERR_HIP;
@@ -80,6 +81,7 @@ int vd_ctx_destroy(VdCtx* ctx) {
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return VD_OK;
@@ -119,6 +121,14 @@ int vd_ctx_set_timing(VdCtx* ctx, int enabled) {
     ctx->timing_enabled = enabled != 0;
     ctx->timed = false;
     return VD_OK;
+}
+
+float vd_last_gpu_ms_stage(VdCtx* ctx, int stage) {
+    if (!ctx || !ctx->timed || !ctx->timed_mid || stage < 0 || stage > 1) return -1.0f;
+    if (hipEventSynchronize(ctx->ev_stop) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    const hipError_t e = stage == 0 ? hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_mid) : hipEventElapsedTime(&ms, ctx->ev_mid, ctx->ev_stop);
+    return e == hipSuccess ? ms : -1.0f;
 }
 
 float vd_last_gpu_ms(VdCtx* ctx) {

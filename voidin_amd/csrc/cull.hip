@@ -543,10 +543,13 @@ void cull_compact_wave_kernel(CullCamera cam, const VdMeshInfo* __restrict__ mes
 // ------------------------------------------------------------------------------------------
 // Multi-GPU wire format: cull -> one bit per instance; expand bits -> ordered draw list.
 // ------------------------------------------------------------------------------------------
+// IdT != void: also write the (clamped) mesh id of every instance as IdT (u8 / u16 / u32 by table
+// size) for the expansion pass of the split single-GPU path.
+template <typename IdT>
 __global__ __launch_bounds__(kBlock, 3) void cull_mask_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes,
                                                                unsigned n_mesh, const VdInstance* __restrict__ inst,
                                                                unsigned n_inst, vd_u64* __restrict__ mask,
-                                                               unsigned n_wave_tiles) {
+                                                               IdT* __restrict__ ids_out, unsigned n_wave_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     char* slab = smem + wave * kSlabBytes;
@@ -569,10 +572,12 @@ __global__ __launch_bounds__(kBlock, 3) void cull_mask_kernel(CullCamera cam, co
         vd_wave_lds_sync();
         const LaneInst li = slab_read(slab, lane);
         vd_wave_lds_sync();
-        const MeshRec m = load_mesh(meshes, min(li.mesh, n_mesh - 1u));
+        const unsigned mid = min(li.mesh, n_mesh - 1u);
+        const MeshRec m = load_mesh(meshes, mid);
         const bool vis = lane < n_valid && is_visible(cam, m, li.T0, li.T1, li.T2, li.T3);
         const unsigned long long b = __ballot(vis);
         if (lane == 0) mask[wt] = b;
+        if (ids_out && lane < n_valid) ids_out[first + lane] = (IdT)mid;
     }
 }
 
@@ -580,9 +585,10 @@ constexpr int kExpandWords = 32;                     // mask words (64 instances
 
 // Tile t covers the mask words [t*64, t*64 + 64) (4 waves x 16 words).  Word w belongs to shard
 // w / wps and holds the instances shard*shard_size + 64*(w % wps) + bit.
+template <typename IdT>
 __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned wps,
-                                                             unsigned shard_size, unsigned n_total,
-                                                             const unsigned* __restrict__ mesh_ids,
+                                                             unsigned shard_size, unsigned n_total, unsigned first_instance,
+                                                             const IdT* __restrict__ mesh_ids,
                                                              const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
                                                              VdDrawIndexedIndirect* __restrict__ out,
                                                              unsigned* __restrict__ out_count, vd_u64* tile_state,
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
         const unsigned w = w0 + k;
         const unsigned shard = w / wps;
         const unsigned inst_idx = shard * shard_size + 64u * (w - shard * wps) + lane;
-        mids[k] = (w < n_words && inst_idx < n_total) ? mesh_ids[inst_idx] : 0u;
+        mids[k] = (w < n_words && inst_idx < n_total) ? (unsigned)mesh_ids[inst_idx] : 0u;
     }
     // survivors of kGroup mask words are staged in LDS at the destination's 16-B phase and leave as
     // 16-B-per-lane stores in one contiguous run (this kernel is write-dominated: 20 B out per 4 B in)
@@ -664,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
                 if (tab) { o[0] = s_tab[mid][0]; o[2] = s_tab[mid][1]; o[3] = s_tab[mid][2]; }
                 else { o[0] = meshes[mid].index_count; o[2] = meshes[mid].base_index; o[3] = (unsigned)meshes[mid].vertex_offset; }
                 o[1] = 1u;
-                o[4] = inst_idx;
+                o[4] = first_instance + inst_idx;
             }
             run += (unsigned)__popcll(m[q]);
         }
@@ -879,6 +885,49 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
     int variant = ctx->cull_variant;
     vd_u64* ticket; vd_u64* states;
     int rc = VD_OK;
+    if (variant <= 0 && n_inst >= (1u << 20)) {
+        // Split form (default for large inputs): pass 1 streams the instances and writes only one bit
+        // + a compact mesh id per instance (reads run at ~6.4 TB/s when no 20-byte commands are stored
+        // in the same kernel); pass 2 expands the bits into the ordered command list.  Mixing the
+        // command stores into the read stream costs more than the 1-5 B/instance round trip
+        // (A/B: profiles/).
+        const unsigned n_words = (n_inst + 63u) / 64u;
+        const unsigned id_bytes = n_mesh <= 256u ? 1u : (n_mesh <= 65536u ? 2u : 4u);
+        const size_t need = (size_t)n_words * 8 + (size_t)n_inst * id_bytes + 512;
+        rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
+        if (rc) return rc;
+        vd_u64* d_mask = reinterpret_cast<vd_u64*>(ctx->scratch);
+        void* d_ids = reinterpret_cast<char*>(ctx->scratch) + (((size_t)n_words * 8 + 255) & ~(size_t)255);
+        const unsigned n_wave_tiles = n_words;
+        unsigned blocks = (n_wave_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+        const unsigned cap = (unsigned)ctx->num_cus * 4u;
+        if (blocks > cap) blocks = cap;
+        const unsigned words_per_tile = kWavesPerBlock * kExpandWords;
+        const unsigned n_tiles = (n_words + words_per_tile - 1) / words_per_tile;
+        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);
+        if (rc) return rc;
+#define VD_SPLIT(IdT)                                                                                              \
+        do {                                                                                                         \
+            hipLaunchKernelGGL(cull_mask_kernel<IdT>, dim3(blocks), dim3(kBlock), kWavesPerBlock * kSlabBytes,       \
+                               ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_mask,         \
+                               reinterpret_cast<IdT*>(d_ids), n_wave_tiles);                                         \
+            vd_time_mid(ctx);                                                                                        \
+            hipLaunchKernelGGL(expand_mask_kernel<IdT>, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, d_mask, n_words, \
+                               n_words, n_inst, n_inst, first_instance, reinterpret_cast<const IdT*>(d_ids), d_meshes, \
+                               n_mesh, d_out, d_out_count, states, ticket, n_tiles);                                 \
+        } while (0)
+        if (id_bytes == 1u) VD_SPLIT(unsigned char);
+        else if (id_bytes == 2u) VD_SPLIT(unsigned short);
+        else VD_SPLIT(unsigned);
+#undef VD_SPLIT
+        vd_time_end(ctx);
+        if (pad_tail) {
+            unsigned pblocks = (unsigned)ctx->num_cus * 4u;
+            hipLaunchKernelGGL(pad_tail_kernel, dim3(pblocks), dim3(kBlock), 0, ctx->stream, d_out, d_out_count, n_inst);
+        }
+        VD_HIP_CHECK(ctx, hipGetLastError());
+        return VD_OK;
+    }
 #define VD_LAUNCH_ABL(A)                                                                                          \
     do {                                                                                                         \
         const unsigned n_tiles = (n_inst + kBlock * 32 - 1) / (kBlock * 32);                                     \
@@ -996,8 +1045,8 @@ int vd_cull_mask_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo
     const unsigned cap = (unsigned)ctx->num_cus * 4u;
     if (blocks > cap) blocks = cap;
     vd_time_begin(ctx);
-    hipLaunchKernelGGL(cull_mask_kernel, dim3(blocks), dim3(kBlock), kWavesPerBlock * kSlabBytes, ctx->stream, make_cam(camera),
-                       d_meshes, n_mesh, d_instances, n_inst, reinterpret_cast<vd_u64*>(d_mask), n_wave_tiles);
+    hipLaunchKernelGGL(cull_mask_kernel<unsigned>, dim3(blocks), dim3(kBlock), kWavesPerBlock * kSlabBytes, ctx->stream, make_cam(camera),
+                       d_meshes, n_mesh, d_instances, n_inst, reinterpret_cast<vd_u64*>(d_mask), (unsigned*)nullptr, n_wave_tiles);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;
@@ -1020,8 +1069,8 @@ int vd_expand_mask_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_total, uin
     vd_u64* ticket; vd_u64* states;
     int rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);
     if (rc) return rc;
-    hipLaunchKernelGGL(expand_mask_kernel, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, reinterpret_cast<const vd_u64*>(d_mask), n_words,
-                       wps, shard_size, n_total, d_mesh_ids, d_meshes, n_mesh, d_out, d_out_count, states, ticket, n_tiles);
+    hipLaunchKernelGGL(expand_mask_kernel<unsigned>, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, reinterpret_cast<const vd_u64*>(d_mask), n_words,
+                       wps, shard_size, n_total, 0u, d_mesh_ids, d_meshes, n_mesh, d_out, d_out_count, states, ticket, n_tiles);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;

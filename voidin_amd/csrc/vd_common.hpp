@@ -16,7 +16,8 @@ struct VdCtx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // stream in use (own or caller's)
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
+    bool timed_mid = false;
     bool timed = false;
     bool timing_enabled = false;        // event pairs around kernels cost a few us of GPU idle each: opt-in
     char err[512] = {0};
@@ -58,7 +59,11 @@ int vd_ensure(VdCtx* ctx, void** buf, size_t* cur, size_t need);
 int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer);
 
 static inline void vd_time_begin(VdCtx* ctx) {
+    ctx->timed_mid = false;
     if (ctx->timing_enabled) (void)hipEventRecord(ctx->ev_start, ctx->stream);
+}
+static inline void vd_time_mid(VdCtx* ctx) {   // boundary between the two passes of a split call
+    if (ctx->timing_enabled) { (void)hipEventRecord(ctx->ev_mid, ctx->stream); ctx->timed_mid = true; }
 }
 static inline void vd_time_end(VdCtx* ctx) {
     if (!ctx->timing_enabled) { ctx->timed = false; return; }

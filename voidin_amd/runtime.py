@@ -68,6 +68,9 @@ class Context:
     def last_gpu_ms(self) -> float:
         return float(self.lib.vd_last_gpu_ms(self.h))
 
+    def last_gpu_ms_stage(self, stage: int) -> float:
+        return float(self.lib.vd_last_gpu_ms_stage(self.h, stage))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.vd_ctx_destroy(self.h)
