@@ -31,7 +31,7 @@ n = args.n
 d_m, d_i = ctx.upload(meshes), ctx.upload(inst)
 d_out = ctx.empty(n * 20)
 d_cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
-variants = [int(v) for v in args.variants.split(",")]
+variants = [int(v) for v in args.variants.replace('m', '-').split(",")]
 ref_bytes = None
 times = {v: [] for v in variants}
 for rnd in range(args.rounds):

@@ -581,6 +581,62 @@ __global__ __launch_bounds__(kBlock, 3) void cull_mask_kernel(CullCamera cam, co
     }
 }
 
+// Tiled form of pass 1: a wave owns kMaskRounds CONSECUTIVE rounds (1024 instances), keeps their
+// mesh ids and ballot words on chip and flushes them once per tile as wide stores, so the read
+// stream is interrupted by one 1-KB store per 147 KB read instead of a 64-B store per 9 KB.
+constexpr int kMaskRounds = 16;
+template <typename IdT>
+__global__ __launch_bounds__(kBlock, 3) void cull_mask_tiled_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes,
+                                                                     unsigned n_mesh, const VdInstance* __restrict__ inst,
+                                                                     unsigned n_inst, vd_u64* __restrict__ mask,
+                                                                     IdT* __restrict__ ids_out, unsigned n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr int kIdBytes = kMaskRounds * kWave * (int)sizeof(IdT);
+    char* slab = smem + wave * (kSlabBytes + kIdBytes);
+    IdT* s_ids = reinterpret_cast<IdT*>(slab + kSlabBytes);
+    const unsigned waves_total = gridDim.x * kWavesPerBlock;
+    auto valid_at = [&](size_t f) -> unsigned { return f < n_inst ? (unsigned)min((size_t)64, (size_t)n_inst - f) : 0u; };
+    u32x4 regs[kChunksPerLane];
+    for (unsigned t = blockIdx.x * kWavesPerBlock + wave; t < n_tiles; t += waves_total) {
+        const size_t tile_first = (size_t)t * (kWave * kMaskRounds);
+        slab_fill<true>(inst, tile_first, valid_at(tile_first), lane, regs);
+        vd_u64 my_word = 0;
+#pragma unroll 1
+        for (int r = 0; r < kMaskRounds; ++r) {
+            const size_t first = tile_first + (size_t)r * kWave;
+            const unsigned n_valid = valid_at(first);
+            slab_store(slab, lane, regs);
+            if (r + 1 < kMaskRounds) slab_fill<true>(inst, first + kWave, valid_at(first + kWave), lane, regs);
+            vd_wave_lds_sync();
+            const LaneInst li = slab_read(slab, lane);
+            vd_wave_lds_sync();
+            const unsigned mid = min(li.mesh, n_mesh - 1u);
+            const MeshRec m = load_mesh(meshes, mid);
+            const bool vis = lane < n_valid && is_visible(cam, m, li.T0, li.T1, li.T2, li.T3);
+            const unsigned long long b = __ballot(vis);
+            if (lane == (unsigned)r) my_word = b;
+            s_ids[r * kWave + lane] = (IdT)mid;
+        }
+        vd_wave_lds_sync();
+        // flush: ballot words (lane r holds round r) and the tile's ids as 16-B stores
+        const size_t w0 = (size_t)t * kMaskRounds;
+        const size_t n_words = ((size_t)n_inst + 63) / 64;
+        if (lane < (unsigned)kMaskRounds && w0 + lane < n_words) mask[w0 + lane] = my_word;
+        const size_t id_base = tile_first * sizeof(IdT);                 // bytes; tile_first % 1024 == 0 -> 16-B aligned
+        const size_t id_end = min((size_t)n_inst, tile_first + (size_t)kWave * kMaskRounds) * sizeof(IdT);
+        char* gids = reinterpret_cast<char*>(ids_out);
+        for (unsigned b0 = lane * 16u; b0 < (unsigned)kIdBytes; b0 += kWave * 16u) {
+            if (id_base + b0 + 16u <= id_end) {
+                *reinterpret_cast<u32x4*>(gids + id_base + b0) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(s_ids) + b0);
+            } else {
+                for (unsigned q = 0; q < 16u && id_base + b0 + q < id_end; ++q) gids[id_base + b0 + q] = reinterpret_cast<const char*>(s_ids)[b0 + q];
+            }
+        }
+        vd_wave_lds_sync();
+    }
+}
+
 constexpr int kExpandWords = 32;                     // mask words (64 instances each) per wave per tile
 
 // Tile t covers the mask words [t*64, t*64 + 64) (4 waves x 16 words).  Word w belongs to shard
@@ -885,7 +941,7 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
     int variant = ctx->cull_variant;
     vd_u64* ticket; vd_u64* states;
     int rc = VD_OK;
-    if (variant <= 0 && n_inst >= (1u << 20)) {
+    if ((variant <= 0) && n_inst >= (1u << 20)) {
         // Split form (default for large inputs): pass 1 streams the instances and writes only one bit
         // + a compact mesh id per instance (reads run at ~6.4 TB/s when no 20-byte commands are stored
         // in the same kernel); pass 2 expands the bits into the ordered command list.  Mixing the
@@ -908,9 +964,19 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
         if (rc) return rc;
 #define VD_SPLIT(IdT)                                                                                              \
         do {                                                                                                         \
-            hipLaunchKernelGGL(cull_mask_kernel<IdT>, dim3(blocks), dim3(kBlock), kWavesPerBlock * kSlabBytes,       \
-                               ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_mask,         \
-                               reinterpret_cast<IdT*>(d_ids), n_wave_tiles);                                         \
+            if (ctx->cull_variant == -70) {                                                                          \
+                hipLaunchKernelGGL(cull_mask_kernel<IdT>, dim3(blocks), dim3(kBlock), kWavesPerBlock * kSlabBytes,   \
+                                   ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_mask,     \
+                                   reinterpret_cast<IdT*>(d_ids), n_wave_tiles);                                     \
+            } else {                                                                                                 \
+                const unsigned n_mt = (n_inst + kWave * kMaskRounds - 1) / (kWave * kMaskRounds);                    \
+                unsigned mb = (n_mt + kWavesPerBlock - 1) / kWavesPerBlock;                                          \
+                if (mb > (unsigned)ctx->num_cus * 3u) mb = (unsigned)ctx->num_cus * 3u;                              \
+                hipLaunchKernelGGL(cull_mask_tiled_kernel<IdT>, dim3(mb), dim3(kBlock),                              \
+                                   kWavesPerBlock * (kSlabBytes + kMaskRounds * kWave * (int)sizeof(IdT)),           \
+                                   ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_mask,     \
+                                   reinterpret_cast<IdT*>(d_ids), n_mt);                                             \
+            }                                                                                                        \
             vd_time_mid(ctx);                                                                                        \
             hipLaunchKernelGGL(expand_mask_kernel<IdT>, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, d_mask, n_words, \
                                n_words, n_inst, n_inst, first_instance, reinterpret_cast<const IdT*>(d_ids), d_meshes, \
