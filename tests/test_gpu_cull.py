@@ -193,3 +193,23 @@ def test_large_mesh_table(ctx, oracle):
     sv.step(cam, d_out, d_cnt)
     torch.cuda.synchronize()
     assert int(d_cnt[0].item()) == wn and d_out.cpu().numpy()[: wn * 20].tobytes() == wc[:wn].tobytes()
+
+
+@pytest.mark.parametrize("n", [(1 << 20) - 1, 1 << 20, (1 << 20) + 77, 1_500_001])
+def test_split_and_fused_forms_agree_around_the_switch(ctx, oracle, n):
+    """vd_cull_compact runs the fused kernel below 2^20 instances and the split form (bitmask +
+    expansion) from 2^20 on: both must equal the oracle, including pad_tail and a shard offset."""
+    import torch
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    inst = synth.instances(n, seed=synth.SEED_BASE + 13, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+    want = oracle.cull_emit(cam, meshes, inst)
+    want["base_instance"] += np.uint32(12345)
+    wc, wn = oracle.compact(want, pad_tail=True)
+    d_m, d_i = ctx.upload(meshes), ctx.upload(inst)
+    d_out = ctx.empty(n * 20)
+    d_out.fill_(0xCD)
+    d_cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+    ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, True, 12345)
+    torch.cuda.synchronize()
+    assert int(d_cnt[0].item()) == wn
+    assert d_out.cpu().numpy()[: n * 20].tobytes() == wc.tobytes()
