@@ -230,15 +230,15 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera /* host 
  *   vd_expand_mask_dev  rebuilds the ordered compacted draw list of a whole scene from the
  *                       concatenated shard masks: shard r covers instances [r*shard_size,
  *                       min(n_total, (r+1)*shard_size)) and owns ceil(shard_size/64) words; the
- *                       per-instance mesh ids (d_mesh_ids[n_total], static per scene, replicated
- *                       once) supply the command fields.  Output == vd_cull_compact on the whole
- *                       scene, bit for bit.                                                       */
+ *                       per-instance mesh ids (d_mesh_ids[n_total], id_bytes = 1, 2 or 4 bytes each;
+ *                       static per scene, replicated once) supply the command fields.  Output ==
+ *                       vd_cull_compact on the whole scene, bit for bit.                          */
 int vd_cull_mask_dev(VdCtx* ctx, const VdCameraUniform* camera /* host */,
                      const VdMeshInfo* d_meshes, uint32_t n_mesh,
                      const VdInstance* d_instances, uint32_t n_inst, uint64_t* d_mask);
 int vd_expand_mask_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_total, uint32_t shard_size,
-                       const uint32_t* d_mesh_ids, const VdMeshInfo* d_meshes, uint32_t n_mesh,
-                       VdDrawIndexedIndirect* d_out, uint32_t* d_out_count);
+                       const void* d_mesh_ids, uint32_t id_bytes, const VdMeshInfo* d_meshes,
+                       uint32_t n_mesh, VdDrawIndexedIndirect* d_out, uint32_t* d_out_count);
 
 /* C3 alone — ordered compaction of an existing emit_draws output (same definition).     */
 int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t n,

@@ -167,7 +167,7 @@ def test_mask_wire_format_equals_fused_compaction(ctx, oracle, n, shards):
     d_ids = ctx.upload(ids)
     d_out = ctx.empty(n * 20)
     d_cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
-    ctx.expand_mask_dev(d_mask_all, n, S, d_ids, d_m, len(meshes), d_out, d_cnt)
+    ctx.expand_mask_dev(d_mask_all, n, S, d_ids, d_m, len(meshes), d_out, d_cnt, id_bytes=4)
     torch.cuda.synchronize()
     cnt = int(d_cnt[0].item())
     assert cnt == wn

@@ -16,7 +16,7 @@ for shards in (1, 8):
     S = n
     wps = vdist.mask_words(S)
     d_mask = torch.zeros(wps * shards, dtype=torch.int64, device="cuda")
-    ids = torch.from_numpy(np.tile(inst["mesh"].astype(np.int32), shards)).cuda()
+    ids = torch.from_numpy(np.tile(inst["mesh"].astype(np.uint8), shards)).cuda()
     d_out = ctx.empty(N * 20); d_cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
     tm, te = [], []
     for it in range(12):

@@ -91,7 +91,7 @@ PROTOTYPES = {
     "vd_cull_emit_shard_dev": (_I, [_P, _P, _P, _U, _P, _U, _U, _P]),
     "vd_cull_compact_shard_dev": (_I, [_P, _P, _P, _U, _P, _U, _U, _P, _P, _I]),
     "vd_cull_mask_dev": (_I, [_P, _P, _P, _U, _P, _U, _P]),
-    "vd_expand_mask_dev": (_I, [_P, _P, _U, _U, _P, _P, _U, _P, _P]),
+    "vd_expand_mask_dev": (_I, [_P, _P, _U, _U, _P, _U, _P, _U, _P, _P]),
     "vd_compact_draws_dev": (_I, [_P, _P, _U, _P, _P]),
     "vd_bvh_build": (_I, [_P, _P, _U, _P, _U, _P, _U, _P]),
     "vd_bvh_build_dev": (_I, [_P, _P, _U, _P, _U, _P, _U, _P]),

@@ -1118,8 +1118,9 @@ int vd_cull_mask_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo
     return VD_OK;
 }
 
-int vd_expand_mask_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_total, uint32_t shard_size, const uint32_t* d_mesh_ids,
-                       const VdMeshInfo* d_meshes, uint32_t n_mesh, VdDrawIndexedIndirect* d_out, uint32_t* d_out_count) {
+int vd_expand_mask_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_total, uint32_t shard_size, const void* d_mesh_ids,
+                       uint32_t id_bytes, const VdMeshInfo* d_meshes, uint32_t n_mesh, VdDrawIndexedIndirect* d_out,
+                       uint32_t* d_out_count) {
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!d_out_count || !d_meshes || n_mesh == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_expand_mask: null count/meshes");
     if (n_total == 0) {
@@ -1127,6 +1128,7 @@ int vd_expand_mask_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_total, uin
         return VD_OK;
     }
     if (!d_mask || !d_mesh_ids || !d_out || shard_size == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_expand_mask: null mask/ids/out or shard_size == 0");
+    if (id_bytes != 1u && id_bytes != 2u && id_bytes != 4u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_expand_mask: id_bytes must be 1, 2 or 4");
     const unsigned n_shards = (n_total + shard_size - 1) / shard_size;
     const unsigned wps = (shard_size + 63u) / 64u;
     const unsigned n_words = n_shards * wps;   // padding bits (beyond a shard's / the scene's end) are 0 by construction
@@ -1135,8 +1137,14 @@ int vd_expand_mask_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_total, uin
     vd_u64* ticket; vd_u64* states;
     int rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);
     if (rc) return rc;
-    hipLaunchKernelGGL(expand_mask_kernel<unsigned>, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, reinterpret_cast<const vd_u64*>(d_mask), n_words,
-                       wps, shard_size, n_total, 0u, d_mesh_ids, d_meshes, n_mesh, d_out, d_out_count, states, ticket, n_tiles);
+#define VD_EXPAND(IdT)                                                                                                    \
+    hipLaunchKernelGGL(expand_mask_kernel<IdT>, dim3(n_tiles), dim3(kBlock), 0, ctx->stream,                                 \
+                       reinterpret_cast<const vd_u64*>(d_mask), n_words, wps, shard_size, n_total, 0u,                       \
+                       reinterpret_cast<const IdT*>(d_mesh_ids), d_meshes, n_mesh, d_out, d_out_count, states, ticket, n_tiles)
+    if (id_bytes == 1u) VD_EXPAND(unsigned char);
+    else if (id_bytes == 2u) VD_EXPAND(unsigned short);
+    else VD_EXPAND(unsigned);
+#undef VD_EXPAND
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;

@@ -56,11 +56,14 @@ class ShardedVisibility:
         # local mask (zero padded to wps words) and the gathered masks of all shards
         self.d_mask = torch.zeros(self.wps, dtype=torch.int64, device=dev)
         self.d_mask_all = torch.zeros(self.wps * self.world, dtype=torch.int64, device=dev)
-        # replicated instance -> mesh table: column 32 of the 36-dword instance records, gathered once
-        ids = torch.zeros(self.S, dtype=torch.int32, device=dev)
+        # replicated instance -> mesh table: column 32 of the 36-dword instance records, gathered once,
+        # stored at the narrowest width the mesh table allows (the expansion pass reads it every frame)
+        id_dtype = torch.uint8 if n_mesh <= 256 else (torch.int16 if n_mesh <= 32768 else torch.int32)
+        ids = torch.zeros(self.S, dtype=id_dtype, device=dev)
         if self.n_local:
-            ids[: self.n_local] = d_inst_shard[: self.n_local * 144].view(torch.int32).view(-1, 36)[:, 32]
-        self.d_mesh_ids = torch.empty(self.S * self.world, dtype=torch.int32, device=dev)
+            col = d_inst_shard[: self.n_local * 144].view(torch.int32).view(-1, 36)[:, 32]
+            ids[: self.n_local] = torch.clamp(col, 0, n_mesh - 1).to(id_dtype)
+        self.d_mesh_ids = torch.empty(self.S * self.world, dtype=id_dtype, device=dev)
         if self.world > 1:
             dist.all_gather_into_tensor(self.d_mesh_ids, ids, group=group)
         else:

@@ -107,8 +107,10 @@ class Context:
         self._chk(self.lib.vd_cull_mask_dev(self.h, cam.ctypes.data, abi.ptr(d_meshes), n_mesh, abi.ptr(d_inst), n_inst,
                                             abi.ptr(d_mask)))
 
-    def expand_mask_dev(self, d_mask, n_total, shard_size, d_mesh_ids, d_meshes, n_mesh, d_out, d_count):
-        self._chk(self.lib.vd_expand_mask_dev(self.h, abi.ptr(d_mask), n_total, shard_size, abi.ptr(d_mesh_ids),
+    def expand_mask_dev(self, d_mask, n_total, shard_size, d_mesh_ids, d_meshes, n_mesh, d_out, d_count, id_bytes=None):
+        if id_bytes is None:
+            id_bytes = d_mesh_ids.element_size() if hasattr(d_mesh_ids, "element_size") else 4
+        self._chk(self.lib.vd_expand_mask_dev(self.h, abi.ptr(d_mask), n_total, shard_size, abi.ptr(d_mesh_ids), id_bytes,
                                               abi.ptr(d_meshes), n_mesh, abi.ptr(d_out), abi.ptr(d_count)))
 
     def compact_draws_dev(self, d_in, n, d_out, d_count):
