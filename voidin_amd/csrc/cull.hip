@@ -6,14 +6,21 @@
 //
 // Data movement (HBM-bound, no MFMA — fp32 compares and index work):
 //   * instances are a 144-byte AoS (not a power of two).  A wave streams 64 consecutive
-//     instances = 9216 contiguous bytes as 9 fully coalesced 16-B-per-lane loads, parks them in
-//     a wave-private LDS slab, and every lane then reads back its own instance's transform
-//     (4 x ds_read_b128 at a 144-B stride: 36-dword stride is conflict-free for b128) and mesh id;
-//   * emit path: the 20-byte commands of a wave (1280 contiguous bytes) go through the same
-//     slab and leave as 16-B-per-lane stores;
-//   * compact path: wave ballot + mbcnt rank the survivors, a 4-wave LDS scan ranks the waves,
-//     and a single-pass decoupled look-back over 8-byte {status,value} granules ranks the
-//     tiles, so instances are read exactly once and only survivors are written.
+//     instances = 9216 contiguous bytes as 9 fully coalesced, nontemporal 16-B-per-lane loads,
+//     parks them in a wave-private LDS slab, and every lane then reads back its own instance's
+//     transform (4 x ds_read_b128 at a 144-B stride: 36-dword stride is conflict-free for b128)
+//     and mesh id; the next round's loads are already in flight (register prefetch);
+//   * emit path (reference format): the 20-byte commands of a wave (1280 contiguous bytes) go
+//     through the same slab and leave as 16-B-per-lane stores;
+//   * compact path, large inputs (split form): pass 1 `cull_mask_tiled_kernel` writes only one
+//     ballot bit + a compact mesh id per instance, so the read stream runs at ~6.3 TB/s; pass 2
+//     `expand_mask_kernel` turns the bits into the ordered command list with a single-pass
+//     decoupled look-back over 8-byte {epoch,status,value} granules and LDS-staged 16-B stores.
+//     (Storing the 20-byte commands from inside the read stream costs ~3x per byte: DESIGN.md §3.1);
+//   * compact path, small inputs (fused form): `cull_compact_kernel<ROUNDS>`, one launch, the same
+//     look-back ranks the tiles while per-round (mesh id | visible) words wait in LDS;
+//   * multi-GPU: the same pass 1 / pass 2 pair with the bitmask all-gathered in between
+//     (vd_cull_mask_dev / vd_expand_mask_dev, voidin_amd/dist.py).
 #include "vd_common.hpp"
 
 #include <math.h>
@@ -30,13 +37,6 @@ constexpr int kChunksPerLane = kSlabBytes / (kWave * 16);  // 9
 
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// One 20-byte command written as dwordx4 + dword: global stores only need 4-byte alignment on gfx950.
-struct __attribute__((packed, aligned(4))) Draw5 { unsigned v[5]; };
-__device__ __forceinline__ void store_draw(VdDrawIndexedIndirect* dst, unsigned a, unsigned b, unsigned c, unsigned d, unsigned e) {
-    Draw5 t; t.v[0] = a; t.v[1] = b; t.v[2] = c; t.v[3] = d; t.v[4] = e;
-    *reinterpret_cast<Draw5*>(dst) = t;
-}
 
 struct CullCamera {   // the slice of CameraUniform the shader reads (shared.wgsl:13-24)
     float view[16];
@@ -184,52 +184,25 @@ __global__ __launch_bounds__(kBlock, 4) void emit_draws_kernel(CullCamera cam, c
 }
 
 // ------------------------------------------------------------------------------------------
-// C1 + C3 fused: cull and emit survivors only, ascending instance order, single pass.
+// C1 + C3 fused: cull and emit survivors only, ascending instance order, single pass (used below
+// 2^20 instances; larger inputs run the split form: cull_mask_tiled_kernel + expand_mask_kernel).
 // ------------------------------------------------------------------------------------------
-// LOAD: 0 = coalesced 16 B/lane nontemporal loads -> VGPR -> LDS slab (next round prefetched)
-//       1 = same with default cache policy
-//       2 = LDS-DMA (global_load_lds_dwordx4), two slabs per wave, next round in flight
-//       3 = no staging: every lane loads its own instance at a 144-B stride
-// OUT : 0 = five dword stores per survivor
-//       1 = survivors staged in LDS at the destination's 16-B phase, stored 16 B per lane
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
-__device__ __forceinline__ void slab_dma(char* slab, const VdInstance* __restrict__ inst, size_t first,
-                                         unsigned n_valid, unsigned lane) {
-    // one 1-KiB piece per instruction: LDS dest = wave-uniform base + 16*lane, source per lane
-    const char* src = reinterpret_cast<const char*>(inst + first);
-    const unsigned n_chunks = n_valid * (kInstBytes / 16);
-    if (n_chunks == 0) return;
-#pragma unroll
-    for (int j = 0; j < kChunksPerLane; ++j) {
-        unsigned c = j * kWave + lane;
-        c = c < n_chunks ? c : n_chunks - 1u;   // ragged tail: re-read a valid chunk, value unused
-        __builtin_amdgcn_global_load_lds((gbl_void*)(src + (size_t)c * 16u), (lds_void*)(slab + j * 1024), 16, 0, 0);
-    }
-}
-
-// ABL (timing-only ablations, wrong results): bit 0 = skip the visibility math, bit 1 = skip the
-// survivor stores, bit 2 = skip ticket + look-back.
-template <int ROUNDS, int LOAD, int OUT, int ABL = 0>
-__global__ __launch_bounds__(kBlock, (LOAD == 0 || LOAD == 1) ? 3 : 4)
+template <int ROUNDS>
+__global__ __launch_bounds__(kBlock, 3)
 void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
                          const VdInstance* __restrict__ inst, unsigned n_inst, VdDrawIndexedIndirect* __restrict__ out,
                          unsigned* __restrict__ out_count, vd_u64* tile_state, vd_u64* ticket_counter,
                          unsigned n_tiles, unsigned first_instance) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int kSlabsPerWave = LOAD == 2 ? 2 : (LOAD == 3 ? 0 : 1);
-    constexpr int kStageBytes = 1312;   // OUT==1 && LOAD==3: per-wave output staging (1280 + 16 phase + pad)
-    constexpr int kWaveLds = kSlabsPerWave * kSlabBytes + ((LOAD == 3 && OUT == 1) ? kStageBytes : 0);
     // dynamic LDS: per-wave slabs, then per-round records (mesh id | visible << 31), then scalars
-    unsigned* s_rec = reinterpret_cast<unsigned*>(smem + kWavesPerBlock * kWaveLds);   // [ROUNDS][kBlock]
-    unsigned* s_misc = s_rec + ROUNDS * kBlock;   // [0] ticket, [1] tile_excl, [2..5] wave totals
+    unsigned* s_rec = reinterpret_cast<unsigned*>(smem + kWavesPerBlock * kSlabBytes);   // [ROUNDS][kBlock]
+    unsigned* s_misc = s_rec + ROUNDS * kBlock;   // [0] ticket, [1] epoch / tile_excl, [2..5] wave totals
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    char* slab = smem + wave * kWaveLds;
+    char* slab = smem + wave * kSlabBytes;
 
-    if (!(ABL & 4) && threadIdx.x == 0) s_misc[0] = vd_take_ticket(ticket_counter, n_tiles, &s_misc[1]);
+    if (threadIdx.x == 0) s_misc[0] = vd_take_ticket(ticket_counter, n_tiles, &s_misc[1]);
     __syncthreads();
-    const unsigned tile = (ABL & 4) ? blockIdx.x : s_misc[0], epoch = s_misc[1];
+    const unsigned tile = s_misc[0], epoch = s_misc[1];
     __syncthreads();
     const size_t tile_first = (size_t)tile * (kBlock * ROUNDS);
     // wave-contiguous ranges keep the output order (wave, round, lane) == instance order
@@ -237,202 +210,16 @@ void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, 
     auto valid_at = [&](size_t f) -> unsigned { return f < n_inst ? (unsigned)min((size_t)64, (size_t)n_inst - f) : 0u; };
 
     unsigned wave_total = 0;
-    u32x4 regs[(LOAD == 0 || LOAD == 1) ? kChunksPerLane : 1];
-    if constexpr (LOAD == 0 || LOAD == 1) slab_fill<LOAD == 0>(inst, wave_first, valid_at(wave_first), lane, regs);
-    if constexpr (LOAD == 2) slab_dma(slab, inst, wave_first, valid_at(wave_first), lane);
-
+    u32x4 regs[kChunksPerLane];
+    slab_fill<true>(inst, wave_first, valid_at(wave_first), lane, regs);
 #pragma unroll 1
     for (int r = 0; r < ROUNDS; ++r) {
         const size_t first = wave_first + (size_t)r * kWave;
         const unsigned n_valid = valid_at(first);
-        LaneInst li;
-        if constexpr (LOAD == 0 || LOAD == 1) {
-            slab_store(slab, lane, regs);
-            if (r + 1 < ROUNDS) slab_fill<LOAD == 0>(inst, first + kWave, valid_at(first + kWave), lane, regs);
-            vd_wave_lds_sync();
-            li = slab_read(slab, lane);
-            vd_wave_lds_sync();
-        } else if constexpr (LOAD == 2) {
-            char* cur = slab + (r & 1) * kSlabBytes;
-            const unsigned nv_next = r + 1 < ROUNDS ? valid_at(first + kWave) : 0u;
-            if (nv_next) {
-                slab_dma(slab + ((r + 1) & 1) * kSlabBytes, inst, first + kWave, nv_next, lane);
-                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // this round's 9 pieces have landed
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            vd_wave_lds_sync();
-            li = slab_read(cur, lane);
-            vd_wave_lds_sync();
-        } else {
-            const size_t i = first + lane;
-            const float4* p = reinterpret_cast<const float4*>(inst + (i < n_inst ? i : (size_t)n_inst - 1));
-            li.T0 = p[0]; li.T1 = p[1]; li.T2 = p[2]; li.T3 = p[3];
-            li.mesh = reinterpret_cast<const unsigned*>(p)[32];
-        }
-        const unsigned mid = min(li.mesh, n_mesh - 1u);
-        const MeshRec m = load_mesh(meshes, mid);
-        const bool vis = lane < n_valid && ((ABL & 1) ? (__float_as_uint(li.T0.x + li.T1.y + li.T2.z + li.T3.w + m.mnx) & 15u) != 0u
-                                                      : is_visible(cam, m, li.T0, li.T1, li.T2, li.T3));
-        s_rec[r * kBlock + threadIdx.x] = mid | (vis ? 0x80000000u : 0u);
-        wave_total += (unsigned)__popcll(__ballot(vis));
-    }
-
-    if (lane == 0) s_misc[2 + wave] = wave_total;
-    __syncthreads();
-    if (wave == 0) {
-        unsigned tile_total = 0;
-#pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) tile_total += s_misc[2 + w];
-        const unsigned excl = (ABL & 4) ? tile * (unsigned)(kBlock * ROUNDS) : vd_lookback(tile_state, epoch, tile, tile_total);
-        if (lane == 0) {
-            s_misc[1] = excl;
-            if (tile == n_tiles - 1u) *out_count = excl + tile_total;
-        }
-    }
-    __syncthreads();
-    unsigned base = s_misc[1];
-    for (unsigned w = 0; w < wave; ++w) base += s_misc[2 + w];
-    if (ABL & 2) { if (base == 0xffffffffu) out[0].vertex_count = wave_total; return; }
-
-    char* stage = (LOAD == 3) ? slab : slab;   // slab memory is free again after the last round
-#pragma unroll 1
-    for (int r = 0; r < ROUNDS; ++r) {
-        const unsigned rec = s_rec[r * kBlock + threadIdx.x];
-        const bool vis = (rec >> 31) != 0u;
-        const unsigned long long mask = __ballot(vis);
-        const unsigned cnt = (unsigned)__popcll(mask);
-        if (cnt == 0u) continue;
-        const unsigned mid = rec & 0x7fffffffu;
-        const uint4* mp = reinterpret_cast<const uint4*>(meshes + mid);
-        const unsigned global_idx = first_instance + (unsigned)(wave_first + (size_t)r * kWave) + lane;
-        if constexpr (OUT == 0 || OUT == 2 || OUT == 3) {
-            if (vis) {
-                unsigned* o = reinterpret_cast<unsigned*>(out + (base + vd_mbcnt(mask)));
-                const unsigned v0 = mp[0].w, v2 = mp[1].w, v3 = (unsigned)meshes[mid].vertex_offset;
-                if constexpr (OUT == 3) {
-                    store_draw(out + (base + vd_mbcnt(mask)), v0, 1u, v2, v3, global_idx);   // dwordx4 + dword
-                } else if constexpr (OUT == 2) {
-                    __builtin_nontemporal_store(v0, o + 0); __builtin_nontemporal_store(1u, o + 1);
-                    __builtin_nontemporal_store(v2, o + 2); __builtin_nontemporal_store(v3, o + 3);
-                    __builtin_nontemporal_store(global_idx, o + 4);
-                } else {
-                    o[0] = v0;                              // index_count
-                    o[1] = 1u;
-                    o[2] = v2;                              // base_index
-                    o[3] = v3;
-                    o[4] = global_idx;
-                }
-            }
-        } else {
-            // destination bytes [A, A + 20*cnt); LDS image starts at A's 16-B phase so that 16-B
-            // aligned global chunks are 16-B aligned LDS chunks
-            char* gbase = reinterpret_cast<char*>(out + base);
-            const unsigned shift = (unsigned)(reinterpret_cast<uintptr_t>(gbase) & 15u);
-            if (vis) {
-                unsigned* o = reinterpret_cast<unsigned*>(stage + shift + 20u * vd_mbcnt(mask));
-                o[0] = mp[0].w;
-                o[1] = 1u;
-                o[2] = mp[1].w;
-                o[3] = (unsigned)meshes[mid].vertex_offset;
-                o[4] = global_idx;
-            }
-            vd_wave_lds_sync();
-            const unsigned total = shift + 20u * cnt;
-            char* g16 = gbase - shift;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const unsigned b0 = (k * kWave + lane) * 16u;
-                if (b0 < total) {
-                    if (b0 >= shift && b0 + 16u <= total) {
-                        *reinterpret_cast<u32x4*>(g16 + b0) = *reinterpret_cast<const u32x4*>(stage + b0);
-                    } else {
-                        const unsigned lo = b0 > shift ? b0 : shift, hi = b0 + 16u < total ? b0 + 16u : total;
-                        for (unsigned b = lo; b < hi; b += 4u)
-                            *reinterpret_cast<unsigned*>(g16 + b) = *reinterpret_cast<const unsigned*>(stage + b);
-                    }
-                }
-            }
-            vd_wave_lds_sync();
-        }
-        base += cnt;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Second-generation fused kernel: stage only what the cull reads.  CH = 16-B chunks staged per
-// instance: 9 = whole record, 5 = transform (chunks 0-3) + the chunk holding mesh id (chunk 8);
-// the skipped chunks share 128-B lines with the staged ones, so HBM traffic is unchanged but
-// VGPR staging (36 -> 20) and the LDS slab (9216 -> 5120 B per wave) shrink.
-// PF = rounds prefetched ahead in registers (0 or 1); MINW = min waves per SIMD for the RA.
-// ------------------------------------------------------------------------------------------
-template <int CH>
-__device__ __forceinline__ void stage_fill(const VdInstance* __restrict__ inst, size_t first, unsigned n_valid,
-                                           unsigned lane, u32x4 (&regs)[CH]) {
-    const u32x4* src = reinterpret_cast<const u32x4*>(inst + first);
-    const unsigned n_k = n_valid * CH;
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
-        const unsigned k = j * kWave + lane;
-        unsigned g = k;
-        if (CH == 5) {
-            const unsigned i = k / 5u, c = k - i * 5u;
-            g = i * 9u + (c < 4u ? c : 8u);
-        }
-        if (k < n_k) regs[j] = __builtin_nontemporal_load(src + g);
-        else regs[j] = u32x4{0u, 0u, 0u, 0u};
-    }
-}
-
-template <int CH>
-__device__ __forceinline__ void stage_store(char* slab, unsigned lane, const u32x4 (&regs)[CH]) {
-    u32x4* dst = reinterpret_cast<u32x4*>(slab);
-#pragma unroll
-    for (int j = 0; j < CH; ++j) dst[j * kWave + lane] = regs[j];
-}
-
-template <int CH>
-__device__ __forceinline__ LaneInst stage_read(const char* slab, unsigned lane) {
-    const char* base = slab + lane * (CH * 16);
-    const float4* p = reinterpret_cast<const float4*>(base);
-    LaneInst li;
-    li.T0 = p[0]; li.T1 = p[1]; li.T2 = p[2]; li.T3 = p[3];
-    li.mesh = *reinterpret_cast<const unsigned*>(base + (CH == 5 ? 64 : 128));
-    return li;
-}
-
-template <int ROUNDS, int CH, int PF, int MINW>
-__global__ __launch_bounds__(kBlock, MINW)
-void cull_compact2_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
-                          const VdInstance* __restrict__ inst, unsigned n_inst, VdDrawIndexedIndirect* __restrict__ out,
-                          unsigned* __restrict__ out_count, vd_u64* tile_state, vd_u64* ticket_counter,
-                          unsigned n_tiles, unsigned first_instance) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int kWaveLds = kWave * CH * 16;
-    unsigned* s_rec = reinterpret_cast<unsigned*>(smem + kWavesPerBlock * kWaveLds);   // [ROUNDS][kBlock]
-    unsigned* s_misc = s_rec + ROUNDS * kBlock;
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    char* slab = smem + wave * kWaveLds;
-
-    if (threadIdx.x == 0) s_misc[0] = vd_take_ticket(ticket_counter, n_tiles, &s_misc[1]);
-    __syncthreads();
-    const unsigned tile = s_misc[0], epoch = s_misc[1];
-    __syncthreads();
-    const size_t wave_first = (size_t)tile * (kBlock * ROUNDS) + (size_t)wave * (kWave * ROUNDS);
-    auto valid_at = [&](size_t f) -> unsigned { return f < n_inst ? (unsigned)min((size_t)64, (size_t)n_inst - f) : 0u; };
-
-    unsigned wave_total = 0;
-    u32x4 regs[CH];
-    if (PF) stage_fill<CH>(inst, wave_first, valid_at(wave_first), lane, regs);
-#pragma unroll 1
-    for (int r = 0; r < ROUNDS; ++r) {
-        const size_t first = wave_first + (size_t)r * kWave;
-        const unsigned n_valid = valid_at(first);
-        if (!PF) stage_fill<CH>(inst, first, n_valid, lane, regs);
-        stage_store<CH>(slab, lane, regs);
-        if (PF && r + 1 < ROUNDS) stage_fill<CH>(inst, first + kWave, valid_at(first + kWave), lane, regs);
+        slab_store(slab, lane, regs);
+        if (r + 1 < ROUNDS) slab_fill<true>(inst, first + kWave, valid_at(first + kWave), lane, regs);
         vd_wave_lds_sync();
-        const LaneInst li = stage_read<CH>(slab, lane);
+        const LaneInst li = slab_read(slab, lane);
         vd_wave_lds_sync();
         const unsigned mid = min(li.mesh, n_mesh - 1u);
         const MeshRec m = load_mesh(meshes, mid);
@@ -476,69 +263,8 @@ void cull_compact2_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes,
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Wave-tile form: every wave is its own tile (64*ROUNDS instances), draws its own ticket and
-// runs its own look-back, so a workgroup never synchronises: no barrier bubbles at tile ends.
-// ------------------------------------------------------------------------------------------
-template <int ROUNDS, int MINW>
-__global__ __launch_bounds__(kBlock, MINW)
-void cull_compact_wave_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
-                              const VdInstance* __restrict__ inst, unsigned n_inst, VdDrawIndexedIndirect* __restrict__ out,
-                              unsigned* __restrict__ out_count, vd_u64* tile_state, vd_u64* ticket_counter,
-                              unsigned n_tiles, unsigned first_instance) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int kWaveLds = kSlabBytes + ROUNDS * kWave * 4;
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char* slab = smem + wave * kWaveLds;
-    unsigned* s_rec = reinterpret_cast<unsigned*>(slab + kSlabBytes);   // [ROUNDS][64]
-
-    if (blockIdx.x * (unsigned)kWavesPerBlock + wave >= n_tiles) return;   // exactly n_tiles tickets are drawn
-    unsigned tile = 0, epoch = 0;
-    if (lane == 0) tile = vd_take_ticket(ticket_counter, n_tiles, &epoch);
-    tile = __builtin_amdgcn_readfirstlane(tile);
-    epoch = __builtin_amdgcn_readfirstlane(epoch);
-    const size_t wave_first = (size_t)tile * (kWave * ROUNDS);
-    auto valid_at = [&](size_t f) -> unsigned { return f < n_inst ? (unsigned)min((size_t)64, (size_t)n_inst - f) : 0u; };
-
-    unsigned wave_total = 0;
-    u32x4 regs[kChunksPerLane];
-    slab_fill<true>(inst, wave_first, valid_at(wave_first), lane, regs);
-#pragma unroll 1
-    for (int r = 0; r < ROUNDS; ++r) {
-        const size_t first = wave_first + (size_t)r * kWave;
-        const unsigned n_valid = valid_at(first);
-        slab_store(slab, lane, regs);
-        if (r + 1 < ROUNDS) slab_fill<true>(inst, first + kWave, valid_at(first + kWave), lane, regs);
-        vd_wave_lds_sync();
-        const LaneInst li = slab_read(slab, lane);
-        vd_wave_lds_sync();
-        const unsigned mid = min(li.mesh, n_mesh - 1u);
-        const MeshRec m = load_mesh(meshes, mid);
-        const bool vis = lane < n_valid && is_visible(cam, m, li.T0, li.T1, li.T2, li.T3);
-        s_rec[r * kWave + lane] = mid | (vis ? 0x80000000u : 0u);
-        wave_total += (unsigned)__popcll(__ballot(vis));
-    }
-    unsigned base = vd_lookback(tile_state, epoch, tile, wave_total);
-    if (tile == n_tiles - 1u && lane == 0) *out_count = base + wave_total;
-#pragma unroll 1
-    for (int r = 0; r < ROUNDS; ++r) {
-        const unsigned rec = s_rec[r * kWave + lane];
-        const bool vis = (rec >> 31) != 0u;
-        const unsigned long long mask = __ballot(vis);
-        if (vis) {
-            const unsigned mid = rec & 0x7fffffffu;
-            const uint4* mp = reinterpret_cast<const uint4*>(meshes + mid);
-            unsigned* o = reinterpret_cast<unsigned*>(out + (base + vd_mbcnt(mask)));
-            o[0] = mp[0].w;
-            o[1] = 1u;
-            o[2] = mp[1].w;
-            o[3] = (unsigned)meshes[mid].vertex_offset;
-            o[4] = first_instance + (unsigned)(wave_first + (size_t)r * kWave) + lane;
-        }
-        base += (unsigned)__popcll(mask);
-    }
-}
+template <int ROUNDS>
+constexpr int compact_lds_bytes() { return kWavesPerBlock * kSlabBytes + ROUNDS * kBlock * 4 + 32; }
 
 // ------------------------------------------------------------------------------------------
 // Multi-GPU wire format: cull -> one bit per instance; expand bits -> ordered draw list.
@@ -745,38 +471,6 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
         vd_wave_lds_sync();
         base += cnt;
     }
-}
-
-// ---- tuning probes (debug variants >= 100): what a pure stream of the same shape reaches ----
-template <bool NT, bool WRITE>
-__global__ __launch_bounds__(kBlock) void probe_stream_kernel(const VdInstance* __restrict__ inst, unsigned n_inst,
-                                                              VdDrawIndexedIndirect* __restrict__ out, unsigned rounds) {
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const size_t wave_first = ((size_t)blockIdx.x * kWavesPerBlock + wave) * (size_t)(kWave * rounds);
-    u32x4 acc = {0u, 0u, 0u, 0u};
-    for (unsigned r = 0; r < rounds; ++r) {
-        const size_t first = wave_first + (size_t)r * kWave;
-        if (first + kWave > n_inst) break;
-        const u32x4* src = reinterpret_cast<const u32x4*>(inst + first);
-#pragma unroll
-        for (int j = 0; j < kChunksPerLane; ++j) {
-            const u32x4 v = NT ? __builtin_nontemporal_load(src + j * kWave + lane) : src[j * kWave + lane];
-            acc ^= v;
-        }
-        if (WRITE) {
-            u32x4* dst = reinterpret_cast<u32x4*>(out + first);   // 1280 B per wave-round
-            dst[lane] = acc;
-            if (lane < 16u) dst[64 + lane] = acc;
-        }
-    }
-    if (!WRITE && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) reinterpret_cast<unsigned*>(out)[lane] = acc.x;
-}
-
-template <int ROUNDS, int LOAD, int OUT>
-constexpr int compact_lds_bytes() {
-    constexpr int slabs = LOAD == 2 ? 2 : (LOAD == 3 ? 0 : 1);
-    constexpr int wave_lds = slabs * kSlabBytes + ((LOAD == 3 && OUT == 1) ? 1312 : 0);
-    return kWavesPerBlock * wave_lds + ROUNDS * kBlock * 4 + 32;
 }
 
 // Zero-fill out[count..n) so the unchanged multi_draw_indexed_indirect(buf, 0, N) consumer
@@ -994,101 +688,23 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
         VD_HIP_CHECK(ctx, hipGetLastError());
         return VD_OK;
     }
-#define VD_LAUNCH_ABL(A)                                                                                          \
-    do {                                                                                                         \
-        const unsigned n_tiles = (n_inst + kBlock * 32 - 1) / (kBlock * 32);                                     \
-        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);                                                       \
-        if (rc) return rc;                                                                                       \
-        hipLaunchKernelGGL((cull_compact_kernel<32, 0, 0, A>), dim3(n_tiles), dim3(kBlock),                      \
-                           (compact_lds_bytes<32, 0, 0>()), ctx->stream, make_cam(camera), d_meshes, n_mesh,     \
-                           d_instances, n_inst, d_out, d_out_count, states, ticket, n_tiles, first_instance);    \
-    } while (0)
-#define VD_LAUNCH_COMPACT(R, L, O)                                                                              \
+#define VD_LAUNCH_COMPACT(R)                                                                                     \
     do {                                                                                                         \
         const unsigned n_tiles = (n_inst + kBlock * (R) - 1) / (kBlock * (R));                                   \
-        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);                                                       \
+        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);                                              \
         if (rc) return rc;                                                                                       \
-        hipLaunchKernelGGL((cull_compact_kernel<R, L, O>), dim3(n_tiles), dim3(kBlock),                          \
-                           (compact_lds_bytes<R, L, O>()), ctx->stream, make_cam(camera), d_meshes, n_mesh,      \
-                           d_instances, n_inst, d_out, d_out_count, states, ticket, n_tiles, first_instance);    \
+        hipLaunchKernelGGL((cull_compact_kernel<R>), dim3(n_tiles), dim3(kBlock), (compact_lds_bytes<R>()),      \
+                           ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_out,          \
+                           d_out_count, states, ticket, n_tiles, first_instance);                                \
     } while (0)
-    if (variant <= 0) {
-        // default: nontemporal coalesced loads -> VGPR -> LDS slab, one round prefetched; tile size
-        // grows with n so that per-tile costs (ticket, two barriers, look-back) amortise while
-        // small inputs still spread over the chip (A/B log: gpurun_out/ab_cull_*.log)
-        variant = n_inst >= (4u << 20) ? 12 : (n_inst >= (1u << 20) ? 11 : (n_inst >= (1u << 18) ? -1 : 9));
-    }
-    switch (variant) {
-        default:
-        case -1: VD_LAUNCH_COMPACT(8, 0, 0); break;
-        case 1: VD_LAUNCH_COMPACT(8, 1, 0); break;
-        case 2: VD_LAUNCH_COMPACT(8, 2, 0); break;
-        case 3: VD_LAUNCH_COMPACT(8, 3, 0); break;
-        case 4: VD_LAUNCH_COMPACT(8, 0, 1); break;
-        case 5: VD_LAUNCH_COMPACT(8, 2, 1); break;
-        case 6: VD_LAUNCH_COMPACT(8, 3, 1); break;
-        case 7: VD_LAUNCH_COMPACT(4, 2, 1); break;
-        case 8: VD_LAUNCH_COMPACT(16, 2, 1); break;
-        case 9: VD_LAUNCH_COMPACT(4, 0, 1); break;
-        case 10: VD_LAUNCH_COMPACT(16, 0, 1); break;
-        case 11: VD_LAUNCH_COMPACT(16, 0, 0); break;
-        case 12: VD_LAUNCH_COMPACT(32, 0, 0); break;
-        case 17: VD_LAUNCH_COMPACT(32, 0, 3); break;
-        case 13: VD_LAUNCH_COMPACT(32, 0, 1); break;
-        case 14: VD_LAUNCH_COMPACT(32, 0, 2); break;
-        case 15: VD_LAUNCH_COMPACT(24, 0, 0); break;
-        case 16: VD_LAUNCH_COMPACT(48, 0, 0); break;
-#define VD_LAUNCH_C2(R, CH, PF, MW)                                                                              \
-    do {                                                                                                         \
-        const unsigned n_tiles = (n_inst + kBlock * (R) - 1) / (kBlock * (R));                                   \
-        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);                                                       \
-        if (rc) return rc;                                                                                       \
-        hipLaunchKernelGGL((cull_compact2_kernel<R, CH, PF, MW>), dim3(n_tiles), dim3(kBlock),                   \
-                           kWavesPerBlock * kWave * (CH) * 16 + (R) * kBlock * 4 + 32, ctx->stream,              \
-                           make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_out, d_out_count, states,  \
-                           ticket, n_tiles, first_instance);                                                     \
-    } while (0)
-        case 30: VD_LAUNCH_C2(16, 9, 1, 3); break;
-        case 31: VD_LAUNCH_C2(16, 5, 1, 3); break;
-        case 32: VD_LAUNCH_C2(16, 5, 1, 4); break;
-        case 33: VD_LAUNCH_C2(16, 5, 1, 5); break;
-        case 34: VD_LAUNCH_C2(16, 5, 0, 4); break;
-        case 35: VD_LAUNCH_C2(16, 5, 0, 5); break;
-        case 36: VD_LAUNCH_C2(16, 5, 0, 6); break;
-        case 37: VD_LAUNCH_C2(16, 5, 0, 8); break;
-        case 38: VD_LAUNCH_C2(8, 5, 0, 6); break;
-        case 39: VD_LAUNCH_C2(8, 5, 1, 4); break;
-        case 40: VD_LAUNCH_C2(16, 9, 0, 4); break;
-        case 41: VD_LAUNCH_C2(16, 9, 0, 6); break;
-#define VD_LAUNCH_WAVE(R, MW)                                                                                    \
-    do {                                                                                                         \
-        const unsigned n_tiles = (n_inst + kWave * (R) - 1) / (kWave * (R));                                     \
-        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);                                                       \
-        if (rc) return rc;                                                                                       \
-        hipLaunchKernelGGL((cull_compact_wave_kernel<R, MW>), dim3((n_tiles + 3) / 4), dim3(kBlock),             \
-                           kWavesPerBlock * (kSlabBytes + (R) * kWave * 4), ctx->stream, make_cam(camera),       \
-                           d_meshes, n_mesh, d_instances, n_inst, d_out, d_out_count, states, ticket, n_tiles,   \
-                           first_instance);                                                                      \
-    } while (0)
-        case 60: VD_LAUNCH_WAVE(8, 3); break;
-        case 61: VD_LAUNCH_WAVE(16, 3); break;
-        case 62: VD_LAUNCH_WAVE(32, 3); break;
-        case 63: VD_LAUNCH_WAVE(64, 3); break;
-        case 64: VD_LAUNCH_WAVE(16, 4); break;
-        case 50: VD_LAUNCH_ABL(1); break;
-        case 51: VD_LAUNCH_ABL(2); break;
-        case 52: VD_LAUNCH_ABL(4); break;
-        case 53: VD_LAUNCH_ABL(7); break;
-        case 54: VD_LAUNCH_ABL(3); break;
-        case 100: case 101: case 102: case 103: {
-            const unsigned rounds = 8, per_block = kBlock * rounds;
-            const unsigned blocks = n_inst / per_block;
-            if (variant == 100) hipLaunchKernelGGL((probe_stream_kernel<true, false>), dim3(blocks), dim3(kBlock), 0, ctx->stream, d_instances, n_inst, d_out, rounds);
-            if (variant == 101) hipLaunchKernelGGL((probe_stream_kernel<false, false>), dim3(blocks), dim3(kBlock), 0, ctx->stream, d_instances, n_inst, d_out, rounds);
-            if (variant == 102) hipLaunchKernelGGL((probe_stream_kernel<true, true>), dim3(blocks), dim3(kBlock), 0, ctx->stream, d_instances, n_inst, d_out, rounds);
-            if (variant == 103) hipLaunchKernelGGL((probe_stream_kernel<false, true>), dim3(blocks), dim3(kBlock), 0, ctx->stream, d_instances, n_inst, d_out, rounds);
-            break;
-        }
+    // fused form: tile size grows with n so that ticket + two barriers + look-back amortise while
+    // small inputs still spread over the chip.  variant > 0 forces a tile size (tools/ab_cull.py).
+    const int rounds = variant > 0 ? variant : (n_inst >= (4u << 20) ? 32 : (n_inst >= (1u << 20) ? 16 : (n_inst >= (1u << 18) ? 8 : 4)));
+    switch (rounds) {
+        case 4: VD_LAUNCH_COMPACT(4); break;
+        case 8: VD_LAUNCH_COMPACT(8); break;
+        case 16: VD_LAUNCH_COMPACT(16); break;
+        default: VD_LAUNCH_COMPACT(32); break;
     }
 #undef VD_LAUNCH_COMPACT
     vd_time_end(ctx);
