@@ -137,7 +137,7 @@ def main():
     step_bytes = n * (144.0 + 20.0 * vis)          # 144 B read + 20 B per survivor
     if split:
         id_bytes = 1 if len(meshes) <= 256 else (2 if len(meshes) <= 65536 else 4)
-        kernel_name = "cull_mask_kernel"
+        kernel_name = "cull_mask_tiled_kernel"
         kernel_ms = sum(k_cull) / len(k_cull)
         alg_bytes = n * (144.0 + 0.125 + id_bytes)  # 144 B instance read + 1 bit + the compact mesh id written
         expand_ms = sum(k_expand) / len(k_expand)
