@@ -75,6 +75,7 @@ int vd_ctx_destroy(VdCtx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scan_state) (void)hipFree(ctx->scan_state);
+    if (ctx->expand_state) (void)hipFree(ctx->expand_state);
     if (ctx->stage_in) (void)hipFree(ctx->stage_in);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
     if (ctx->stage_aux) (void)hipFree(ctx->stage_aux);

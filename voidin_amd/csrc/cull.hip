@@ -363,75 +363,150 @@ __global__ __launch_bounds__(kBlock, 3) void cull_mask_tiled_kernel(CullCamera c
     }
 }
 
-constexpr int kExpandWords = 32;                     // mask words (64 instances each) per wave per tile
+constexpr int kExpandGroup = 4;                      // mask words staged and stored as one contiguous run
+constexpr int kExpandWords = 32;                     // mask words (64 instances each) per wave
+constexpr int kChunkWords = kWavesPerBlock * kExpandWords;   // per workgroup: 128 words = 8192 instances
 
-// Tile t covers the mask words [t*64, t*64 + 64) (4 waves x 16 words).  Word w belongs to shard
-// w / wps and holds the instances shard*shard_size + 64*(w % wps) + bit.
-template <typename IdT>
+// Pass 2a of the split form: survivors per 8192-instance chunk, then (last workgroup to finish) their exclusive
+// scan in place and the total.  Keeping the scan out of pass 2b leaves that kernel without tickets, look-back or
+// any other load that depends on another workgroup: under a saturated store stream every dependent load costs
+// microseconds (on gfx950 loads and stores share vmcnt and the same queue), and 2b had four of them in a chain.
+__global__ __launch_bounds__(kBlock) void mask_scan_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned n_chunks,
+                                                           unsigned* chunk_offset, unsigned* done_counter,
+                                                           unsigned* __restrict__ out_count) {
+    __shared__ unsigned s_last, s_wave_sum[kWavesPerBlock], s_carry;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (unsigned c = blockIdx.x * kWavesPerBlock + wave; c < n_chunks; c += gridDim.x * kWavesPerBlock) {
+        const unsigned w = c * kChunkWords + lane;
+        unsigned v = (w < n_words ? (unsigned)__popcll(mask[w]) : 0u) + (w + 64u < n_words ? (unsigned)__popcll(mask[w + 64u]) : 0u);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) __hip_atomic_store(&chunk_offset[c], v, VD_RLX_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    constexpr unsigned kPer = 4;
+    for (unsigned c0 = 0; c0 < n_chunks; c0 += kBlock * kPer) {
+        unsigned v[kPer], sum = 0;
+#pragma unroll
+        for (unsigned k = 0; k < kPer; ++k) {
+            const unsigned c = c0 + threadIdx.x * kPer + k;
+            v[k] = c < n_chunks ? __hip_atomic_load(&chunk_offset[c], VD_RLX_AGENT) : 0u;
+            sum += v[k];
+        }
+        unsigned incl = sum;                               // inclusive scan across the wave
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off);
+            if (lane >= (unsigned)off) incl += t;
+        }
+        if (lane == kWave - 1u) s_wave_sum[wave] = incl;
+        __syncthreads();
+        unsigned before = s_carry;
+        for (unsigned w = 0; w < wave; ++w) before += s_wave_sum[w];
+        unsigned run = before + incl - sum;
+#pragma unroll
+        for (unsigned k = 0; k < kPer; ++k) {
+            const unsigned c = c0 + threadIdx.x * kPer + k;
+            if (c < n_chunks) chunk_offset[c] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1u) s_carry = run;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *out_count = s_carry;
+        __hip_atomic_store(done_counter, 0u, VD_RLX_AGENT);   // re-armed for the next launch on this stream
+    }
+}
+
+// Pass 2b: workgroup c expands the 128 mask words of chunk c to out[chunk_offset[c] ...); word w belongs to shard
+// w / wps and holds the instances shard*shard_size + 64*(w % wps) + bit.  Every load is issued before the first
+// store (one round trip per workgroup).
+//   WIDE: 1-byte ids, every group of 4 words inside one shard and 4-byte aligned -> a group's 256 ids are one dword
+//         per lane, redistributed with ds_bpermute (instead of four 64-byte-wide byte loads);
+//   TAB:  the mesh table fits the LDS copy (no global loads in the store loop).
+template <typename IdT, bool WIDE, bool TAB>
 __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned wps,
                                                              unsigned shard_size, unsigned n_total, unsigned first_instance,
                                                              const IdT* __restrict__ mesh_ids,
                                                              const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
                                                              VdDrawIndexedIndirect* __restrict__ out,
-                                                             unsigned* __restrict__ out_count, vd_u64* tile_state,
-                                                             vd_u64* ticket_counter, unsigned n_tiles) {
-    __shared__ unsigned s_ticket, s_epoch, s_wave_total[kWavesPerBlock], s_tile_excl;
-    constexpr unsigned kTab = 512;                        // mesh tables up to this size are served from LDS
+                                                             const unsigned* __restrict__ chunk_offset) {
+    constexpr int kGroups = kExpandWords / kExpandGroup;
+    constexpr unsigned kTab = TAB ? 512 : 1;              // mesh tables up to 512 entries are served from LDS
     __shared__ unsigned s_tab[kTab][3];                   // {index_count, base_index, vertex_offset}
+    constexpr int kStageBytes = kExpandGroup * 1280 + 32;
+    __shared__ __attribute__((aligned(16))) char s_stage[kWavesPerBlock][kStageBytes];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_ticket = vd_take_ticket(ticket_counter, n_tiles, &s_epoch);
-    const bool tab = n_mesh <= kTab;
-    if (tab)
+    const unsigned chunk = blockIdx.x;
+    const unsigned cw0 = chunk * kChunkWords;
+    const unsigned w0 = cw0 + wave * kExpandWords;        // wave-uniform
+    unsigned base = chunk_offset[chunk];
+    // survivors of the chunk's earlier waves: lane l looks at words cw0 + l and cw0 + 64 + l
+    unsigned before = 0;
+    if (lane < wave * kExpandWords && cw0 + lane < n_words) before = (unsigned)__popcll(mask[cw0 + lane]);
+    if (lane + 64u < wave * kExpandWords && cw0 + 64u + lane < n_words) before += (unsigned)__popcll(mask[cw0 + 64u + lane]);
+    // lane l < 32 holds mask word w0 + l
+    vd_u64 my_word = 0;
+    if (lane < (unsigned)kExpandWords && w0 + lane < n_words) my_word = mask[w0 + lane];
+    // first instance of each word of group g (one division per group)
+    auto group_first = [&](unsigned wg, unsigned (&f)[kExpandGroup]) {
+        unsigned shard = wg / wps, r = wg - shard * wps;
+#pragma unroll
+        for (int q = 0; q < kExpandGroup; ++q) {
+            f[q] = shard * shard_size + 64u * r;
+            if (++r >= wps) { r = 0u; ++shard; }
+        }
+    };
+    constexpr int kIdRegs = WIDE ? kGroups : kExpandWords;
+    unsigned ids[kIdRegs];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+        const unsigned wg = w0 + g * kExpandGroup;
+        unsigned f[kExpandGroup];
+        group_first(wg, f);
+        if (WIDE) {
+            ids[g] = 0u;
+            if (wg < n_words) {
+                const unsigned i0 = f[0] + 4u * lane;
+                if (i0 + 4u <= n_total) ids[g] = *reinterpret_cast<const unsigned*>(mesh_ids + i0);
+                else for (unsigned q = 0; q < 4u && i0 + q < n_total; ++q) ids[g] |= (unsigned)mesh_ids[i0 + q] << (8u * q);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kExpandGroup; ++q) {
+                const unsigned idx = f[q] + lane;
+                ids[WIDE ? 0 : g * kExpandGroup + q] = (wg + q < n_words && idx < n_total) ? (unsigned)mesh_ids[idx] : 0u;
+            }
+        }
+    }
+    if (TAB)
         for (unsigned i = threadIdx.x; i < n_mesh; i += kBlock) {
             s_tab[i][0] = meshes[i].index_count; s_tab[i][1] = meshes[i].base_index; s_tab[i][2] = (unsigned)meshes[i].vertex_offset;
         }
-    __syncthreads();
-    const unsigned tile = s_ticket, epoch = s_epoch;
-    const unsigned w0 = tile * (kWavesPerBlock * kExpandWords) + wave * kExpandWords;
-    // lane l < 16 loads word w0 + l; popcounts give the wave total
-    vd_u64 my_word = 0;
-    if (lane < (unsigned)kExpandWords && w0 + lane < n_words) my_word = mask[w0 + lane];
-    unsigned wave_total = (unsigned)__popcll(my_word);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wave_total += __shfl_xor(wave_total, off);
-    wave_total = __shfl(wave_total, 0);
-    if (lane == 0) s_wave_total[wave] = wave_total;
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    base += before;
     __syncthreads();
-    if (wave == 0) {
-        unsigned tile_total = 0;
-#pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) tile_total += s_wave_total[w];
-        const unsigned excl = vd_lookback(tile_state, epoch, tile, tile_total);
-        if (lane == 0) {
-            s_tile_excl = excl;
-            if (tile == n_tiles - 1u) *out_count = excl + tile_total;
-        }
-    }
-    __syncthreads();
-    unsigned base = s_tile_excl;
-    for (unsigned w = 0; w < wave; ++w) base += s_wave_total[w];
-    // all sixteen mesh-id loads of this lane are issued up front (independent, 4 B coalesced)
-    unsigned mids[kExpandWords];
-#pragma unroll
-    for (int k = 0; k < kExpandWords; ++k) {
-        const unsigned w = w0 + k;
-        const unsigned shard = w / wps;
-        const unsigned inst_idx = shard * shard_size + 64u * (w - shard * wps) + lane;
-        mids[k] = (w < n_words && inst_idx < n_total) ? (unsigned)mesh_ids[inst_idx] : 0u;
-    }
-    // survivors of kGroup mask words are staged in LDS at the destination's 16-B phase and leave as
-    // 16-B-per-lane stores in one contiguous run (this kernel is write-dominated: 20 B out per 4 B in)
-    constexpr int kGroup = 4;
-    constexpr int kStageBytes = kGroup * 1280 + 32;
-    __shared__ __attribute__((aligned(16))) char s_stage[kWavesPerBlock][kStageBytes];
+    // survivors of kExpandGroup mask words are staged in LDS at the destination's 16-B phase and leave as
+    // 16-B-per-lane stores in one contiguous run (this kernel is write-dominated: 20 B out per ~1 B in)
     char* stage = s_stage[wave];
 #pragma unroll
-    for (int g = 0; g < kExpandWords / kGroup; ++g) {
-        vd_u64 m[kGroup];
+    for (int g = 0; g < kGroups; ++g) {
+        const unsigned wg = w0 + g * kExpandGroup;
+        vd_u64 m[kExpandGroup];
         unsigned cnt = 0;
 #pragma unroll
-        for (int q = 0; q < kGroup; ++q) {
-            const int k = g * kGroup + q;
+        for (int q = 0; q < kExpandGroup; ++q) {
+            const int k = g * kExpandGroup + q;
             const unsigned lo = __shfl((unsigned)my_word, k), hi = __shfl((unsigned)(my_word >> 32), k);
             m[q] = ((vd_u64)hi << 32) | lo;
             cnt += (unsigned)__popcll(m[q]);
@@ -440,19 +515,24 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
         char* gbase = reinterpret_cast<char*>(out + base);
         const unsigned shift = (unsigned)(reinterpret_cast<uintptr_t>(gbase) & 15u);
         unsigned run = 0;
+        unsigned first[kExpandGroup];
+        group_first(wg, first);
 #pragma unroll
-        for (int q = 0; q < kGroup; ++q) {
-            const int k = g * kGroup + q;
+        for (int q = 0; q < kExpandGroup; ++q) {
+            unsigned mid;
+            if (WIDE) {
+                const unsigned v = (unsigned)__shfl((int)ids[WIDE ? g : 0], q * 16 + (int)(lane >> 2));
+                mid = (v >> (8u * (lane & 3u))) & 0xffu;
+            } else {
+                mid = ids[WIDE ? 0 : g * kExpandGroup + q];
+            }
             if ((m[q] >> lane) & 1ull) {
-                const unsigned w = w0 + k;
-                const unsigned shard = w / wps;
-                const unsigned inst_idx = shard * shard_size + 64u * (w - shard * wps) + lane;
-                const unsigned mid = min(mids[k], n_mesh - 1u);
+                mid = min(mid, n_mesh - 1u);
                 unsigned* o = reinterpret_cast<unsigned*>(stage + shift + 20u * (run + vd_mbcnt(m[q])));
-                if (tab) { o[0] = s_tab[mid][0]; o[2] = s_tab[mid][1]; o[3] = s_tab[mid][2]; }
+                if (TAB) { o[0] = s_tab[mid][0]; o[2] = s_tab[mid][1]; o[3] = s_tab[mid][2]; }
                 else { o[0] = meshes[mid].index_count; o[2] = meshes[mid].base_index; o[3] = (unsigned)meshes[mid].vertex_offset; }
                 o[1] = 1u;
-                o[4] = first_instance + inst_idx;
+                o[4] = first_instance + first[q] + lane;
             }
             run += (unsigned)__popcll(m[q]);
         }
@@ -471,6 +551,39 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
         vd_wave_lds_sync();
         base += cnt;
     }
+}
+
+// Host side of pass 2 (shared by vd_cull_compact* and vd_expand_mask_dev).
+static int launch_expand(VdCtx* ctx, const vd_u64* d_mask, unsigned n_words, unsigned wps, unsigned shard_size,
+                         unsigned n_total, unsigned first_instance, const void* d_ids, unsigned id_bytes,
+                         const VdMeshInfo* d_meshes, unsigned n_mesh, VdDrawIndexedIndirect* d_out, unsigned* d_out_count) {
+    const unsigned n_chunks = (n_words + kChunkWords - 1) / kChunkWords;
+    const size_t need = 16 + (((size_t)n_chunks * 4 + 15) & ~(size_t)15);
+    if (need > ctx->expand_state_bytes || !ctx->expand_state) {
+        int rc = vd_ensure(ctx, &ctx->expand_state, &ctx->expand_state_bytes, need);
+        if (rc) return rc;
+        VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->expand_state, 0, 16, ctx->stream));   // the done counter
+    }
+    unsigned* done = reinterpret_cast<unsigned*>(ctx->expand_state);
+    unsigned* offsets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->expand_state) + 16);
+    unsigned sblocks = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (sblocks > (unsigned)ctx->num_cus * 2u) sblocks = (unsigned)ctx->num_cus * 2u;
+    hipLaunchKernelGGL(mask_scan_kernel, dim3(sblocks), dim3(kBlock), 0, ctx->stream, d_mask, n_words, n_chunks, offsets, done,
+                       d_out_count);
+    const bool one_shard = wps >= n_words;
+    const bool wide = id_bytes == 1u && (one_shard || shard_size % (64u * kExpandGroup) == 0u) &&
+                      (reinterpret_cast<uintptr_t>(d_ids) & 3u) == 0u;
+    const bool tab = n_mesh <= 512u;
+#define VD_EXPAND(IdT, W, T)                                                                                               \
+    hipLaunchKernelGGL((expand_mask_kernel<IdT, W, T>), dim3(n_chunks), dim3(kBlock), 0, ctx->stream, d_mask, n_words, wps,  \
+                       shard_size, n_total, first_instance, reinterpret_cast<const IdT*>(d_ids), d_meshes, n_mesh, d_out,    \
+                       offsets)
+    if (wide && tab) VD_EXPAND(unsigned char, true, true);
+    else if (id_bytes == 1u) { if (tab) VD_EXPAND(unsigned char, false, true); else VD_EXPAND(unsigned char, false, false); }
+    else if (id_bytes == 2u) { if (tab) VD_EXPAND(unsigned short, false, true); else VD_EXPAND(unsigned short, false, false); }
+    else { if (tab) VD_EXPAND(unsigned, false, true); else VD_EXPAND(unsigned, false, false); }
+#undef VD_EXPAND
+    return VD_OK;
 }
 
 // Zero-fill out[count..n) so the unchanged multi_draw_indexed_indirect(buf, 0, N) consumer
@@ -648,14 +761,11 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
         if (rc) return rc;
         vd_u64* d_mask = reinterpret_cast<vd_u64*>(ctx->scratch);
         void* d_ids = reinterpret_cast<char*>(ctx->scratch) + (((size_t)n_words * 8 + 255) & ~(size_t)255);
+        vd_time_begin(ctx);
         const unsigned n_wave_tiles = n_words;
         unsigned blocks = (n_wave_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
         const unsigned cap = (unsigned)ctx->num_cus * 4u;
         if (blocks > cap) blocks = cap;
-        const unsigned words_per_tile = kWavesPerBlock * kExpandWords;
-        const unsigned n_tiles = (n_words + words_per_tile - 1) / words_per_tile;
-        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);
-        if (rc) return rc;
 #define VD_SPLIT(IdT)                                                                                              \
         do {                                                                                                         \
             if (ctx->cull_variant == -70) {                                                                          \
@@ -671,15 +781,15 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
                                    ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_mask,     \
                                    reinterpret_cast<IdT*>(d_ids), n_mt);                                             \
             }                                                                                                        \
-            vd_time_mid(ctx);                                                                                        \
-            hipLaunchKernelGGL(expand_mask_kernel<IdT>, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, d_mask, n_words, \
-                               n_words, n_inst, n_inst, first_instance, reinterpret_cast<const IdT*>(d_ids), d_meshes, \
-                               n_mesh, d_out, d_out_count, states, ticket, n_tiles);                                 \
         } while (0)
         if (id_bytes == 1u) VD_SPLIT(unsigned char);
         else if (id_bytes == 2u) VD_SPLIT(unsigned short);
         else VD_SPLIT(unsigned);
 #undef VD_SPLIT
+        vd_time_mid(ctx);
+        rc = launch_expand(ctx, d_mask, n_words, n_words, n_inst, n_inst, first_instance, d_ids, id_bytes, d_meshes, n_mesh,
+                           d_out, d_out_count);
+        if (rc) return rc;
         vd_time_end(ctx);
         if (pad_tail) {
             unsigned pblocks = (unsigned)ctx->num_cus * 4u;
@@ -748,19 +858,10 @@ int vd_expand_mask_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_total, uin
     const unsigned n_shards = (n_total + shard_size - 1) / shard_size;
     const unsigned wps = (shard_size + 63u) / 64u;
     const unsigned n_words = n_shards * wps;   // padding bits (beyond a shard's / the scene's end) are 0 by construction
-    const unsigned words_per_tile = kWavesPerBlock * kExpandWords;
-    const unsigned n_tiles = (n_words + words_per_tile - 1) / words_per_tile;
-    vd_u64* ticket; vd_u64* states;
-    int rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);
+    vd_time_begin(ctx);
+    int rc = launch_expand(ctx, reinterpret_cast<const vd_u64*>(d_mask), n_words, wps, shard_size, n_total, 0u, d_mesh_ids,
+                           id_bytes, d_meshes, n_mesh, d_out, d_out_count);
     if (rc) return rc;
-#define VD_EXPAND(IdT)                                                                                                    \
-    hipLaunchKernelGGL(expand_mask_kernel<IdT>, dim3(n_tiles), dim3(kBlock), 0, ctx->stream,                                 \
-                       reinterpret_cast<const vd_u64*>(d_mask), n_words, wps, shard_size, n_total, 0u,                       \
-                       reinterpret_cast<const IdT*>(d_mesh_ids), d_meshes, n_mesh, d_out, d_out_count, states, ticket, n_tiles)
-    if (id_bytes == 1u) VD_EXPAND(unsigned char);
-    else if (id_bytes == 2u) VD_EXPAND(unsigned short);
-    else VD_EXPAND(unsigned);
-#undef VD_EXPAND
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;

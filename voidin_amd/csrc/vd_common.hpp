@@ -27,6 +27,7 @@ struct VdCtx {
     // grow-only device scratch arenas
     void* scratch = nullptr;     size_t scratch_bytes = 0;     // general purpose
     void* scan_state = nullptr;  size_t scan_state_bytes = 0;  // look-back granules + ticket word (epoch-tagged)
+    void* expand_state = nullptr; size_t expand_state_bytes = 0;  // mask_scan_kernel: done counter + chunk offsets
     unsigned long long scan_launches = 0;
     void* dbg_ptr = nullptr; unsigned dbg_count = 0;   // tuning hooks
     void* stage_in = nullptr;    size_t stage_in_bytes = 0;    // host-pointer API staging
