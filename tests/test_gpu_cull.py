@@ -144,20 +144,26 @@ def test_full_size_10m_properties(ctx, oracle):
     assert emit.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("n,shards", [(1, 1), (100_000, 1), (100_001, 3), (1_000_000, 8), (130, 2)])
-def test_mask_wire_format_equals_fused_compaction(ctx, oracle, n, shards):
+@pytest.mark.parametrize("id_bytes", [1, 2, 4])
+@pytest.mark.parametrize("n,shards", [(1, 1), (100_000, 1), (100_001, 3), (1_000_000, 8), (130, 2),
+                                      (262_221, 4),      # shard 65556: multiple of 4, 1025 mask words (groups straddle shards)
+                                      (1_000, 5),        # 4 mask words per shard
+                                      (13_000_000, 4)])  # > 12 Mi instances: LDS-staged form of the 1-byte-id kernel
+def test_mask_wire_format_equals_fused_compaction(ctx, oracle, n, shards, id_bytes):
     """Multi-GPU wire format on one GPU: cull every shard into its bitmask, concatenate the
     shard masks as the all-gather would, expand -> identical to the fused single-pass list."""
     import torch
     from voidin_amd import dist as vdist
     cam, meshes = synth.camera_uniform(), synth.mesh_infos()
     inst = synth.instances(n, seed=synth.SEED_BASE + 4, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
-    want, wn = oracle.compact(oracle.cull_emit(cam, meshes, inst))
+    if n > 2_000_000 and id_bytes != 1:
+        pytest.skip("large case covers the 1-byte-id kernel only")
+    want, wn = oracle.compact(oracle.cull_emit(cam, meshes, inst, threads=8))
     d_m = ctx.upload(meshes)
     S = vdist.shard_size(n, shards)
     wps = vdist.mask_words(S)
     d_mask_all = torch.zeros(wps * shards, dtype=torch.int64, device="cuda")
-    ids = np.zeros(S * shards, np.uint32)
+    ids = np.zeros(S * shards, {1: np.uint8, 2: np.uint16, 4: np.uint32}[id_bytes])
     ids[:n] = inst["mesh"]
     for r in range(shards):
         lo, hi = vdist.shard_range(n, r, shards)
@@ -167,7 +173,7 @@ def test_mask_wire_format_equals_fused_compaction(ctx, oracle, n, shards):
     d_ids = ctx.upload(ids)
     d_out = ctx.empty(n * 20)
     d_cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
-    ctx.expand_mask_dev(d_mask_all, n, S, d_ids, d_m, len(meshes), d_out, d_cnt, id_bytes=4)
+    ctx.expand_mask_dev(d_mask_all, n, S, d_ids, d_m, len(meshes), d_out, d_cnt, id_bytes=id_bytes)
     torch.cuda.synchronize()
     cnt = int(d_cnt[0].item())
     assert cnt == wn

@@ -374,55 +374,56 @@ constexpr int kChunkWords = kWavesPerBlock * kExpandWords;   // per workgroup: 1
 __global__ __launch_bounds__(kBlock) void mask_scan_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned n_chunks,
                                                            unsigned* chunk_offset, unsigned* done_counter,
                                                            unsigned* __restrict__ out_count) {
-    __shared__ unsigned s_last, s_wave_sum[kWavesPerBlock], s_carry;
+    __shared__ unsigned s_last, s_wave_sum[kWavesPerBlock];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (unsigned c = blockIdx.x * kWavesPerBlock + wave; c < n_chunks; c += gridDim.x * kWavesPerBlock) {
         const unsigned w = c * kChunkWords + lane;
         unsigned v = (w < n_words ? (unsigned)__popcll(mask[w]) : 0u) + (w + 64u < n_words ? (unsigned)__popcll(mask[w + 64u]) : 0u);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) __hip_atomic_store(&chunk_offset[c], v, VD_RLX_AGENT);
+        if (lane == 0) __hip_atomic_store(&chunk_offset[c], v, VD_RLX_AGENT);   // write-through, like the look-back granules
     }
-    __threadfence();
+    // No fence (an agent-scope release writes back the whole L2 of the XCD, ~100 ns per workgroup while the previous
+    // frame's command list is still dirty in it): the write-through stores above have completed at agent scope once
+    // vmcnt is 0, and the workgroup's arrival is only counted after every wave got there.
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done_counter, 1u, VD_RLX_AGENT) == gridDim.x - 1u;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
-    if (threadIdx.x == 0) s_carry = 0u;
-    __syncthreads();
-    constexpr unsigned kPer = 4;
-    for (unsigned c0 = 0; c0 < n_chunks; c0 += kBlock * kPer) {
-        unsigned v[kPer], sum = 0;
-#pragma unroll
-        for (unsigned k = 0; k < kPer; ++k) {
-            const unsigned c = c0 + threadIdx.x * kPer + k;
-            v[k] = c < n_chunks ? __hip_atomic_load(&chunk_offset[c], VD_RLX_AGENT) : 0u;
-            sum += v[k];
-        }
-        unsigned incl = sum;                               // inclusive scan across the wave
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const unsigned t = __shfl_up(incl, off);
-            if (lane >= (unsigned)off) incl += t;
-        }
-        if (lane == kWave - 1u) s_wave_sum[wave] = incl;
-        __syncthreads();
-        unsigned before = s_carry;
-        for (unsigned w = 0; w < wave; ++w) before += s_wave_sum[w];
-        unsigned run = before + incl - sum;
-#pragma unroll
-        for (unsigned k = 0; k < kPer; ++k) {
-            const unsigned c = c0 + threadIdx.x * kPer + k;
-            if (c < n_chunks) chunk_offset[c] = run;
-            run += v[k];
-        }
-        __syncthreads();
-        if (threadIdx.x == kBlock - 1u) s_carry = run;
-        __syncthreads();
+    // thread t scans the contiguous range [t*per, (t+1)*per): all its loads are independent (one round trip) and
+    // read at agent scope (other XCDs wrote the sums)
+    const unsigned per = ((n_chunks + kBlock - 1) / kBlock + 3u) & ~3u;
+    const unsigned begin = min(threadIdx.x * per, n_chunks), end = min(begin + per, n_chunks);
+    vd_u64* pairs = reinterpret_cast<vd_u64*>(chunk_offset);
+    unsigned sum = 0;
+    for (unsigned c = begin; c < end; c += 2u) {
+        if (c + 2u <= end) { const vd_u64 v = __hip_atomic_load(&pairs[c >> 1], VD_RLX_AGENT); sum += (unsigned)v + (unsigned)(v >> 32); }
+        else sum += __hip_atomic_load(&chunk_offset[c], VD_RLX_AGENT);
     }
-    if (threadIdx.x == 0) {
-        *out_count = s_carry;
+    unsigned incl = sum;                                   // inclusive scan of the per-thread sums
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off);
+        if (lane >= (unsigned)off) incl += t;
+    }
+    if (lane == kWave - 1u) s_wave_sum[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (unsigned w = 0; w < wave; ++w) run += s_wave_sum[w];
+    for (unsigned c = begin; c < end; c += 2u) {
+        if (c + 2u <= end) {
+            const vd_u64 v = __hip_atomic_load(&pairs[c >> 1], VD_RLX_AGENT);
+            pairs[c >> 1] = (vd_u64)run | ((vd_u64)(run + (unsigned)v) << 32);
+            run += (unsigned)v + (unsigned)(v >> 32);
+        } else {
+            const unsigned v = __hip_atomic_load(&chunk_offset[c], VD_RLX_AGENT);
+            chunk_offset[c] = run;
+            run += v;
+        }
+    }
+    if (threadIdx.x == kBlock - 1u) {
+        *out_count = run;
         __hip_atomic_store(done_counter, 0u, VD_RLX_AGENT);   // re-armed for the next launch on this stream
     }
 }
@@ -430,10 +431,9 @@ __global__ __launch_bounds__(kBlock) void mask_scan_kernel(const vd_u64* __restr
 // Pass 2b: workgroup c expands the 128 mask words of chunk c to out[chunk_offset[c] ...); word w belongs to shard
 // w / wps and holds the instances shard*shard_size + 64*(w % wps) + bit.  Every load is issued before the first
 // store (one round trip per workgroup).
-//   WIDE: 1-byte ids, every group of 4 words inside one shard and 4-byte aligned -> a group's 256 ids are one dword
-//         per lane, redistributed with ds_bpermute (instead of four 64-byte-wide byte loads);
+// General form (any id width, any shard size); expand_mask_u8_kernel below is the tuned common case.
 //   TAB:  the mesh table fits the LDS copy (no global loads in the store loop).
-template <typename IdT, bool WIDE, bool TAB>
+template <typename IdT, bool TAB>
 __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned wps,
                                                              unsigned shard_size, unsigned n_total, unsigned first_instance,
                                                              const IdT* __restrict__ mesh_ids,
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned chunk = blockIdx.x;
     const unsigned cw0 = chunk * kChunkWords;
-    const unsigned w0 = cw0 + wave * kExpandWords;        // wave-uniform
+    const unsigned w0 = __builtin_amdgcn_readfirstlane(cw0 + wave * kExpandWords);   // wave-uniform: scalar index math
     unsigned base = chunk_offset[chunk];
     // survivors of the chunk's earlier waves: lane l looks at words cw0 + l and cw0 + 64 + l
     unsigned before = 0;
@@ -466,26 +466,16 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
             if (++r >= wps) { r = 0u; ++shard; }
         }
     };
-    constexpr int kIdRegs = WIDE ? kGroups : kExpandWords;
-    unsigned ids[kIdRegs];
+    unsigned ids[kExpandWords];
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
         const unsigned wg = w0 + g * kExpandGroup;
         unsigned f[kExpandGroup];
         group_first(wg, f);
-        if (WIDE) {
-            ids[g] = 0u;
-            if (wg < n_words) {
-                const unsigned i0 = f[0] + 4u * lane;
-                if (i0 + 4u <= n_total) ids[g] = *reinterpret_cast<const unsigned*>(mesh_ids + i0);
-                else for (unsigned q = 0; q < 4u && i0 + q < n_total; ++q) ids[g] |= (unsigned)mesh_ids[i0 + q] << (8u * q);
-            }
-        } else {
 #pragma unroll
-            for (int q = 0; q < kExpandGroup; ++q) {
-                const unsigned idx = f[q] + lane;
-                ids[WIDE ? 0 : g * kExpandGroup + q] = (wg + q < n_words && idx < n_total) ? (unsigned)mesh_ids[idx] : 0u;
-            }
+        for (int q = 0; q < kExpandGroup; ++q) {
+            const unsigned idx = f[q] + lane;
+            ids[g * kExpandGroup + q] = (wg + q < n_words && idx < n_total) ? (unsigned)mesh_ids[idx] : 0u;
         }
     }
     if (TAB)
@@ -519,13 +509,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
         group_first(wg, first);
 #pragma unroll
         for (int q = 0; q < kExpandGroup; ++q) {
-            unsigned mid;
-            if (WIDE) {
-                const unsigned v = (unsigned)__shfl((int)ids[WIDE ? g : 0], q * 16 + (int)(lane >> 2));
-                mid = (v >> (8u * (lane & 3u))) & 0xffu;
-            } else {
-                mid = ids[WIDE ? 0 : g * kExpandGroup + q];
-            }
+            unsigned mid = ids[g * kExpandGroup + q];
             if ((m[q] >> lane) & 1ull) {
                 mid = min(mid, n_mesh - 1u);
                 unsigned* o = reinterpret_cast<unsigned*>(stage + shift + 20u * (run + vd_mbcnt(m[q])));
@@ -553,6 +537,137 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
     }
 }
 
+// Pass 2b, fast path: 1-byte ids, mesh table <= 256 entries, every group of 4 mask words inside one shard and the id
+// table 4-byte aligned.  This kernel is bound by instruction issue (a wave64 instruction takes 4 cycles), not by LDS
+// or store bandwidth, so the per-survivor instruction count is what is tuned here:
+//   * all index math that is uniform across the wave runs on the scalar unit (w0 through readfirstlane, shard walk
+//     by increments instead of a division per word);
+//   * the mask word is the exec mask of the survivor branch (inverse ballot), no per-lane bit test;
+//   * a group's 256 ids are one dword per lane, redistributed with ds_bpermute;
+//   * the LDS mesh table holds ready-made {index_count, 1, base_index, vertex_offset} rows: one ds_read_b128;
+//   * DIRECT: a command leaves as one 16-byte + one 4-byte store at a 20-byte lane stride (L2 merges the lines);
+//     otherwise it is staged in LDS at the destination's 16-B phase and leaves in 16-B-per-lane runs.
+// The dword that holds the last valid id may extend past n_total: an aligned dword that contains one valid byte
+// never crosses a page, and the extra bytes belong to instances whose mask bit is 0.
+template <bool DIRECT>
+__global__ __launch_bounds__(kBlock) void expand_mask_u8_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned wps,
+                                                                unsigned shard_size, unsigned n_total, unsigned first_instance,
+                                                                const unsigned char* __restrict__ mesh_ids,
+                                                                const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
+                                                                VdDrawIndexedIndirect* __restrict__ out,
+                                                                const unsigned* __restrict__ chunk_offset) {
+    constexpr int kGroups = kExpandWords / kExpandGroup;
+    __shared__ __attribute__((aligned(16))) unsigned s_tab[256][4];
+    constexpr int kStageBytes = DIRECT ? 16 : kExpandGroup * 1280 + 32;
+    __shared__ __attribute__((aligned(16))) char s_stage[kWavesPerBlock][kStageBytes];
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned chunk = blockIdx.x;
+    const unsigned cw0 = chunk * kChunkWords;
+    const unsigned w0 = cw0 + wave * kExpandWords;
+    unsigned base = chunk_offset[chunk];
+    // survivors of the chunk's earlier waves: lane l looks at words cw0 + l and cw0 + 64 + l
+    unsigned before = 0;
+    if (lane < wave * kExpandWords && cw0 + lane < n_words) before = (unsigned)__popcll(mask[cw0 + lane]);
+    if (lane + 64u < wave * kExpandWords && cw0 + 64u + lane < n_words) before += (unsigned)__popcll(mask[cw0 + 64u + lane]);
+    vd_u64 my_word = 0;                                   // lane l < 32 holds mask word w0 + l
+    if (lane < (unsigned)kExpandWords && w0 + lane < n_words) my_word = mask[w0 + lane];
+    // ids: lanes 16q..16q+15 of register g hold the 64 ids of the group's word q, four per lane (one dword); the
+    // shard walk advances by increments (wps >= 4), one division per wave
+    unsigned ids[kGroups];
+    {
+        const unsigned wl = w0 + (lane >> 4);
+        unsigned shard = wl / wps, r = wl - shard * wps;
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            const unsigned i0 = shard * shard_size + 64u * r + 4u * (lane & 15u);
+            ids[g] = (wl + g * kExpandGroup < n_words && i0 < n_total) ? *reinterpret_cast<const unsigned*>(mesh_ids + i0) : 0u;
+            r += kExpandGroup;
+            if (r >= wps) { r -= wps; ++shard; }
+        }
+    }
+    unsigned s_shard = w0 / wps, s_r = w0 - s_shard * wps;   // scalar walk over the wave's words
+    unsigned word_first = s_shard * shard_size + 64u * s_r;
+    if (threadIdx.x < n_mesh) {
+        const VdMeshInfo mi = meshes[threadIdx.x];
+        s_tab[threadIdx.x][0] = mi.index_count; s_tab[threadIdx.x][1] = 1u;
+        s_tab[threadIdx.x][2] = mi.base_index;  s_tab[threadIdx.x][3] = (unsigned)mi.vertex_offset;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    base = __builtin_amdgcn_readfirstlane(base + before);
+    __syncthreads();
+    const unsigned max_mid = n_mesh - 1u;
+    const unsigned inst_lane = first_instance + lane;
+    const unsigned id_shift = 8u * (lane & 3u);
+    char* stage = s_stage[wave];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+        vd_u64 m[kExpandGroup];
+        unsigned cnt = 0;
+#pragma unroll
+        for (int q = 0; q < kExpandGroup; ++q) {
+            const int k = g * kExpandGroup + q;
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)my_word, k), hi = __builtin_amdgcn_readlane((unsigned)(my_word >> 32), k);
+            m[q] = ((vd_u64)hi << 32) | lo;
+            cnt += (unsigned)__popcll(m[q]);
+        }
+        unsigned wf[kExpandGroup];                         // first instance of each word of the group
+#pragma unroll
+        for (int q = 0; q < kExpandGroup; ++q) {
+            wf[q] = word_first;
+            if (++s_r >= wps) { s_r = 0u; ++s_shard; }
+            word_first = s_shard * shard_size + 64u * s_r;
+        }
+        if (cnt == 0u) continue;
+        if (DIRECT) {
+            unsigned run = base;
+#pragma unroll
+            for (int q = 0; q < kExpandGroup; ++q) {
+                const unsigned v = (unsigned)__shfl((int)ids[g], q * 16 + (int)(lane >> 2));
+                const unsigned mid = min((v >> id_shift) & 0xffu, max_mid);
+                if (__builtin_amdgcn_inverse_ballot_w64(m[q])) {
+                    unsigned* o = reinterpret_cast<unsigned*>(out + (run + vd_mbcnt(m[q])));
+                    typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
+                    *reinterpret_cast<u32x4_a4*>(o) = *reinterpret_cast<const u32x4*>(s_tab[mid]);
+                    o[4] = inst_lane + wf[q];
+                }
+                run += (unsigned)__popcll(m[q]);
+            }
+        } else {
+            char* gbase = reinterpret_cast<char*>(out + base);
+            const unsigned shift = (unsigned)(reinterpret_cast<uintptr_t>(gbase) & 15u);
+            unsigned run = 0;
+#pragma unroll
+            for (int q = 0; q < kExpandGroup; ++q) {
+                const unsigned v = (unsigned)__shfl((int)ids[g], q * 16 + (int)(lane >> 2));
+                const unsigned mid = min((v >> id_shift) & 0xffu, max_mid);
+                if (__builtin_amdgcn_inverse_ballot_w64(m[q])) {
+                    unsigned* o = reinterpret_cast<unsigned*>(stage + shift + 20u * (run + vd_mbcnt(m[q])));
+                    const u32x4 c = *reinterpret_cast<const u32x4*>(s_tab[mid]);
+                    o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+                    o[4] = inst_lane + wf[q];
+                }
+                run += (unsigned)__popcll(m[q]);
+            }
+            vd_wave_lds_sync();
+            const unsigned total = shift + 20u * cnt;
+            char* g16 = gbase - shift;
+            for (unsigned b0 = lane * 16u; b0 < total; b0 += kWave * 16u) {
+                if (b0 >= shift && b0 + 16u <= total) {
+                    *reinterpret_cast<u32x4*>(g16 + b0) = *reinterpret_cast<const u32x4*>(stage + b0);
+                } else {
+                    const unsigned lo_b = b0 > shift ? b0 : shift, hi_b = b0 + 16u < total ? b0 + 16u : total;
+                    for (unsigned b = lo_b; b < hi_b; b += 4u)
+                        *reinterpret_cast<unsigned*>(g16 + b) = *reinterpret_cast<const unsigned*>(stage + b);
+                }
+            }
+            vd_wave_lds_sync();
+        }
+        base += cnt;
+    }
+}
+
 // Host side of pass 2 (shared by vd_cull_compact* and vd_expand_mask_dev).
 static int launch_expand(VdCtx* ctx, const vd_u64* d_mask, unsigned n_words, unsigned wps, unsigned shard_size,
                          unsigned n_total, unsigned first_instance, const void* d_ids, unsigned id_bytes,
@@ -566,22 +681,34 @@ static int launch_expand(VdCtx* ctx, const vd_u64* d_mask, unsigned n_words, uns
     }
     unsigned* done = reinterpret_cast<unsigned*>(ctx->expand_state);
     unsigned* offsets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->expand_state) + 16);
-    unsigned sblocks = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (sblocks > (unsigned)ctx->num_cus * 2u) sblocks = (unsigned)ctx->num_cus * 2u;
+    unsigned sblocks = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;      // one wave per chunk, grid-stride beyond 4 per CU
+    if (sblocks > (unsigned)ctx->num_cus * 4u) sblocks = (unsigned)ctx->num_cus * 4u;
     hipLaunchKernelGGL(mask_scan_kernel, dim3(sblocks), dim3(kBlock), 0, ctx->stream, d_mask, n_words, n_chunks, offsets, done,
                        d_out_count);
     const bool one_shard = wps >= n_words;
-    const bool wide = id_bytes == 1u && (one_shard || shard_size % (64u * kExpandGroup) == 0u) &&
-                      (reinterpret_cast<uintptr_t>(d_ids) & 3u) == 0u;
     const bool tab = n_mesh <= 512u;
-#define VD_EXPAND(IdT, W, T)                                                                                               \
-    hipLaunchKernelGGL((expand_mask_kernel<IdT, W, T>), dim3(n_chunks), dim3(kBlock), 0, ctx->stream, d_mask, n_words, wps,  \
+    // fast path: 1-byte ids that can be fetched as aligned dwords (every word's first instance is a multiple of 4)
+    const bool fast = id_bytes == 1u && n_mesh <= 256u && (one_shard || (shard_size % 4u == 0u && wps >= (unsigned)kExpandGroup)) &&
+                      (reinterpret_cast<uintptr_t>(d_ids) & 3u) == 0u;
+    if (fast) {
+        // up to ~250 MB of commands (the Infinity Cache absorbs them) the direct form is at the write ceiling; past
+        // that the L2 merges fewer of its 4-byte pieces in time and the LDS-staged 16-byte runs win (A/B: -71 / -74)
+        const bool direct = ctx->cull_variant == -74 || (ctx->cull_variant != -71 && n_total <= (12u << 20));
+#define VD_EXPAND_U8(D)                                                                                                   \
+        hipLaunchKernelGGL((expand_mask_u8_kernel<D>), dim3(n_chunks), dim3(kBlock), 0, ctx->stream, d_mask, n_words, wps,  \
+                           shard_size, n_total, first_instance, reinterpret_cast<const unsigned char*>(d_ids), d_meshes,    \
+                           n_mesh, d_out, offsets)
+        if (direct) VD_EXPAND_U8(true); else VD_EXPAND_U8(false);
+#undef VD_EXPAND_U8
+        return VD_OK;
+    }
+#define VD_EXPAND(IdT, T)                                                                                               \
+    hipLaunchKernelGGL((expand_mask_kernel<IdT, T>), dim3(n_chunks), dim3(kBlock), 0, ctx->stream, d_mask, n_words, wps,  \
                        shard_size, n_total, first_instance, reinterpret_cast<const IdT*>(d_ids), d_meshes, n_mesh, d_out,    \
                        offsets)
-    if (wide && tab) VD_EXPAND(unsigned char, true, true);
-    else if (id_bytes == 1u) { if (tab) VD_EXPAND(unsigned char, false, true); else VD_EXPAND(unsigned char, false, false); }
-    else if (id_bytes == 2u) { if (tab) VD_EXPAND(unsigned short, false, true); else VD_EXPAND(unsigned short, false, false); }
-    else { if (tab) VD_EXPAND(unsigned, false, true); else VD_EXPAND(unsigned, false, false); }
+    if (id_bytes == 1u) { if (tab) VD_EXPAND(unsigned char, true); else VD_EXPAND(unsigned char, false); }
+    else if (id_bytes == 2u) { if (tab) VD_EXPAND(unsigned short, true); else VD_EXPAND(unsigned short, false); }
+    else { if (tab) VD_EXPAND(unsigned, true); else VD_EXPAND(unsigned, false); }
 #undef VD_EXPAND
     return VD_OK;
 }
