@@ -44,6 +44,8 @@ constexpr int kItem = 1024;             // phase A: positions per workgroup item
 constexpr unsigned kNone = 0xffffffffu;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct TriBox { float mn[3]; float pad0; float mx[3]; float pad1; };   // 32 B, by triangle id
 struct TmpNode { float mn[3]; unsigned left_first; float mx[3]; unsigned count; };   // == VdBvhNode layout
@@ -78,11 +80,12 @@ __device__ __forceinline__ float cand_pos(const float* cbmin, const float* cbmax
 
 // ---- precompute: centroid payload + triangle boxes + root box -------------------------------
 __global__ __launch_bounds__(256) void blas_precompute_kernel(const float* __restrict__ verts, const unsigned* __restrict__ idx,
-                                                              unsigned n_tri, unsigned n_vert, u32x4* __restrict__ payload,
-                                                              TriBox* __restrict__ boxes, int* __restrict__ root_keys /*[6]*/,
+                                                              unsigned n_tri, unsigned n_vert, u32x2* __restrict__ slim,
+                                                              f32x4* __restrict__ cent, TriBox* __restrict__ boxes,
+                                                              int* __restrict__ root_keys /*[12]: box, centroid box*/,
                                                               unsigned* __restrict__ err) {
-    __shared__ int s_k[6];
-    if (threadIdx.x < 6) s_k[threadIdx.x] = threadIdx.x < 3 ? kBig : -kBig - 1;
+    __shared__ int s_k[12];
+    if (threadIdx.x < 12) s_k[threadIdx.x] = (threadIdx.x % 6) < 3 ? kBig : -kBig - 1;
     __syncthreads();
     const unsigned t = blockIdx.x * 256u + threadIdx.x;
     if (t < n_tri) {
@@ -99,23 +102,29 @@ __global__ __launch_bounds__(256) void blas_precompute_kernel(const float* __res
                 bx.mx[k] = vd_max_to(vd_max_to(a[k], b[k]), c[k]);
                 atomicMin(&s_k[k], vd_key(bx.mn[k]));
                 atomicMax(&s_k[3 + k], vd_key(bx.mx[k]));
+                atomicMin(&s_k[6 + k], vd_key(ce[k]));
+                atomicMax(&s_k[9 + k], vd_key(ce[k]));
             }
             bx.pad0 = bx.pad1 = 0.0f;
-            u32x4 p = {t, __float_as_uint(ce[0]), __float_as_uint(ce[1]), __float_as_uint(ce[2])};
-            payload[t] = p;
+            const u32x2 p = {t, 0u};
+            const f32x4 c4 = {ce[0], ce[1], ce[2], 0.0f};
+            slim[t] = p;
+            cent[t] = c4;
             boxes[t] = bx;
         }
     }
     __syncthreads();
-    if (threadIdx.x < 3) atomicMin(&root_keys[threadIdx.x], s_k[threadIdx.x]);
-    else if (threadIdx.x < 6) atomicMax(&root_keys[threadIdx.x], s_k[threadIdx.x]);
+    if (threadIdx.x < 12) {
+        if ((threadIdx.x % 6) < 3) atomicMin(&root_keys[threadIdx.x], s_k[threadIdx.x]);
+        else atomicMax(&root_keys[threadIdx.x], s_k[threadIdx.x]);
+    }
 }
 
 // Cost of one candidate from binned statistics + the held-out `u` elements (blas.rs:149-155).
 // bins: [8][3] keys of the candidate's axis (non-u elements only); u list: payload + box.
 struct EvalIn {
     const int* bin_min; const int* bin_max;      // [8][3] for this axis
-    const u32x4* u_pay; const TriBox* boxes; int n_u; unsigned own_u;   // own_u = id of this candidate's u
+    const u32x2* u_pay; const TriBox* boxes; int n_u; unsigned own_u;   // own_u = id of this candidate's u
 };
 __device__ __forceinline__ float eval_candidate(const EvalIn& in, int axis, int k, float pos, unsigned n1, unsigned n) {
     int tmn[3] = {kBig, kBig, kBig}, tmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
@@ -129,12 +138,12 @@ __device__ __forceinline__ float eval_candidate(const EvalIn& in, int axis, int 
         }
     }
     for (int j = 0; j < in.n_u; ++j) {
-        const u32x4 v = in.u_pay[j];
+        const u32x2 v = in.u_pay[j];
         bool dup = false;
         for (int i = 0; i < j; ++i) dup |= in.u_pay[i].x == v.x;
         if (dup) continue;
         const TriBox bx = in.boxes[v.x];
-        const bool to_left = v.x != in.own_u && pay_c(v, axis) < pos;   // left = examined trues; u itself goes right
+        const bool to_left = v.x != in.own_u && ((v.y >> (axis * 7 + k - 1)) & 1u);   // left = examined trues; u itself goes right
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int lo = vd_key(bx.mn[q]), hi = vd_key(bx.mx[q]);
@@ -380,7 +389,7 @@ __device__ __forceinline__ unsigned lane_partition(WaveLds& L, unsigned short* p
 
 __global__ __launch_bounds__(64 * kSubWaves, 4)
 void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
-                       const u32x4* __restrict__ payload, const TriBox* __restrict__ boxes,
+                       const u32x2* __restrict__ slim, const f32x4* __restrict__ cent, const TriBox* __restrict__ boxes,
                        TmpNode* __restrict__ subnodes, unsigned short* __restrict__ submap,
                        unsigned* __restrict__ sub_interior, unsigned* __restrict__ final_ids, unsigned* __restrict__ err,
                        unsigned* __restrict__ dbg_cycles) {
@@ -399,14 +408,16 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     unsigned short* nmap = submap + 2u * (size_t)base;
 
     for (unsigned x = tid; x < N; x += 64u * kSubWaves) {
-        const u32x4 v = payload[base + x];
-        const TriBox bx = boxes[v.x];
-        L.gid[x] = v.x;
+        const unsigned id = slim[base + x].x;
+        const TriBox bx = boxes[id];
+        const f32x4 c4 = cent[id];
+        const float ce[3] = {c4.x, c4.y, c4.z};
+        L.gid[x] = id;
         L.perm[0][x] = (unsigned short)x;
         L.perm[1][x] = (unsigned short)x;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            L.cent[k][x] = pay_c(v, k);
+            L.cent[k][x] = ce[k];
             L.box[k][x] = vd_key(bx.mn[k]);
             L.box[3 + k][x] = vd_key(bx.mx[k]);
         }
@@ -614,11 +625,11 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
 struct Seg {
     unsigned start, count, node, item_first;
     unsigned n_items, best, Lst, ttot_cur;
-    int cbk[6];                       // centroid-bound keys (min xyz, max xyz)
-    int child_k[12];                  // children box keys: left min/max, right min/max
+    int cbk[6];                       // centroid-bound keys (min xyz, max xyz), inherited from the parent's a_child pass
+    int child_k[24];                  // children: box keys left min/max, right min/max; then centroid keys likewise
     float pos[kCand + 3];
     unsigned ttot[kCand + 3], u_p[kCand + 3];
-    u32x4 u_pay[kCand + 1];
+    u32x2 u_pay[kCand + 1];           // {triangle id, predicate bits} of each trial's never-examined element
     int bin_min[3][8][3], bin_max[3][8][3];
 };
 
@@ -641,8 +652,7 @@ __global__ void a_seg_begin_kernel(Seg* segs, LevelCtl* ctl) {
     if (i >= ctl->n_seg) return;
     Seg& sg = segs[i];
     sg.n_items = (sg.count + kItem - 1) / kItem;
-    for (int k = 0; k < 3; ++k) { sg.cbk[k] = kBig; sg.cbk[3 + k] = -kBig - 1; }
-    for (int k = 0; k < 3; ++k) { sg.child_k[k] = kBig; sg.child_k[3 + k] = -kBig - 1; sg.child_k[6 + k] = kBig; sg.child_k[9 + k] = -kBig - 1; }
+    for (int k = 0; k < 24; ++k) sg.child_k[k] = (k % 6) < 3 ? kBig : -kBig - 1;
     for (int k = 0; k < 72; ++k) { (&sg.bin_min[0][0][0])[k] = kBig; (&sg.bin_max[0][0][0])[k] = -kBig - 1; }
 }
 
@@ -686,28 +696,28 @@ __device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_s
     return true;
 }
 
-// centroid bounds of each segment (blas.rs:142)
-__global__ __launch_bounds__(256) void a_cb_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                   const u32x4* __restrict__ pay) {
-    __shared__ int s_k[6];
+// The 21 split planes of a segment are fixed before its first trial (blas.rs:142-146), so every predicate of the
+// level is evaluated once: bit c of slim[x].y = centroid[axis(c)] < pos[c].  The 22 shuffles then move 8 bytes.
+__global__ __launch_bounds__(256) void a_bits_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
+                                                     u32x2* __restrict__ slim, const f32x4* __restrict__ cent) {
+    __shared__ float s_pos[kCand + 3];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
-    if (threadIdx.x < 6) s_k[threadIdx.x] = threadIdx.x < 3 ? kBig : -kBig - 1;
+    if (threadIdx.x < (unsigned)kCand) s_pos[threadIdx.x] = sg->pos[threadIdx.x];
     __syncthreads();
-    int kmn[3] = {kBig, kBig, kBig}, kmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
     for (unsigned x = threadIdx.x; x < ic.n_here; x += 256u) {
-        const u32x4 v = pay[sg->start + ic.rel0 + x];
+        u32x2 v = slim[sg->start + ic.rel0 + x];
+        const f32x4 c = cent[v.x];
+        unsigned bits = 0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { const int key = vd_key(pay_c(v, k)); kmn[k] = min(kmn[k], key); kmx[k] = max(kmx[k], key); }
+        for (int k = 0; k < 7; ++k) {
+            bits |= (c.x < s_pos[k] ? 1u : 0u) << k;
+            bits |= (c.y < s_pos[7 + k] ? 1u : 0u) << (7 + k);
+            bits |= (c.z < s_pos[14 + k] ? 1u : 0u) << (14 + k);
+        }
+        v.y = bits;
+        slim[sg->start + ic.rel0 + x] = v;
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int a = wave_min_i(kmn[k]), b = wave_max_i(kmx[k]);
-        if ((threadIdx.x & 63u) == 0u) { atomicMin(&s_k[k], a); atomicMax(&s_k[3 + k], b); }
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) atomicMin(&segs[ic.seg].cbk[threadIdx.x], s_k[threadIdx.x]);
-    else if (threadIdx.x < 6) atomicMax(&segs[ic.seg].cbk[threadIdx.x], s_k[threadIdx.x]);
 }
 
 __global__ void a_planes_kernel(Seg* segs, const LevelCtl* ctl) {
@@ -720,11 +730,9 @@ __global__ void a_planes_kernel(Seg* segs, const LevelCtl* ctl) {
 }
 
 // predicate mask of this lane group: returns ballot per j (4 per wave)
-__device__ __forceinline__ void item_masks(const Seg* sg, const ItemCtx& ic, const u32x4* __restrict__ pay, int c,
-                                           unsigned long long (&masks)[4], u32x4 (&vals)[4]) {
-    const int cc = c >= 0 ? c : (int)sg->best;
-    const int axis = cc / 7;
-    const float pos = sg->pos[cc];
+__device__ __forceinline__ void item_masks(const Seg* sg, const ItemCtx& ic, const u32x2* __restrict__ pay, int c,
+                                           unsigned long long (&masks)[4], u32x2 (&vals)[4]) {
+    const unsigned cc = c >= 0 ? (unsigned)c : sg->best;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -732,7 +740,7 @@ __device__ __forceinline__ void item_masks(const Seg* sg, const ItemCtx& ic, con
         bool p = false;
         if (x < ic.n_here) {
             vals[j] = pay[sg->start + ic.rel0 + x];
-            p = pay_c(vals[j], axis) < pos;
+            p = (vals[j].y >> cc) & 1u;
         }
         masks[j] = __ballot(p);
     }
@@ -740,11 +748,11 @@ __device__ __forceinline__ void item_masks(const Seg* sg, const ItemCtx& ic, con
 
 // round step 1: true count of every item
 __global__ __launch_bounds__(256) void a_count_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                      const u32x4* __restrict__ pay, int c, unsigned* item_cnt) {
+                                                      const u32x2* __restrict__ pay, int c, unsigned* item_cnt) {
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
-    unsigned long long masks[4]; u32x4 vals[4];
+    unsigned long long masks[4]; u32x2 vals[4];
     item_masks(sg, ic, pay, c, masks, vals);
     unsigned t = 0;
 #pragma unroll
@@ -783,12 +791,12 @@ __global__ __launch_bounds__(1024) void a_scan_kernel(Seg* segs, const LevelCtl*
 
 // round step 3: TL per position + rank -> position tables
 __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                      const u32x4* __restrict__ pay, int c, const unsigned* item_pre,
+                                                      const u32x2* __restrict__ pay, int c, const unsigned* item_pre,
                                                       unsigned* __restrict__ falsepos, unsigned* __restrict__ truepos) {
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
-    unsigned long long masks[4]; u32x4 vals[4];
+    unsigned long long masks[4]; u32x2 vals[4];
     item_masks(sg, ic, pay, c, masks, vals);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned t = 0;
@@ -815,14 +823,14 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
 
 // round step 4: destinations, scatter, `u`
 __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                      const u32x4* __restrict__ src, u32x4* __restrict__ dst, int c,
+                                                      const u32x2* __restrict__ src, u32x2* __restrict__ dst, int c,
                                                       const unsigned* item_pre, const unsigned* __restrict__ falsepos,
                                                       const unsigned* __restrict__ truepos, unsigned char* __restrict__ is_u_flag) {
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     // predicates and TL are recomputed from the payload (cheaper than a per-position word through HBM)
-    unsigned long long masks[4]; u32x4 vals[4];
+    unsigned long long masks[4]; u32x2 vals[4];
     item_masks(sg, ic, src, c, masks, vals);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned t = 0;
@@ -863,25 +871,20 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
 
 // binning over the non-u elements (one pass per level)
 __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                    const u32x4* __restrict__ pay, const TriBox* __restrict__ boxes,
+                                                    const u32x2* __restrict__ pay, const TriBox* __restrict__ boxes,
                                                     const unsigned char* __restrict__ is_u_flag) {
     __shared__ int s_min[3][8][3], s_max[3][8][3];
-    __shared__ float s_pos[kCand + 3];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     for (unsigned i = threadIdx.x; i < 72u; i += 256u) { (&s_min[0][0][0])[i] = kBig; (&s_max[0][0][0])[i] = -kBig - 1; }
-    if (threadIdx.x < (unsigned)kCand) s_pos[threadIdx.x] = sg->pos[threadIdx.x];
     __syncthreads();
     for (unsigned xr = threadIdx.x; xr < ic.n_here; xr += 256u) {
-        const u32x4 v = pay[sg->start + ic.rel0 + xr];
+        const u32x2 v = pay[sg->start + ic.rel0 + xr];
         if (is_u_flag[v.x]) continue;
         const TriBox bx = boxes[v.x];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float ce = pay_c(v, a);
-            int b = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) b += !(ce < s_pos[a * 7 + k]);
+            const int b = 7 - __popc((v.y >> (7 * a)) & 0x7fu);   // bin = number of planes the centroid is not below
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 atomicMin(&s_min[a][b][q], vd_key(bx.mn[q]));
@@ -918,34 +921,42 @@ __global__ __launch_bounds__(64) void a_eval_kernel(Seg* segs, LevelCtl* ctl, co
 
 // children boxes from the final arrangement (blas.rs:115-123)
 __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                      const u32x4* __restrict__ pay, const TriBox* __restrict__ boxes) {
-    __shared__ int s_k[12];
+                                                      const u32x2* __restrict__ pay, const TriBox* __restrict__ boxes,
+                                                      const f32x4* __restrict__ cent) {
+    __shared__ int s_k[24];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
-    if (threadIdx.x < 12) s_k[threadIdx.x] = (threadIdx.x % 6) < 3 ? kBig : -kBig - 1;
+    if (threadIdx.x < 24) s_k[threadIdx.x] = (threadIdx.x % 6) < 3 ? kBig : -kBig - 1;
     __syncthreads();
-    int k12[12];
+    // [0,12): vertex boxes of the left / right child (blas.rs:115-123); [12,24): their centroid boxes, which are
+    // the next level's `cb` (blas.rs:142) and save that level a pass
+    int k24[24];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) k12[i] = (i % 6) < 3 ? kBig : -kBig - 1;
+    for (int i = 0; i < 24; ++i) k24[i] = (i % 6) < 3 ? kBig : -kBig - 1;
     const unsigned Lst = sg->Lst;
     for (unsigned xr = threadIdx.x; xr < ic.n_here; xr += 256u) {
         const unsigned x = ic.rel0 + xr;
-        const TriBox bx = boxes[pay[sg->start + x].x];
+        const unsigned id = pay[sg->start + x].x;
+        const TriBox bx = boxes[id];
+        const f32x4 c = cent[id];
+        const float ce[3] = {c.x, c.y, c.z};
         const int o = x < Lst ? 0 : 6;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            k12[o + q] = min(k12[o + q], vd_key(bx.mn[q]));
-            k12[o + 3 + q] = max(k12[o + 3 + q], vd_key(bx.mx[q]));
+            k24[o + q] = min(k24[o + q], vd_key(bx.mn[q]));
+            k24[o + 3 + q] = max(k24[o + 3 + q], vd_key(bx.mx[q]));
+            k24[12 + o + q] = min(k24[12 + o + q], vd_key(ce[q]));
+            k24[12 + o + 3 + q] = max(k24[12 + o + 3 + q], vd_key(ce[q]));
         }
     }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < 24; ++i) {
         const bool is_min = (i % 6) < 3;
-        const int r = is_min ? wave_min_i(k12[i]) : wave_max_i(k12[i]);
+        const int r = is_min ? wave_min_i(k24[i]) : wave_max_i(k24[i]);
         if ((threadIdx.x & 63u) == 0u) { if (is_min) atomicMin(&s_k[i], r); else atomicMax(&s_k[i], r); }
     }
     __syncthreads();
-    if (threadIdx.x < 12) {
+    if (threadIdx.x < 24) {
         const bool is_min = (threadIdx.x % 6) < 3;
         if (is_min) atomicMin(&segs[ic.seg].child_k[threadIdx.x], s_k[threadIdx.x]);
         else atomicMax(&segs[ic.seg].child_k[threadIdx.x], s_k[threadIdx.x]);
@@ -982,6 +993,7 @@ __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, Top
             const unsigned ni = atomicAdd(&ctl->n_seg_next, 1u);
             Seg& ns = next[ni];
             ns.start = t.start; ns.count = t.count; ns.node = pair + side;
+            for (int q = 0; q < 6; ++q) ns.cbk[q] = sg.child_k[12 + side * 6 + q];
         }
         top[pair + side] = t;
     }
@@ -1021,7 +1033,7 @@ __global__ __launch_bounds__(256) void c_sub_kernel(const SmallRoot* roots, cons
     }
 }
 
-__global__ void c_ids_big_leaves_kernel(const TopNode* top, unsigned n_top, const u32x4* pay, unsigned* final_ids) {
+__global__ void c_ids_big_leaves_kernel(const TopNode* top, unsigned n_top, const u32x2* pay, unsigned* final_ids) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_top || i == 1u) return;
     const TopNode t = top[i];
@@ -1047,7 +1059,10 @@ __global__ void c_root_kernel(TopNode* top, const int* root_keys, unsigned n_tri
     ctl->n_top = 2; ctl->n_small = 0; ctl->n_seg = 0; ctl->n_seg_next = 0; ctl->n_items = 0;
     if (n_tri <= 3u) t.kind = 0u;
     else if (n_tri <= (unsigned)kSmallMax) { t.kind = 2u; small[0] = SmallRoot{0u, n_tri, 0u, 0u}; ctl->n_small = 1; }
-    else { t.kind = 1u; segs[0].start = 0; segs[0].count = n_tri; segs[0].node = 0; ctl->n_seg = 1; }
+    else {
+        t.kind = 1u; segs[0].start = 0; segs[0].count = n_tri; segs[0].node = 0; ctl->n_seg = 1;
+        for (int q = 0; q < 6; ++q) segs[0].cbk[q] = root_keys[6 + q];
+    }
     top[0] = t;
     TopNode z; memset(&z, 0, sizeof(z));
     top[1] = z;
@@ -1077,17 +1092,17 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     // ---- scratch layout ----
     Arena probe{nullptr, 0};
     auto layout = [&](Arena& a, bool) {
-        struct P { u32x4 *pay0, *pay1; TriBox* boxes; unsigned *tmp, *falsepos, *truepos, *final_ids, *stack, *idx_copy;
+        struct P { u32x2 *pay0, *pay1; f32x4* cent; TriBox* boxes; unsigned *falsepos, *truepos, *final_ids, *stack, *idx_copy;
                    unsigned char* is_u; Seg *seg0, *seg1; unsigned *item_seg, *item_cnt, *item_pre; TopNode* top; SmallRoot* small;
                    unsigned* sub_interior; TmpNode* subnodes; unsigned short* submap; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair; } p;
-        p.pay0 = a.take<u32x4>(T); p.pay1 = a.take<u32x4>(T); p.boxes = a.take<TriBox>(T);
-        p.tmp = a.take<unsigned>(T); p.falsepos = a.take<unsigned>(T); p.truepos = a.take<unsigned>(T);
+        p.pay0 = a.take<u32x2>(T); p.pay1 = a.take<u32x2>(T); p.cent = a.take<f32x4>(T); p.boxes = a.take<TriBox>(T);
+        p.falsepos = a.take<unsigned>(T); p.truepos = a.take<unsigned>(T);
         p.final_ids = a.take<unsigned>(T); p.stack = a.take<unsigned>(T); p.idx_copy = a.take<unsigned>(3 * T);
         p.is_u = a.take<unsigned char>(T);
         p.seg0 = a.take<Seg>(seg_cap); p.seg1 = a.take<Seg>(seg_cap);
         p.item_seg = a.take<unsigned>(item_cap); p.item_cnt = a.take<unsigned>(item_cap); p.item_pre = a.take<unsigned>(item_cap + 1);
         p.top = a.take<TopNode>(top_cap); p.small = a.take<SmallRoot>(small_cap); p.sub_interior = a.take<unsigned>(small_cap);
-        p.subnodes = a.take<TmpNode>(2 * T + 2); p.submap = a.take<unsigned short>(2 * T + 2); p.ctl = a.take<LevelCtl>(1); p.root_keys = a.take<int>(8);
+        p.subnodes = a.take<TmpNode>(2 * T + 2); p.submap = a.take<unsigned short>(2 * T + 2); p.ctl = a.take<LevelCtl>(1); p.root_keys = a.take<int>(16);
         p.tout = a.take<TopOut>(top_cap); p.root_pair = a.take<unsigned>(small_cap);
         return p;
     };
@@ -1100,7 +1115,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
 
     vd_time_begin(ctx);
     {
-        int h_keys[8] = {kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1, 0, 0};
+        int h_keys[16] = {kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1, kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1, 0, 0, 0, 0};
         VD_HIP_CHECK(ctx, hipMemcpyAsync(P.root_keys, h_keys, sizeof(h_keys), hipMemcpyHostToDevice, st));
         VD_HIP_CHECK(ctx, hipMemsetAsync(P.ctl, 0, sizeof(LevelCtl), st));
         VD_HIP_CHECK(ctx, hipMemsetAsync(P.is_u, 0, T, st));
@@ -1108,7 +1123,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     }
     const unsigned tri_blocks = (unsigned)((T + 255) / 256);
     hipLaunchKernelGGL(blas_precompute_kernel, dim3(tri_blocks), dim3(256), 0, st, d_verts, P.idx_copy, n_tri, n_vert, P.pay0,
-                       P.boxes, P.root_keys, &P.ctl->err);
+                       P.cent, P.boxes, P.root_keys, &P.ctl->err);
     hipLaunchKernelGGL(c_root_kernel, dim3(1), dim3(64), 0, st, P.top, P.root_keys, n_tri, P.small, P.ctl, P.seg0);
 
     // ---- phase A: level loop ----
@@ -1126,9 +1141,9 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         hipLaunchKernelGGL(a_seg_begin_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, P.ctl);
         hipLaunchKernelGGL(a_items_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl);
         hipLaunchKernelGGL(a_items_fill_kernel, dim3(n_seg), dim3(64), 0, st, seg_cur, P.ctl, P.item_seg);
-        hipLaunchKernelGGL(a_cb_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, P.pay0);
         hipLaunchKernelGGL(a_planes_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, P.ctl);
-        u32x4* src = P.pay0; u32x4* dst = P.pay1;
+        hipLaunchKernelGGL(a_bits_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, P.pay0, P.cent);
+        u32x2* src = P.pay0; u32x2* dst = P.pay1;
         for (int c = 0; c <= kCand; ++c) {
             const int cc = c < kCand ? c : -1;       // -1: final re-shuffle with each segment's best plane
             if (c == kCand) {
@@ -1141,10 +1156,10 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
                                P.falsepos, P.truepos);
             hipLaunchKernelGGL(a_apply_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, P.item_pre,
                                P.falsepos, P.truepos, P.is_u);
-            u32x4* t = src; src = dst; dst = t;
+            u32x2* t = src; src = dst; dst = t;
         }
         // 22 swaps: the arrangement is back in pay0
-        hipLaunchKernelGGL(a_child_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, P.pay0, P.boxes);
+        hipLaunchKernelGGL(a_child_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, P.pay0, P.boxes, P.cent);
         hipLaunchKernelGGL(a_finalize_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, seg_next, P.ctl, P.top, P.small, P.is_u,
                            top_cap, small_cap);
         hipLaunchKernelGGL(a_level_swap_kernel, dim3(1), dim3(64), 0, st, P.ctl);
@@ -1162,7 +1177,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     const unsigned n_small = h_ctl.n_small, n_top = h_ctl.n_top;
     if (n_small) {
         hipLaunchKernelGGL(blas_small_kernel, dim3(n_small), dim3(64 * kSubWaves), sizeof(WaveLds) + sizeof(WaveQueues), st, P.small, &P.ctl->n_small, P.pay0,
-                           P.boxes, P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err, P.stack);
+                           P.cent, P.boxes, P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err, P.stack);
         ctx->dbg_ptr = P.stack; ctx->dbg_count = 2 * n_small;
     }
     // ---- phase C: DFS numbering of the top tree on the host ----
