@@ -1,0 +1,31 @@
+#!/bin/bash
+# kernel-to-kernel gaps of one BLAS build (rocprofv3 kernel trace)
+set -u
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/prof_gaps; rm -rf $O; mkdir -p $O
+rocprofv3 --kernel-trace --output-format csv -d $O -o g -- python3 tools/bench_bvh.py --u 2048 --v 2048 --reps 1 --tlas 1000 > $O/stdout.log 2>&1
+python3 - <<'PY'
+import csv,glob,collections
+f=glob.glob('gpurun_out/prof_gaps/**/g_kernel_trace.csv',recursive=True)[0]
+rows=list(csv.DictReader(open(f)))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+# last build: find last blas_precompute
+starts=[i for i,r in enumerate(rows) if 'blas_precompute' in r['Kernel_Name']]
+ends=[i for i,r in enumerate(rows) if 'c_permute' in r['Kernel_Name']]
+idx,end=max(zip(starts,ends),key=lambda se:int(rows[se[0]]['End_Timestamp'])-int(rows[se[0]]['Start_Timestamp']))
+seq=rows[idx:end+1]
+busy=sum(int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in seq)
+span=int(seq[-1]['End_Timestamp'])-int(seq[0]['Start_Timestamp'])
+gaps=[int(seq[i+1]['Start_Timestamp'])-int(seq[i]['End_Timestamp']) for i in range(len(seq)-1)]
+gs=sorted(gaps)
+print(f"kernels {len(seq)} span {span/1e6:.2f} ms busy {busy/1e6:.2f} ms gaps {sum(gaps)/1e6:.2f} ms; gap median {gs[len(gs)//2]/1e3:.1f} us p90 {gs[int(len(gs)*.9)]/1e3:.1f} us max {gs[-1]/1e3:.1f} us")
+agg=collections.defaultdict(lambda:[0,0])
+for r in seq:
+    n=r['Kernel_Name'].replace('(anonymous namespace)::','').split('(')[0][:30]; agg[n][0]+=1; agg[n][1]+=int(r['End_Timestamp'])-int(r['Start_Timestamp'])
+for n,(c,t) in sorted(agg.items(),key=lambda kv:-kv[1][1])[:16]: print(f"  {n:32s} calls {c:5d} total {t/1e6:7.2f} ms avg {t/c/1e3:8.1f} us")
+big=[(g,seq[i]['Kernel_Name'][:40],seq[i+1]['Kernel_Name'][:40]) for i,g in enumerate(gaps) if g>30000]
+print("gaps > 30 us:",len(big), "sum %.2f ms"%(sum(b[0] for b in big)/1e6))
+for b in big[:8]: print("  %.1f us after %s before %s"%(b[0]/1e3,b[1],b[2]))
+PY
+find $O -name "*kernel_trace.csv" -delete

@@ -13,7 +13,7 @@
 //    a pure stream of 24 B per slot; the argmin is a 64-bit {area bits, slot} key reduced by
 //    wave shuffles + LDS, which reproduces "strict <, first slot wins";
 //  * refit: leaves recomputed, interior boxes by a bottom-up walk with per-node arrival counters
-//    (agent-scope release/acquire around the counter; boxes re-read L1-bypassing).
+//    (write-through agent-scope stores, no fences; boxes re-read L1/L2-bypassing).
 #include "vd_common.hpp"
 
 namespace {
@@ -191,11 +191,19 @@ __global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restr
 }
 
 // ---- refit -------------------------------------------------------------------------------
+// Launch 1: thread i < n recomputes leaf i+1; the same thread records the parent of the two children of interior node
+// n+1+i and clears its arrival counter.
 template <typename Node>
-__global__ __launch_bounds__(256) void tlas_parents_kernel(const Node* __restrict__ nodes, unsigned n,
-                                                           unsigned* __restrict__ parent, unsigned* __restrict__ arrivals) {
-    const unsigned k = blockIdx.x * 256u + threadIdx.x + n + 1u;   // interior nodes n+1 .. 2n
-    if (k > 2u * n) return;
+__global__ __launch_bounds__(256) void tlas_refit_prep_kernel(const VdInstance* __restrict__ inst, unsigned n,
+                                                              const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
+                                                              Node* __restrict__ nodes, unsigned* __restrict__ parent,
+                                                              unsigned* __restrict__ arrivals) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const Box b = leaf_box(inst, meshes, n_mesh, nodes[i + 1].instance_idx);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { nodes[i + 1].min[c] = b.mn[c]; nodes[i + 1].max[c] = b.mx[c]; }
+    const unsigned k = n + 1u + i;
     unsigned l, r;
     node_get_children(nodes[k], l, r);
     parent[l] = k;
@@ -203,22 +211,22 @@ __global__ __launch_bounds__(256) void tlas_parents_kernel(const Node* __restric
     arrivals[k] = 0u;
 }
 
+// Launch 2: one lane per leaf climbs; the second arrival at a node owns it.  No fences: an agent-scope release
+// writes back the XCD's whole L2 (microseconds per hop).  Boxes travel as write-through agent-scope stores, which
+// have completed once vmcnt is 0, and are read back L1/L2-bypassing after the counter says both are there.
 template <typename Node>
 __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigned n, const unsigned* __restrict__ parent,
                                                             unsigned* arrivals) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     unsigned k = parent[i + 1];
-    // publish this leaf's box (written by the leaves kernel in an earlier launch: already visible)
     while (k != 0u) {
         unsigned l, r;
         node_get_children(nodes[k], l, r);
         const unsigned need = l == r ? 1u : 2u;          // node 2n merges the true root with itself
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ROCm 7.2 can drop the fence's own wait
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned seen = __hip_atomic_fetch_add(&arrivals[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (seen + 1u < need) return;                    // sibling subtree not finished yet
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         float mn[3], mx[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -234,14 +242,13 @@ __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigne
             __hip_atomic_store(&nodes[k].min[c], mn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&nodes[k].max[c], mx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (k == 2u * n) return;
+        if (k == 2u * n) {                               // tlas.rs:84: nodes[0] is a copy of the last node
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { nodes[0].min[c] = mn[c]; nodes[0].max[c] = mx[c]; }
+            return;
+        }
         k = parent[k];
     }
-}
-
-template <typename Node>
-__global__ void tlas_root_copy_kernel(Node* nodes, unsigned n) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) nodes[0] = nodes[2u * n];
 }
 
 template <typename Node>
@@ -275,12 +282,9 @@ int tlas_refit_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     unsigned* parent = reinterpret_cast<unsigned*>(ctx->scratch);
     unsigned* arrivals = parent + total;
     vd_time_begin(ctx);
-    VD_HIP_CHECK(ctx, hipMemsetAsync(parent, 0, total * 8, ctx->stream));
-    hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
-                       n_mesh, d_nodes, (float*)nullptr, (unsigned*)nullptr, 0u, 1);
-    hipLaunchKernelGGL((tlas_parents_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_nodes, n, parent, arrivals);
+    hipLaunchKernelGGL((tlas_refit_prep_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes, n_mesh,
+                       d_nodes, parent, arrivals);
     hipLaunchKernelGGL((tlas_refit_up_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_nodes, n, parent, arrivals);
-    hipLaunchKernelGGL((tlas_root_copy_kernel<Node>), dim3(1), dim3(64), 0, ctx->stream, d_nodes, n);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;

@@ -73,11 +73,15 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
         ray.ix = 1.0f / ray.dx; ray.iy = 1.0f / ray.dy; ray.iz = 1.0f / ray.dz;   // ray_new: inv_dir = 1. / dir
     }
     VdHit res; res.dist = kMaxDist; res.hit = 0u; res.instance = 0xffffffffu; res.triangle = 0xffffffffu;
+    // The reference pushes the near child last and pops it straight away (bvh.wgsl:66-74, 113-121).  Here the near
+    // child stays in a register and only the far child touches the (scratch-memory) stack: same visiting order,
+    // half the stack traffic and no store->load round trip on the critical path.
     bool ovf = false;
     unsigned thead = 0;
-    tstack[thead++] = 0u;
-    while (thead > 0u) {                                           // bvh.wgsl:94
-        const VdTlasNode node = s.tlas[tstack[--thead]];
+    unsigned tcur = 0u;
+    for (;;) {                                                     // bvh.wgsl:94
+        const VdTlasNode node = s.tlas[tcur];
+        bool pop = true;
         if (node.left_right == 0u) {                               // leaf: instance_intersect (bvh.wgsl:78-87)
             const VdInstance* I = s.inst + node.instance_idx;
             const unsigned mesh_id = min(I->mesh, s.n_meshes - 1u);
@@ -93,10 +97,11 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
             nr.ix = 1.0f / nr.dx; nr.iy = 1.0f / nr.dy; nr.iz = 1.0f / nr.dz;
             // traverse_bvh (bvh.wgsl:35-76)
             unsigned bhead = 0;
-            bstack[bhead++] = mesh.bvh_index;
+            unsigned bcur = mesh.bvh_index;
             float hit = res.dist;
-            while (bhead > 0u) {
-                const VdBvhNode bn = s.bvh[bstack[--bhead]];
+            for (;;) {
+                const VdBvhNode bn = s.bvh[bcur];
+                bool bpop = true;
                 if (bn.count > 0u) {
                     for (unsigned k = 0; k < bn.count; ++k) {
                         const unsigned idx = bn.left_first + k;
@@ -121,12 +126,21 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
                         const unsigned ti = min_index; min_index = max_index; max_index = ti;
                         const float tf = min_dist; min_dist = max_dist; max_dist = tf;
                     }
-                    if (min_dist >= hit) continue;
-                    if (bhead + 2u > (unsigned)kStack) { ovf = true; break; }
-                    if (max_dist <= hit) bstack[bhead++] = max_index;
-                    bstack[bhead++] = min_index;
+                    if (!(min_dist >= hit)) {
+                        if (max_dist <= hit) {
+                            if (bhead + 1u > (unsigned)kStack) { ovf = true; break; }
+                            bstack[bhead++] = max_index;
+                        }
+                        bcur = min_index;
+                        bpop = false;
+                    }
+                }
+                if (bpop) {
+                    if (bhead == 0u) break;
+                    bcur = bstack[--bhead];
                 }
             }
+            if (ovf) break;
         } else {
             unsigned min_index = node.left_right & 0xffffu;
             unsigned max_index = node.left_right >> 16u;
@@ -137,10 +151,18 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
                 const unsigned ti = min_index; min_index = max_index; max_index = ti;
                 const float tf = min_dist; min_dist = max_dist; max_dist = tf;
             }
-            if (min_dist >= res.dist) continue;
-            if (thead + 2u > (unsigned)kStack) { ovf = true; break; }
-            if (max_dist < res.dist) tstack[thead++] = max_index;
-            tstack[thead++] = min_index;
+            if (!(min_dist >= res.dist)) {
+                if (max_dist < res.dist) {
+                    if (thead + 1u > (unsigned)kStack) { ovf = true; break; }
+                    tstack[thead++] = max_index;
+                }
+                tcur = min_index;
+                pop = false;
+            }
+        }
+        if (pop) {
+            if (thead == 0u) break;
+            tcur = tstack[--thead];
         }
     }
     if (ovf) atomicOr(overflow, 1u);
