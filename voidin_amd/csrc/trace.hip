@@ -65,7 +65,9 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
                                                    VdHit* __restrict__ out, unsigned* __restrict__ overflow) {
     const unsigned i = blockIdx.x * 64u + threadIdx.x;
     if (i >= n_rays) return;
-    unsigned tstack[kStack], bstack[kStack];
+    // a stack entry is the popped node's payload ({left_right, instance} / {left_first, count}): its box is never
+    // looked at again (bvh.wgsl:45-47, 96-98), so a pop costs no node fetch
+    uint2 tstack[kStack], bstack[kStack];
     Ray ray;
     {
         const float4 a = reinterpret_cast<const float4*>(rays + i)[0], b = reinterpret_cast<const float4*>(rays + i)[1];
@@ -74,16 +76,17 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
     }
     VdHit res; res.dist = kMaxDist; res.hit = 0u; res.instance = 0xffffffffu; res.triangle = 0xffffffffu;
     // The reference pushes the near child last and pops it straight away (bvh.wgsl:66-74, 113-121).  Here the near
-    // child stays in a register and only the far child touches the (scratch-memory) stack: same visiting order,
-    // half the stack traffic and no store->load round trip on the critical path.
+    // child stays in registers - including the payload that was fetched with its box - and only the far child
+    // touches the (scratch-memory) stack: same visiting order, one dependent fetch per step instead of two.
     bool ovf = false;
     unsigned thead = 0;
-    unsigned tcur = 0u;
+    uint2 tn;                                                      // {left_right, instance_idx} of the current node
+    { const VdTlasNode root = s.tlas[0]; tn.x = root.left_right; tn.y = root.instance_idx; }
     for (;;) {                                                     // bvh.wgsl:94
-        const VdTlasNode node = s.tlas[tcur];
         bool pop = true;
-        if (node.left_right == 0u) {                               // leaf: instance_intersect (bvh.wgsl:78-87)
-            const VdInstance* I = s.inst + node.instance_idx;
+        if (tn.x == 0u) {                                          // leaf: instance_intersect (bvh.wgsl:78-87)
+            const unsigned instance_idx = tn.y;
+            const VdInstance* I = s.inst + instance_idx;
             const unsigned mesh_id = min(I->mesh, s.n_meshes - 1u);
             const VdMeshInfo mesh = s.meshes[mesh_id];
             const float* M = I->inv_transform;
@@ -97,14 +100,14 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
             nr.ix = 1.0f / nr.dx; nr.iy = 1.0f / nr.dy; nr.iz = 1.0f / nr.dz;
             // traverse_bvh (bvh.wgsl:35-76)
             unsigned bhead = 0;
-            unsigned bcur = mesh.bvh_index;
+            uint2 bn;                                              // {left_first, count} of the current node
+            { const VdBvhNode root = s.bvh[mesh.bvh_index]; bn.x = root.left_first; bn.y = root.count; }
             float hit = res.dist;
             for (;;) {
-                const VdBvhNode bn = s.bvh[bcur];
                 bool bpop = true;
-                if (bn.count > 0u) {
-                    for (unsigned k = 0; k < bn.count; ++k) {
-                        const unsigned idx = bn.left_first + k;
+                if (bn.y > 0u) {
+                    for (unsigned k = 0; k < bn.y; ++k) {
+                        const unsigned idx = bn.x + k;
                         const unsigned i0 = (unsigned)mesh.vertex_offset + s.indices[mesh.base_index + 3u * idx + 0u];
                         const unsigned i1 = (unsigned)mesh.vertex_offset + s.indices[mesh.base_index + 3u * idx + 1u];
                         const unsigned i2 = (unsigned)mesh.vertex_offset + s.indices[mesh.base_index + 3u * idx + 2u];
@@ -113,56 +116,55 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
                         const float* v2 = s.verts + 3u * (size_t)i2;
                         const float a0[3] = {v0[0], v0[1], v0[2]}, a1[3] = {v1[0], v1[1], v1[2]}, a2[3] = {v2[0], v2[1], v2[2]};
                         if (intersect_trig(nr, a0, a1, a2, hit)) {
-                            res.dist = hit; res.hit = 1u; res.instance = node.instance_idx; res.triangle = idx;
+                            res.dist = hit; res.hit = 1u; res.instance = instance_idx; res.triangle = idx;
                         }
                     }
                 } else {
-                    unsigned min_index = mesh.bvh_index + bn.left_first;
-                    unsigned max_index = mesh.bvh_index + bn.left_first + 1u;
-                    const VdBvhNode c0 = s.bvh[min_index], c1 = s.bvh[max_index];
+                    const unsigned pair = mesh.bvh_index + bn.x;
+                    const VdBvhNode c0 = s.bvh[pair], c1 = s.bvh[pair + 1u];
                     float min_dist = intersect_aabb(nr, c0.min, c0.max, hit);
                     float max_dist = intersect_aabb(nr, c1.min, c1.max, hit);
+                    uint2 near = make_uint2(c0.left_first, c0.count), far = make_uint2(c1.left_first, c1.count);
                     if (min_dist > max_dist) {
-                        const unsigned ti = min_index; min_index = max_index; max_index = ti;
+                        const uint2 tu = near; near = far; far = tu;
                         const float tf = min_dist; min_dist = max_dist; max_dist = tf;
                     }
                     if (!(min_dist >= hit)) {
                         if (max_dist <= hit) {
                             if (bhead + 1u > (unsigned)kStack) { ovf = true; break; }
-                            bstack[bhead++] = max_index;
+                            bstack[bhead++] = far;
                         }
-                        bcur = min_index;
+                        bn = near;
                         bpop = false;
                     }
                 }
                 if (bpop) {
                     if (bhead == 0u) break;
-                    bcur = bstack[--bhead];
+                    bn = bstack[--bhead];
                 }
             }
             if (ovf) break;
         } else {
-            unsigned min_index = node.left_right & 0xffffu;
-            unsigned max_index = node.left_right >> 16u;
-            const VdTlasNode c0 = s.tlas[min_index], c1 = s.tlas[max_index];
+            const VdTlasNode c0 = s.tlas[tn.x & 0xffffu], c1 = s.tlas[tn.x >> 16u];
             float min_dist = intersect_aabb(ray, c0.min, c0.max, res.dist);
             float max_dist = intersect_aabb(ray, c1.min, c1.max, res.dist);
+            uint2 near = make_uint2(c0.left_right, c0.instance_idx), far = make_uint2(c1.left_right, c1.instance_idx);
             if (min_dist > max_dist) {
-                const unsigned ti = min_index; min_index = max_index; max_index = ti;
+                const uint2 tu = near; near = far; far = tu;
                 const float tf = min_dist; min_dist = max_dist; max_dist = tf;
             }
             if (!(min_dist >= res.dist)) {
                 if (max_dist < res.dist) {
                     if (thead + 1u > (unsigned)kStack) { ovf = true; break; }
-                    tstack[thead++] = max_index;
+                    tstack[thead++] = far;
                 }
-                tcur = min_index;
+                tn = near;
                 pop = false;
             }
         }
         if (pop) {
             if (thead == 0u) break;
-            tcur = tstack[--thead];
+            tn = tstack[--thead];
         }
     }
     if (ovf) atomicOr(overflow, 1u);
