@@ -762,25 +762,38 @@ __global__ __launch_bounds__(256) void a_count_kernel(const Seg* segs, const uns
     if (threadIdx.x == 0) item_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// round step 2 (single workgroup): exclusive scan of item counts; per-segment Ttot
+// round step 2 (single workgroup): exclusive scan of item counts; per-segment Ttot.  Thread t owns the contiguous
+// range [t*per, (t+1)*per), per a multiple of 4 (16-byte loads, all in flight at once); two barriers in total.
 __global__ __launch_bounds__(1024) void a_scan_kernel(Seg* segs, const LevelCtl* ctl, const unsigned* item_cnt, unsigned* item_pre) {
-    __shared__ unsigned s_part[1024];
-    const unsigned n = ctl->n_items, tid = threadIdx.x;
-    const unsigned per = (n + 1023u) / 1024u;
+    __shared__ unsigned s_wave[16];
+    const unsigned n = ctl->n_items, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned per = ((n + 1023u) / 1024u + 3u) & ~3u;
     const unsigned lo = min(n, tid * per), hi = min(n, lo + per);
     unsigned sum = 0;
-    for (unsigned i = lo; i < hi; ++i) sum += item_cnt[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (unsigned off = 1; off < 1024u; off <<= 1) {
-        const unsigned v = tid >= off ? s_part[tid - off] : 0u;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    for (unsigned i = lo; i < hi; i += 4u) {
+        if (i + 4u <= hi) { const u32x4 v = *reinterpret_cast<const u32x4*>(item_cnt + i); sum += (v.x + v.y) + (v.z + v.w); }
+        else for (unsigned k = i; k < hi; ++k) sum += item_cnt[k];
     }
-    unsigned run = s_part[tid] - sum;
-    for (unsigned i = lo; i < hi; ++i) { item_pre[i] = run; run += item_cnt[i]; }
-    if (tid == 1023u) item_pre[n] = s_part[1023];
+    unsigned incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off);
+        if (lane >= (unsigned)off) incl += t;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - sum, total = 0;
+    for (unsigned w = 0; w < 16u; ++w) { if (w < wave) run += s_wave[w]; total += s_wave[w]; }
+    for (unsigned i = lo; i < hi; i += 4u) {
+        if (i + 4u <= hi) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(item_cnt + i);
+            u32x4 o; o.x = run; o.y = run + v.x; o.z = o.y + v.y; o.w = o.z + v.z; run = o.w + v.w;
+            *reinterpret_cast<u32x4*>(item_pre + i) = o;
+        } else {
+            for (unsigned k = i; k < hi; ++k) { item_pre[k] = run; run += item_cnt[k]; }
+        }
+    }
+    if (tid == 0u) item_pre[n] = total;
     __syncthreads();
     __threadfence_block();
     for (unsigned i = tid; i < ctl->n_seg; i += 1024u) {
