@@ -235,4 +235,12 @@ inline std::vector<VdHit> traverse_tlas(const Gpu& gpu, const VdTraceScene& scen
     return out;
 }
 
+// The shadow pass's occlusion test (src/bin/raytraced_shadows.wgsl:90-102) for one point light: one ray per G-buffer
+// point, `occluded[i]` = traverse_tlas(ray).hit.  Scene pointers, positions and normals are device memory.
+inline void shadow_occlusion(const Gpu& gpu, const VdTraceScene& d_scene, const float* d_positions, const float* d_normals,
+                             uint32_t n_points, const float light_position[3], VdRay* d_rays_scratch, uint32_t* d_occluded) {
+    gpu.check(vd_shadow_rays_dev(gpu.ctx(), d_positions, d_normals, n_points, light_position, d_rays_scratch));
+    gpu.check(vd_trace_any_dev(gpu.ctx(), &d_scene, d_rays_scratch, n_points, d_occluded));
+}
+
 }  // namespace voidin

@@ -312,6 +312,17 @@ int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t 
 int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene /* struct on host, pointers on device */,
                  const VdRay* d_rays, uint32_t n_rays, VdHit* d_out);
 
+/* Occlusion query: d_out_hit[i] = traverse_tlas(ray i).hit, which is all the
+ * reference's shadow pass reads (src/bin/raytraced_shadows.wgsl:97-102).  Same walk as vd_trace
+ * up to the first accepted triangle, where the lane stops; the flag equals vd_trace's `hit`.  */
+int vd_trace_any_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_rays, uint32_t n_rays,
+                     uint32_t* d_out_hit);
+/* The shadow rays of that pass for one point light: eye = pos + nor * 0.0001, dir = light - pos
+ * (not normalised; raytraced_shadows.wgsl:90-97).  positions / normals: n_points x 3 floats,
+ * device; light_position: 3 floats, host.                                                  */
+int vd_shadow_rays_dev(VdCtx* ctx, const float* d_positions, const float* d_normals, uint32_t n_points,
+                       const float* light_position, VdRay* d_rays);
+
 /* ------------------------------------------------------------------------------------ */
 /* Instance animation  (SURVEY.md §8f N2 — the upstream mutator of the cull / TLAS input)  */
 /* ------------------------------------------------------------------------------------ */

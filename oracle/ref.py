@@ -42,6 +42,7 @@ def load() -> C.CDLL:
             "vd_ref_tlas_refit_wide": (_I, [_P, _U, _P, _U, _P]),
             "vd_ref_trace": (_I, [C.POINTER(abi.TraceScene), _P, _U, _P, _P, _I]),
             "vd_ref_traverse_iter": (_I, [_P, _U, _P, _P, _P, _U, _P]),
+            "vd_ref_shadow_rays": (_I, [_P, _P, _U, _P, _P]),
             "vd_ref_compute_update": (_I, [_P, _U, _P, _U, C.c_float, C.c_float, _I]),
             "vd_ref_version": (C.c_char_p, []),
         }
@@ -159,6 +160,14 @@ def trace(scene_arrays, rays, threads=1):
     ms = C.c_uint32(0)
     _chk(load().vd_ref_trace(C.byref(s), rays.ctypes.data, len(rays), out.ctypes.data, C.addressof(ms), threads))
     return out, ms.value
+
+
+def shadow_rays(positions, normals, light_position):
+    pos, nor = _c(positions, np.float32).reshape(-1, 3), _c(normals, np.float32).reshape(-1, 3)
+    lp = _c(light_position, np.float32).reshape(3)
+    out = np.zeros(len(pos), dtype=abi.RAY)
+    _chk(load().vd_ref_shadow_rays(pos.ctypes.data, nor.ctypes.data, len(pos), lp.ctypes.data, out.ctypes.data))
+    return out
 
 
 def traverse_iter(nodes, verts, indices, rays):

@@ -62,6 +62,10 @@ int vd_ref_trace(const VdTraceScene* scene, const VdRay* rays, uint32_t n_rays, 
                  uint32_t* out_max_stack, int threads);
 /* crates/bvh/src/blas.rs:247-295 + intersection.rs:47-92 (R2, BLAS only, Rust CPU harness).
  * out_dist[i] = t, or -1 for Dist::Miss.                                                 */
+/* Shadow rays of src/bin/raytraced_shadows.wgsl:90-97: eye = pos + nor * 0.0001, dir = light - pos. */
+int vd_ref_shadow_rays(const float* positions, const float* normals, uint32_t n_points, const float* light_position,
+                       VdRay* out);
+
 int vd_ref_traverse_iter(const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz,
                          const uint32_t* indices, const VdRay* rays, uint32_t n_rays,
                          float* out_dist);

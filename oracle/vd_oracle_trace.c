@@ -287,3 +287,20 @@ int vd_ref_traverse_iter(const VdBvhNode* nodes, uint32_t n_nodes, const float* 
     }
     return VD_OK;
 }
+
+/* src/bin/raytraced_shadows.wgsl:90 `let light_vec = light.position - pos;` and :97
+ * `ray_new(pos + nor * 0.0001, light_vec)`; the pass reads only `.hit` of the traversal (:98-101). */
+int vd_ref_shadow_rays(const float* positions, const float* normals, uint32_t n_points, const float* light_position,
+                       VdRay* out) {
+    if (n_points && (!positions || !normals || !light_position || !out)) return VD_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n_points; ++i) {
+        memset(&out[i], 0, sizeof(out[i]));
+        for (int k = 0; k < 3; ++k) {
+            const float p = positions[3 * (size_t)i + k];
+            const float off = normals[3 * (size_t)i + k] * 0.0001f;
+            out[i].eye[k] = p + off;
+            out[i].dir[k] = light_position[k] - p;
+        }
+    }
+    return VD_OK;
+}

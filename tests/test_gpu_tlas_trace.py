@@ -103,3 +103,29 @@ def test_trace_seeded_scene_vs_oracle(ctx, oracle):
     hit = want["hit"] == 1
     assert np.all(np.abs(got["dist"][hit] - want["dist"][hit]) <= REL_TOL * np.abs(want["dist"][hit]))
     assert max_stack <= 64
+    # device-pointer entry point + the occlusion query of the shadow pass (raytraced_shadows.wgsl:97-102): its flag
+    # is the closest-hit traversal's `hit`
+    import torch
+    ds = ctx.device_scene(scene)
+    d_rays = ctx.upload(rays)
+    d_hits = ctx.empty(len(rays) * 16)
+    d_any = torch.full((len(rays),), 7, dtype=torch.int32, device="cuda")
+    ctx.trace_dev(ds, d_rays, len(rays), d_hits)
+    ctx.trace_any_dev(ds, d_rays, len(rays), d_any)
+    torch.cuda.synchronize()
+    assert d_hits.cpu().numpy().view(abi.HIT).tobytes() == got.tobytes()
+    assert np.array_equal(d_any.cpu().numpy().astype(np.uint32), want["hit"])
+    # shadow rays from the hit points towards a point light: generator bit-exact, occlusion flags equal the oracle's
+    pts = (rays["eye"] + rays["dir"] * want["dist"][:, None])[hit][:20000]
+    nor = -rays["dir"][hit][:20000]
+    light = np.array([3.0, 40.0, 20.0], np.float32)
+    want_rays = oracle.shadow_rays(pts, nor, light)
+    d_sr = ctx.empty(len(pts) * 32)
+    ctx.shadow_rays_dev(ctx.upload(pts.astype(np.float32)), ctx.upload(nor.astype(np.float32)), len(pts), light, d_sr)
+    d_occ = torch.zeros(len(pts), dtype=torch.int32, device="cuda")
+    ctx.trace_any_dev(ds, d_sr, len(pts), d_occ)
+    torch.cuda.synchronize()
+    assert d_sr.cpu().numpy()[: len(pts) * 32].tobytes() == want_rays.tobytes()
+    occ_want, _ = oracle.trace(scene, want_rays, threads=8)
+    assert np.array_equal(d_occ.cpu().numpy().astype(np.uint32), occ_want["hit"])
+    assert 0 < occ_want["hit"].sum() < len(pts)

@@ -88,3 +88,10 @@ for r in range(3):
     assert rc == 0, ctx.lib.vd_last_error(ctx.h)
 hits = d_hits.cpu().numpy()[: len(rays) * 16].view(abi.HIT)
 print(f"trace: {len(rays)} rays, {dt*1e3:.2f} ms = {len(rays)/dt/1e6:.1f} Mrays/s, hit fraction {hits['hit'].mean():.3f}", flush=True)
+d_any = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
+for r in range(3):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    rc = ctx.lib.vd_trace_any_dev(ctx.h, C.byref(s), d_rays.data_ptr(), len(rays), d_any.data_ptr())
+    torch.cuda.synchronize(); dta = time.perf_counter() - t
+assert rc == 0 and np.array_equal(d_any.cpu().numpy().astype(np.uint32), hits["hit"])
+print(f"trace_any (occlusion): {dta*1e3:.2f} ms = {len(rays)/dta/1e6:.1f} Mrays/s (flags equal vd_trace's)", flush=True)

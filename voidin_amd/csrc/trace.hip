@@ -61,8 +61,13 @@ struct Scene {
     const float* verts; const unsigned* indices; unsigned n_meshes;
 };
 
+// ANY: occlusion query - the lane stops at the first accepted triangle and only `hit` is reported.  That flag is
+// the same as the closest-hit traversal's: until something is accepted nothing is pruned by distance, so both walks
+// visit the same nodes up to that point (the reference's shadow pass uses only `.hit`: raytraced_shadows.wgsl:97-102).
+template <bool ANY>
 __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restrict__ rays, unsigned n_rays,
-                                                   VdHit* __restrict__ out, unsigned* __restrict__ overflow) {
+                                                   VdHit* __restrict__ out, unsigned* __restrict__ out_any,
+                                                   unsigned* __restrict__ overflow) {
     const unsigned i = blockIdx.x * 64u + threadIdx.x;
     if (i >= n_rays) return;
     // a stack entry is the popped node's payload ({left_right, instance} / {left_first, count}): its box is never
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
                         const float a0[3] = {v0[0], v0[1], v0[2]}, a1[3] = {v1[0], v1[1], v1[2]}, a2[3] = {v2[0], v2[1], v2[2]};
                         if (intersect_trig(nr, a0, a1, a2, hit)) {
                             res.dist = hit; res.hit = 1u; res.instance = instance_idx; res.triangle = idx;
+                            if (ANY) break;
                         }
                     }
                 } else {
@@ -138,12 +144,13 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
                         bpop = false;
                     }
                 }
+                if (ANY && res.hit) break;
                 if (bpop) {
                     if (bhead == 0u) break;
                     bn = bstack[--bhead];
                 }
             }
-            if (ovf) break;
+            if (ovf || (ANY && res.hit)) break;
         } else {
             const VdTlasNode c0 = s.tlas[tn.x & 0xffffu], c1 = s.tlas[tn.x >> 16u];
             float min_dist = intersect_aabb(ray, c0.min, c0.max, res.dist);
@@ -168,17 +175,33 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
         }
     }
     if (ovf) atomicOr(overflow, 1u);
-    out[i] = res;
+    if (ANY) out_any[i] = res.hit; else out[i] = res;
 }
 
-int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out) {
+// Shadow rays of the reference's deferred pass (src/bin/raytraced_shadows.wgsl:97): origin = pos + nor * 0.0001,
+// dir = light.position - pos (not normalised: t is in units of the light vector, and the pass ignores it).
+__global__ __launch_bounds__(256) void shadow_rays_kernel(const float* __restrict__ pos, const float* __restrict__ nor, unsigned n,
+                                                          float lx, float ly, float lz, VdRay* __restrict__ rays) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float px = pos[3u * i], py = pos[3u * i + 1u], pz = pos[3u * i + 2u];
+    VdRay r;
+    r.eye[0] = px + nor[3u * i] * 0.0001f; r.eye[1] = py + nor[3u * i + 1u] * 0.0001f; r.eye[2] = pz + nor[3u * i + 2u] * 0.0001f;
+    r._pad0 = 0.0f;
+    r.dir[0] = lx - px; r.dir[1] = ly - py; r.dir[2] = lz - pz;
+    r._pad1 = 0.0f;
+    rays[i] = r;
+}
+
+int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out, uint32_t* d_any = nullptr) {
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256);
     if (rc) return rc;
     unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);
     Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes};
     vd_time_begin(ctx);
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 16, ctx->stream));
-    hipLaunchKernelGGL(trace_kernel, dim3((n_rays + 63) / 64), dim3(64), 0, ctx->stream, s, d_rays, n_rays, d_out, d_flag);
+    if (d_any) hipLaunchKernelGGL(trace_kernel<true>, dim3((n_rays + 63) / 64), dim3(64), 0, ctx->stream, s, d_rays, n_rays, d_out, d_any, d_flag);
+    else hipLaunchKernelGGL(trace_kernel<false>, dim3((n_rays + 63) / 64), dim3(64), 0, ctx->stream, s, d_rays, n_rays, d_out, d_any, d_flag);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -202,6 +225,25 @@ int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_rays, u
     if (n_rays == 0) return VD_OK;
     if (!d_rays || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: null rays/out");
     return launch_trace(ctx, d_scene, d_rays, n_rays, d_out);
+}
+
+int vd_trace_any_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_rays, uint32_t n_rays, uint32_t* d_out_hit) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!scene_ok(d_scene)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_any: incomplete scene");
+    if (n_rays == 0) return VD_OK;
+    if (!d_rays || !d_out_hit) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_any: null rays/out");
+    return launch_trace(ctx, d_scene, d_rays, n_rays, nullptr, d_out_hit);
+}
+
+int vd_shadow_rays_dev(VdCtx* ctx, const float* d_positions, const float* d_normals, uint32_t n_points, const float* light_position,
+                       VdRay* d_rays) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (n_points == 0) return VD_OK;
+    if (!d_positions || !d_normals || !light_position || !d_rays) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_shadow_rays: null pointer");
+    hipLaunchKernelGGL(shadow_rays_kernel, dim3((n_points + 255) / 256), dim3(256), 0, ctx->stream, d_positions, d_normals, n_points,
+                       light_position[0], light_position[1], light_position[2], d_rays);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    return VD_OK;
 }
 
 int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t n_rays, VdHit* out) {

@@ -203,6 +203,37 @@ class Context:
         return out
 
 
+    class DeviceScene:
+        """Device-resident copy of a trace scene; keeps the tensors alive next to the VdTraceScene."""
+
+        def __init__(self, ctx, scene_arrays):
+            dts = [abi.TLAS_NODE, abi.INSTANCE, abi.MESH_INFO, abi.BVH_NODE, np.float32, np.uint32]
+            arrs = [np.ascontiguousarray(a, dtype=d).reshape(-1) for a, d in zip(scene_arrays, dts)]
+            self.tensors = [ctx.upload(a) for a in arrs]
+            s = abi.TraceScene()
+            s.tlas_nodes, s.n_tlas_nodes = self.tensors[0].data_ptr(), len(arrs[0])
+            s.instances, s.n_instances = self.tensors[1].data_ptr(), len(arrs[1])
+            s.meshes, s.n_meshes = self.tensors[2].data_ptr(), len(arrs[2])
+            s.bvh_nodes, s.n_bvh_nodes = self.tensors[3].data_ptr(), len(arrs[3])
+            s.vertices, s.n_vertices = self.tensors[4].data_ptr(), len(arrs[4]) // 3
+            s.indices, s.n_indices = self.tensors[5].data_ptr(), len(arrs[5])
+            self.struct = s
+
+    def device_scene(self, scene_arrays) -> "Context.DeviceScene":
+        return Context.DeviceScene(self, scene_arrays)
+
+    def trace_dev(self, scene: "Context.DeviceScene", d_rays, n_rays, d_out):
+        self._chk(self.lib.vd_trace_dev(self.h, C.byref(scene.struct), abi.ptr(d_rays), n_rays, abi.ptr(d_out)))
+
+    def trace_any_dev(self, scene: "Context.DeviceScene", d_rays, n_rays, d_out_hit):
+        """Occlusion query: d_out_hit[i] (u32) = 1 iff ray i hits anything (raytraced_shadows.wgsl:97-102)."""
+        self._chk(self.lib.vd_trace_any_dev(self.h, C.byref(scene.struct), abi.ptr(d_rays), n_rays, abi.ptr(d_out_hit)))
+
+    def shadow_rays_dev(self, d_positions, d_normals, n_points, light_position, d_rays):
+        lp = (C.c_float * 3)(*[float(x) for x in light_position])
+        self._chk(self.lib.vd_shadow_rays_dev(self.h, abi.ptr(d_positions), abi.ptr(d_normals), n_points, lp, abi.ptr(d_rays)))
+
+
 # ------------------------------------------------------------------------------------------
 # Reference-shaped façade
 # ------------------------------------------------------------------------------------------
