@@ -15,9 +15,13 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "voidin_abi.h"
@@ -165,6 +169,105 @@ class MeshPool {
 
    private:
     const Gpu& gpu_;
+};
+
+// ---- OBJ ingest --------------------------------------------------------------
+// ObjModel::import (crates/app/src/models/mod.rs:19-57) loads with tobj 4.0.0's GPU_LOAD_OPTIONS
+// (triangulate + single_index, points and lines ignored) and hands every model's positions / indices
+// to MeshPool::add.  tobj is not on disk; this reader restates its documented behaviour (parity
+// unpinned): a new model starts at every `o` / `g` statement and when `usemtl` switches material
+// after faces were read; polygons are fan-triangulated (v0, vi, vi+1); each distinct v/vt/vn triple
+// becomes one vertex, numbered per model in order of first use; indices may be negative (relative).
+struct ObjMesh {
+    std::string name;
+    std::vector<Vec3> positions, normals;
+    std::vector<float> texcoords;                    // u, v pairs
+    std::vector<uint32_t> indices;
+    int material_id = -1;                            // order of `usemtl` names' first appearance (no .mtl parsing)
+};
+
+class ObjModel {
+   public:
+    static std::vector<ObjMesh> load(const std::string& path) {
+        std::FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f) throw Error(VD_ERR_INVALID_ARG, "ObjModel: failed to open file: " + path);
+        std::vector<Vec3> v, vn;
+        std::vector<float> vt;
+        std::vector<ObjMesh> out;
+        ObjMesh cur; cur.name = "unnamed_object";
+        std::map<std::tuple<long, long, long>, uint32_t> seen;
+        std::map<std::string, int> materials;
+        auto flush = [&](std::string next_name) {
+            const int mat = cur.material_id;
+            if (!cur.indices.empty()) out.push_back(std::move(cur));
+            cur = ObjMesh{}; cur.name = next_name; cur.material_id = mat;
+            seen.clear();
+        };
+        auto rest = [](const char* p) { std::string r(p); while (!r.empty() && (r.back() == '\n' || r.back() == '\r' || r.back() == ' ')) r.pop_back(); return r; };
+        char line[4096];
+        while (std::fgets(line, sizeof line, f)) {
+            const char* p = line;
+            while (*p == ' ' || *p == '\t') ++p;
+            if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+                char* e; Vec3 a; a.x = std::strtof(p + 2, &e); a.y = std::strtof(e, &e); a.z = std::strtof(e, &e); v.push_back(a);
+            } else if (p[0] == 'v' && p[1] == 'n') {
+                char* e; Vec3 a; a.x = std::strtof(p + 2, &e); a.y = std::strtof(e, &e); a.z = std::strtof(e, &e); vn.push_back(a);
+            } else if (p[0] == 'v' && p[1] == 't') {
+                char* e; const float a = std::strtof(p + 2, &e), b = std::strtof(e, &e); vt.push_back(a); vt.push_back(b);
+            } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+                std::vector<uint32_t> poly;
+                const char* q = p + 1;
+                for (;;) {
+                    while (*q == ' ' || *q == '\t') ++q;
+                    if (*q == '\0' || *q == '\n' || *q == '\r' || *q == '#') break;
+                    long idx[3] = {0, 0, 0};           // 1-based as written; 0 = absent
+                    for (int k = 0; k < 3; ++k) {
+                        char* e; const long t = std::strtol(q, &e, 10);
+                        if (e != q) idx[k] = t;
+                        q = e;
+                        if (*q != '/') break;
+                        ++q;
+                    }
+                    while (*q && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') ++q;
+                    const long nv = (long)v.size(), nt = (long)vt.size() / 2, nn = (long)vn.size();
+                    const long iv = idx[0] < 0 ? nv + idx[0] : idx[0] - 1;
+                    const long it = idx[1] == 0 ? -1 : (idx[1] < 0 ? nt + idx[1] : idx[1] - 1);
+                    const long in = idx[2] == 0 ? -1 : (idx[2] < 0 ? nn + idx[2] : idx[2] - 1);
+                    if (iv < 0 || iv >= nv || it >= nt || in >= nn) { std::fclose(f); throw Error(VD_ERR_INVALID_ARG, "ObjModel: face index out of range in " + path); }
+                    const auto key = std::make_tuple(iv, it, in);
+                    auto hit = seen.find(key);
+                    if (hit == seen.end()) {
+                        hit = seen.emplace(key, (uint32_t)cur.positions.size()).first;
+                        cur.positions.push_back(v[(size_t)iv]);
+                        if (it >= 0) { cur.texcoords.push_back(vt[2 * (size_t)it]); cur.texcoords.push_back(vt[2 * (size_t)it + 1]); }
+                        if (in >= 0) cur.normals.push_back(vn[(size_t)in]);
+                    }
+                    poly.push_back(hit->second);
+                }
+                for (size_t k = 1; k + 1 < poly.size(); ++k) {   // fan; points and lines (< 3 vertices) are dropped
+                    cur.indices.push_back(poly[0]); cur.indices.push_back(poly[k]); cur.indices.push_back(poly[k + 1]);
+                }
+            } else if ((p[0] == 'o' || p[0] == 'g') && (p[1] == ' ' || p[1] == '\t')) {
+                flush(rest(p + 2));
+            } else if (std::strncmp(p, "usemtl", 6) == 0) {
+                const std::string name = rest(p + 7);
+                const int id = materials.emplace(name, (int)materials.size()).first->second;
+                if (id != cur.material_id && !cur.indices.empty()) flush(cur.name);
+                cur.material_id = id;
+            }
+        }
+        std::fclose(f);
+        if (!cur.indices.empty()) out.push_back(std::move(cur));
+        return out;
+    }
+
+    // one MeshPool entry (and BLAS) per model, as `app.add_mesh(MeshRef{..})` does in models/mod.rs:40-53
+    static std::vector<uint32_t> import(MeshPool& pool, const std::string& path) {
+        std::vector<uint32_t> ids;
+        for (ObjMesh& m : load(path))
+            ids.push_back(pool.add(MeshRef{m.positions.data(), m.positions.size(), m.indices.data(), m.indices.size()}));
+        return ids;
+    }
 };
 
 class InstancePool {

@@ -25,6 +25,18 @@ def test_mirror_header_compiles_and_links():
     assert os.path.exists(EXE)
 
 
+def test_obj_reader_restates_tobj_gpu_load_options():
+    """voidin::ObjModel::load (OBJ ingest of models/mod.rs:19-57) on a hand-written fixture; host code only."""
+    src = os.path.join(ROOT, "tests", "cpp", "obj_reader_test.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "obj_reader_test")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), src,
+           "-L", os.path.join(ROOT, "voidin_amd", "csrc"), "-lvoidin_hip", f"-Wl,-rpath,{os.path.join(ROOT, 'voidin_amd', 'csrc')}",
+           "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "two_objects.obj")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "obj_reader_test OK" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.gpu
 def test_mirror_drives_the_path_bit_exact():
     if not os.path.exists(EXE):
