@@ -126,3 +126,40 @@ def test_bitmask_exchange_reconstructs_the_scene(oracle):
         assert np.array_equal(surv, want["base_instance"][:wn])
         mesh_of = np.concatenate([ids[r] for r in range(world)])
         assert np.array_equal(meshes["index_count"][mesh_of[surv]], want["vertex_count"][:wn])
+
+
+def _blas_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ref
+        meshes = [synth.uv_sphere(1.0, 3), synth.triangle_soup(64), synth.knot_mesh(24, 8), synth.plane_mesh(6)]
+        built = []
+        def build(v, i):                       # stand-in producer on CPU: the oracle's builder
+            built.append(len(i))
+            return ref.bvh_build(v, i)
+        res = vdist.build_blas_batch(build, meshes)
+        q.put((rank, len(built), [(n.tobytes(), i.tobytes()) for n, i in res]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_blas_batch_is_partitioned_by_mesh_and_replicated(oracle):
+    """Different meshes build on different ranks; every rank ends with every BLAS (gloo, world 2)."""
+    meshes = [synth.uv_sphere(1.0, 3), synth.triangle_soup(64), synth.knot_mesh(24, 8), synth.plane_mesh(6)]
+    want = [oracle.bvh_build(v, i) for v, i in meshes]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_blas_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, n_built, blobs in res:
+        assert n_built == 2, "each rank builds its own half of the meshes"
+        for (nb, ib), (wn, wi) in zip(blobs, want):
+            assert nb == wn.tobytes() and ib == wi.tobytes(), f"rank {rank}"

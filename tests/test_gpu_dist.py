@@ -69,3 +69,46 @@ def test_sharded_visibility_two_ranks_one_gpu(oracle, world, n):
     for rank, cnt, blob in res:
         assert cnt >= 0, blob
         assert cnt == wn and blob == want[:wn].tobytes(), f"rank {rank}"
+
+
+def _blas_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from voidin_amd import dist as vdist
+        from voidin_amd.runtime import Context
+        torch.cuda.set_device(0)
+        ctx = Context(0)
+        meshes = [synth.uv_sphere(1.0, 10), synth.triangle_soup(64), synth.knot_mesh(96, 24), synth.knot_mesh(40, 16, seed=5)]
+        res = vdist.build_blas_batch(ctx.bvh_build, meshes, device="cuda")
+        q.put((rank, [(n.tobytes(), i.tobytes()) for n, i in res]))
+        ctx.close()
+    except Exception as e:
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_blas_batch_two_ranks_one_gpu(oracle):
+    """Scene load with many meshes: rank r builds meshes r, r+2, ... on the GPU, owners broadcast; every
+    rank holds every BLAS, bit-exact against the oracle's builder."""
+    meshes = [synth.uv_sphere(1.0, 10), synth.triangle_soup(64), synth.knot_mesh(96, 24), synth.knot_mesh(40, 16, seed=5)]
+    want = [oracle.bvh_build(v, i) for v, i in meshes]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_blas_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, blobs in res:
+        assert isinstance(blobs, list), blobs
+        for (nb, ib), (wn, wi) in zip(blobs, want):
+            assert ib == wi.tobytes(), f"rank {rank}: index permutation"
+            from conftest import fields_equal
+            got = np.frombuffer(nb, dtype=wn.dtype)
+            assert len(got) == len(wn) and fields_equal(got, wn), f"rank {rank}: nodes"

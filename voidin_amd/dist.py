@@ -116,3 +116,39 @@ def allgather_draws(local_draws_u8: torch.Tensor, counts: torch.Tensor, out_u8: 
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return total
+
+
+def build_blas_batch(build_fn, meshes, group=None, device=None):
+    """Scene-load step for many meshes (SURVEY.md §8e "replicas only", §8f N3): one BLAS build does not
+    shard — every split of BvhBuilder is a global, order-dependent pass over its segment
+    (crates/bvh/src/blas.rs:135-182) — but different meshes are independent, so rank r builds meshes
+    r, r + world, ... and the results are broadcast from their owners.
+
+    build_fn(vertices (V,3) f32, indices (3T,) u32) -> (nodes: VdBvhNode array, permuted indices); the
+    product passes Context.bvh_build.  `meshes` is the same list on every rank (the asset files are
+    replicated).  Returns [(nodes, indices)] for ALL meshes on every rank, in input order.
+    device: where the exchange buffers live ("cuda" for RCCL, "cpu" for gloo); default by backend."""
+    import numpy as np
+    from . import abi
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if device is None:
+        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = {k: build_fn(v, i) for k, (v, i) in enumerate(meshes) if k % world == rank}
+    out = []
+    for k, (v, i) in enumerate(meshes):
+        owner = k % world
+        src = dist.get_global_rank(group, owner) if group else owner
+        n_idx = int(np.asarray(i).size)
+        n_nodes = torch.tensor([len(mine[k][0]) if owner == rank else 0], dtype=torch.int64, device=device)
+        dist.broadcast(n_nodes, src=src, group=group)
+        nn = int(n_nodes.item())
+        buf = torch.empty(nn * abi.BVH_NODE.itemsize + n_idx * 4, dtype=torch.uint8, device=device)
+        if owner == rank:
+            nodes, idx = mine[k]
+            blob = np.concatenate([np.ascontiguousarray(nodes).view(np.uint8).reshape(-1),
+                                   np.ascontiguousarray(idx, dtype=np.uint32).view(np.uint8).reshape(-1)])
+            buf.copy_(torch.from_numpy(blob))
+        dist.broadcast(buf, src=src, group=group)
+        host = buf.cpu().numpy()
+        out.append((host[: nn * abi.BVH_NODE.itemsize].view(abi.BVH_NODE).copy(), host[nn * abi.BVH_NODE.itemsize:].view(np.uint32).copy()))
+    return out
