@@ -177,6 +177,18 @@ int         vd_ctx_synchronize(VdCtx* ctx);
 const char* vd_last_error(const VdCtx* ctx);
 const char* vd_version(void);
 
+/* HIP -> wgpu hand-off.  The renderer owns `draw_cmd_buffer`
+ * (ResizableBuffer<DrawIndexedIndirect>, crates/components/src/buffer.rs:42-47, created in
+ * app.rs:167-171); to let Geometry::record consume the commands without a PCIe round trip the
+ * Vulkan allocation behind it is exported as an opaque fd (VK_KHR_external_memory_fd) and mapped
+ * here; the returned device pointer is then passed as `d_out` of vd_cull_emit_dev /
+ * vd_cull_compact_dev.  The fd is consumed on success (Vulkan/HIP convention).  Ordering
+ * against the consumer is the caller's: vd_ctx_synchronize, or an exported semaphore.        */
+typedef struct VdExternalBuffer VdExternalBuffer;
+int vd_import_external_buffer(VdCtx* ctx, int opaque_fd, uint64_t size_bytes, VdExternalBuffer** out_handle,
+                              void** out_device_ptr);
+int vd_release_external_buffer(VdCtx* ctx, VdExternalBuffer* handle);
+
 /* ------------------------------------------------------------------------------------ */
 /* Cull + emit                                                      */
 /* ------------------------------------------------------------------------------------ */

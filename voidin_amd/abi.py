@@ -104,6 +104,8 @@ PROTOTYPES = {
     "vd_tlas_refit_wide_dev": (_I, [_P, _P, _U, _P, _U, _P]),
     "vd_trace": (_I, [_P, C.POINTER(TraceScene), _P, _U, _P]),
     "vd_trace_dev": (_I, [_P, C.POINTER(TraceScene), _P, _U, _P]),
+    "vd_import_external_buffer": (_I, [_P, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "vd_release_external_buffer": (_I, [_P, _P]),
     "vd_trace_any_dev": (_I, [_P, C.POINTER(TraceScene), _P, _U, _P]),
     "vd_shadow_rays_dev": (_I, [_P, _P, _P, _U, C.POINTER(C.c_float), _P]),
     "vd_compute_update_dev": (_I, [_P, _P, _U, _P, _U, C.c_float, C.c_float, _I]),

@@ -111,6 +111,44 @@ int vd_ctx_synchronize(VdCtx* ctx) {
 const char* vd_last_error(const VdCtx* ctx) { return ctx ? ctx->err : "null ctx"; }
 
 // Tuning hook (not part of the reference boundary): pick the cull_compact kernel variant.
+struct VdExternalBuffer { hipExternalMemory_t mem; void* ptr; };
+
+int vd_import_external_buffer(VdCtx* ctx, int opaque_fd, uint64_t size_bytes, VdExternalBuffer** out_handle, void** out_device_ptr) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (opaque_fd < 0 || size_bytes == 0 || !out_handle || !out_device_ptr) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_import_external_buffer: bad fd/size/out pointer");
+    *out_handle = nullptr; *out_device_ptr = nullptr;
+    hipExternalMemoryHandleDesc hd;
+    memset(&hd, 0, sizeof(hd));
+    hd.type = hipExternalMemoryHandleTypeOpaqueFd;
+    hd.handle.fd = opaque_fd;
+    hd.size = size_bytes;
+    hipExternalMemory_t mem;
+    VD_HIP_CHECK(ctx, hipImportExternalMemory(&mem, &hd));
+    hipExternalMemoryBufferDesc bd;
+    memset(&bd, 0, sizeof(bd));
+    bd.offset = 0; bd.size = size_bytes;
+    void* ptr = nullptr;
+    hipError_t e = hipExternalMemoryGetMappedBuffer(&ptr, mem, &bd);
+    if (e != hipSuccess) {
+        (void)hipDestroyExternalMemory(mem);
+        snprintf(ctx->err, sizeof(ctx->err), "hipExternalMemoryGetMappedBuffer -> %s", hipGetErrorString(e));
+        return VD_ERR_HIP;
+    }
+    VdExternalBuffer* h = new (std::nothrow) VdExternalBuffer{mem, ptr};
+    if (!h) { (void)hipDestroyExternalMemory(mem); return VD_ERR_OOM; }
+    *out_handle = h; *out_device_ptr = ptr;
+    return VD_OK;
+}
+
+int vd_release_external_buffer(VdCtx* ctx, VdExternalBuffer* handle) {
+    if (!ctx || !handle) return VD_ERR_INVALID_ARG;
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipDestroyExternalMemory(handle->mem);
+    delete handle;
+    if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "hipDestroyExternalMemory -> %s", hipGetErrorString(e)); return VD_ERR_HIP; }
+    return VD_OK;
+}
+
 int vd_debug_set_cull_variant(VdCtx* ctx, int variant) {
     if (!ctx) return VD_ERR_INVALID_ARG;
     ctx->cull_variant = variant;
