@@ -20,10 +20,13 @@
 //    elements, which are added back per candidate;
 //  * children boxes are reduced from the final arrangement, as the reference does.
 //
-// Phases: A (segments > kSmallMax prims): level-synchronous, many workgroups per segment, the
-// arrangement ping-pongs between two 16-B payload arrays in HBM.  B (<= kSmallMax): one wave
-// builds the whole subtree in DFS order out of LDS, which yields the reference's pre-order node
-// numbering locally.  C: DFS numbering of the (small) top tree on the host, parallel copy-out.
+// Phases: A (segments > kMidMax prims): level-synchronous, many workgroups per segment; the 21
+// predicates of a level are evaluated once and the arrangement ping-pongs between two 8-byte
+// {triangle id, predicate bits} arrays in HBM.  Mid tier (kSmallMax < n <= kMidMax): one workgroup
+// per segment, the same rounds with the arrangement in LDS (barriers instead of launches).
+// B (<= kSmallMax): one workgroup builds the whole subtree in DFS order out of LDS, which yields
+// the reference's pre-order node numbering locally.  C: DFS numbering of the (small) top tree on
+// the host, parallel copy-out.
 #include "vd_common.hpp"
 
 #include <vector>
@@ -41,6 +44,12 @@ constexpr int kChunks = kSmallMax / 64;
 constexpr int kCand = 21;               // 3 axes x 7 planes (blas.rs:144-145; `bins` hard-coded to 8)
 constexpr int kBig = 0x7fffffff;
 constexpr int kItem = 1024;             // phase A: positions per workgroup item (256 lanes x 4)
+#ifndef VD_MID_MAX
+#define VD_MID_MAX 2048
+#endif
+constexpr int kMidMax = VD_MID_MAX;      // largest segment split by ONE workgroup out of LDS (mid tier); 0 disables the tier
+constexpr int kMidThreads = kMidMax > 0 ? kMidMax / 8 : 64;   // 8 positions per lane
+constexpr int kMidPer = 8;              // positions per lane: position = wave*512 + j*64 + lane
 constexpr unsigned kNone = 0xffffffffu;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -642,8 +651,10 @@ struct TopNode {                      // temporary top-tree node
     unsigned pad;
 };
 
+struct MidRoot { unsigned start, count, node, pad; int cbk[6]; int pad2[2]; };   // a segment the mid tier takes over
+
 struct LevelCtl {                     // device-side counters
-    unsigned n_seg, n_seg_next, n_items, n_top, n_small, err, pad0, pad1;
+    unsigned n_seg, n_seg_next, n_items, n_top, n_small, err, n_mid, pad1;
 };
 
 // one thread per segment: items per segment, centroid keys / bins reset
@@ -978,7 +989,7 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
 
 // one thread per segment: emit the two children, classify them, clear u flags
 __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, TopNode* top, SmallRoot* small,
-                                  unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap) {
+                                  unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap, MidRoot* mid, unsigned mid_cap) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ctl->n_seg) return;
     const Seg& sg = segs[i];
@@ -1001,6 +1012,14 @@ __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, Top
             if (si < small_cap) small[si] = SmallRoot{t.start, t.count, pair + side, 0u};
             else atomicOr(&ctl->err, 4u);
             t.small = si;
+        } else if (t.count <= (unsigned)kMidMax) {
+            t.kind = 1u;
+            const unsigned mi = atomicAdd(&ctl->n_mid, 1u);
+            if (mi < mid_cap) {
+                MidRoot& m = mid[mi];
+                m.start = t.start; m.count = t.count; m.node = pair + side; m.pad = 0;
+                for (int q = 0; q < 6; ++q) m.cbk[q] = sg.child_k[12 + side * 6 + q];
+            } else atomicOr(&ctl->err, 4u);
         } else {
             t.kind = 1u;
             const unsigned ni = atomicAdd(&ctl->n_seg_next, 1u);
@@ -1010,6 +1029,238 @@ __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, Top
         }
         top[pair + side] = t;
     }
+}
+
+// =============================================================================================
+// Mid tier: one 1024-lane workgroup takes a segment of kSmallMax < n <= kMidMax elements and splits it - and every
+// child that is still larger than kSmallMax - with the arrangement resident in LDS: the 22 shuffles of a split are
+// 22 x 4 barriers instead of 22 x 4 kernel launches over all of HBM.  Same arithmetic as the a_* kernels
+// (closed-form partition_shuffle, held-out `u` elements, binned SAH), same top-tree / small-root outputs.
+// =============================================================================================
+struct MidNode { unsigned s0, n, node; int cbk[6]; };
+struct MidLds {
+    u32x2 pay[kMidMax > 0 ? kMidMax : 1];
+    unsigned short tpos[kMidMax > 0 ? kMidMax : 1], fpos[kMidMax > 0 ? kMidMax : 1];
+    int bin_min[3][8][3], bin_max[3][8][3];
+    int child_k[24];
+    float pos[kCand + 3];
+    u32x2 u_pay[kCand + 1];
+    unsigned u_p[kCand + 1], ttot[kCand + 1];
+    unsigned wave_cnt[kMidThreads / 64];
+    unsigned best, Lst, n_stack, pair;
+    MidNode stack[16];
+};
+
+// one partition_shuffle of the node [s0, s0+n) on predicate bit `cc` (blas.rs:168-182 in closed form);
+// c >= 0 records the trial's never-examined element
+__device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, unsigned cc, int c) {
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u32x2 v[kMidPer];
+    unsigned long long masks[kMidPer];
+    unsigned t = 0;
+#pragma unroll
+    for (int j = 0; j < kMidPer; ++j) {
+        const unsigned x = wave * 512u + j * 64u + lane;
+        bool p = false;
+        if (x < n) { v[j] = L.pay[s0 + x]; p = (v[j].y >> cc) & 1u; }
+        masks[j] = __ballot(p);
+        t += (unsigned)__popcll(masks[j]);
+    }
+    if (lane == 0u) L.wave_cnt[wave] = t;
+    __syncthreads();
+    unsigned before = 0, ttot = 0;
+#pragma unroll
+    for (unsigned w = 0; w < (unsigned)kMidThreads / 64u; ++w) { const unsigned cw = L.wave_cnt[w]; if (w < wave) before += cw; ttot += cw; }
+    unsigned run = before;
+#pragma unroll
+    for (int j = 0; j < kMidPer; ++j) {
+        const unsigned x = wave * 512u + j * 64u + lane;
+        if (x < n) {
+            const bool p = (masks[j] >> lane) & 1ull;
+            const unsigned tl = run + vd_mbcnt(masks[j]);
+            if (p) L.tpos[s0 + (ttot - tl - 1u)] = (unsigned short)x;     // index T: (T+1)-th true from the right
+            else L.fpos[s0 + (x - tl)] = (unsigned short)x;               // index F: (F+1)-th false from the left
+        }
+        run += (unsigned)__popcll(masks[j]);
+    }
+    __syncthreads();
+    const unsigned ftot = n - ttot;
+    unsigned dest[kMidPer];
+    run = before;
+#pragma unroll
+    for (int j = 0; j < kMidPer; ++j) {
+        const unsigned x = wave * 512u + j * 64u + lane;
+        dest[j] = kNone;
+        if (x < n) {
+            const bool p = (masks[j] >> lane) & 1ull;
+            const unsigned tl = run + vd_mbcnt(masks[j]);
+            const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
+            const int tF = F == 0u ? (int)n : (F <= ttot ? (int)L.tpos[s0 + F - 1u] : -1);
+            const bool left = (int)x < tF;
+            const unsigned fj = (T + 1u <= ftot) ? (unsigned)L.fpos[s0 + T] : n;
+            const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
+            const bool is_u = fetch == n - 1u;
+            unsigned d;
+            if (is_u) d = ttot - (p ? 1u : 0u);
+            else if (left) d = p ? x : (unsigned)tF - 1u;
+            else d = p ? fj : x - 1u;
+            dest[j] = d;
+            if (is_u && c >= 0) { L.u_pay[c] = v[j]; L.u_p[c] = p ? 1u : 0u; L.ttot[c] = ttot; }
+        }
+        run += (unsigned)__popcll(masks[j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kMidPer; ++j)
+        if (dest[j] != kNone) L.pay[s0 + dest[j]] = v[j];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
+                                                               u32x2* __restrict__ slim, const f32x4* __restrict__ cent,
+                                                               const TriBox* __restrict__ boxes, LevelCtl* ctl, TopNode* top,
+                                                               SmallRoot* small, unsigned top_cap, unsigned small_cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MidLds& L = *reinterpret_cast<MidLds*>(smem);
+    if (blockIdx.x >= *n_roots_p) return;
+    const MidRoot root = roots[blockIdx.x];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (unsigned x = tid; x < root.count; x += kMidThreads) L.pay[x] = slim[root.start + x];
+    if (tid == 0) {
+        L.n_stack = 1;
+        L.stack[0].s0 = 0; L.stack[0].n = root.count; L.stack[0].node = root.node;
+        for (int q = 0; q < 6; ++q) L.stack[0].cbk[q] = root.cbk[q];
+    }
+    __syncthreads();
+    while (L.n_stack > 0u) {
+        const MidNode nd = L.stack[L.n_stack - 1u];
+        __syncthreads();
+        const unsigned s0 = nd.s0, n = nd.n;
+        if (tid == 0) L.n_stack -= 1u;
+        // planes (blas.rs:142-146) and per-node resets
+        if (tid < (unsigned)kCand) {
+            float cbmin[3], cbmax[3];
+            for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(nd.cbk[k]); cbmax[k] = box_hi(nd.cbk[3 + k]); }
+            L.pos[tid] = cand_pos(cbmin, cbmax, (int)tid);
+        }
+        if (tid >= 64u && tid < 64u + 72u) { (&L.bin_min[0][0][0])[tid - 64u] = kBig; (&L.bin_max[0][0][0])[tid - 64u] = -kBig - 1; }
+        if (tid >= 192u && tid < 192u + 24u) L.child_k[tid - 192u] = ((tid - 192u) % 6u) < 3u ? kBig : -kBig - 1;
+        __syncthreads();
+        // predicate bits of the 21 planes
+        for (unsigned x = tid; x < n; x += kMidThreads) {
+            u32x2 v = L.pay[s0 + x];
+            const f32x4 c = cent[v.x];
+            unsigned bits = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                bits |= (c.x < L.pos[k] ? 1u : 0u) << k;
+                bits |= (c.y < L.pos[7 + k] ? 1u : 0u) << (7 + k);
+                bits |= (c.z < L.pos[14 + k] ? 1u : 0u) << (14 + k);
+            }
+            v.y = bits;
+            L.pay[s0 + x] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < kCand; ++c) mid_shuffle(L, s0, n, (unsigned)c, c);
+        // bins over the non-u elements
+        for (unsigned x = tid; x < n; x += kMidThreads) {
+            const u32x2 v = L.pay[s0 + x];
+            bool is_u = false;
+#pragma unroll
+            for (int c = 0; c < kCand; ++c) is_u |= L.u_pay[c].x == v.x;
+            if (is_u) continue;
+            const TriBox bx = boxes[v.x];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int b = 7 - __popc((v.y >> (7 * a)) & 0x7fu);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    atomicMin(&L.bin_min[a][b][q], vd_key(bx.mn[q]));
+                    atomicMax(&L.bin_max[a][b][q], vd_key(bx.mx[q]));
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0u) {
+            vd_u64 key = ~0ull;
+            if (lane < (unsigned)kCand) {
+                const int c = (int)lane, a = c / 7, k = c % 7 + 1;
+                EvalIn in{&L.bin_min[a][0][0], &L.bin_max[a][0][0], L.u_pay, boxes, kCand, L.u_pay[c].x};
+                const unsigned n1 = L.ttot[c] - L.u_p[c];
+                key = cost_key(eval_candidate(in, a, k, L.pos[c], n1, n), (unsigned)c);
+            }
+            key = wave_min_u64(key);
+            if (lane == 0u) {
+                if (key == ~0ull) { atomicOr(&ctl->err, ERR_DEGENERATE); L.best = 0; L.Lst = 1; }
+                else { L.best = (unsigned)key; L.Lst = L.ttot[L.best] - L.u_p[L.best]; }
+            }
+        }
+        __syncthreads();
+        mid_shuffle(L, s0, n, L.best, -1);
+        // children: vertex boxes (blas.rs:115-123) and centroid boxes (the children's `cb`)
+        const unsigned Lst = L.Lst;
+        {
+            int k24[24];
+#pragma unroll
+            for (int i = 0; i < 24; ++i) k24[i] = (i % 6) < 3 ? kBig : -kBig - 1;
+            for (unsigned x = tid; x < n; x += kMidThreads) {
+                const unsigned id = L.pay[s0 + x].x;
+                const TriBox bx = boxes[id];
+                const f32x4 c = cent[id];
+                const float ce[3] = {c.x, c.y, c.z};
+                const int o = x < Lst ? 0 : 6;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    k24[o + q] = min(k24[o + q], vd_key(bx.mn[q]));
+                    k24[o + 3 + q] = max(k24[o + 3 + q], vd_key(bx.mx[q]));
+                    k24[12 + o + q] = min(k24[12 + o + q], vd_key(ce[q]));
+                    k24[12 + o + 3 + q] = max(k24[12 + o + 3 + q], vd_key(ce[q]));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const bool is_min = (i % 6) < 3;
+                const int r = is_min ? wave_min_i(k24[i]) : wave_max_i(k24[i]);
+                if (lane == 0u) { if (is_min) atomicMin(&L.child_k[i], r); else atomicMax(&L.child_k[i], r); }
+            }
+        }
+        __syncthreads();
+        // emit the two children (as a_finalize_kernel does)
+        if (tid == 0) {
+            const unsigned pair = atomicAdd(&ctl->n_top, 2u);
+            if (pair + 2u > top_cap) { atomicOr(&ctl->err, 4u); L.n_stack = 0; }
+            else {
+                top[nd.node].kind = 1u;
+                top[nd.node].left = pair;
+                for (int side = 0; side < 2; ++side) {
+                    TopNode t;
+                    for (int q = 0; q < 3; ++q) { t.mn[q] = box_lo(L.child_k[side * 6 + q]); t.mx[q] = box_hi(L.child_k[side * 6 + 3 + q]); }
+                    const unsigned ls = side == 0 ? s0 : s0 + Lst;
+                    t.start = root.start + ls;
+                    t.count = side == 0 ? Lst : n - Lst;
+                    t.left = 0; t.small = 0; t.pad = 0;
+                    if (t.count <= 3u) {
+                        t.kind = 0u;
+                    } else if (t.count <= (unsigned)kSmallMax) {
+                        t.kind = 2u;
+                        const unsigned si = atomicAdd(&ctl->n_small, 1u);
+                        if (si < small_cap) small[si] = SmallRoot{t.start, t.count, pair + side, 0u};
+                        else atomicOr(&ctl->err, 4u);
+                        t.small = si;
+                    } else {
+                        t.kind = 1u;
+                        MidNode& m = L.stack[L.n_stack++];        // depth <= log2(kMidMax / kSmallMax) + 1 pending nodes
+                        m.s0 = ls; m.n = t.count; m.node = pair + side;
+                        for (int q = 0; q < 6; ++q) m.cbk[q] = L.child_k[12 + side * 6 + q];
+                    }
+                    top[pair + side] = t;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (unsigned x = tid; x < root.count; x += kMidThreads) slim[root.start + x] = L.pay[x];
 }
 
 // =============================================================================================
@@ -1064,15 +1315,19 @@ __global__ void c_permute_kernel(const unsigned* __restrict__ final_ids, const u
     idx_out[3u * (size_t)i + 2] = idx_in[3u * (size_t)t + 2];
 }
 
-__global__ void c_root_kernel(TopNode* top, const int* root_keys, unsigned n_tri, SmallRoot* small, LevelCtl* ctl, Seg* segs) {
+__global__ void c_root_kernel(TopNode* top, const int* root_keys, unsigned n_tri, SmallRoot* small, LevelCtl* ctl, Seg* segs, MidRoot* mid) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     TopNode t;
     for (int q = 0; q < 3; ++q) { t.mn[q] = box_lo(root_keys[q]); t.mx[q] = box_hi(root_keys[3 + q]); }
     t.start = 0; t.count = n_tri; t.left = 0; t.small = 0; t.pad = 0;
-    ctl->n_top = 2; ctl->n_small = 0; ctl->n_seg = 0; ctl->n_seg_next = 0; ctl->n_items = 0;
+    ctl->n_top = 2; ctl->n_small = 0; ctl->n_seg = 0; ctl->n_seg_next = 0; ctl->n_items = 0; ctl->n_mid = 0;
     if (n_tri <= 3u) t.kind = 0u;
     else if (n_tri <= (unsigned)kSmallMax) { t.kind = 2u; small[0] = SmallRoot{0u, n_tri, 0u, 0u}; ctl->n_small = 1; }
-    else {
+    else if (n_tri <= (unsigned)kMidMax) {
+        t.kind = 1u; ctl->n_mid = 1;
+        mid[0].start = 0; mid[0].count = n_tri; mid[0].node = 0; mid[0].pad = 0;
+        for (int q = 0; q < 6; ++q) mid[0].cbk[q] = root_keys[6 + q];
+    } else {
         t.kind = 1u; segs[0].start = 0; segs[0].count = n_tri; segs[0].node = 0; ctl->n_seg = 1;
         for (int q = 0; q < 6; ++q) segs[0].cbk[q] = root_keys[6 + q];
     }
@@ -1099,6 +1354,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
                        VdBvhNode* d_out, uint32_t node_cap, uint32_t* out_n_nodes) {
     const size_t T = n_tri;
     const unsigned seg_cap = (unsigned)(T / kSmallMax + 2);
+    const unsigned mid_cap = seg_cap;
     const unsigned item_cap = (unsigned)(T / kItem + seg_cap + 2);
     const unsigned small_cap = (unsigned)(T / 4 + 2);
     const unsigned top_cap = (unsigned)(2 * (size_t)small_cap + 4 * (size_t)seg_cap + 64);
@@ -1106,13 +1362,13 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     Arena probe{nullptr, 0};
     auto layout = [&](Arena& a, bool) {
         struct P { u32x2 *pay0, *pay1; f32x4* cent; TriBox* boxes; unsigned *falsepos, *truepos, *final_ids, *stack, *idx_copy;
-                   unsigned char* is_u; Seg *seg0, *seg1; unsigned *item_seg, *item_cnt, *item_pre; TopNode* top; SmallRoot* small;
+                   unsigned char* is_u; Seg *seg0, *seg1; MidRoot* mid; unsigned *item_seg, *item_cnt, *item_pre; TopNode* top; SmallRoot* small;
                    unsigned* sub_interior; TmpNode* subnodes; unsigned short* submap; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair; } p;
         p.pay0 = a.take<u32x2>(T); p.pay1 = a.take<u32x2>(T); p.cent = a.take<f32x4>(T); p.boxes = a.take<TriBox>(T);
         p.falsepos = a.take<unsigned>(T); p.truepos = a.take<unsigned>(T);
         p.final_ids = a.take<unsigned>(T); p.stack = a.take<unsigned>(T); p.idx_copy = a.take<unsigned>(3 * T);
         p.is_u = a.take<unsigned char>(T);
-        p.seg0 = a.take<Seg>(seg_cap); p.seg1 = a.take<Seg>(seg_cap);
+        p.seg0 = a.take<Seg>(seg_cap); p.seg1 = a.take<Seg>(seg_cap); p.mid = a.take<MidRoot>(mid_cap);
         p.item_seg = a.take<unsigned>(item_cap); p.item_cnt = a.take<unsigned>(item_cap); p.item_pre = a.take<unsigned>(item_cap + 1);
         p.top = a.take<TopNode>(top_cap); p.small = a.take<SmallRoot>(small_cap); p.sub_interior = a.take<unsigned>(small_cap);
         p.subnodes = a.take<TmpNode>(2 * T + 2); p.submap = a.take<unsigned short>(2 * T + 2); p.ctl = a.take<LevelCtl>(1); p.root_keys = a.take<int>(16);
@@ -1137,7 +1393,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     const unsigned tri_blocks = (unsigned)((T + 255) / 256);
     hipLaunchKernelGGL(blas_precompute_kernel, dim3(tri_blocks), dim3(256), 0, st, d_verts, P.idx_copy, n_tri, n_vert, P.pay0,
                        P.cent, P.boxes, P.root_keys, &P.ctl->err);
-    hipLaunchKernelGGL(c_root_kernel, dim3(1), dim3(64), 0, st, P.top, P.root_keys, n_tri, P.small, P.ctl, P.seg0);
+    hipLaunchKernelGGL(c_root_kernel, dim3(1), dim3(64), 0, st, P.top, P.root_keys, n_tri, P.small, P.ctl, P.seg0, P.mid);
 
     // ---- phase A: level loop ----
     Seg* seg_cur = P.seg0; Seg* seg_next = P.seg1;
@@ -1174,7 +1430,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         // 22 swaps: the arrangement is back in pay0
         hipLaunchKernelGGL(a_child_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, P.pay0, P.boxes, P.cent);
         hipLaunchKernelGGL(a_finalize_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, seg_next, P.ctl, P.top, P.small, P.is_u,
-                           top_cap, small_cap);
+                           top_cap, small_cap, P.mid, mid_cap);
         hipLaunchKernelGGL(a_level_swap_kernel, dim3(1), dim3(64), 0, st, P.ctl);
         VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
         VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -1186,6 +1442,21 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         if (++levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
     }
 
+    // ---- mid tier: segments of kSmallMax < n <= kMidMax, one workgroup each, down to small roots ----
+    if (h_ctl.n_mid) {
+        static bool lds_opt_in = false;
+        if (!lds_opt_in) {
+            VD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(blas_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds)));
+            lds_opt_in = true;
+        }
+        hipLaunchKernelGGL(blas_mid_kernel, dim3(h_ctl.n_mid), dim3(kMidThreads), sizeof(MidLds), st, P.mid, &P.ctl->n_mid, P.pay0, P.cent, P.boxes,
+                           P.ctl, P.top, P.small, top_cap, small_cap);
+        VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
+        VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        if (h_ctl.err & ERR_DEGENERATE)
+            VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
+        if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
+    }
     // ---- phase B ----
     const unsigned n_small = h_ctl.n_small, n_top = h_ctl.n_top;
     if (n_small) {
