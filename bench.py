@@ -289,7 +289,7 @@ def main():
                          "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "second_kernel": None if not split else {
-                             "kernel": "expand_mask_kernel", "kernel_ms": round(expand_ms, 4),
+                             "kernel": "mask_scan_kernel + expand_mask_u8_kernel", "kernel_ms": round(expand_ms, 4),
                              "algorithmic_bytes_per_launch": int(expand_bytes),
                              "achieved": round(expand_bytes / (expand_ms * 1e-3) / 1e9, 1)},
                          "step": {"kernels_ms": round(step_kernel_ms, 4), "algorithmic_bytes": int(step_bytes),

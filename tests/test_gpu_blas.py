@@ -30,7 +30,7 @@ def test_golden_fixtures(ctx, name):
     assert np.array_equal(idx, g["indices_out"])
 
 
-@pytest.mark.parametrize("n_tri", [1, 3, 4, 5, 17, 64, 65, 300, 511, 512, 513, 700, 1024, 1025, 3000])
+@pytest.mark.parametrize("n_tri", [1, 3, 4, 5, 17, 64, 65, 300, 511, 512, 513, 700, 1024, 1025, 2048, 2049, 3000])
 def test_soup_sizes_vs_oracle(ctx, oracle, n_tri):
     # sizes around the wave (64), the LDS-subtree limit (512) and the phase-A item size (1024)
     v, i = synth.triangle_soup(n_tri, seed=synth.SEED_BASE + 30 + n_tri)

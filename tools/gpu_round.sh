@@ -21,7 +21,7 @@ out={'note':'mean per launch; rocprofv3 --pmc, one counter per pass; units KB; g
 for d,c in [('pmc_fetch','FETCH_SIZE'),('pmc_write','WRITE_SIZE')]:
     for f in glob.glob(f'gpurun_out/round/{d}/*counter_collection.csv'):
         rows=list(csv.DictReader(open(f)))
-        for kern in ['cull_mask_tiled_kernel','expand_mask_kernel','cull_compact_kernel']:
+        for kern in ['cull_mask_tiled_kernel','expand_mask_u8_kernel','mask_scan_kernel','cull_compact_kernel']:
             v=[float(r['Counter_Value']) for r in rows if kern in r['Kernel_Name'] and r['Counter_Name']==c]
             if v:
                 out.setdefault(kern,{})[c+'_KB']=sum(v)/len(v); out[kern][c+'_launches']=len(v)
