@@ -44,6 +44,7 @@ constexpr int kChunks = kSmallMax / 64;
 constexpr int kCand = 21;               // 3 axes x 7 planes (blas.rs:144-145; `bins` hard-coded to 8)
 constexpr int kBig = 0x7fffffff;
 constexpr int kItem = 1024;             // phase A: positions per workgroup item (256 lanes x 4)
+constexpr int kBinItems = 8;            // a_bin_kernel: consecutive items per workgroup
 #ifndef VD_MID_MAX
 #define VD_MID_MAX 2048
 #endif
@@ -897,31 +898,54 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
 __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                     const u32x2* __restrict__ pay, const TriBox* __restrict__ boxes,
                                                     const unsigned char* __restrict__ is_u_flag) {
-    __shared__ int s_min[3][8][3], s_max[3][8][3];
-    ItemCtx ic; const Seg* sg;
-    if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
-    for (unsigned i = threadIdx.x; i < 72u; i += 256u) { (&s_min[0][0][0])[i] = kBig; (&s_max[0][0][0])[i] = -kBig - 1; }
+    // four private copies of the 144 bins (by quarter wave): neighbouring elements fall into the same few bins, and
+    // same-address LDS atomics serialise.  A workgroup covers kBinItems consecutive items and flushes to the segment
+    // record only when the segment changes: the flush is 144 same-address global atomics per workgroup (~5 ns each,
+    // serialised per address), which at the top levels - one segment, 8 k items - used to be the floor of the kernel.
+    __shared__ int s_min[4][3][8][3], s_max[4][3][8][3];
+    const unsigned n_items = ctl->n_items;
+    const unsigned copy = (threadIdx.x >> 4) & 3u;
+    unsigned cur_seg = kNone;
+    auto reset = [&]() { for (unsigned i = threadIdx.x; i < 288u; i += 256u) { (&s_min[0][0][0][0])[i] = kBig; (&s_max[0][0][0][0])[i] = -kBig - 1; } };
+    auto flush = [&](unsigned seg) {
+        for (unsigned i = threadIdx.x; i < 72u; i += 256u) {
+            int lo = kBig, hi = -kBig - 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { lo = min(lo, (&s_min[k][0][0][0])[i]); hi = max(hi, (&s_max[k][0][0][0])[i]); }
+            if (lo != kBig) atomicMin(&(&segs[seg].bin_min[0][0][0])[i], lo);
+            if (hi != -kBig - 1) atomicMax(&(&segs[seg].bin_max[0][0][0])[i], hi);
+        }
+    };
+    reset();
     __syncthreads();
-    for (unsigned xr = threadIdx.x; xr < ic.n_here; xr += 256u) {
-        const u32x2 v = pay[sg->start + ic.rel0 + xr];
-        if (is_u_flag[v.x]) continue;
-        const TriBox bx = boxes[v.x];
+    for (unsigned k = 0; k < (unsigned)kBinItems; ++k) {
+        const unsigned item = blockIdx.x * kBinItems + k;
+        if (item >= n_items) break;
+        const unsigned seg = item_seg[item];
+        if (seg != cur_seg) {
+            if (cur_seg != kNone) { __syncthreads(); flush(cur_seg); __syncthreads(); reset(); __syncthreads(); }
+            cur_seg = seg;
+        }
+        const Seg* sg = segs + seg;
+        const unsigned rel0 = (item - sg->item_first) * kItem;
+        const unsigned n_here = min((unsigned)kItem, sg->count - rel0);
+        for (unsigned xr = threadIdx.x; xr < n_here; xr += 256u) {
+            const u32x2 v = pay[sg->start + rel0 + xr];
+            if (is_u_flag[v.x]) continue;
+            const TriBox bx = boxes[v.x];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int b = 7 - __popc((v.y >> (7 * a)) & 0x7fu);   // bin = number of planes the centroid is not below
+            for (int a = 0; a < 3; ++a) {
+                const int b = 7 - __popc((v.y >> (7 * a)) & 0x7fu);   // bin = number of planes the centroid is not below
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                atomicMin(&s_min[a][b][q], vd_key(bx.mn[q]));
-                atomicMax(&s_max[a][b][q], vd_key(bx.mx[q]));
+                for (int q = 0; q < 3; ++q) {
+                    atomicMin(&s_min[copy][a][b][q], vd_key(bx.mn[q]));
+                    atomicMax(&s_max[copy][a][b][q], vd_key(bx.mx[q]));
+                }
             }
         }
     }
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < 72u; i += 256u) {
-        const int lo = (&s_min[0][0][0])[i], hi = (&s_max[0][0][0])[i];
-        if (lo != kBig) atomicMin(&(&segs[ic.seg].bin_min[0][0][0])[i], lo);
-        if (hi != -kBig - 1) atomicMax(&(&segs[ic.seg].bin_max[0][0][0])[i], hi);
-    }
+    if (cur_seg != kNone) flush(cur_seg);
 }
 
 // one wave per segment: 21 costs -> best plane, stale pivot
@@ -1416,7 +1440,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         for (int c = 0; c <= kCand; ++c) {
             const int cc = c < kCand ? c : -1;       // -1: final re-shuffle with each segment's best plane
             if (c == kCand) {
-                hipLaunchKernelGGL(a_bin_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, P.boxes, P.is_u);
+                hipLaunchKernelGGL(a_bin_kernel, dim3((items_ub + kBinItems - 1) / kBinItems), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, P.boxes, P.is_u);
                 hipLaunchKernelGGL(a_eval_kernel, dim3(n_seg), dim3(64), 0, st, seg_cur, P.ctl, P.boxes);
             }
             hipLaunchKernelGGL(a_count_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_cnt);
