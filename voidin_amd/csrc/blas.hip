@@ -587,7 +587,8 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             }
         }
     }
-    __threadfence();     // node records written by all lanes are re-read below
+    __threadfence_block();   // node records written by all lanes are re-read below, by this workgroup only (an agent-scope
+                             // fence would write back the whole L2 of the XCD, once per subtree)
     __syncthreads();
     if (Q.bad) { if (tid == 0) atomicOr(err, ERR_DEGENERATE); return; }
     const unsigned pool = Q.pool, root_left = Q.root_left;
