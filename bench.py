@@ -253,6 +253,47 @@ def main():
             ctx.tlas_refit_dev(d_ti, n_tl, d_m, len(meshes), d_t)
             torch.cuda.synchronize(); t_refit = time.perf_counter() - t
         extra["tlas"] = {"n_instances": n_tl, "build_ms": round(t_build * 1e3, 1), "refit_ms": round(t_refit * 1e3, 3)}
+        # BASELINE config 5 names a 64k-instance refit: beyond the reference's 16-bit child ids (tlas.rs:71), so in
+        # the wide layout; timed with HIP events by the library (wall clock of a 0.1 ms call is mostly launch latency)
+        n_w = 65536
+        winst = synth.instances(n_w, seed=synth.SEED_BASE + 7, extent=400.0)
+        d_wi = ctx.upload(winst)
+        d_w = ctx.empty((2 * n_w + 1) * 48)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        ctx.tlas_build_dev(d_wi, n_w, d_m, len(meshes), d_w, wide=True)
+        torch.cuda.synchronize(); t_wbuild = time.perf_counter() - t
+        ctx.set_timing(True)
+        g = []
+        for _ in range(5):
+            ctx.tlas_refit_dev(d_wi, n_w, d_m, len(meshes), d_w, wide=True)
+            g.append(ctx.last_gpu_ms())
+        ctx.set_timing(False)
+        extra["tlas_wide_64k"] = {"n_instances": n_w, "build_ms": round(t_wbuild * 1e3, 1), "refit_gpu_ms": round(min(g), 4)}
+        del d_wi, d_w
+        # traversal (no roofline claim: latency/L1-bound): bvh_gpu.rs-shaped scene, 1 M primary rays
+        tv, ti = synth.knot_mesh(512, 128)                        # 131k triangles
+        nodes_b, idx_b = ctx.bvh_build(tv, ti)
+        infos = np.zeros(1, dtype=abi.MESH_INFO)
+        infos[0]["min"], infos[0]["max"] = synth.mesh_bounds(tv)
+        infos[0]["index_count"] = len(idx_b)
+        inst_t = synth.instances(2000, n_mesh=1, seed=synth.SEED_BASE + 8, extent=120.0, scale_range=(0.5, 2.0))
+        tl = ctx.tlas_build(inst_t, infos)
+        rays = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 90), pitch_deg=0), 1024, 1024)
+        ds = ctx.device_scene((tl, inst_t, infos, nodes_b, tv, idx_b))
+        d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
+        d_any = torch.zeros(len(rays), dtype=torch.int32, device=dev)
+        ctx.set_timing(True)
+        t_cl, t_any = [], []
+        for _ in range(3):
+            ctx.trace_dev(ds, d_rays, len(rays), d_hits); t_cl.append(ctx.last_gpu_ms())
+            ctx.trace_any_dev(ds, d_rays, len(rays), d_any); t_any.append(ctx.last_gpu_ms())
+        ctx.set_timing(False)
+        hits = d_hits.cpu().numpy()[: len(rays) * 16].view(abi.HIT)
+        extra["trace"] = {"n_rays": len(rays), "scene": "2000 instances x 131k-triangle mesh",
+                          "closest_hit_Mrays_per_s": round(len(rays) / min(t_cl) / 1e3, 1),
+                          "occlusion_Mrays_per_s": round(len(rays) / min(t_any) / 1e3, 1),
+                          "hit_fraction": round(float(hits["hit"].mean()), 3),
+                          "occlusion_flags_equal_closest_hit": bool(np.array_equal(d_any.cpu().numpy().astype(np.uint32), hits["hit"]))}
 
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_cull_pmc.json")
