@@ -283,9 +283,6 @@ __device__ __forceinline__ void wave_shuffle_any(WaveLds& L, int src, unsigned s
     else wave_shuffle<kChunks>(L, src, s, n, axis, pos, tt, ue, up);
 }
 
-#ifndef VD_BLAS_ABL
-#define VD_BLAS_ABL 0
-#endif
 constexpr int kLaneMax = VD_LANE_MAX;   // nodes up to this size are built one-per-lane (literal sequential algorithm)
 constexpr int kQueue = kSmallMax / 4;   // a BFS level holds at most N/4 splittable nodes
 
@@ -447,7 +444,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     int qi = 0;
 
     while (n_big > 0u) {
-        for (unsigned bi = wave; bi < (((VD_BLAS_ABL & 4) && !root_level) ? 0u : n_big); bi += kSubWaves) {
+        for (unsigned bi = wave; bi < n_big; bi += kSubWaves) {
             const unsigned ent = Q.big[qi][bi];
             const unsigned node_id = ent & 1023u, s = (ent >> 10) & 1023u, n = ent >> 20;
             const bool is_root = root_level;
@@ -463,7 +460,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(wave_min_i(kmn[k])); cbmax[k] = box_hi(wave_max_i(kmx[k])); }
             if (lane < (unsigned)kCand) W.pos[lane] = cand_pos(cbmin, cbmax, (int)lane);
             vd_wave_lds_sync();
-            for (int c = 0; c < ((VD_BLAS_ABL & 8) ? 1 : kCand); ++c) {                              // blas.rs:144-147
+            for (int c = 0; c < kCand; ++c) {                                         // blas.rs:144-147
                 unsigned tt, ue, up;
                 wave_shuffle_any(L, cur, s, n, c / 7, W.pos[c], tt, ue, up);
                 cur ^= 1;
@@ -556,7 +553,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
 
     // ---------------- lane-serial phase: one whole sub-subtree (<= kLaneMax prims) per lane ----------------
     const unsigned n_small = Q.n_small;
-    for (unsigned b0 = 0; b0 < ((VD_BLAS_ABL & 1) ? 0u : n_small); b0 += 64u * kSubWaves) {
+    for (unsigned b0 = 0; b0 < n_small; b0 += 64u * kSubWaves) {
         if (b0 + tid < n_small) {
             unsigned ent = Q.small[b0 + tid];
             unsigned sp = 0;
@@ -608,7 +605,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
         I[j] = 0;
     }
     __syncthreads();
-    if (tid == 0 && !(VD_BLAS_ABL & 2)) {
+    if (tid == 0) {
         for (int j = (int)n_nodes - 1; j >= 0; --j)
             if (LC[j] != 0xffffu) I[j] = (unsigned short)(1u + I[LC[j]] + I[LC[j] + 1u]);
         // forward: parents first
