@@ -102,14 +102,23 @@ __device__ __forceinline__ vd_u64 wave_min_u64(vd_u64 v) {
 }
 
 // tlas.rs:87-105 over the compacted slot arrays; every thread returns the same slot.
+// A scan is bound by VALU issue on the one CU that runs the chain (16 k slots x ~50 instructions / 64 lanes per
+// clock ~ 5 us), not by the 24 B per slot it streams from L2, so the per-slot arithmetic is what counts.
+// FAST (no NaN in any leaf box, checked once; unions of NaN-free boxes are NaN-free): the union extents use
+// v_min/v_max instead of the total-order min/max.  Only the sign of a zero extent can differ, the area is then the
+// same +0/-0-normalised value, so the argmin is unchanged; the boxes written to the nodes always use the total order.
+// Per thread the slots come in increasing order, so `strictly smaller area` alone keeps the first slot.
+template <bool FAST>
 __device__ __forceinline__ unsigned find_best_match(const float* sb, unsigned cap, unsigned cnt,
                                                     unsigned target, vd_u64* s_red, unsigned call) {
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     vd_u64 best = ~0ull;
+    unsigned fbits = 0xffffffffu, fslot = 0;
     if (target < cap) {
         const float t0 = sb[target], t1 = sb[cap + target], t2 = sb[2 * cap + target];
         const float t3 = sb[3 * cap + target], t4 = sb[4 * cap + target], t5 = sb[5 * cap + target];
-        // four consecutive slots per lane per step: six independent 16-B loads in flight
+        // four consecutive slots per lane per step: six independent 16-B loads in flight (issuing the next step's
+        // loads before this step's arithmetic was measured: 20 % slower)
         for (unsigned i0 = tid * 4u; i0 < cnt; i0 += kBuildThreads * 4u) {
             const float4 a0 = *reinterpret_cast<const float4*>(sb + i0), a1 = *reinterpret_cast<const float4*>(sb + cap + i0);
             const float4 a2 = *reinterpret_cast<const float4*>(sb + 2 * cap + i0), a3 = *reinterpret_cast<const float4*>(sb + 3 * cap + i0);
@@ -119,19 +128,30 @@ __device__ __forceinline__ unsigned find_best_match(const float* sb, unsigned ca
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const unsigned i = i0 + k;
-                const float dx = vd_max_to(t3, mx0[k]) - vd_min_to(t0, mn0[k]);
-                const float dy = vd_max_to(t4, mx1[k]) - vd_min_to(t1, mn1[k]);
-                const float dz = vd_max_to(t5, mx2[k]) - vd_min_to(t2, mn2[k]);
-                const float area = vd_area(dx, dy, dz);
-                if (i < cnt && i != target && area < 1e30f) {   // `surface_area < smallest` from 1e30, NaN never passes
-                    const vd_u64 kk = match_key(area, i);
-                    best = kk < best ? kk : best;
+                if (FAST) {
+                    const float dx = __builtin_fmaxf(t3, mx0[k]) - __builtin_fminf(t0, mn0[k]);
+                    const float dy = __builtin_fmaxf(t4, mx1[k]) - __builtin_fminf(t1, mn1[k]);
+                    const float dz = __builtin_fmaxf(t5, mx2[k]) - __builtin_fminf(t2, mn2[k]);
+                    const float area = vd_area(dx, dy, dz) + 0.0f;           // -0 -> +0: the bit pattern is then monotone
+                    const bool ok = i < cnt && i != target && area < 1e30f;    // from 1e30, NaN (inf * 0) never passes
+                    const unsigned bits = ok ? __float_as_uint(area) : 0xffffffffu;
+                    if (bits < fbits) { fbits = bits; fslot = i; }
+                } else {
+                    const float dx = vd_max_to(t3, mx0[k]) - vd_min_to(t0, mn0[k]);
+                    const float dy = vd_max_to(t4, mx1[k]) - vd_min_to(t1, mn1[k]);
+                    const float dz = vd_max_to(t5, mx2[k]) - vd_min_to(t2, mn2[k]);
+                    const float area = vd_area(dx, dy, dz);
+                    if (i < cnt && i != target && area < 1e30f) {   // `surface_area < smallest` from 1e30, NaN never passes
+                        const vd_u64 kk = match_key(area, i);
+                        best = kk < best ? kk : best;
+                    }
                 }
             }
         }
     }
     // one barrier per scan: waves fold their best key into a rotating LDS slot with a 64-bit atomic
     // min; the slot two scans ahead is re-armed by thread 0 while nobody can be reading it
+    if (FAST && fbits != 0xffffffffu) best = match_key(__uint_as_float(fbits), fslot);
     best = wave_min_u64(best);
     vd_u64* slot = s_red + (call % 3u);
     if (lane == 0 && best != ~0ull) atomicMin(slot, best);
@@ -142,18 +162,14 @@ __device__ __forceinline__ unsigned find_best_match(const float* sb, unsigned ca
 }
 
 // tlas.rs:56-84 — one workgroup runs the whole chain.
-template <typename Node>
-__global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restrict__ nodes, unsigned n,
-                                                                   float* sb, unsigned* slot_node,
-                                                                   unsigned cap) {
-    __shared__ vd_u64 s_red[4];
-    if (threadIdx.x < 4) s_red[threadIdx.x] = ~0ull;
-    __syncthreads();
+template <typename Node, bool FAST>
+__device__ __forceinline__ void tlas_build_chain(Node* __restrict__ nodes, unsigned n, float* sb, unsigned* slot_node,
+                                                 unsigned cap, vd_u64* s_red) {
     unsigned call = 0;
     unsigned cnt = n, used = n + 1, a = 0;
-    unsigned b = find_best_match(sb, cap, cnt, a, s_red, call++);
+    unsigned b = find_best_match<FAST>(sb, cap, cnt, a, s_red, call++);
     while (cnt > 0) {
-        const unsigned c = find_best_match(sb, cap, cnt, b, s_red, call++);
+        const unsigned c = find_best_match<FAST>(sb, cap, cnt, b, s_red, call++);
         if (a == c) {
             if (threadIdx.x == 0) {
                 const unsigned idx_a = slot_node[a], idx_b = slot_node[b];
@@ -181,13 +197,29 @@ __global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restr
             used += 1;
             cnt -= 1;
             __syncthreads();
-            b = find_best_match(sb, cap, cnt, a, s_red, call++);
+            b = find_best_match<FAST>(sb, cap, cnt, a, s_red, call++);
         } else {
             a = b;
             b = c;
         }
     }
     if (threadIdx.x == 0) nodes[0] = nodes[slot_node[a]];   // tlas.rs:84
+}
+
+template <typename Node>
+__global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restrict__ nodes, unsigned n,
+                                                                   float* sb, unsigned* slot_node,
+                                                                   unsigned cap) {
+    __shared__ vd_u64 s_red[4];
+    if (threadIdx.x < 4) s_red[threadIdx.x] = ~0ull;
+    int nan = 0;
+    for (unsigned i = threadIdx.x; i < n; i += kBuildThreads) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { const float v = sb[q * cap + i]; nan |= v != v; }
+    }
+    const bool any_nan = __syncthreads_or(nan) != 0;         // also orders the s_red initialisation
+    if (any_nan) tlas_build_chain<Node, false>(nodes, n, sb, slot_node, cap, s_red);
+    else tlas_build_chain<Node, true>(nodes, n, sb, slot_node, cap, s_red);
 }
 
 // ---- refit -------------------------------------------------------------------------------
