@@ -32,6 +32,22 @@ def test_tlas_build_seeded_vs_oracle(ctx, oracle, n):
     assert np.array_equal(wide["min"], want["min"]) and np.array_equal(wide["instance_idx"], want["instance_idx"])
 
 
+def test_tlas_build_with_nan_and_inf_boxes(ctx, oracle):
+    """A NaN or infinite transform makes leaf boxes with NaN / inf: the builder then runs its total-order
+    (exact) scan arithmetic instead of the NaN-free fast path; both must reproduce the oracle's chain."""
+    meshes = synth.mesh_infos()
+    for poison in (np.float32("nan"), np.float32("inf")):
+        inst = synth.instances(700, seed=synth.SEED_BASE + 12, extent=100.0)
+        inst["transform"][13, 12] = poison            # translation x of instance 13
+        inst["transform"][400, 5] = -poison
+        got = ctx.tlas_build(inst, meshes)
+        want = oracle.tlas_build(inst, meshes)
+        for f in ("left_right", "instance_idx"):
+            assert np.array_equal(got[f], want[f])
+        for f in ("min", "max"):                      # NaN != NaN: compare bit patterns
+            assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32))
+
+
 def test_tlas_refit_after_motion(ctx, oracle):
     """compute_update-style motion (rotz(theta) * transform on 10 % of the instances,
     shaders/compute_update.wgsl:12-28), then refit == oracle refit == same-topology recompute."""
