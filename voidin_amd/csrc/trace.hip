@@ -11,7 +11,10 @@
 
 namespace {
 
-constexpr int kStack = 64;
+#ifndef VD_TRACE_STACK
+#define VD_TRACE_STACK 64
+#endif
+constexpr int kStack = VD_TRACE_STACK;
 constexpr float kMaxDist = 1e30f;
 
 struct Ray { float ex, ey, ez, dx, dy, dz, ix, iy, iz; };
@@ -70,9 +73,13 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
                                                    unsigned* __restrict__ overflow) {
     const unsigned i = blockIdx.x * 64u + threadIdx.x;
     if (i >= n_rays) return;
-    // a stack entry is the popped node's payload ({left_right, instance} / {left_first, count}): its box is never
-    // looked at again (bvh.wgsl:45-47, 96-98), so a pop costs no node fetch
-    uint2 tstack[kStack], bstack[kStack];
+    // a stack entry is the popped node's payload, packed into one word: its box is never looked at again
+    // (bvh.wgsl:45-47, 96-98), so a pop costs no node fetch.  The stacks live in scratch memory, and the scratch a
+    // wave needs bounds how many waves the runtime keeps resident: 512 B per lane instead of 1 KB.
+    //   BLAS: count (<= 3... any u2 would do, kept as 2 bits) << 30 | left_first (n_tri <= 2^30 - 1)
+    //   TLAS: interior = left_right (its low half, the left child, is never 0: node 0 is only the root copy);
+    //         leaf = instance_idx << 16 (low half 0)
+    unsigned tstack[kStack], bstack[kStack];
     Ray ray;
     {
         const float4 a = reinterpret_cast<const float4*>(rays + i)[0], b = reinterpret_cast<const float4*>(rays + i)[1];
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
                     if (!(min_dist >= hit)) {
                         if (max_dist <= hit) {
                             if (bhead + 1u > (unsigned)kStack) { ovf = true; break; }
-                            bstack[bhead++] = far;
+                            bstack[bhead++] = far.x | (far.y << 30);
                         }
                         bn = near;
                         bpop = false;
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
                 if (ANY && res.hit) break;
                 if (bpop) {
                     if (bhead == 0u) break;
-                    bn = bstack[--bhead];
+                    { const unsigned w = bstack[--bhead]; bn = make_uint2(w & 0x3fffffffu, w >> 30); }
                 }
             }
             if (ovf || (ANY && res.hit)) break;
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
             if (!(min_dist >= res.dist)) {
                 if (max_dist < res.dist) {
                     if (thead + 1u > (unsigned)kStack) { ovf = true; break; }
-                    tstack[thead++] = far;
+                    tstack[thead++] = far.x != 0u ? far.x : (far.y << 16);
                 }
                 tn = near;
                 pop = false;
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restr
         }
         if (pop) {
             if (thead == 0u) break;
-            tn = tstack[--thead];
+            { const unsigned w = tstack[--thead]; tn = (w & 0xffffu) ? make_uint2(w, 0xffffffffu) : make_uint2(0u, w >> 16); }
         }
     }
     if (ovf) atomicOr(overflow, 1u);
