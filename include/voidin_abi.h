@@ -317,8 +317,10 @@ typedef struct VdTraceScene {
 } VdTraceScene;
 
 /* Replaces `traverse_tlas(ray)` (shaders/utils/bvh.wgsl:89-123) for a batch of rays.
- * out[i].dist matches the WGSL result within 1e-5 relative; the traversal stack is 64
- * deep (reference: 24, unchecked) and overflow is reported as VD_ERR_STACK_OVERFLOW.    */
+ * out[i].dist matches the WGSL result within 1e-5 relative; a ray has 128 stack entries
+ * for its TLAS + BLAS walk, pushing far children only (reference: 24 per walk, unchecked);
+ * overflow is reported as VD_ERR_STACK_OVERFLOW.  BLAS leaves hold at most 3 triangles
+ * (what BvhBuilder makes, blas.rs:108); anything else is VD_ERR_INVALID_ARG.             */
 int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t n_rays,
              VdHit* out);
 int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene /* struct on host, pointers on device */,

@@ -3,18 +3,16 @@
 // Replaces `traverse_tlas(ray)` (reference: shaders/utils/bvh.wgsl:89-123) and its callees
 // `instance_intersect` (bvh.wgsl:78-87), `traverse_bvh` (bvh.wgsl:35-76), `fetch_vertex`
 // (bvh.wgsl:30-33), `intersect_aabb` / `intersect_trig` (shaders/utils/intersections.wgsl:13-45).
-// One lane per ray; the arithmetic order is the WGSL source order with no FMA, so hit distances
-// are reproduced to the bit on the oracle's evaluation model (tolerance in tests: 1e-5).
-// The reference's 24-entry stack is unchecked (shaders/utils/stack.wgsl:1-20); here the stack is
-// 64 deep per traversal level and overflow is reported, not ignored.
+// One lane per ray at a time, persistent waves that refill (see trace_kernel); the arithmetic order is the WGSL
+// source order with no FMA, so hit distances are reproduced to the bit on the oracle's evaluation model (tolerance
+// in tests: 1e-5).  The reference's 24-entry stack is unchecked (shaders/utils/stack.wgsl:1-20); here one 128-entry
+// stack serves the TLAS and the BLAS walk of a ray and overflow is reported, not ignored.  Leaves of more than 3
+// triangles do not occur (BvhBuilder stops at <= 3: blas.rs:108) and are not representable in a stack entry.
 #include "vd_common.hpp"
 
 namespace {
 
-#ifndef VD_TRACE_STACK
-#define VD_TRACE_STACK 64
-#endif
-constexpr int kStack = VD_TRACE_STACK;
+constexpr int kStack = 64;
 constexpr float kMaxDist = 1e30f;
 
 struct Ray { float ex, ey, ez, dx, dy, dz, ix, iy, iz; };
@@ -64,125 +62,142 @@ struct Scene {
     const float* verts; const unsigned* indices; unsigned n_meshes;
 };
 
+// A fixed grid of waves; a lane whose ray is finished draws the next ray from a counter, so a wave stays full while
+// rays of very different cost (a few node visits to tens of thousands) pass through it, and there is no tail of
+// half-empty waves (one wave per 64 consecutive rays, nested TLAS/BLAS loops: 33 instead of 39 Mrays/s closest hit,
+// 50 instead of 62 Mrays/s occlusion on the bench scene).  To let a lane restart at any point the TLAS walk and the per-instance BLAS walk
+// are ONE state machine over ONE stack (TLAS and BLAS nodes share the 32-byte {min, u32, max, u32} layout), with the
+// interior steps in an inner loop that lanes sitting at a leaf sit out.  Each ray still sees exactly the reference's
+// sequence of node visits and triangle tests (bvh.wgsl:35-123); only the interleaving across lanes changes.
 // ANY: occlusion query - the lane stops at the first accepted triangle and only `hit` is reported.  That flag is
 // the same as the closest-hit traversal's: until something is accepted nothing is pruned by distance, so both walks
 // visit the same nodes up to that point (the reference's shadow pass uses only `.hit`: raytraced_shadows.wgsl:97-102).
+constexpr unsigned kRefillBelow = 56;   // draw new rays when fewer than this many lanes are busy
+constexpr unsigned kWavesPerCu = 32;    // persistent grid   // draw new rays when fewer than this many lanes are busy
 template <bool ANY>
-__global__ __launch_bounds__(64) void trace_kernel(Scene s, const VdRay* __restrict__ rays, unsigned n_rays,
-                                                   VdHit* __restrict__ out, unsigned* __restrict__ out_any,
-                                                   unsigned* __restrict__ overflow) {
-    const unsigned i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= n_rays) return;
-    // a stack entry is the popped node's payload, packed into one word: its box is never looked at again
-    // (bvh.wgsl:45-47, 96-98), so a pop costs no node fetch.  The stacks live in scratch memory, and the scratch a
-    // wave needs bounds how many waves the runtime keeps resident: 512 B per lane instead of 1 KB.
-    //   BLAS: count (<= 3... any u2 would do, kept as 2 bits) << 30 | left_first (n_tri <= 2^30 - 1)
-    //   TLAS: interior = left_right (its low half, the left child, is never 0: node 0 is only the root copy);
-    //         leaf = instance_idx << 16 (low half 0)
-    unsigned tstack[kStack], bstack[kStack];
-    Ray ray;
-    {
-        const float4 a = reinterpret_cast<const float4*>(rays + i)[0], b = reinterpret_cast<const float4*>(rays + i)[1];
-        ray.ex = a.x; ray.ey = a.y; ray.ez = a.z; ray.dx = b.x; ray.dy = b.y; ray.dz = b.z;
-        ray.ix = 1.0f / ray.dx; ray.iy = 1.0f / ray.dy; ray.iz = 1.0f / ray.dz;   // ray_new: inv_dir = 1. / dir
-    }
-    VdHit res; res.dist = kMaxDist; res.hit = 0u; res.instance = 0xffffffffu; res.triangle = 0xffffffffu;
-    // The reference pushes the near child last and pops it straight away (bvh.wgsl:66-74, 113-121).  Here the near
-    // child stays in registers - including the payload that was fetched with its box - and only the far child
-    // touches the (scratch-memory) stack: same visiting order, one dependent fetch per step instead of two.
-    bool ovf = false;
-    unsigned thead = 0;
-    uint2 tn;                                                      // {left_right, instance_idx} of the current node
-    { const VdTlasNode root = s.tlas[0]; tn.x = root.left_right; tn.y = root.instance_idx; }
-    for (;;) {                                                     // bvh.wgsl:94
-        bool pop = true;
-        if (tn.x == 0u) {                                          // leaf: instance_intersect (bvh.wgsl:78-87)
-            const unsigned instance_idx = tn.y;
-            const VdInstance* I = s.inst + instance_idx;
-            const unsigned mesh_id = min(I->mesh, s.n_meshes - 1u);
-            const VdMeshInfo mesh = s.meshes[mesh_id];
-            const float* M = I->inv_transform;
-            Ray nr;
-            nr.ex = ((M[0] * ray.ex + M[4] * ray.ey) + M[8] * ray.ez) + M[12] * 1.0f;
-            nr.ey = ((M[1] * ray.ex + M[5] * ray.ey) + M[9] * ray.ez) + M[13] * 1.0f;
-            nr.ez = ((M[2] * ray.ex + M[6] * ray.ey) + M[10] * ray.ez) + M[14] * 1.0f;
-            nr.dx = ((M[0] * ray.dx + M[4] * ray.dy) + M[8] * ray.dz) + M[12] * 0.0f;
-            nr.dy = ((M[1] * ray.dx + M[5] * ray.dy) + M[9] * ray.dz) + M[13] * 0.0f;
-            nr.dz = ((M[2] * ray.dx + M[6] * ray.dy) + M[10] * ray.dz) + M[14] * 0.0f;
-            nr.ix = 1.0f / nr.dx; nr.iy = 1.0f / nr.dy; nr.iz = 1.0f / nr.dz;
-            // traverse_bvh (bvh.wgsl:35-76)
-            unsigned bhead = 0;
-            uint2 bn;                                              // {left_first, count} of the current node
-            { const VdBvhNode root = s.bvh[mesh.bvh_index]; bn.x = root.left_first; bn.y = root.count; }
-            float hit = res.dist;
-            for (;;) {
-                bool bpop = true;
-                if (bn.y > 0u) {
-                    for (unsigned k = 0; k < bn.y; ++k) {
-                        const unsigned idx = bn.x + k;
-                        const unsigned i0 = (unsigned)mesh.vertex_offset + s.indices[mesh.base_index + 3u * idx + 0u];
-                        const unsigned i1 = (unsigned)mesh.vertex_offset + s.indices[mesh.base_index + 3u * idx + 1u];
-                        const unsigned i2 = (unsigned)mesh.vertex_offset + s.indices[mesh.base_index + 3u * idx + 2u];
-                        const float* v0 = s.verts + 3u * (size_t)i0;
-                        const float* v1 = s.verts + 3u * (size_t)i1;
-                        const float* v2 = s.verts + 3u * (size_t)i2;
-                        const float a0[3] = {v0[0], v0[1], v0[2]}, a1[3] = {v1[0], v1[1], v1[2]}, a2[3] = {v2[0], v2[1], v2[2]};
-                        if (intersect_trig(nr, a0, a1, a2, hit)) {
-                            res.dist = hit; res.hit = 1u; res.instance = instance_idx; res.triangle = idx;
-                            if (ANY) break;
-                        }
-                    }
-                } else {
-                    const unsigned pair = mesh.bvh_index + bn.x;
-                    const VdBvhNode c0 = s.bvh[pair], c1 = s.bvh[pair + 1u];
-                    float min_dist = intersect_aabb(nr, c0.min, c0.max, hit);
-                    float max_dist = intersect_aabb(nr, c1.min, c1.max, hit);
-                    uint2 near = make_uint2(c0.left_first, c0.count), far = make_uint2(c1.left_first, c1.count);
-                    if (min_dist > max_dist) {
-                        const uint2 tu = near; near = far; far = tu;
-                        const float tf = min_dist; min_dist = max_dist; max_dist = tf;
-                    }
-                    if (!(min_dist >= hit)) {
-                        if (max_dist <= hit) {
-                            if (bhead + 1u > (unsigned)kStack) { ovf = true; break; }
-                            bstack[bhead++] = far.x | (far.y << 30);
-                        }
-                        bn = near;
-                        bpop = false;
-                    }
-                }
-                if (ANY && res.hit) break;
-                if (bpop) {
-                    if (bhead == 0u) break;
-                    { const unsigned w = bstack[--bhead]; bn = make_uint2(w & 0x3fffffffu, w >> 30); }
+__global__ __launch_bounds__(64, 7) void trace_kernel(Scene s, const VdRay* __restrict__ rays, unsigned n_rays,
+                                                              VdHit* __restrict__ out, unsigned* __restrict__ out_any,
+                                                              unsigned* __restrict__ overflow, unsigned* next_ray) {
+    const unsigned lane = threadIdx.x;
+    unsigned stack[2 * kStack];            // BLAS entries sit above the TLAS entries of the same ray
+    Ray world, ray;                        // `ray` is the active one (object space inside an instance)
+    VdHit res;
+    unsigned ray_id = 0;
+    bool busy = false, exhausted = false, ovf = false, bad_leaf = false, in_blas = false;
+    unsigned head = 0, blas_base = 0;
+    unsigned instance_idx = 0, bvh_index = 0, base_index = 0, vertex_offset = 0;
+    uint2 cn = make_uint2(0u, 0u);         // payload of the current node
+    bool ray_done = false;
+
+    auto pop = [&]() {                     // leave the current node
+        if (in_blas && head == blas_base) { in_blas = false; ray = world; }
+        if (head == 0u) { ray_done = true; return; }
+        const unsigned w = stack[--head];
+        if (in_blas) cn = make_uint2(w & 0x3fffffffu, w >> 30);
+        else cn = (w & 0xffffu) ? make_uint2(w, 0xffffffffu) : make_uint2(0u, w >> 16);
+    };
+    for (;;) {
+        // ---- retire finished rays, refill idle lanes ----
+        if (busy && ray_done) {
+            if (ANY) out_any[ray_id] = res.hit; else out[ray_id] = res;
+            busy = false;
+        }
+        const unsigned long long busy_mask = __ballot(busy);
+        if (!exhausted && (unsigned)__popcll(busy_mask) < kRefillBelow) {
+            const unsigned long long idle = ~busy_mask;
+            const unsigned want = (unsigned)__popcll(idle);
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(next_ray, want);
+            base = __shfl(base, 0);
+            if (!busy) {
+                const unsigned id = base + vd_mbcnt(idle);
+                if (id < n_rays) {
+                    const float4 a = reinterpret_cast<const float4*>(rays + id)[0], b = reinterpret_cast<const float4*>(rays + id)[1];
+                    world.ex = a.x; world.ey = a.y; world.ez = a.z; world.dx = b.x; world.dy = b.y; world.dz = b.z;
+                    world.ix = 1.0f / world.dx; world.iy = 1.0f / world.dy; world.iz = 1.0f / world.dz;   // ray_new: inv_dir = 1. / dir
+                    ray = world;
+                    res.dist = kMaxDist; res.hit = 0u; res.instance = 0xffffffffu; res.triangle = 0xffffffffu;
+                    const VdTlasNode root = s.tlas[0];
+                    cn = make_uint2(root.left_right, root.instance_idx);
+                    ray_id = id; busy = true; ray_done = false; in_blas = false; head = 0; blas_base = 0;
                 }
             }
-            if (ovf || (ANY && res.hit)) break;
-        } else {
-            const VdTlasNode c0 = s.tlas[tn.x & 0xffffu], c1 = s.tlas[tn.x >> 16u];
-            float min_dist = intersect_aabb(ray, c0.min, c0.max, res.dist);
-            float max_dist = intersect_aabb(ray, c1.min, c1.max, res.dist);
-            uint2 near = make_uint2(c0.left_right, c0.instance_idx), far = make_uint2(c1.left_right, c1.instance_idx);
+            if (base + want >= n_rays) exhausted = true;     // wave-uniform
+        }
+        if (!__ballot(busy)) break;
+        // ---- interior steps (bvh.wgsl:56-74 and 104-121) ----
+        while (busy && !ray_done && (in_blas ? cn.y == 0u : cn.x != 0u)) {
+            const char* p0; const char* p1;
+            if (in_blas) {
+                p0 = reinterpret_cast<const char*>(s.bvh + (bvh_index + cn.x));
+                p1 = p0 + sizeof(VdBvhNode);
+            } else {
+                p0 = reinterpret_cast<const char*>(s.tlas + (cn.x & 0xffffu));
+                p1 = reinterpret_cast<const char*>(s.tlas + (cn.x >> 16u));
+            }
+            const float4 a0 = reinterpret_cast<const float4*>(p0)[0], a1 = reinterpret_cast<const float4*>(p0)[1];
+            const float4 b0 = reinterpret_cast<const float4*>(p1)[0], b1 = reinterpret_cast<const float4*>(p1)[1];
+            const float mn0[3] = {a0.x, a0.y, a0.z}, mx0[3] = {a1.x, a1.y, a1.z};
+            const float mn1[3] = {b0.x, b0.y, b0.z}, mx1[3] = {b1.x, b1.y, b1.z};
+            float min_dist = intersect_aabb(ray, mn0, mx0, res.dist);
+            float max_dist = intersect_aabb(ray, mn1, mx1, res.dist);
+            uint2 near = make_uint2(__float_as_uint(a0.w), __float_as_uint(a1.w));
+            uint2 far = make_uint2(__float_as_uint(b0.w), __float_as_uint(b1.w));
             if (min_dist > max_dist) {
                 const uint2 tu = near; near = far; far = tu;
                 const float tf = min_dist; min_dist = max_dist; max_dist = tf;
             }
-            if (!(min_dist >= res.dist)) {
-                if (max_dist < res.dist) {
-                    if (thead + 1u > (unsigned)kStack) { ovf = true; break; }
-                    tstack[thead++] = far.x != 0u ? far.x : (far.y << 16);
-                }
-                tn = near;
-                pop = false;
+            if (min_dist >= res.dist) { pop(); continue; }
+            // far child: the BLAS loop keeps it on `<=` (a missed child, 1e30, is pushed while nothing is hit yet),
+            // the TLAS loop on `<`
+            if (in_blas ? max_dist <= res.dist : max_dist < res.dist) {
+                if (head + 1u > 2u * (unsigned)kStack) { ovf = true; ray_done = true; continue; }
+                if (in_blas && far.y > 3u) bad_leaf = true;   // not representable in a stack entry
+                stack[head++] = in_blas ? (far.x | (far.y << 30)) : (far.x != 0u ? far.x : (far.y << 16));
             }
+            cn = near;
         }
-        if (pop) {
-            if (thead == 0u) break;
-            { const unsigned w = tstack[--thead]; tn = (w & 0xffffu) ? make_uint2(w, 0xffffffffu) : make_uint2(0u, w >> 16); }
+        if (!busy || ray_done) continue;
+        if (!in_blas) {
+            // ---- TLAS leaf: instance_intersect (bvh.wgsl:78-87) ----
+            instance_idx = cn.y;
+            const VdInstance* I = s.inst + instance_idx;
+            const VdMeshInfo mesh = s.meshes[min(I->mesh, s.n_meshes - 1u)];
+            bvh_index = mesh.bvh_index; base_index = mesh.base_index; vertex_offset = (unsigned)mesh.vertex_offset;
+            const float* M = I->inv_transform;
+            ray.ex = ((M[0] * world.ex + M[4] * world.ey) + M[8] * world.ez) + M[12] * 1.0f;
+            ray.ey = ((M[1] * world.ex + M[5] * world.ey) + M[9] * world.ez) + M[13] * 1.0f;
+            ray.ez = ((M[2] * world.ex + M[6] * world.ey) + M[10] * world.ez) + M[14] * 1.0f;
+            ray.dx = ((M[0] * world.dx + M[4] * world.dy) + M[8] * world.dz) + M[12] * 0.0f;
+            ray.dy = ((M[1] * world.dx + M[5] * world.dy) + M[9] * world.dz) + M[13] * 0.0f;
+            ray.dz = ((M[2] * world.dx + M[6] * world.dy) + M[10] * world.dz) + M[14] * 0.0f;
+            ray.ix = 1.0f / ray.dx; ray.iy = 1.0f / ray.dy; ray.iz = 1.0f / ray.dz;
+            const VdBvhNode root = s.bvh[bvh_index];               // traverse_bvh starts at the mesh's root
+            cn = make_uint2(root.left_first, root.count);
+            in_blas = true;
+            blas_base = head;
+        } else {
+            // ---- BLAS leaf (bvh.wgsl:48-55) ----
+            for (unsigned k = 0; k < cn.y; ++k) {
+                const unsigned idx = cn.x + k;
+                const unsigned i0 = vertex_offset + s.indices[base_index + 3u * idx + 0u];
+                const unsigned i1 = vertex_offset + s.indices[base_index + 3u * idx + 1u];
+                const unsigned i2 = vertex_offset + s.indices[base_index + 3u * idx + 2u];
+                const float* v0 = s.verts + 3u * (size_t)i0;
+                const float* v1 = s.verts + 3u * (size_t)i1;
+                const float* v2 = s.verts + 3u * (size_t)i2;
+                const float a0[3] = {v0[0], v0[1], v0[2]}, a1[3] = {v1[0], v1[1], v1[2]}, a2[3] = {v2[0], v2[1], v2[2]};
+                float hit = res.dist;
+                if (intersect_trig(ray, a0, a1, a2, hit)) {
+                    res.dist = hit; res.hit = 1u; res.instance = instance_idx; res.triangle = idx;
+                    if (ANY) break;
+                }
+            }
+            if (ANY && res.hit) ray_done = true; else pop();
         }
     }
     if (ovf) atomicOr(overflow, 1u);
-    if (ANY) out_any[i] = res.hit; else out[i] = res;
+    if (bad_leaf) atomicOr(overflow, 2u);
 }
 
 // Shadow rays of the reference's deferred pass (src/bin/raytraced_shadows.wgsl:97): origin = pos + nor * 0.0001,
@@ -207,13 +222,15 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32
     Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes};
     vd_time_begin(ctx);
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 16, ctx->stream));
-    if (d_any) hipLaunchKernelGGL(trace_kernel<true>, dim3((n_rays + 63) / 64), dim3(64), 0, ctx->stream, s, d_rays, n_rays, d_out, d_any, d_flag);
-    else hipLaunchKernelGGL(trace_kernel<false>, dim3((n_rays + 63) / 64), dim3(64), 0, ctx->stream, s, d_rays, n_rays, d_out, d_any, d_flag);
+    const unsigned waves = (unsigned)ctx->num_cus * kWavesPerCu;
+    if (d_any) hipLaunchKernelGGL(trace_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, s, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1);
+    else hipLaunchKernelGGL(trace_kernel<false>, dim3(waves), dim3(64), 0, ctx->stream, s, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->host_pinned[0]) VD_FAIL(ctx, VD_ERR_STACK_OVERFLOW, "vd_trace: traversal stack (64) exceeded");
+    if (ctx->host_pinned[0] & 2u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: BVH leaf with more than 3 triangles (BvhBuilder never makes one: blas.rs:108)");
+    if (ctx->host_pinned[0]) VD_FAIL(ctx, VD_ERR_STACK_OVERFLOW, "vd_trace: traversal stack (128 entries per ray) exceeded");
     return VD_OK;
 }
 
