@@ -294,6 +294,22 @@ def main():
                           "occlusion_Mrays_per_s": round(len(rays) / min(t_any) / 1e3, 1),
                           "hit_fraction": round(float(hits["hit"].mean()), 3),
                           "occlusion_flags_equal_closest_hit": bool(np.array_equal(d_any.cpu().numpy().astype(np.uint32), hits["hit"]))}
+        del ds, d_rays, d_hits, d_any
+        # the reference's own harness shape (src/bin/bvh_gpu.rs:107-131): one large mesh + four small ones, 4 M primary rays
+        inst2, infos2, B2, V2, I2 = synth.harness_scene(ctx.bvh_build)
+        tl2 = ctx.tlas_build(inst2, infos2)
+        rays2 = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 15), pitch_deg=0), 2048, 2048)
+        ds2 = ctx.device_scene((tl2, inst2, infos2, B2, V2, I2))
+        d_r2, d_h2 = ctx.upload(rays2), ctx.empty(len(rays2) * 16)
+        ctx.set_timing(True)
+        t2 = []
+        for _ in range(3):
+            ctx.trace_dev(ds2, d_r2, len(rays2), d_h2); t2.append(ctx.last_gpu_ms())
+        ctx.set_timing(False)
+        h2 = d_h2.cpu().numpy()[: len(rays2) * 16].view(abi.HIT)
+        extra["trace_harness_scene"] = {"n_rays": len(rays2), "scene": f"bvh_gpu.rs shape: {len(I2)//3} triangles, 5 instances",
+                                        "closest_hit_Mrays_per_s": round(len(rays2) / min(t2) / 1e3, 1),
+                                        "hit_fraction": round(float(h2["hit"].mean()), 3)}
 
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_cull_pmc.json")

@@ -95,3 +95,17 @@ for r in range(3):
     torch.cuda.synchronize(); dta = time.perf_counter() - t
 assert rc == 0 and np.array_equal(d_any.cpu().numpy().astype(np.uint32), hits["hit"])
 print(f"trace_any (occlusion): {dta*1e3:.2f} ms = {len(rays)/dta/1e6:.1f} Mrays/s (flags equal vd_trace's)", flush=True)
+
+# ---- the reference's own harness shape (src/bin/bvh_gpu.rs:107-131, camera at (0, 2.5, 15): bvh_gpu.rs:221) ----
+inst2, infos2, B, V, I = synth.harness_scene(ctx.bvh_build)
+tl2 = ctx.tlas_build(inst2, infos2)
+rays2 = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 15), pitch_deg=0), 2048, 2048)
+ds2 = ctx.device_scene((tl2, inst2, infos2, B, V, I))
+d_r2, d_h2 = ctx.upload(rays2), ctx.empty(len(rays2) * 16)
+ctx.set_timing(True)
+best = 1e9
+for r in range(3):
+    ctx.trace_dev(ds2, d_r2, len(rays2), d_h2); best = min(best, ctx.last_gpu_ms())
+h2 = d_h2.cpu().numpy()[: len(rays2) * 16].view(abi.HIT)
+print(f"trace, bvh_gpu.rs-shaped scene ({len(I)//3} triangles, 5 instances, {len(rays2)} primary rays): {best:.2f} ms = "
+      f"{len(rays2)/best/1e3:.0f} Mrays/s, hit fraction {h2['hit'].mean():.3f}", flush=True)

@@ -302,3 +302,32 @@ def primary_rays(cam: np.ndarray, width: int, height: int) -> np.ndarray:
     rays["eye"] = eye.astype(np.float32)
     rays["dir"] = d.astype(np.float32)
     return rays
+
+
+def harness_scene(build_fn, big=(1024, 256), small_res=100):
+    """The shape of the reference's GPU harness (src/bin/bvh_gpu.rs:107-131): one large mesh
+    `rotY(pi/2) * T(0,2,0) * S(..)` and four small ones `T(+-8,+-8,0) * S(3)`.  bunny.obj / dragon.obj are
+    not in the checkout: a knot mesh stands in for the dragon, uv-spheres for the bunnies.
+    build_fn(vertices, indices) -> (nodes, permuted indices).  Returns (instances, mesh_infos,
+    bvh_nodes, vertices, indices)."""
+    def mat(tr, scale, roty=0.0):
+        c, s_ = math.cos(roty), math.sin(roty)
+        R = np.array([[c, 0, s_, 0], [0, 1, 0, 0], [-s_, 0, c, 0], [0, 0, 0, 1]], np.float64)
+        T = np.eye(4)
+        T[:3, 3] = tr
+        return (R @ T @ np.diag([scale, scale, scale, 1.0])).T.reshape(16)      # column-major
+    mesh_src = [knot_mesh(*big), uv_sphere(1.0, small_res)]
+    V, I, B = [], [], []
+    infos = np.zeros(len(mesh_src), dtype=abi.MESH_INFO)
+    vo = bo = no = 0
+    for k, (mv, mi) in enumerate(mesh_src):
+        nodes_k, idx_k = build_fn(mv, mi)
+        infos[k]["min"], infos[k]["max"] = mesh_bounds(mv)
+        infos[k]["index_count"], infos[k]["base_index"] = len(idx_k), bo
+        infos[k]["vertex_offset"], infos[k]["bvh_index"] = vo, no
+        V.append(mv); I.append(idx_k); B.append(nodes_k)
+        vo += len(mv); bo += len(idx_k); no += len(nodes_k)
+    ext = float(max(np.abs(infos[0]["min"]).max(), np.abs(infos[0]["max"]).max()))
+    insts = [instance_from_matrix(mat((0, 2, 0), 5.0 / ext, math.pi / 2), 0)]
+    insts += [instance_from_matrix(mat((x, y, 0), 3.0), 1) for x, y in ((8, 8), (-8, 8), (8, -8), (-8, -8))]
+    return np.array(insts, dtype=abi.INSTANCE), infos, np.concatenate(B), np.concatenate(V), np.concatenate(I)
