@@ -219,3 +219,10 @@ def test_split_and_fused_forms_agree_around_the_switch(ctx, oracle, n):
     torch.cuda.synchronize()
     assert int(d_cnt[0].item()) == wn
     assert d_out.cpu().numpy()[: n * 20].tobytes() == wc.tobytes()
+    # vd_cull_emit switches at the same size (mask pass + emit_from_mask_kernel); ragged n exercises the tail quad
+    d_emit = ctx.empty(n * 20 + 64)
+    d_emit.fill_(0xEE)
+    ctx.cull_emit_dev(cam, d_m, len(meshes), d_i, n, d_emit, 12345)
+    torch.cuda.synchronize()
+    got = d_emit.cpu().numpy()
+    assert got[: n * 20].tobytes() == want.tobytes() and (got[n * 20:] == 0xEE).all()

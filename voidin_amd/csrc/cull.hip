@@ -668,6 +668,101 @@ __global__ __launch_bounds__(kBlock) void expand_mask_u8_kernel(const vd_u64* __
     }
 }
 
+// Reference-format emission (C1: every slot written, shaders/emit_draws.wgsl:49-63) from pass 1's bits and ids: the
+// split form of vd_cull_emit for large inputs.  A lane owns 4 consecutive instances = 80 contiguous bytes = five
+// aligned 16-byte stores; no scan is needed (slot = instance index).
+template <typename IdT>
+__global__ __launch_bounds__(kBlock) void emit_from_mask_kernel(const vd_u64* __restrict__ mask, const IdT* __restrict__ mesh_ids,
+                                                               const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
+                                                               unsigned n_inst, unsigned first_instance,
+                                                               VdDrawIndexedIndirect* __restrict__ out) {
+    constexpr unsigned kTab = 512;
+    __shared__ __attribute__((aligned(16))) unsigned s_tab[kTab][4];
+    const bool tab = n_mesh <= kTab;
+    if (tab)
+        for (unsigned i = threadIdx.x; i < n_mesh; i += kBlock) {
+            s_tab[i][0] = meshes[i].index_count; s_tab[i][1] = 0u;
+            s_tab[i][2] = meshes[i].base_index;  s_tab[i][3] = (unsigned)meshes[i].vertex_offset;
+        }
+    __syncthreads();
+    const unsigned n_quads = (n_inst + 3u) / 4u;
+    for (unsigned q = blockIdx.x * kBlock + threadIdx.x; q < n_quads; q += gridDim.x * kBlock) {
+        const unsigned i0 = q * 4u;
+        const unsigned bits = (unsigned)(mask[i0 >> 6] >> (i0 & 63u)) & 15u;
+        unsigned mid[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mid[k] = i0 + k < n_inst ? min((unsigned)mesh_ids[i0 + k], n_mesh - 1u) : 0u;
+        unsigned w[20];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            u32x4 c;
+            if (tab) c = *reinterpret_cast<const u32x4*>(s_tab[mid[k]]);
+            else { c.x = meshes[mid[k]].index_count; c.z = meshes[mid[k]].base_index; c.w = (unsigned)meshes[mid[k]].vertex_offset; }
+            w[5 * k] = c.x; w[5 * k + 1] = (bits >> k) & 1u; w[5 * k + 2] = c.z; w[5 * k + 3] = c.w; w[5 * k + 4] = first_instance + i0 + k;
+        }
+        unsigned* o = reinterpret_cast<unsigned*>(out + i0);
+        if (i0 + 4u <= n_inst) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                u32x4 v; v.x = w[4 * k]; v.y = w[4 * k + 1]; v.z = w[4 * k + 2]; v.w = w[4 * k + 3];
+                *reinterpret_cast<u32x4*>(o + 4 * k) = v;
+            }
+        } else {
+            for (unsigned k = 0; k < 5u * (n_inst - i0); ++k) o[k] = w[k];
+        }
+    }
+}
+
+// The same for 1-byte ids and a table of <= 256 meshes, with the access pattern of expand_mask_u8_kernel's direct
+// form (a lane per instance: one 16-byte + one 4-byte store at a 20-byte lane stride, ids as one dword per lane
+// redistributed with ds_bpermute), which runs at the store ceiling of the part.
+__global__ __launch_bounds__(kBlock) void emit_all_u8_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned n_inst,
+                                                             unsigned first_instance, const unsigned char* __restrict__ mesh_ids,
+                                                             const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
+                                                             VdDrawIndexedIndirect* __restrict__ out) {
+    constexpr int kGroups = kExpandWords / kExpandGroup;
+    __shared__ __attribute__((aligned(16))) unsigned s_tab[256][4];
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned w0 = (blockIdx.x * kWavesPerBlock + wave) * kExpandWords;
+    vd_u64 my_word = 0;                                   // lane l < 32 holds mask word w0 + l
+    if (lane < (unsigned)kExpandWords && w0 + lane < n_words) my_word = mask[w0 + lane];
+    unsigned ids[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+        const unsigned i0 = 64u * (w0 + g * kExpandGroup + (lane >> 4)) + 4u * (lane & 15u);
+        ids[g] = i0 < n_inst ? *reinterpret_cast<const unsigned*>(mesh_ids + i0) : 0u;   // aligned dword with >= 1 valid byte
+    }
+    if (threadIdx.x < n_mesh) {
+        const VdMeshInfo mi = meshes[threadIdx.x];
+        s_tab[threadIdx.x][0] = mi.index_count; s_tab[threadIdx.x][1] = 0u;
+        s_tab[threadIdx.x][2] = mi.base_index;  s_tab[threadIdx.x][3] = (unsigned)mi.vertex_offset;
+    }
+    __syncthreads();
+    const unsigned max_mid = n_mesh - 1u;
+    const unsigned id_shift = 8u * (lane & 3u);
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+#pragma unroll
+        for (int q = 0; q < kExpandGroup; ++q) {
+            const int k = g * kExpandGroup + q;
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)my_word, k), hi = __builtin_amdgcn_readlane((unsigned)(my_word >> 32), k);
+            const vd_u64 m = ((vd_u64)hi << 32) | lo;
+            const unsigned v = (unsigned)__shfl((int)ids[g], q * 16 + (int)(lane >> 2));
+            const unsigned mid = min((v >> id_shift) & 0xffu, max_mid);
+            const unsigned i = 64u * (w0 + (unsigned)k) + lane;
+            if (i < n_inst) {
+                u32x4 c = *reinterpret_cast<const u32x4*>(s_tab[mid]);
+                c.y = (unsigned)(m >> lane) & 1u;
+                unsigned* o = reinterpret_cast<unsigned*>(out + i);
+                typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
+                *reinterpret_cast<u32x4_a4*>(o) = c;
+                o[4] = first_instance + i;
+            }
+        }
+    }
+}
+
 // Host side of pass 2 (shared by vd_cull_compact* and vd_expand_mask_dev).
 static int launch_expand(VdCtx* ctx, const vd_u64* d_mask, unsigned n_words, unsigned wps, unsigned shard_size,
                          unsigned n_total, unsigned first_instance, const void* d_ids, unsigned id_bytes,
@@ -836,6 +931,46 @@ int vd_cull_emit_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo
     return vd_cull_emit_shard_dev(ctx, camera, d_meshes, n_mesh, d_instances, n_inst, 0u, d_out);
 }
 
+// Pass 1 of the split forms: instances -> one bit + a compact mesh id each, in ctx scratch.
+static int launch_mask_pass(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                            const VdInstance* d_instances, uint32_t n_inst, vd_u64** out_mask, void** out_ids, unsigned* out_id_bytes) {
+    const unsigned n_words = (n_inst + 63u) / 64u;
+    const unsigned id_bytes = n_mesh <= 256u ? 1u : (n_mesh <= 65536u ? 2u : 4u);
+    const size_t need = (size_t)n_words * 8 + (size_t)n_inst * id_bytes + 512;
+    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
+    if (rc) return rc;
+    vd_u64* d_mask = reinterpret_cast<vd_u64*>(ctx->scratch);
+    void* d_ids = reinterpret_cast<char*>(ctx->scratch) + (((size_t)n_words * 8 + 255) & ~(size_t)255);
+    vd_time_begin(ctx);
+    const unsigned n_wave_tiles = n_words;
+    unsigned blocks = (n_wave_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned cap = (unsigned)ctx->num_cus * 4u;
+    if (blocks > cap) blocks = cap;
+#define VD_SPLIT(IdT)                                                                                              \
+    do {                                                                                                         \
+        if (ctx->cull_variant == -70) {                                                                          \
+            hipLaunchKernelGGL(cull_mask_kernel<IdT>, dim3(blocks), dim3(kBlock), kWavesPerBlock * kSlabBytes,   \
+                               ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_mask,     \
+                               reinterpret_cast<IdT*>(d_ids), n_wave_tiles);                                     \
+        } else {                                                                                                 \
+            const unsigned n_mt = (n_inst + kWave * kMaskRounds - 1) / (kWave * kMaskRounds);                    \
+            unsigned mb = (n_mt + kWavesPerBlock - 1) / kWavesPerBlock;                                          \
+            if (mb > (unsigned)ctx->num_cus * 3u) mb = (unsigned)ctx->num_cus * 3u;                              \
+            hipLaunchKernelGGL(cull_mask_tiled_kernel<IdT>, dim3(mb), dim3(kBlock),                              \
+                               kWavesPerBlock * (kSlabBytes + kMaskRounds * kWave * (int)sizeof(IdT)),           \
+                               ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_mask,     \
+                               reinterpret_cast<IdT*>(d_ids), n_mt);                                             \
+        }                                                                                                        \
+    } while (0)
+    if (id_bytes == 1u) VD_SPLIT(unsigned char);
+    else if (id_bytes == 2u) VD_SPLIT(unsigned short);
+    else VD_SPLIT(unsigned);
+#undef VD_SPLIT
+    vd_time_mid(ctx);
+    *out_mask = d_mask; *out_ids = d_ids; *out_id_bytes = id_bytes;
+    return VD_OK;
+}
+
 int vd_cull_emit_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                            const VdInstance* d_instances, uint32_t n_inst, uint32_t first_instance,
                            VdDrawIndexedIndirect* d_out) {
@@ -843,6 +978,26 @@ int vd_cull_emit_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMe
     if (!camera || !d_meshes || n_mesh == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_emit: null camera/meshes or n_mesh == 0");
     if (n_inst == 0) return VD_OK;
     if (!d_instances || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_emit: null instances/out");
+    if (ctx->cull_variant <= 0 && ctx->cull_variant != -80 && n_inst >= (1u << 20)) {
+        // split form, as for the compacted list: the 20-byte stores leave the read stream
+        vd_u64* d_mask; void* d_ids; unsigned id_bytes;
+        int rc = launch_mask_pass(ctx, camera, d_meshes, n_mesh, d_instances, n_inst, &d_mask, &d_ids, &id_bytes);
+        if (rc) return rc;
+        const unsigned quads = (n_inst + 3u) / 4u;
+        unsigned eb = (quads + kBlock - 1) / kBlock;
+        if (eb > (unsigned)ctx->num_cus * 16u) eb = (unsigned)ctx->num_cus * 16u;
+#define VD_EMIT(IdT) hipLaunchKernelGGL(emit_from_mask_kernel<IdT>, dim3(eb), dim3(kBlock), 0, ctx->stream, d_mask,               \
+                                        reinterpret_cast<const IdT*>(d_ids), d_meshes, n_mesh, n_inst, first_instance, d_out)
+        if (id_bytes == 1u) {
+            const unsigned n_words = (n_inst + 63u) / 64u;
+            hipLaunchKernelGGL(emit_all_u8_kernel, dim3((n_words + kChunkWords - 1) / kChunkWords), dim3(kBlock), 0, ctx->stream, d_mask,
+                               n_words, n_inst, first_instance, reinterpret_cast<const unsigned char*>(d_ids), d_meshes, n_mesh, d_out);
+        } else if (id_bytes == 2u) VD_EMIT(unsigned short); else VD_EMIT(unsigned);
+#undef VD_EMIT
+        vd_time_end(ctx);
+        VD_HIP_CHECK(ctx, hipGetLastError());
+        return VD_OK;
+    }
     const unsigned n_wave_tiles = (n_inst + kWave - 1) / kWave;
     unsigned blocks = (n_wave_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const unsigned cap = (unsigned)ctx->num_cus * 4u;   // 4 x 36 KB LDS slabs per CU
@@ -881,39 +1036,10 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
         // in the same kernel); pass 2 expands the bits into the ordered command list.  Mixing the
         // command stores into the read stream costs more than the 1-5 B/instance round trip
         // (A/B: profiles/).
-        const unsigned n_words = (n_inst + 63u) / 64u;
-        const unsigned id_bytes = n_mesh <= 256u ? 1u : (n_mesh <= 65536u ? 2u : 4u);
-        const size_t need = (size_t)n_words * 8 + (size_t)n_inst * id_bytes + 512;
-        rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
+        vd_u64* d_mask; void* d_ids; unsigned id_bytes;
+        rc = launch_mask_pass(ctx, camera, d_meshes, n_mesh, d_instances, n_inst, &d_mask, &d_ids, &id_bytes);
         if (rc) return rc;
-        vd_u64* d_mask = reinterpret_cast<vd_u64*>(ctx->scratch);
-        void* d_ids = reinterpret_cast<char*>(ctx->scratch) + (((size_t)n_words * 8 + 255) & ~(size_t)255);
-        vd_time_begin(ctx);
-        const unsigned n_wave_tiles = n_words;
-        unsigned blocks = (n_wave_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-        const unsigned cap = (unsigned)ctx->num_cus * 4u;
-        if (blocks > cap) blocks = cap;
-#define VD_SPLIT(IdT)                                                                                              \
-        do {                                                                                                         \
-            if (ctx->cull_variant == -70) {                                                                          \
-                hipLaunchKernelGGL(cull_mask_kernel<IdT>, dim3(blocks), dim3(kBlock), kWavesPerBlock * kSlabBytes,   \
-                                   ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_mask,     \
-                                   reinterpret_cast<IdT*>(d_ids), n_wave_tiles);                                     \
-            } else {                                                                                                 \
-                const unsigned n_mt = (n_inst + kWave * kMaskRounds - 1) / (kWave * kMaskRounds);                    \
-                unsigned mb = (n_mt + kWavesPerBlock - 1) / kWavesPerBlock;                                          \
-                if (mb > (unsigned)ctx->num_cus * 3u) mb = (unsigned)ctx->num_cus * 3u;                              \
-                hipLaunchKernelGGL(cull_mask_tiled_kernel<IdT>, dim3(mb), dim3(kBlock),                              \
-                                   kWavesPerBlock * (kSlabBytes + kMaskRounds * kWave * (int)sizeof(IdT)),           \
-                                   ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_mask,     \
-                                   reinterpret_cast<IdT*>(d_ids), n_mt);                                             \
-            }                                                                                                        \
-        } while (0)
-        if (id_bytes == 1u) VD_SPLIT(unsigned char);
-        else if (id_bytes == 2u) VD_SPLIT(unsigned short);
-        else VD_SPLIT(unsigned);
-#undef VD_SPLIT
-        vd_time_mid(ctx);
+        const unsigned n_words = (n_inst + 63u) / 64u;
         rc = launch_expand(ctx, d_mask, n_words, n_words, n_inst, n_inst, first_instance, d_ids, id_bytes, d_meshes, n_mesh,
                            d_out, d_out_count);
         if (rc) return rc;
