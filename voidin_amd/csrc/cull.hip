@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
 //     otherwise it is staged in LDS at the destination's 16-B phase and leaves in 16-B-per-lane runs.
 // The dword that holds the last valid id may extend past n_total: an aligned dword that contains one valid byte
 // never crosses a page, and the extra bytes belong to instances whose mask bit is 0.
-template <bool DIRECT>
+template <bool DIRECT, int PF>
 __global__ __launch_bounds__(kBlock) void expand_mask_u8_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned wps,
                                                                 unsigned shard_size, unsigned n_total, unsigned first_instance,
                                                                 const unsigned char* __restrict__ mesh_ids,
@@ -588,6 +588,22 @@ __global__ __launch_bounds__(kBlock) void expand_mask_u8_kernel(const vd_u64* __
     }
     unsigned s_shard = w0 / wps, s_r = w0 - s_shard * wps;   // scalar walk over the wave's words
     unsigned word_first = s_shard * shard_size + 64u * s_r;
+    // PF > 0: touch the mask words and ids of chunk c + 8 PF.  Workgroups are dealt to the 8 XCDs round-robin, so that
+    // chunk will be expanded on this XCD and finds its inputs in this L2: behind a write-saturated L2 a load MISS
+    // waits for an eviction (tens of microseconds), and these misses are nobody's critical path.
+    unsigned pf = 0;
+    if (PF > 0) {
+        const unsigned pw = (chunk + 8u * PF) * kChunkWords + (threadIdx.x >> 1);
+        if (pw < n_words) {
+            const unsigned ps = pw / wps;
+            const unsigned pi = ps * shard_size + 64u * (pw - ps * wps) + 32u * (threadIdx.x & 1u);
+            if (pi + 32u <= n_total) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(mesh_ids + pi), b = *reinterpret_cast<const u32x4*>(mesh_ids + pi + 16u);
+                pf = a.x ^ a.w ^ b.x ^ b.w;
+            }
+            if ((threadIdx.x & 1u) == 0u) pf ^= (unsigned)mask[pw];
+        }
+    }
     if (threadIdx.x < n_mesh) {
         const VdMeshInfo mi = meshes[threadIdx.x];
         s_tab[threadIdx.x][0] = mi.index_count; s_tab[threadIdx.x][1] = 1u;
@@ -666,6 +682,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_u8_kernel(const vd_u64* __
         }
         base += cnt;
     }
+    if (PF > 0 && pf == 0x9e3779b9u && n_mesh == 0u) out[0].instance_count = pf;   // never true: keeps the prefetch loads
 }
 
 // Reference-format emission (C1: every slot written, shaders/emit_draws.wgsl:49-63) from pass 1's bits and ids: the
@@ -788,12 +805,14 @@ static int launch_expand(VdCtx* ctx, const vd_u64* d_mask, unsigned n_words, uns
     if (fast) {
         // up to ~250 MB of commands (the Infinity Cache absorbs them) the direct form is at the write ceiling; past
         // that the L2 merges fewer of its 4-byte pieces in time and the LDS-staged 16-byte runs win (A/B: -71 / -74)
-        const bool direct = ctx->cull_variant == -74 || (ctx->cull_variant != -71 && n_total <= (12u << 20));
-#define VD_EXPAND_U8(D)                                                                                                   \
-        hipLaunchKernelGGL((expand_mask_u8_kernel<D>), dim3(n_chunks), dim3(kBlock), 0, ctx->stream, d_mask, n_words, wps,  \
+        const bool direct = ctx->cull_variant == -74 || (ctx->cull_variant > -71 && n_total <= (12u << 20));
+#define VD_EXPAND_U8(D, P)                                                                                                \
+        hipLaunchKernelGGL((expand_mask_u8_kernel<D, P>), dim3(n_chunks), dim3(kBlock), 0, ctx->stream, d_mask, n_words, wps,  \
                            shard_size, n_total, first_instance, reinterpret_cast<const unsigned char*>(d_ids), d_meshes,    \
                            n_mesh, d_out, offsets)
-        if (direct) VD_EXPAND_U8(true); else VD_EXPAND_U8(false);
+        if (direct) VD_EXPAND_U8(true, 0);
+        else if (ctx->cull_variant == -81) VD_EXPAND_U8(false, 0);          // A/B: without the same-XCD prefetch
+        else VD_EXPAND_U8(false, 32);
 #undef VD_EXPAND_U8
         return VD_OK;
     }
