@@ -201,6 +201,25 @@ def test_large_mesh_table(ctx, oracle):
     assert int(d_cnt[0].item()) == wn and d_out.cpu().numpy()[: wn * 20].tobytes() == wc[:wn].tobytes()
 
 
+@pytest.mark.parametrize("n_mesh", [1, 257, 600, 66_000])
+def test_split_forms_with_every_id_width_and_table_size(ctx, oracle, n_mesh):
+    """Above 2^20 instances both vd_cull_emit and vd_cull_compact go through pass 1's bits + ids: 1-byte ids
+    (<= 256 meshes), 2-byte ids with the LDS table (<= 512) and without, 4-byte ids (> 65536 meshes)."""
+    cam = synth.camera_uniform()
+    meshes = synth.mesh_infos(n_mesh, seed=synth.SEED_BASE + 50)
+    if n_mesh > 60_000:                                   # base_index would overflow u32 with the default index counts
+        meshes["index_count"] = 36
+        meshes["base_index"] = np.arange(n_mesh, dtype=np.uint32) * 36
+        meshes["vertex_offset"] = np.arange(n_mesh, dtype=np.int32) * 12
+    n = (1 << 20) + 12_345
+    inst = synth.instances(n, n_mesh=n_mesh, seed=synth.SEED_BASE + 51, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+    want = oracle.cull_emit(cam, meshes, inst, threads=8)
+    wc, wn = oracle.compact(want)
+    emit, comp, cnt = run_dev(ctx, cam, meshes, inst)
+    assert emit.tobytes() == want.tobytes()
+    assert cnt == wn and comp[:cnt].tobytes() == wc[:wn].tobytes()
+
+
 @pytest.mark.parametrize("n", [(1 << 20) - 1, 1 << 20, (1 << 20) + 77, 1_500_001])
 def test_split_and_fused_forms_agree_around_the_switch(ctx, oracle, n):
     """vd_cull_compact runs the fused kernel below 2^20 instances and the split form (bitmask +
