@@ -633,6 +633,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
 struct Seg {
     unsigned start, count, node, item_first;
     unsigned n_items, best, Lst, ttot_cur;
+    unsigned act[3], pad_act;         // act[c % 3]: first position round c still has to shuffle (see round_window)
     int cbk[6];                       // centroid-bound keys (min xyz, max xyz), inherited from the parent's a_child pass
     int child_k[24];                  // children: box keys left min/max, right min/max; then centroid keys likewise
     float pos[kCand + 3];
@@ -662,6 +663,7 @@ __global__ void a_seg_begin_kernel(Seg* segs, LevelCtl* ctl) {
     if (i >= ctl->n_seg) return;
     Seg& sg = segs[i];
     sg.n_items = (sg.count + kItem - 1) / kItem;
+    sg.act[0] = sg.act[1] = sg.act[2] = 0u;
     for (int k = 0; k < 24; ++k) sg.child_k[k] = (k % 6) < 3 ? kBig : -kBig - 1;
     for (int k = 0; k < 72; ++k) { (&sg.bin_min[0][0][0])[k] = kBig; (&sg.bin_max[0][0][0])[k] = -kBig - 1; }
 }
@@ -740,15 +742,30 @@ __global__ void a_planes_kernel(Seg* segs, const LevelCtl* ctl) {
 }
 
 // predicate mask of this lane group: returns ballot per j (4 per wave)
+// The seven planes of an axis grow with k (blas.rs:146), so whatever trial k left of its pivot is also below the plane of
+// trial k+1: partition_shuffle (blas.rs:168-182) walks over that prefix without a swap, and trial k+1 is exactly
+// partition_shuffle on the suffix [L_k, n) - same never-examined element, same pivot, same arrangement.  Round c of a
+// level therefore shuffles only [act, n), act = pivot of the previous trial on the same axis (0 for the first trial of
+// an axis and for the final shuffle), and copies the band [band, act) that the previous round froze, so that the
+// buffer it writes holds the whole arrangement again.  `r` is the round index 0..21.
+struct Window { unsigned band, act; };
+__device__ __forceinline__ Window round_window(const Seg* sg, int r) {
+    Window w;
+    if (r % 7 == 0) { w.band = w.act = 0u; }
+    else { w.act = sg->act[r % 3]; w.band = (r % 7 == 1) ? 0u : sg->act[(r + 2) % 3]; }
+    return w;
+}
+
+// predicates of the item's positions that lie in the shuffled window (positions below `act` stay out of the ballots)
 __device__ __forceinline__ void item_masks(const Seg* sg, const ItemCtx& ic, const u32x2* __restrict__ pay, int c,
-                                           unsigned long long (&masks)[4], u32x2 (&vals)[4]) {
+                                           unsigned act, unsigned long long (&masks)[4], u32x2 (&vals)[4]) {
     const unsigned cc = c >= 0 ? (unsigned)c : sg->best;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const unsigned x = wave * 256u + j * 64u + lane;
         bool p = false;
-        if (x < ic.n_here) {
+        if (x < ic.n_here && ic.rel0 + x >= act) {
             vals[j] = pay[sg->start + ic.rel0 + x];
             p = (vals[j].y >> cc) & 1u;
         }
@@ -762,8 +779,10 @@ __global__ __launch_bounds__(256) void a_count_kernel(const Seg* segs, const uns
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
+    const Window win = round_window(sg, c >= 0 ? c : kCand);
+    if (ic.rel0 + ic.n_here <= win.act) { if (threadIdx.x == 0) item_cnt[blockIdx.x] = 0u; return; }   // wholly frozen
     unsigned long long masks[4]; u32x2 vals[4];
-    item_masks(sg, ic, pay, c, masks, vals);
+    item_masks(sg, ic, pay, c, win.act, masks, vals);
     unsigned t = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) t += (unsigned)__popcll(masks[j]);
@@ -819,8 +838,10 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
+    const Window win = round_window(sg, c >= 0 ? c : kCand);
+    if (ic.rel0 + ic.n_here <= win.act) return;             // wholly frozen
     unsigned long long masks[4]; u32x2 vals[4];
-    item_masks(sg, ic, pay, c, masks, vals);
+    item_masks(sg, ic, pay, c, win.act, masks, vals);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned t = 0;
 #pragma unroll
@@ -829,12 +850,13 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
     __syncthreads();
     unsigned run = item_pre[blockIdx.x] - item_pre[sg->item_first];
     for (unsigned w = 0; w < wave; ++w) run += s_w[w];
-    const unsigned ttot = sg->ttot_cur, s = sg->start;
+    // positions and table indices are relative to the window [act, n); the tables of the window start at s + act
+    const unsigned ttot = sg->ttot_cur, s = sg->start + win.act;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const unsigned xr = wave * 256u + j * 64u + lane;
-        if (xr < ic.n_here) {
-            const unsigned x = ic.rel0 + xr;
+        if (xr < ic.n_here && ic.rel0 + xr >= win.act) {
+            const unsigned x = ic.rel0 + xr - win.act;
             const bool p = (masks[j] >> lane) & 1ull;
             const unsigned tl = run + vd_mbcnt(masks[j]);
             if (p) truepos[s + (ttot - tl - 1u)] = x;     // index T: (T+1)-th true from the right
@@ -852,10 +874,20 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
+    const int r = c >= 0 ? c : kCand;
+    const Window win = round_window(sg, r);
+    if (ic.rel0 + ic.n_here <= win.band) return;           // frozen before the previous round: both buffers agree
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // the band the previous round froze: straight copy, so that `dst` holds the whole arrangement
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned xr = wave * 256u + j * 64u + lane, xa = ic.rel0 + xr;
+        if (xr < ic.n_here && xa >= win.band && xa < win.act) dst[sg->start + xa] = src[sg->start + xa];
+    }
+    if (ic.rel0 + ic.n_here <= win.act) return;
     // predicates and TL are recomputed from the payload (cheaper than a per-position word through HBM)
     unsigned long long masks[4]; u32x2 vals[4];
-    item_masks(sg, ic, src, c, masks, vals);
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    item_masks(sg, ic, src, c, win.act, masks, vals);
     unsigned t = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) t += (unsigned)__popcll(masks[j]);
@@ -863,12 +895,13 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     __syncthreads();
     unsigned run = item_pre[blockIdx.x] - item_pre[sg->item_first];
     for (unsigned w = 0; w < wave; ++w) run += s_w[w];
-    const unsigned n = sg->count, s = sg->start, ttot = sg->ttot_cur, ftot = n - ttot;
+    // everything below is partition_shuffle on the window [act, n): positions relative to act
+    const unsigned n = sg->count - win.act, s = sg->start + win.act, ttot = sg->ttot_cur, ftot = n - ttot;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const unsigned xr = wave * 256u + j * 64u + lane;
-        if (xr < ic.n_here) {
-            const unsigned x = ic.rel0 + xr;
+        if (xr < ic.n_here && ic.rel0 + xr >= win.act) {
+            const unsigned x = ic.rel0 + xr - win.act;
             const bool p = (masks[j] >> lane) & 1ull;
             const unsigned tl = run + vd_mbcnt(masks[j]);
             const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
@@ -884,7 +917,9 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
             dst[s + dest] = vals[j];
             if (is_u && c >= 0) {
                 Seg& w = segs[ic.seg];
-                w.u_pay[c] = vals[j]; w.u_p[c] = p ? 1u : 0u; w.ttot[c] = ttot;
+                // counts as the reference sees them: examined trues of the WHOLE segment = frozen prefix + this window's
+                w.u_pay[c] = vals[j]; w.u_p[c] = p ? 1u : 0u; w.ttot[c] = win.act + ttot;
+                w.act[(r + 1) % 3] = win.act + ttot - (p ? 1u : 0u);   // this trial's pivot: where the next round starts
                 is_u_flag[vals[j].x] = 1;
             }
         }
