@@ -132,6 +132,13 @@ def load(path: str | None = None) -> C.CDLL:
         raise VoidinHipMissing(
             f"{p} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C voidin_amd/csrc`; there is no CPU fallback")
+    # A process must hold ONE HIP runtime.  PyTorch ships its own libamdhip64 and loads it by path; if the system copy
+    # this library links against is loaded first, torch later finds "No HIP GPUs".  Loading torch first lets the
+    # dynamic loader satisfy our DT_NEEDED with the copy that is already in the process.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
