@@ -335,8 +335,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[2]: 10M synthetic AABB instances, cull + prefix-sum compaction "
-                                   "(BASELINE.md §3 distribution, model.rs camera)",
+            "config": {"workload": ("configs[2]: 10M synthetic AABB instances, cull + prefix-sum compaction "
+                                    "(BASELINE.md §3 distribution, model.rs camera)") if not distributed else
+                                   ("configs[3] shape, weak-scaled: 10M synthetic AABB instances PER GPU, sharded by instance; "
+                                    "every GPU ends the step with the ordered compacted draw list of the whole scene"),
                        "instances_per_gpu": n, "instances_total": n_total, "n_meshes": int(len(meshes)),
                        "visible_fraction": round(vis, 4), "distribution": args.dist,
                        "parallelism": f"instance-shard x{world}" + (" + visibility-bitmask all-gather (RCCL) + local expansion to the full draw list" if distributed else ""),
