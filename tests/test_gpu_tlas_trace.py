@@ -81,6 +81,18 @@ def test_tlas_overflow_and_bad_args(ctx):
         ctx.tlas_build(inst, meshes)
     assert e.value.code == abi.VD_ERR_TLAS_OVERFLOW
     assert ctx.lib.vd_tlas_build(ctx.h, None, 0, None, 0, None) == abi.VD_ERR_INVALID_ARG
+    # the other entry points of this file: incomplete scene, null buffers, bad external-buffer arguments
+    import ctypes as C
+    empty = abi.TraceScene()
+    assert ctx.lib.vd_trace_dev(ctx.h, C.byref(empty), None, 8, None) == abi.VD_ERR_INVALID_ARG
+    assert ctx.lib.vd_trace_any_dev(ctx.h, C.byref(empty), None, 8, None) == abi.VD_ERR_INVALID_ARG
+    assert b"incomplete scene" in ctx.lib.vd_last_error(ctx.h)
+    assert ctx.lib.vd_shadow_rays_dev(ctx.h, None, None, 8, None, None) == abi.VD_ERR_INVALID_ARG
+    assert ctx.lib.vd_shadow_rays_dev(ctx.h, None, None, 0, None, None) == abi.VD_OK          # nothing to do
+    hnd, ptr = C.c_void_p(), C.c_void_p()
+    assert ctx.lib.vd_import_external_buffer(ctx.h, -1, 4096, C.byref(hnd), C.byref(ptr)) == abi.VD_ERR_INVALID_ARG
+    assert ctx.lib.vd_import_external_buffer(ctx.h, 0, 0, C.byref(hnd), C.byref(ptr)) == abi.VD_ERR_INVALID_ARG
+    assert ctx.lib.vd_release_external_buffer(ctx.h, None) == abi.VD_ERR_INVALID_ARG
 
 
 def test_trace_matches_golden(ctx):
