@@ -371,12 +371,14 @@ constexpr int kChunkWords = kWavesPerBlock * kExpandWords;   // per workgroup: 1
 // scan in place and the total.  Keeping the scan out of pass 2b leaves that kernel without tickets, look-back or
 // any other load that depends on another workgroup: under a saturated store stream every dependent load costs
 // microseconds (on gfx950 loads and stores share vmcnt and the same queue), and 2b had four of them in a chain.
-__global__ __launch_bounds__(kBlock) void mask_scan_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned n_chunks,
+constexpr int kScanBlock = 1024;                     // 16 waves: the last workgroup's scan is one round trip even at 80 M
+__global__ __launch_bounds__(kScanBlock) void mask_scan_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned n_chunks,
                                                            unsigned* chunk_offset, unsigned* done_counter,
                                                            unsigned* __restrict__ out_count) {
-    __shared__ unsigned s_last, s_wave_sum[kWavesPerBlock];
+    constexpr int kScanWaves = kScanBlock / kWave;
+    __shared__ unsigned s_last, s_wave_sum[kScanWaves];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (unsigned c = blockIdx.x * kWavesPerBlock + wave; c < n_chunks; c += gridDim.x * kWavesPerBlock) {
+    for (unsigned c = blockIdx.x * kScanWaves + wave; c < n_chunks; c += gridDim.x * kScanWaves) {
         const unsigned w = c * kChunkWords + lane;
         unsigned v = (w < n_words ? (unsigned)__popcll(mask[w]) : 0u) + (w + 64u < n_words ? (unsigned)__popcll(mask[w + 64u]) : 0u);
 #pragma unroll
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void mask_scan_kernel(const vd_u64* __restr
     if (!s_last) return;
     // thread t scans the contiguous range [t*per, (t+1)*per): all its loads are independent (one round trip) and
     // read at agent scope (other XCDs wrote the sums)
-    const unsigned per = ((n_chunks + kBlock - 1) / kBlock + 3u) & ~3u;
+    const unsigned per = ((n_chunks + kScanBlock - 1) / kScanBlock + 1u) & ~1u;     // even: 8-byte loads
     const unsigned begin = min(threadIdx.x * per, n_chunks), end = min(begin + per, n_chunks);
     vd_u64* pairs = reinterpret_cast<vd_u64*>(chunk_offset);
     unsigned sum = 0;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void mask_scan_kernel(const vd_u64* __restr
             run += v;
         }
     }
-    if (threadIdx.x == kBlock - 1u) {
+    if (threadIdx.x == kScanBlock - 1u) {
         *out_count = run;
         __hip_atomic_store(done_counter, 0u, VD_RLX_AGENT);   // re-armed for the next launch on this stream
     }
@@ -793,9 +795,9 @@ static int launch_expand(VdCtx* ctx, const vd_u64* d_mask, unsigned n_words, uns
     }
     unsigned* done = reinterpret_cast<unsigned*>(ctx->expand_state);
     unsigned* offsets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->expand_state) + 16);
-    unsigned sblocks = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;      // one wave per chunk, grid-stride beyond 4 per CU
-    if (sblocks > (unsigned)ctx->num_cus * 4u) sblocks = (unsigned)ctx->num_cus * 4u;
-    hipLaunchKernelGGL(mask_scan_kernel, dim3(sblocks), dim3(kBlock), 0, ctx->stream, d_mask, n_words, n_chunks, offsets, done,
+    unsigned sblocks = (n_chunks + 15u) / 16u;                                // one wave per chunk, grid-stride beyond 2 per CU
+    if (sblocks > (unsigned)ctx->num_cus * 2u) sblocks = (unsigned)ctx->num_cus * 2u;
+    hipLaunchKernelGGL(mask_scan_kernel, dim3(sblocks), dim3(kScanBlock), 0, ctx->stream, d_mask, n_words, n_chunks, offsets, done,
                        d_out_count);
     const bool one_shard = wps >= n_words;
     const bool tab = n_mesh <= 512u;
