@@ -216,6 +216,8 @@ __global__ __launch_bounds__(256) void shadow_rays_kernel(const float* __restric
 }
 
 int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out, uint32_t* d_any = nullptr) {
+    // idle waves keep drawing from the ray counter after the last ray: leave it room below 2^32
+    if (n_rays > 0xf0000000u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: more than 0xf0000000 rays in one call");
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256);
     if (rc) return rc;
     unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);
