@@ -62,5 +62,22 @@ for it in range(max(10, args.iters // 10)):
     if ref_n is None: ref_n, ref_i, ref_nn = d_n[: nn * 32].clone(), d_idx.clone(), nn
     elif nn != ref_nn or not torch.equal(d_n[: nn * 32], ref_n) or not torch.equal(d_idx, ref_i): bad += 1; print(f"bvh_build: run {it} differs")
 print(f"bvh_build {n_tri} tris: {max(10, args.iters // 10)} runs identical", flush=True)
+# traversal: persistent waves draw rays from a counter; results must not depend on which lane got which ray
+from voidin_amd import abi
+inst2, infos2, B2, V2, I2 = synth.harness_scene(ctx.bvh_build, big=(256, 64), small_res=24)
+tl2 = ctx.tlas_build(inst2, infos2)
+rays = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 15), pitch_deg=0), 509, 383)      # ragged ray count
+ds = ctx.device_scene((tl2, inst2, infos2, B2, V2, I2))
+d_r, d_h = ctx.upload(rays), ctx.empty(len(rays) * 16)
+d_a = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
+ref_h = ref_a = None
+for it in range(args.iters):
+    d_h.zero_(); d_a.zero_()
+    ctx.trace_dev(ds, d_r, len(rays), d_h); ctx.trace_any_dev(ds, d_r, len(rays), d_a)
+    if ref_h is None: ref_h, ref_a = d_h.clone(), d_a.clone()
+    elif not torch.equal(d_h, ref_h) or not torch.equal(d_a, ref_a): bad += 1; print(f"trace: run {it} differs")
+hits = ref_h.cpu().numpy()[: len(rays) * 16].view(abi.HIT)
+assert np.array_equal(ref_a.cpu().numpy().astype(np.uint32), hits["hit"]) and 0 < hits["hit"].sum() < len(rays)
+print(f"trace + trace_any, {len(rays)} rays: {args.iters} runs identical, occlusion flags == closest-hit flags", flush=True)
 print("STRESS", "FAILED" if bad else "OK", bad)
 sys.exit(1 if bad else 0)
