@@ -62,6 +62,24 @@ class Gpu {
     VdCtx* ctx_ = nullptr;
 };
 
+// HIP view of a buffer the renderer owns (ResizableBuffer<T>, crates/components/src/buffer.rs:42-47) that was exported
+// as an opaque fd on the Vulkan side: `ptr()` is what the *_dev entry points take as `d_out` / `d_instances`.
+class ExternalBuffer {
+   public:
+    ExternalBuffer(const Gpu& gpu, int opaque_fd, uint64_t size_bytes) : gpu_(gpu) {
+        gpu.check(vd_import_external_buffer(gpu.ctx(), opaque_fd, size_bytes, &handle_, &ptr_));   // consumes the fd
+    }
+    ~ExternalBuffer() { if (handle_) vd_release_external_buffer(gpu_.ctx(), handle_); }
+    ExternalBuffer(const ExternalBuffer&) = delete;
+    ExternalBuffer& operator=(const ExternalBuffer&) = delete;
+    void* ptr() const { return ptr_; }
+
+   private:
+    const Gpu& gpu_;
+    VdExternalBuffer* handle_ = nullptr;
+    void* ptr_ = nullptr;
+};
+
 // ---- crates/bvh ---------------------------------------------------------------------------
 struct Bvh {
     std::vector<BvhNode> nodes;   // `pub nodes: Vec<BvhNode>` (blas.rs:206-208)
