@@ -160,7 +160,7 @@ def main():
                 head = d_all.cpu().numpy()[: count * 20]
                 total = int(d_cnt_all[0].item())
                 verified = bool(verified and head.tobytes() == wc[:wn].tobytes() and total >= count)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not distributed:      # reported at N = 1 only
             cores = os.cpu_count() or 1
             m = min(n, 10_000_000)
             reps1 = 3
@@ -182,7 +182,7 @@ def main():
                              f"1-thread cull: {m / t1 / 1e6:.2f} M inst/s"}
 
     extra = {}
-    if not args.no_extra and rank == 0:
+    if not args.no_extra and rank == 0 and not distributed:   # single-GPU extras (they use no collective; N > 1 runs skip them)
         d_emit = ctx.empty(n * 20)
         for _ in range(3):
             ctx.cull_emit_dev(cam, d_m, len(meshes), d_i, n, d_emit)
