@@ -1,7 +1,8 @@
 """A/B the forms of vd_cull_compact in ONE process (interleaved rounds, median + min).
 Variants: 0 = library default (split form from 2^20 instances on), 4/8/16/32 = fused single-pass
 kernel with that many rounds per wave per tile, m70 (-70) = split form with per-round id stores in pass 1,
-m71 (-71) / m74 (-74) = pass 2 forced to its LDS-staged / direct-store form (default: direct up to 12 Mi instances).
+m71 (-71) / m74 (-74) = pass 2 forced to its LDS-staged / direct-store form (default: direct up to 12 Mi instances),
+m81 (-81) = staged form without the same-XCD prefetch, m80 (-80) = vd_cull_emit as one kernel (no split).
 (The r01 logs under profiles/ use the numbering of the variants that were pruned afterwards:
 LDS-DMA, strided loads, compact staging, persistent, wave-tile, ablations, stream probes.)
 Usage (on a GPU box): python tools/ab_cull.py [--variants 0,32,16,m70] [--n 10000000] [--dist baseline|small]"""
