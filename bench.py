@@ -88,11 +88,26 @@ def main():
     d_cnt_all = torch.zeros(4, dtype=torch.int32, device=dev) if distributed else None
     sv = vdist.ShardedVisibility(ctx, n_total, d_m, len(meshes), d_i) if distributed else None
 
+    # N = 1: consecutive steps see DIFFERENT instance buffers - the second is the first after one compute_update
+    # animation step (every transform changed, mesh assignment unchanged: what the reference's dynamic scene does,
+    # shaders/compute_update.wgsl:10-28) - so nothing but the per-scene instance->mesh table can carry over between
+    # steps (pass 1 re-derives that table every step and rewrites only rows that changed).
+    d_i_b = None
+    if not distributed:
+        d_i_b = d_i.clone()
+        d_all_idx = torch.arange(n, dtype=torch.int32, device=dev)
+        ctx.compute_update_dev(d_all_idx, n, d_i_b, n, 1.0, 0.016)
+        torch.cuda.synchronize()
+        del d_all_idx
+    step_no = [0]
+
     def step():
         if distributed:
             sv.step(cam, d_all, d_cnt_all)
         else:
-            ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)
+            src = d_i if (step_no[0] & 1) == 0 else d_i_b
+            step_no[0] += 1
+            ctx.cull_compact_dev(cam, d_m, len(meshes), src, n, d_out, d_cnt, False, first)
 
     def barrier():
         if distributed:
@@ -139,7 +154,7 @@ def main():
         id_bytes = 1 if len(meshes) <= 256 else (2 if len(meshes) <= 65536 else 4)
         kernel_name = "cull_mask_tiled_kernel"
         kernel_ms = sum(k_cull) / len(k_cull)
-        alg_bytes = n * (144.0 + 0.125 + id_bytes)  # 144 B instance read + 1 bit + the compact mesh id written
+        alg_bytes = n * (144.0 + 0.125 + id_bytes)  # 144 B instance read + 1 bit written + the compact mesh id (compared; rewritten when it changed)
         expand_ms = sum(k_expand) / len(k_expand)
         expand_bytes = n * (0.125 + id_bytes) + count * 20.0
     else:
@@ -212,6 +227,24 @@ def main():
         torch.cuda.synchronize()
         same = bool(int(d_c2[0].item()) == count and torch.equal(d_o2[: count * 20], d_out[: count * 20]))
         extra["mask_then_expand_1gpu"] = {"ms": round(e0.elapsed_time(e1) / args.steps, 4), "equals_fused": same}
+        # worst case for pass 1's id table: every instance changes its mesh between consecutive steps (all rows rewritten)
+        inst_c = inst.copy()
+        inst_c["mesh"] = (inst_c["mesh"] + 1) % len(meshes)
+        d_i_c = ctx.upload(inst_c)
+        del inst_c
+        for k in range(4):
+            ctx.cull_compact_dev(cam, d_m, len(meshes), d_i if k & 1 else d_i_c, n, d_out, d_cnt, False, first)
+        torch.cuda.synchronize()
+        e0.record()
+        for k in range(args.steps):
+            ctx.cull_compact_dev(cam, d_m, len(meshes), d_i if k & 1 else d_i_c, n, d_out, d_cnt, False, first)
+        e1.record()
+        torch.cuda.synchronize()
+        extra["cull_compact_all_mesh_ids_changing"] = {"ms": round(e0.elapsed_time(e1) / args.steps, 4),
+                                                       "note": "every step rewrites the whole instance->mesh table; the headline steps alternate two buffers with equal mesh ids and different transforms"}
+        del d_i_c
+        ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)   # leave d_out / the table as the later legs expect
+        torch.cuda.synchronize()
         del d_o2, sv1
         # --- BASELINE config 5: SAH BVH build of a dragon-like 8M-tri mesh, TLAS build/refit ---
         from oracle import ref

@@ -327,6 +327,19 @@ __global__ __launch_bounds__(kBlock, 3) void cull_mask_tiled_kernel(CullCamera c
     for (unsigned t = blockIdx.x * kWavesPerBlock + wave; t < n_tiles; t += waves_total) {
         const size_t tile_first = (size_t)t * (kWave * kMaskRounds);
         slab_fill<true>(inst, tile_first, valid_at(tile_first), lane, regs);
+        // what the id table holds for this tile now: mesh assignment is static in practice (only transforms animate:
+        // shaders/compute_update.wgsl), and a row that already matches is not written again - a store interleaved
+        // with the read stream costs ~3x its bytes, a load does not.  Always correct: any row that
+        // differs (first frame, reallocated scratch, edited instances) is rewritten.
+        constexpr int kIdRows = kIdBytes / (kWave * 16);
+        u32x4 old_ids[kIdRows];
+        const size_t id_base0 = tile_first * sizeof(IdT);
+        const bool full_tile = tile_first + (size_t)kWave * kMaskRounds <= (size_t)n_inst;
+        if (full_tile) {
+#pragma unroll
+            for (int r = 0; r < kIdRows; ++r)
+                old_ids[r] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(ids_out) + id_base0 + (size_t)r * kWave * 16 + lane * 16u);
+        }
         vd_u64 my_word = 0;
 #pragma unroll 1
         for (int r = 0; r < kMaskRounds; ++r) {
@@ -352,11 +365,21 @@ __global__ __launch_bounds__(kBlock, 3) void cull_mask_tiled_kernel(CullCamera c
         const size_t id_base = tile_first * sizeof(IdT);                 // bytes; tile_first % 1024 == 0 -> 16-B aligned
         const size_t id_end = min((size_t)n_inst, tile_first + (size_t)kWave * kMaskRounds) * sizeof(IdT);
         char* gids = reinterpret_cast<char*>(ids_out);
-        for (unsigned b0 = lane * 16u; b0 < (unsigned)kIdBytes; b0 += kWave * 16u) {
-            if (id_base + b0 + 16u <= id_end) {
-                *reinterpret_cast<u32x4*>(gids + id_base + b0) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(s_ids) + b0);
-            } else {
-                for (unsigned q = 0; q < 16u && id_base + b0 + q < id_end; ++q) gids[id_base + b0 + q] = reinterpret_cast<const char*>(s_ids)[b0 + q];
+        if (full_tile) {
+#pragma unroll
+            for (int r = 0; r < kIdRows; ++r) {
+                const unsigned b0 = (unsigned)r * kWave * 16u + lane * 16u;
+                const u32x4 nv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(s_ids) + b0);
+                const bool diff = nv.x != old_ids[r].x || nv.y != old_ids[r].y || nv.z != old_ids[r].z || nv.w != old_ids[r].w;
+                if (__any(diff)) *reinterpret_cast<u32x4*>(gids + id_base + b0) = nv;
+            }
+        } else {
+            for (unsigned b0 = lane * 16u; b0 < (unsigned)kIdBytes; b0 += kWave * 16u) {
+                if (id_base + b0 + 16u <= id_end) {
+                    *reinterpret_cast<u32x4*>(gids + id_base + b0) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(s_ids) + b0);
+                } else {
+                    for (unsigned q = 0; q < 16u && id_base + b0 + q < id_end; ++q) gids[id_base + b0 + q] = reinterpret_cast<const char*>(s_ids)[b0 + q];
+                }
             }
         }
         vd_wave_lds_sync();
