@@ -11,7 +11,9 @@ n = 10_000_000
 cam, meshes = synth.camera_uniform(), synth.mesh_infos()
 inst = synth.instances(n, seed=synth.SEED_BASE + 3, with_inverse=False)
 d_m, d_i = ctx.upload(meshes), ctx.upload(inst)
-for shards in (1, 8):
+import sys as _s
+SH = tuple(int(x) for x in _s.argv[1].split(",")) if len(_s.argv) > 1 else (1, 8)
+for shards in SH:
     N = n * shards
     S = n
     wps = vdist.mask_words(S)
