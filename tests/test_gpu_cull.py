@@ -220,6 +220,28 @@ def test_split_forms_with_every_id_width_and_table_size(ctx, oracle, n_mesh):
     assert cnt == wn and comp[:cnt].tobytes() == wc[:wn].tobytes()
 
 
+def test_id_table_follows_edited_instances(ctx, oracle):
+    """Pass 1 keeps the instance->mesh table between calls and rewrites only rows that changed: alternate inputs whose
+    mesh ids differ everywhere / in a few rows / not at all (only transforms), and sizes that move the table."""
+    import torch
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    n = (1 << 20) + 999
+    a = synth.instances(n, seed=synth.SEED_BASE + 60, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+    b = a.copy(); b["mesh"] = (b["mesh"] + 5) % len(meshes)                      # every row differs
+    c = a.copy(); c["mesh"][[3, 1024, 500_000, n - 1]] = [7, 7, 0, 11]           # four rows differ
+    d = synth.instances(n, seed=synth.SEED_BASE + 61, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+    d["mesh"] = a["mesh"]                                                        # other transforms, same meshes
+    small = a[: (1 << 20) + 1]
+    d_m = ctx.upload(meshes)
+    d_out, d_cnt = ctx.empty(n * 20), torch.zeros(4, dtype=torch.int32, device="cuda")
+    for name, inst in [("a", a), ("b", b), ("a", a), ("c", c), ("d", d), ("small", small), ("a", a)]:
+        want, wn = oracle.compact(oracle.cull_emit(cam, meshes, inst, threads=8))
+        ctx.cull_compact_dev(cam, d_m, len(meshes), ctx.upload(inst), len(inst), d_out, d_cnt)
+        torch.cuda.synchronize()
+        assert int(d_cnt[0].item()) == wn, name
+        assert d_out.cpu().numpy()[: wn * 20].tobytes() == want[:wn].tobytes(), name
+
+
 @pytest.mark.parametrize("n", [(1 << 20) - 1, 1 << 20, (1 << 20) + 77, 1_500_001])
 def test_split_and_fused_forms_agree_around_the_switch(ctx, oracle, n):
     """vd_cull_compact runs the fused kernel below 2^20 instances and the split form (bitmask +
