@@ -36,6 +36,9 @@ namespace {
 #ifndef VD_SMALL_MAX
 #define VD_SMALL_MAX 512
 #endif
+#ifndef VD_BINEVAL_MIN
+#define VD_BINEVAL_MIN 64
+#endif
 #ifndef VD_LANE_MAX
 #define VD_LANE_MAX 8
 #endif
@@ -196,6 +199,7 @@ struct WaveScratch {                              // per-wave: the node this wav
     unsigned ttot[kCand + 3];
     unsigned short u_e[kCand + 3];
     unsigned short u_p[kCand + 3];
+    int bin_min[3][8][3], bin_max[3][8][3];       // nodes > 64 prims: box keys of the non-`u` elements by (axis, bin)
 };
 struct WaveLds {
     float cent[3][kSmallMax];
@@ -204,6 +208,7 @@ struct WaveLds {
     unsigned short perm[2][kSmallMax];            // arrangement ping-pong (position -> local element)
     unsigned short falsepos[kSmallMax + 2];       // indexed by ABSOLUTE position s + j: segments are disjoint,
     unsigned short truepos[kSmallMax + 2];        // so waves working on different nodes never collide
+    unsigned char uflag[kSmallMax];               // marks the <= 21 never-examined elements of the node being evaluated
     WaveScratch w[kSubWaves];
 };
 
@@ -420,6 +425,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
         const f32x4 c4 = cent[id];
         const float ce[3] = {c4.x, c4.y, c4.z};
         L.gid[x] = id;
+        L.uflag[x] = 0;
         L.perm[0][x] = (unsigned short)x;
         L.perm[1][x] = (unsigned short)x;
 #pragma unroll
@@ -467,9 +473,68 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 if (lane == 0) { W.u_e[c] = (unsigned short)ue; W.u_p[c] = (unsigned short)up; W.ttot[c] = tt; }
             }
             vd_wave_lds_sync();
+            vd_u64 key = ~0ull;
+            if (n > (unsigned)VD_BINEVAL_MIN) {
+                // evaluate (blas.rs:149-161) from binned statistics, as phase A does: the cost of a trial depends on the
+                // arrangement only through its never-examined element `u` (left = trues \ {u}), so one pass bins the
+                // box keys of the non-`u` elements by (axis, number of planes not above the centroid) and each
+                // candidate adds the <= 21 `u` elements back on the side its own predicate puts them.  (Walking the
+                // node once per candidate, as below, is 56 % of a 350-prim node's time.)
+                for (unsigned i = lane; i < 72u; i += 64u) { (&W.bin_min[0][0][0])[i] = kBig; (&W.bin_max[0][0][0])[i] = -kBig - 1; }
+                if (lane < (unsigned)kCand) L.uflag[W.u_e[lane]] = 1;
+                vd_wave_lds_sync();
+                for (unsigned x = lane; x < n; x += 64u) {
+                    const unsigned e = L.perm[cur][s + x];
+                    if (L.uflag[e]) continue;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const float ce = L.cent[a][e];
+                        int b = 0;
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) b += !(ce < W.pos[a * 7 + k]);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) { atomicMin(&W.bin_min[a][b][q], L.box[q][e]); atomicMax(&W.bin_max[a][b][q], L.box[3 + q][e]); }
+                    }
+                }
+                vd_wave_lds_sync();
+                if (lane < (unsigned)kCand) {
+                    const int c = (int)lane, a = c / 7, k = c % 7 + 1;
+                    int tmn[3] = {kBig, kBig, kBig}, tmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
+                    int fmn[3] = {kBig, kBig, kBig}, fmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
+                    for (int b = 0; b < 8; ++b) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            const int lo = W.bin_min[a][b][q], hi = W.bin_max[a][b][q];
+                            if (b < k) { tmn[q] = min(tmn[q], lo); tmx[q] = max(tmx[q], hi); }
+                            else { fmn[q] = min(fmn[q], lo); fmx[q] = max(fmx[q], hi); }
+                        }
+                    }
+                    const float pos = W.pos[c];
+                    const unsigned own_u = W.u_e[c];
+                    for (int j = 0; j < kCand; ++j) {
+                        const unsigned e = W.u_e[j];
+                        bool dup = false;
+                        for (int i = 0; i < j; ++i) dup |= W.u_e[i] == e;
+                        if (dup) continue;
+                        const bool to_left = e != own_u && L.cent[a][e] < pos;   // left = examined trues; u itself goes right
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            const int lo = L.box[q][e], hi = L.box[3 + q][e];
+                            if (to_left) { tmn[q] = min(tmn[q], lo); tmx[q] = max(tmx[q], hi); }
+                            else { fmn[q] = min(fmn[q], lo); fmx[q] = max(fmx[q], hi); }
+                        }
+                    }
+                    const unsigned n1 = W.ttot[c] - W.u_p[c];
+                    const float a1 = vd_area(box_hi(tmx[0]) - box_lo(tmn[0]), box_hi(tmx[1]) - box_lo(tmn[1]), box_hi(tmx[2]) - box_lo(tmn[2]));
+                    const float a2 = vd_area(box_hi(fmx[0]) - box_lo(fmn[0]), box_hi(fmx[1]) - box_lo(fmn[1]), box_hi(fmx[2]) - box_lo(fmn[2]));
+                    key = cost_key(a1 * (float)n1 + a2 * (float)(n - n1), (unsigned)c);
+                }
+                vd_wave_lds_sync();
+                if (lane < (unsigned)kCand) L.uflag[W.u_e[lane]] = 0;
+                vd_wave_lds_sync();
+            } else {
             // evaluate (blas.rs:149-161): lane = 3*c + part owns a third of candidate c's elements;
             // left = examined trues = {e : p_c(e) and e != u_c}, right = the rest (incl. u_c)
-            vd_u64 key = ~0ull;
             {
                 const unsigned c = lane / 3u, part = lane - c * 3u;
                 int k12[12];
@@ -497,6 +562,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                     const float a2 = vd_area(box_hi(k12[9]) - box_lo(k12[6]), box_hi(k12[10]) - box_lo(k12[7]), box_hi(k12[11]) - box_lo(k12[8]));
                     key = cost_key(a1 * (float)n1 + a2 * (float)(n - n1), c);
                 }
+            }
             }
             key = wave_min_u64(key);
             if (key == ~0ull) { if (lane == 0) Q.bad = 1; continue; }
