@@ -466,11 +466,60 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(wave_min_i(kmn[k])); cbmax[k] = box_hi(wave_max_i(kmx[k])); }
             if (lane < (unsigned)kCand) W.pos[lane] = cand_pos(cbmin, cbmax, (int)lane);
             vd_wave_lds_sync();
-            for (int c = 0; c < kCand; ++c) {                                         // blas.rs:144-147
-                unsigned tt, ue, up;
-                wave_shuffle_any(L, cur, s, n, c / 7, W.pos[c], tt, ue, up);
-                cur ^= 1;
-                if (lane == 0) { W.u_e[c] = (unsigned short)ue; W.u_p[c] = (unsigned short)up; W.ttot[c] = tt; }
+            if (n <= 64u) {
+                // One position per lane: the arrangement (element id + its centroid) stays in registers across the 21
+                // trials and moves through the LDS crossbar (ds_permute / ds_bpermute), the rank -> position tables
+                // likewise.  A trial is then three dependent crossbar hops instead of five dependent LDS accesses -
+                // and the many levels that hold only a few small nodes cost exactly that chain, 22 times each.
+                const bool valid = lane < n;
+                unsigned el = valid ? (unsigned)L.perm[cur][s + lane] : 0u;
+                float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+                if (valid) { cx = L.cent[0][el]; cy = L.cent[1][el]; cz = L.cent[2][el]; }
+                for (int c = 0; c < kCand; ++c) {                                     // blas.rs:144-147
+                    const int axis = c / 7;
+                    const float pos = W.pos[c];
+                    const float ce = axis == 0 ? cx : (axis == 1 ? cy : cz);
+                    const bool p = valid && ce < pos;
+                    const unsigned long long mask = __ballot(p);
+                    const unsigned ttot = (unsigned)__popcll(mask), ftot = n - ttot, tl = vd_mbcnt(mask), x = lane;
+                    // lane k receives truepos[k + 1] resp. falsepos[k + 1] (0-based here); lane 63 is the dump slot (a table
+                    // that needs all 64 lanes has no lane left over to dump)
+                    const int tp_tab = __builtin_amdgcn_ds_permute((int)((p ? ttot - tl - 1u : 63u) << 2), (int)x);
+                    const int fp_tab = __builtin_amdgcn_ds_permute((int)(((valid && !p) ? x - tl : 63u) << 2), (int)x);
+                    const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
+                    const int tp_at = __builtin_amdgcn_ds_bpermute((int)(((F - 1u) & 63u) << 2), tp_tab);
+                    const int fp_at = __builtin_amdgcn_ds_bpermute((int)((T & 63u) << 2), fp_tab);
+                    unsigned dest = lane;
+                    bool is_u = false;
+                    if (valid) {
+                        const int tF = F == 0u ? (int)n : (F <= ttot ? tp_at : -1);
+                        const bool left = (int)x < tF;
+                        const unsigned fj = (T + 1u <= ftot) ? (unsigned)fp_at : n;
+                        const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
+                        is_u = fetch == n - 1u;
+                        if (is_u) dest = ttot - (p ? 1u : 0u);
+                        else if (left) dest = p ? x : (unsigned)tF - 1u;
+                        else dest = p ? fj : x - 1u;
+                    }
+                    const unsigned long long um = __ballot(is_u);
+                    const int ul = um ? __builtin_ctzll(um) : 0;
+                    const unsigned ue = (unsigned)__shfl((int)el, ul), up = (unsigned)__shfl(p ? 1 : 0, ul);
+                    if (lane == 0) { W.u_e[c] = (unsigned short)ue; W.u_p[c] = (unsigned short)up; W.ttot[c] = ttot; }
+                    const int da = (int)(dest << 2);
+                    el = (unsigned)__builtin_amdgcn_ds_permute(da, (int)el);
+                    cx = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cx)));
+                    cy = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cy)));
+                    cz = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cz)));
+                }
+                cur ^= 1;                                                             // 21 flips
+                if (valid) L.perm[cur][s + lane] = (unsigned short)el;
+            } else {
+                for (int c = 0; c < kCand; ++c) {                                     // blas.rs:144-147
+                    unsigned tt, ue, up;
+                    wave_shuffle_any(L, cur, s, n, c / 7, W.pos[c], tt, ue, up);
+                    cur ^= 1;
+                    if (lane == 0) { W.u_e[c] = (unsigned short)ue; W.u_p[c] = (unsigned short)up; W.ttot[c] = tt; }
+                }
             }
             vd_wave_lds_sync();
             vd_u64 key = ~0ull;
