@@ -125,18 +125,32 @@ __device__ __forceinline__ unsigned find_best_match(const float* sb, unsigned ca
             const float4 a4 = *reinterpret_cast<const float4*>(sb + 4 * cap + i0), a5 = *reinterpret_cast<const float4*>(sb + 5 * cap + i0);
             const float mn0[4] = {a0.x, a0.y, a0.z, a0.w}, mn1[4] = {a1.x, a1.y, a1.z, a1.w}, mn2[4] = {a2.x, a2.y, a2.z, a2.w};
             const float mx0[4] = {a3.x, a3.y, a3.z, a3.w}, mx1[4] = {a4.x, a4.y, a4.z, a4.w}, mx2[4] = {a5.x, a5.y, a5.z, a5.w};
+            if (FAST) {
+                // two slots per instruction where gfx950 has packed fp32 (v_pk_add_f32 / v_pk_mul_f32); min / max stay
+                // scalar.  Same operations in the same order as vd_area, no contraction.
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned i = i0 + k;
-                if (FAST) {
-                    const float dx = __builtin_fmaxf(t3, mx0[k]) - __builtin_fminf(t0, mn0[k]);
-                    const float dy = __builtin_fmaxf(t4, mx1[k]) - __builtin_fminf(t1, mn1[k]);
-                    const float dz = __builtin_fmaxf(t5, mx2[k]) - __builtin_fminf(t2, mn2[k]);
-                    const float area = vd_area(dx, dy, dz) + 0.0f;           // -0 -> +0: the bit pattern is then monotone
-                    const bool ok = i < cnt && i != target && area < 1e30f;    // from 1e30, NaN (inf * 0) never passes
-                    const unsigned bits = ok ? __float_as_uint(area) : 0xffffffffu;
-                    if (bits < fbits) { fbits = bits; fslot = i; }
-                } else {
+                for (int k = 0; k < 4; k += 2) {
+                    const f32x2 hx = {__builtin_fmaxf(t3, mx0[k]), __builtin_fmaxf(t3, mx0[k + 1])}, lx = {__builtin_fminf(t0, mn0[k]), __builtin_fminf(t0, mn0[k + 1])};
+                    const f32x2 hy = {__builtin_fmaxf(t4, mx1[k]), __builtin_fmaxf(t4, mx1[k + 1])}, ly = {__builtin_fminf(t1, mn1[k]), __builtin_fminf(t1, mn1[k + 1])};
+                    const f32x2 hz = {__builtin_fmaxf(t5, mx2[k]), __builtin_fmaxf(t5, mx2[k + 1])}, lz = {__builtin_fminf(t2, mn2[k]), __builtin_fminf(t2, mn2[k + 1])};
+                    const f32x2 dx = hx - lx, dy = hy - ly, dz = hz - lz;
+                    const f32x2 two = {2.0f, 2.0f}, zero = {0.0f, 0.0f};
+                    const f32x2 ar = ((dx * dy + dx * dz) + dy * dz) * two + zero;   // -0 -> +0: the bit pattern is then monotone
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned i = i0 + k + h;
+                        const float area = ar[h];
+                        const bool ok = i < cnt && i != target && area < 1e30f;    // from 1e30, NaN (inf * 0) never passes
+                        const unsigned bits = ok ? __float_as_uint(area) : 0xffffffffu;
+                        if (bits < fbits) { fbits = bits; fslot = i; }
+                    }
+                }
+            }
+            if (!FAST) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned i = i0 + k;
                     const float dx = vd_max_to(t3, mx0[k]) - vd_min_to(t0, mn0[k]);
                     const float dy = vd_max_to(t4, mx1[k]) - vd_min_to(t1, mn1[k]);
                     const float dz = vd_max_to(t5, mx2[k]) - vd_min_to(t2, mn2[k]);
