@@ -343,6 +343,27 @@ def main():
         extra["trace_harness_scene"] = {"n_rays": len(rays2), "scene": f"bvh_gpu.rs shape: {len(I2)//3} triangles, 5 instances",
                                         "closest_hit_Mrays_per_s": round(len(rays2) / min(t2) / 1e3, 1),
                                         "hit_fraction": round(float(h2["hit"].mean()), 3)}
+        # the CPU harness (src/bin/bvh_cpu.rs:39-96): per-pixel rays + Bvh::traverse_iter against ONE mesh, on the device;
+        # the harness's own 64-triangle soup at 640 x 640, and the large mesh of the scene above at 2048 x 2048
+        cam_h = synth.camera_uniform(eye=(0, 0, 15), pitch_deg=0)
+        sv, si = synth.triangle_soup(64)
+        sn, si = ctx.bvh_build(sv, si)
+        big_v, big_i = synth.knot_mesh(1024, 256)
+        big_v = np.ascontiguousarray(big_v * np.float32(3.0))
+        bn, bi = ctx.bvh_build(big_v, big_i)
+        res = {}
+        for tag, (nn, vv, ii, w) in {"soup64_640x640": (sn, sv, si, 640), "knot_524k_2048x2048": (bn, big_v, bi, 2048)}.items():
+            d_pr = ctx.empty(w * w * 32)
+            d_t = torch.zeros(w * w, dtype=torch.float32, device=dev)
+            d_n, d_v, d_ix = ctx.upload(nn), ctx.upload(np.ascontiguousarray(vv, dtype=np.float32)), ctx.upload(ii)
+            ctx.primary_rays_dev(cam_h, w, w, d_pr)
+            ctx.set_timing(True)
+            tt = []
+            for _ in range(3):
+                ctx.traverse_iter_dev(d_n, len(nn), d_v, d_ix, d_pr, w * w, d_t); tt.append(ctx.last_gpu_ms())
+            ctx.set_timing(False)
+            res[tag] = {"Mrays_per_s": round(w * w / min(tt) / 1e3, 1), "hit_fraction": round(float((d_t >= 0).float().mean()), 3)}
+        extra["traverse_iter_cpu_harness"] = res
 
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_cull_pmc.json")

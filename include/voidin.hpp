@@ -81,9 +81,34 @@ class ExternalBuffer {
 };
 
 // ---- crates/bvh ---------------------------------------------------------------------------
+enum class DistKind { Hit, Miss };   // enum Dist { Hit(f32), Miss } (crates/bvh/src/intersection.rs:22-26)
+struct Dist {
+    DistKind kind = DistKind::Miss;
+    float t = 0.0f;
+    bool is_hit() const { return kind == DistKind::Hit; }
+};
+
 struct Bvh {
     std::vector<BvhNode> nodes;   // `pub nodes: Vec<BvhNode>` (blas.rs:206-208)
+    // `Bvh::traverse_iter(&self, &[Vec3], &[UVec3], Ray) -> Dist` (blas.rs:247-295), for a batch of rays
+    std::vector<Dist> traverse_iter(const Gpu& gpu, const Vec3* vertices, size_t n_vertices, const UVec3* indices, size_t n_triangles,
+                                    const std::vector<VdRay>& rays) const {
+        std::vector<float> t(rays.size());
+        gpu.check(vd_traverse_iter(gpu.ctx(), nodes.data(), (uint32_t)nodes.size(), &vertices->x, (uint32_t)n_vertices, &indices->x,
+                                   (uint32_t)n_triangles, rays.data(), (uint32_t)rays.size(), t.data()));
+        std::vector<Dist> out(rays.size());
+        for (size_t i = 0; i < t.size(); ++i)
+            if (t[i] >= 0.0f) out[i] = Dist{DistKind::Hit, t[i]};
+        return out;
+    }
 };
+
+// One ray per pixel from camera.clip_to_world, as the CPU harness makes them (src/bin/bvh_cpu.rs:71-83)
+inline std::vector<VdRay> primary_rays(const Gpu& gpu, const CameraUniform& camera, uint32_t width, uint32_t height) {
+    std::vector<VdRay> rays((size_t)width * height);
+    gpu.check(vd_primary_rays(gpu.ctx(), &camera, width, height, rays.data()));
+    return rays;
+}
 
 // BvhBuilder::new(&[Vec3], &mut [UVec3]) — borrows both slices; build() permutes `indices` in
 // place exactly as blas.rs:95-100 does.

@@ -337,6 +337,30 @@ int vd_trace_any_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_ray
 int vd_shadow_rays_dev(VdCtx* ctx, const float* d_positions, const float* d_normals, uint32_t n_points,
                        const float* light_position, VdRay* d_rays);
 
+/* The CPU harness of the reference, batched on the device.
+ * vd_primary_rays_dev: one ray per pixel from camera->clip_to_world, as src/bin/bvh_cpu.rs:71-83
+ * builds them (pixel i: x = (i % width) / width, y = (i / height) / height - the source's own
+ * row formula; eye = unprojected (x, y, 1), dir = normalised unprojected (x, y, 0)).  camera on
+ * the host, d_rays: width * height rays, device.  The fragment-shader harness
+ * (src/bin/bvh_trace.wgsl:225-234) makes the same rays from interpolated uv.
+ * vd_traverse_iter_dev: `Bvh::traverse_iter` (crates/bvh/src/blas.rs:247-295) for every ray
+ * against ONE mesh (mesh-local node ids, no TLAS): slab test dividing by dir
+ * (intersection.rs:47-55), two-sided triangle test with EPS 1e-4 (intersection.rs:68-92),
+ * near child pushed first.  d_out_dist[i] = closest t, or -1 for Dist::Miss.  The reference's
+ * 32-entry stack panics when it overflows (blas.rs:298-324); here 128 entries and
+ * VD_ERR_STACK_OVERFLOW.                                                                  */
+int vd_primary_rays_dev(VdCtx* ctx, const VdCameraUniform* camera /* host */, uint32_t width,
+                        uint32_t height, VdRay* d_rays);
+int vd_traverse_iter_dev(VdCtx* ctx, const VdBvhNode* d_nodes, uint32_t n_nodes,
+                         const float* d_verts_xyz, const uint32_t* d_indices,
+                         const VdRay* d_rays, uint32_t n_rays, float* d_out_dist);
+/* host-pointer forms (staged through the context, synchronous)                            */
+int vd_primary_rays(VdCtx* ctx, const VdCameraUniform* camera, uint32_t width, uint32_t height,
+                    VdRay* rays);
+int vd_traverse_iter(VdCtx* ctx, const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz,
+                     uint32_t n_vert, const uint32_t* indices /* 3 * n_tri, as vd_bvh_build left them */,
+                     uint32_t n_tri, const VdRay* rays, uint32_t n_rays, float* out_dist);
+
 /* ------------------------------------------------------------------------------------ */
 /* Instance animation  (SURVEY.md §8f N2 — the upstream mutator of the cull / TLAS input)  */
 /* ------------------------------------------------------------------------------------ */

@@ -43,6 +43,7 @@ def load() -> C.CDLL:
             "vd_ref_trace": (_I, [C.POINTER(abi.TraceScene), _P, _U, _P, _P, _I]),
             "vd_ref_traverse_iter": (_I, [_P, _U, _P, _P, _P, _U, _P]),
             "vd_ref_shadow_rays": (_I, [_P, _P, _U, _P, _P]),
+            "vd_ref_primary_rays": (_I, [_P, _U, _U, _P]),
             "vd_ref_compute_update": (_I, [_P, _U, _P, _U, C.c_float, C.c_float, _I]),
             "vd_ref_version": (C.c_char_p, []),
         }
@@ -167,6 +168,13 @@ def shadow_rays(positions, normals, light_position):
     lp = _c(light_position, np.float32).reshape(3)
     out = np.zeros(len(pos), dtype=abi.RAY)
     _chk(load().vd_ref_shadow_rays(pos.ctypes.data, nor.ctypes.data, len(pos), lp.ctypes.data, out.ctypes.data))
+    return out
+
+
+def primary_rays(camera, width, height):
+    cam = _c(camera, abi.CAMERA).reshape(1)
+    out = np.zeros(width * height, dtype=abi.RAY)
+    _chk(load().vd_ref_primary_rays(cam.ctypes.data, width, height, out.ctypes.data))
     return out
 
 

@@ -66,6 +66,9 @@ int vd_ref_trace(const VdTraceScene* scene, const VdRay* rays, uint32_t n_rays, 
 int vd_ref_shadow_rays(const float* positions, const float* normals, uint32_t n_points, const float* light_position,
                        VdRay* out);
 
+/* src/bin/bvh_cpu.rs:71-83: one ray per pixel from camera.clip_to_world */
+int vd_ref_primary_rays(const VdCameraUniform* camera, uint32_t width, uint32_t height, VdRay* out);
+
 int vd_ref_traverse_iter(const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz,
                          const uint32_t* indices, const VdRay* rays, uint32_t n_rays,
                          float* out_dist);

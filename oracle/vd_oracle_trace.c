@@ -288,6 +288,38 @@ int vd_ref_traverse_iter(const VdBvhNode* nodes, uint32_t n_nodes, const float* 
     return VD_OK;
 }
 
+/* Per-pixel primary rays of the CPU harness (src/bin/bvh_cpu.rs:71-83):
+ *   x = (i % WIDTH) / WIDTH; y = (i / HEIGHT) / HEIGHT; (x, y) = ((x, y) - 0.5) * (2, -2);
+ *   view_pos = clip_to_world * (x, y, 1, 1); view_tang = clip_to_world * (x, y, 0, 1);
+ *   eye = view_pos.xyz / view_pos.w; dir = view_tang.xyz.normalize()
+ * The row of pixel i is i / HEIGHT as the source has it (WIDTH == HEIGHT == 640 there).  glam 0.24.1 (not on disk,
+ * from memory): Mat4 * Vec4 = ((c0*x + c1*y) + c2*z) + c3*w; Vec3::normalize = v * (1 / sqrt((x*x + y*y) + z*z)).
+ * The fragment-shader harness (src/bin/bvh_trace.wgsl:225-234) builds the same rays from rasteriser-interpolated
+ * uv and WGSL normalize, neither of which is specified to the bit; this follows the Rust source. */
+int vd_ref_primary_rays(const VdCameraUniform* camera, uint32_t width, uint32_t height, VdRay* out) {
+    const size_t n = (size_t)width * height;
+    if (!camera || (n != 0 && !out)) return VD_ERR_INVALID_ARG;
+    const float* M = camera->clip_to_world;
+    for (size_t i = 0; i < n; ++i) {
+        float x = (float)(i % width) / (float)width;
+        float y = (float)(i / height) / (float)height;
+        x = (x - 0.5f) * 2.0f;
+        y = (y - 0.5f) * -2.0f;
+        float p[4], t[4];
+        for (int r = 0; r < 4; ++r) {
+            p[r] = ((M[r] * x + M[4 + r] * y) + M[8 + r] * 1.0f) + M[12 + r] * 1.0f;
+            t[r] = ((M[r] * x + M[4 + r] * y) + M[8 + r] * 0.0f) + M[12 + r] * 1.0f;
+        }
+        const float rl = 1.0f / sqrtf((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+        memset(&out[i], 0, sizeof(out[i]));
+        for (int k = 0; k < 3; ++k) {
+            out[i].eye[k] = p[k] / p[3];
+            out[i].dir[k] = t[k] * rl;
+        }
+    }
+    return VD_OK;
+}
+
 /* src/bin/raytraced_shadows.wgsl:90 `let light_vec = light.position - pos;` and :97
  * `ray_new(pos + nor * 0.0001, light_vec)`; the pass reads only `.hit` of the traversal (:98-101). */
 int vd_ref_shadow_rays(const float* positions, const float* normals, uint32_t n_points, const float* light_position,

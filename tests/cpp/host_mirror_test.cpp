@@ -125,6 +125,31 @@ int main() {
     REQUIRE(vd_ref_compact(ref_draws.data(), (uint32_t)inst.size(), ref_comp.data(), &ref_count, 1) == VD_OK);
     REQUIRE(count == ref_count && std::memcmp(draws.data(), ref_comp.data(), draws.size() * sizeof(draws[0])) == 0);
 
+    // the CPU harness (src/bin/bvh_cpu.rs:71-96): per-pixel rays from clip_to_world, Bvh::traverse_iter per ray.
+    // clip_to_world here: eye = (x, y, 15), dir = normalize(x, y, -1)
+    {
+        VdCameraUniform hc; std::memset(&hc, 0, sizeof(hc));
+        hc.clip_to_world[0] = 1.0f; hc.clip_to_world[5] = 1.0f;                 // columns 0, 1
+        hc.clip_to_world[10] = 16.0f; hc.clip_to_world[11] = 1.0f;              // column 2 = (0, 0, 16, 1)
+        hc.clip_to_world[14] = -1.0f;                                           // column 3 = (0, 0, -1, 0)
+        const uint32_t W = 96, H = 96;
+        std::vector<VdRay> prim = voidin::primary_rays(gpu, hc, W, H), ref_prim(W * H);
+        REQUIRE(vd_ref_primary_rays(&hc, W, H, ref_prim.data()) == VD_OK);
+        REQUIRE(std::memcmp(prim.data(), ref_prim.data(), prim.size() * sizeof(VdRay)) == 0);
+        voidin::Bvh soup_bvh;
+        soup_bvh.nodes.assign(ref_nodes.begin(), ref_nodes.begin() + ref_n);
+        std::vector<voidin::Dist> dist = soup_bvh.traverse_iter(gpu, soup_v.data(), soup_v.size(),
+                                                                reinterpret_cast<const voidin::UVec3*>(soup_i.data()), 900, prim);
+        std::vector<float> ref_dist(prim.size());
+        REQUIRE(vd_ref_traverse_iter(ref_nodes.data(), ref_n, &soup_v[0].x, ref_i.data(), ref_prim.data(), W * H, ref_dist.data()) == VD_OK);
+        size_t n_h = 0;
+        for (size_t i = 0; i < dist.size(); ++i) {
+            REQUIRE(dist[i].is_hit() == (ref_dist[i] >= 0.0f));
+            if (dist[i].is_hit()) { REQUIRE(std::memcmp(&dist[i].t, &ref_dist[i], 4) == 0); ++n_h; }
+        }
+        REQUIRE(n_h > 100 && n_h < dist.size());
+    }
+
     // error behaviour: degenerate input is an error code, not a crash (blas.rs:137-140 would panic)
     std::vector<voidin::Vec3> tv = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}};
     std::vector<uint32_t> ti; for (int k = 0; k < 5; ++k) { ti.push_back(0); ti.push_back(1); ti.push_back(2); }

@@ -32,6 +32,47 @@ def test_tlas_build_seeded_vs_oracle(ctx, oracle, n):
     assert np.array_equal(wide["min"], want["min"]) and np.array_equal(wide["instance_idx"], want["instance_idx"])
 
 
+def test_cpu_harness_rays_and_traverse_iter(ctx, oracle):
+    """The reference's CPU harness on the device: per-pixel rays (bvh_cpu.rs:71-83) bit-exact,
+    Bvh::traverse_iter (blas.rs:247-295) bit-exact - same visit order, same arithmetic."""
+    import torch
+    cam = synth.camera_uniform(eye=(0, 0, 15), pitch_deg=0)                     # bvh_cpu.rs:134
+    for w, h in ((64, 64), (640, 640), (1, 1)):
+        want = oracle.primary_rays(cam, w, h)
+        d_rays = torch.zeros(w * h * abi.RAY.itemsize, dtype=torch.uint8, device="cuda")
+        ctx.primary_rays_dev(cam, w, h, d_rays)
+        ctx.synchronize()
+        assert d_rays.cpu().numpy().tobytes() == want.tobytes()
+    ctx.primary_rays_dev(cam, 0, 0, None)                                       # nothing to do
+    assert ctx.lib.vd_primary_rays_dev(ctx.h, None, 4, 4, None) == abi.VD_ERR_INVALID_ARG
+    rays = oracle.primary_rays(cam, 160, 160)
+    for name in ("blas_soup64.npz", "blas_sphere_1_10.npz", "blas_knot_2k.npz", "blas_plane.npz"):
+        g = golden(name)
+        want = oracle.traverse_iter(g["nodes"], g["vertices"], g["indices_out"], rays)
+        d_out = torch.full((len(rays),), 7.0, dtype=torch.float32, device="cuda")
+        ctx.traverse_iter_dev(ctx.upload(g["nodes"]), len(g["nodes"]), ctx.upload(g["vertices"].astype(np.float32)),
+                              ctx.upload(g["indices_out"].astype(np.uint32)), ctx.upload(rays), len(rays), d_out)
+        got = d_out.cpu().numpy()
+        assert got.tobytes() == want.tobytes(), name
+        if name != "blas_plane.npz":
+            assert (got >= 0).any() and (got < 0).any()
+    # a freshly built big mesh, rays from all around it (two-sided test: back faces count)
+    v, i = synth.knot_mesh(256, 64)
+    nodes, idx = ctx.bvh_build(v, i)
+    n = 20000
+    u = synth.uniform01(synth.SEED_BASE + 31, 0, 6 * n).reshape(n, 6).astype(np.float64)
+    o = u[:, :3] * 2 - 1
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * 6.0
+    t = (u[:, 3:] * 2 - 1) * 1.5
+    rs = np.zeros(n, dtype=abi.RAY)
+    rs["eye"], rs["dir"] = o, (t - o) / np.linalg.norm(t - o, axis=1, keepdims=True)
+    want = oracle.traverse_iter(nodes, v, idx, rs)
+    d_out = torch.zeros(len(rs), dtype=torch.float32, device="cuda")
+    ctx.traverse_iter_dev(ctx.upload(nodes), len(nodes), ctx.upload(v.astype(np.float32)), ctx.upload(idx), ctx.upload(rs), len(rs), d_out)
+    assert d_out.cpu().numpy().tobytes() == want.tobytes()
+    assert ctx.lib.vd_traverse_iter_dev(ctx.h, None, 0, None, None, None, 4, None) == abi.VD_ERR_INVALID_ARG
+
+
 def test_tlas_build_with_nan_and_inf_boxes(ctx, oracle):
     """A NaN or infinite transform makes leaf boxes with NaN / inf: the builder then runs its total-order
     (exact) scan arithmetic instead of the NaN-free fast path; both must reproduce the oracle's chain."""

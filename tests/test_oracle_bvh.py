@@ -162,6 +162,21 @@ def test_trace_brute_force_agrees(oracle):
     assert np.allclose(best[hit], want[hit], rtol=1e-4)
 
 
+def test_primary_rays_follow_the_cpu_harness(oracle):
+    """vd_ref_primary_rays (bvh_cpu.rs:71-83) against the float64 numpy restatement: fp32 rounding apart."""
+    cam = synth.camera_uniform(eye=(0, 0, 15), pitch_deg=0)
+    for w, h in ((48, 48), (64, 64), (1, 1)):
+        got = oracle.primary_rays(cam, w, h)
+        want = synth.primary_rays(cam, w, h)
+        assert np.abs(got["eye"] - want["eye"]).max() < 1e-5 and np.abs(got["dir"] - want["dir"]).max() < 1e-6
+        assert np.abs(np.linalg.norm(got["dir"].astype(np.float64), axis=1) - 1).max() < 1e-6
+        assert not got["_pad0"].any() and not got["_pad1"].any()
+    # centre pixel of an even grid looks straight down -z from the eye (camera yaw 0 pitch 0)
+    r = oracle.primary_rays(cam, 64, 64)[32 * 64 + 32]
+    assert np.allclose(r["dir"], (0, 0, -1), atol=1e-6) and np.allclose(r["eye"][:2], (0, 0), atol=1e-4)
+    assert len(oracle.primary_rays(cam, 0, 0)) == 0
+
+
 def test_rust_cpu_traversal_variant(oracle):
     # R2 (blas.rs:247-295): two-sided, divides by dir; agrees with R1 on front-facing hits
     g = golden("blas_soup64.npz")

@@ -108,6 +108,10 @@ PROTOTYPES = {
     "vd_release_external_buffer": (_I, [_P, _P]),
     "vd_trace_any_dev": (_I, [_P, C.POINTER(TraceScene), _P, _U, _P]),
     "vd_shadow_rays_dev": (_I, [_P, _P, _P, _U, C.POINTER(C.c_float), _P]),
+    "vd_primary_rays_dev": (_I, [_P, _P, _U, _U, _P]),
+    "vd_traverse_iter_dev": (_I, [_P, _P, _U, _P, _P, _P, _U, _P]),
+    "vd_primary_rays": (_I, [_P, _P, _U, _U, _P]),
+    "vd_traverse_iter": (_I, [_P, _P, _U, _P, _U, _P, _U, _P, _U, _P]),
     "vd_compute_update_dev": (_I, [_P, _P, _U, _P, _U, C.c_float, C.c_float, _I]),
     "vd_ctx_set_timing": (_I, [_P, _I]),
     "vd_last_gpu_ms": (C.c_float, [_P]),

@@ -215,6 +215,110 @@ __global__ __launch_bounds__(256) void shadow_rays_kernel(const float* __restric
     rays[i] = r;
 }
 
+// One ray per pixel as the CPU harness makes them (src/bin/bvh_cpu.rs:71-83): pixel i -> x = (i % W) / W,
+// y = (i / H) / H (the source divides by HEIGHT for the row; W == H == 640 there), ((x, y) - 0.5) * (2, -2),
+// eye = (clip_to_world * (x, y, 1, 1)).xyz / .w, dir = normalize((clip_to_world * (x, y, 0, 1)).xyz).
+struct Mat4 { float m[16]; };
+__global__ __launch_bounds__(256) void primary_rays_kernel(Mat4 c2w, unsigned width, unsigned height, unsigned n, VdRay* __restrict__ rays) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float* M = c2w.m;
+    float x = (float)(i % width) / (float)width;
+    float y = (float)(i / height) / (float)height;
+    x = (x - 0.5f) * 2.0f;
+    y = (y - 0.5f) * -2.0f;
+    float p[4], t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        p[r] = ((M[r] * x + M[4 + r] * y) + M[8 + r] * 1.0f) + M[12 + r] * 1.0f;
+        t[r] = ((M[r] * x + M[4 + r] * y) + M[8 + r] * 0.0f) + M[12 + r] * 1.0f;
+    }
+    const float rl = 1.0f / sqrtf((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+    VdRay r;
+    r.eye[0] = p[0] / p[3]; r.eye[1] = p[1] / p[3]; r.eye[2] = p[2] / p[3]; r._pad0 = 0.0f;
+    r.dir[0] = t[0] * rl; r.dir[1] = t[1] * rl; r.dir[2] = t[2] * rl; r._pad1 = 0.0f;
+    rays[i] = r;
+}
+
+// `Bvh::traverse_iter` of the CPU harness (crates/bvh/src/blas.rs:247-295): one mesh, no TLAS.  It is NOT the WGSL
+// walk above: the slab test divides by dir (intersection.rs:47-55), the triangle test is two-sided with EPS = 1e-4
+// on the determinant and on t (intersection.rs:68-92), a child whose box is missed is never pushed, the near child
+// is pushed first (so the far one is popped first), and pruning uses the closest hit so far or 1e30.  One lane per
+// ray walks exactly that sequence.  The reference's stack holds 32 entries and panics past them (blas.rs:298-324);
+// here 128, and overflow is an error code.  out_dist[r] = closest t, or -1 for Dist::Miss.
+constexpr int kIterStack = 128;
+struct DistRs { bool hit; float t; };
+__device__ __forceinline__ DistRs intersect_aabb_rs(float ox, float oy, float oz, float dx, float dy, float dz,
+                                                    const float* mn, const float* mx, float t) {
+    const float ax = (mn[0] - ox) / dx, ay = (mn[1] - oy) / dy, az = (mn[2] - oz) / dz;
+    const float bx = (mx[0] - ox) / dx, by = (mx[1] - oy) / dy, bz = (mx[2] - oz) / dz;
+    const float tmax = min3(fmaxf(ax, bx), fmaxf(ay, by), fmaxf(az, bz));
+    const float tmin = max3(fminf(ax, bx), fminf(ay, by), fminf(az, bz));
+    return DistRs{tmax >= tmin && tmin < t && tmax > 0.0f, tmin};
+}
+// intersection.rs:68-92; t, or -1 for Miss
+__device__ __forceinline__ float ray_intersect_rs(float ox, float oy, float oz, float dx, float dy, float dz,
+                                                  const float* v0, const float* v1, const float* v2) {
+    constexpr float EPS = 0.0001f;
+    const float e1x = v1[0] - v0[0], e1y = v1[1] - v0[1], e1z = v1[2] - v0[2];
+    const float e2x = v2[0] - v0[0], e2y = v2[1] - v0[1], e2z = v2[2] - v0[2];
+    const float hx = dy * e2z - e2y * dz, hy = dz * e2x - e2z * dx, hz = dx * e2y - e2x * dy;   // dir x edge2
+    const float a = dot3(e1x, e1y, e1z, hx, hy, hz);
+    if (-EPS < a && a < EPS) return -1.0f;
+    const float f = 1.0f / a;
+    const float sx = ox - v0[0], sy = oy - v0[1], sz = oz - v0[2];
+    const float u = f * dot3(sx, sy, sz, hx, hy, hz);
+    if (!(0.0f <= u && u <= 1.0f)) return -1.0f;
+    const float qx = sy * e1z - e1y * sz, qy = sz * e1x - e1z * sx, qz = sx * e1y - e1x * sy;   // s x edge1
+    const float v = f * dot3(dx, dy, dz, qx, qy, qz);
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    const float t = f * dot3(e2x, e2y, e2z, qx, qy, qz);
+    return t > EPS ? t : -1.0f;
+}
+
+__global__ __launch_bounds__(64) void traverse_iter_kernel(const VdBvhNode* __restrict__ nodes, const float* __restrict__ verts,
+                                                           const unsigned* __restrict__ indices, const VdRay* __restrict__ rays,
+                                                           unsigned n_rays, float* __restrict__ out_dist, unsigned* __restrict__ overflow) {
+    const unsigned r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= n_rays) return;
+    const float4 e4 = reinterpret_cast<const float4*>(rays + r)[0], d4 = reinterpret_cast<const float4*>(rays + r)[1];
+    const float ox = e4.x, oy = e4.y, oz = e4.z, dx = d4.x, dy = d4.y, dz = d4.z;
+    unsigned stack[kIterStack];
+    int head = 0;
+    stack[head++] = 0u;
+    float hit = -1.0f;   // Dist::Miss
+    bool ovf = false;
+    while (head > 0) {
+        const VdBvhNode node = nodes[stack[--head]];
+        if (node.count > 0u) {
+            for (unsigned i = 0; i < node.count; ++i) {
+                const unsigned* idx = indices + 3u * (size_t)(node.left_first + i);
+                const float d = ray_intersect_rs(ox, oy, oz, dx, dy, dz, verts + 3u * (size_t)idx[0], verts + 3u * (size_t)idx[1],
+                                                 verts + 3u * (size_t)idx[2]);
+                if (d >= 0.0f) hit = hit >= 0.0f ? fminf(hit, d) : d;
+            }
+        } else {
+            unsigned min_index = node.left_first, max_index = node.left_first + 1u;
+            const VdBvhNode mc = nodes[min_index], xc = nodes[max_index];
+            const float lim = hit >= 0.0f ? hit : kMaxDist;
+            DistRs min_dist = intersect_aabb_rs(ox, oy, oz, dx, dy, dz, mc.min, mc.max, lim);
+            DistRs max_dist = intersect_aabb_rs(ox, oy, oz, dx, dy, dz, xc.min, xc.max, lim);
+            // derive(PartialOrd) on enum Dist { Hit(f32), Miss } (intersection.rs:22-26): Hit(x) < Miss
+            const bool gt = min_dist.hit != max_dist.hit ? !min_dist.hit : (min_dist.hit && min_dist.t > max_dist.t);
+            if (gt) {
+                const unsigned ti = min_index; min_index = max_index; max_index = ti;
+                const DistRs td = min_dist; min_dist = max_dist; max_dist = td;
+            }
+            if (!min_dist.hit) continue;
+            if (head + 2 > kIterStack) { ovf = true; break; }
+            stack[head++] = min_index;
+            if (max_dist.hit) stack[head++] = max_index;
+        }
+    }
+    out_dist[r] = hit;
+    if (ovf) atomicOr(overflow, 1u);
+}
+
 int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out, uint32_t* d_any = nullptr) {
     // idle waves keep drawing from the ray counter after the last ray: leave it room below 2^32
     if (n_rays > 0xf0000000u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: more than 0xf0000000 rays in one call");
@@ -272,6 +376,41 @@ int vd_shadow_rays_dev(VdCtx* ctx, const float* d_positions, const float* d_norm
     return VD_OK;
 }
 
+int vd_primary_rays_dev(VdCtx* ctx, const VdCameraUniform* camera, uint32_t width, uint32_t height, VdRay* d_rays) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!camera) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_primary_rays: null camera");
+    const uint64_t n = (uint64_t)width * height;
+    if (n == 0) return VD_OK;
+    if (!d_rays) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_primary_rays: null rays");
+    if (n > 0xffffff00ull) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_primary_rays: width * height does not fit 32 bits");
+    Mat4 c2w;
+    for (int k = 0; k < 16; ++k) c2w.m[k] = camera->clip_to_world[k];
+    hipLaunchKernelGGL(primary_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, c2w, width, height, (unsigned)n, d_rays);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    return VD_OK;
+}
+
+int vd_traverse_iter_dev(VdCtx* ctx, const VdBvhNode* d_nodes, uint32_t n_nodes, const float* d_verts_xyz, const uint32_t* d_indices,
+                         const VdRay* d_rays, uint32_t n_rays, float* d_out_dist) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!d_nodes || n_nodes == 0 || !d_verts_xyz || !d_indices) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse_iter: incomplete mesh");
+    if (n_rays == 0) return VD_OK;
+    if (!d_rays || !d_out_dist) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse_iter: null rays/out");
+    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256);
+    if (rc) return rc;
+    unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);
+    vd_time_begin(ctx);
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(traverse_iter_kernel, dim3((n_rays + 63u) / 64u), dim3(64), 0, ctx->stream, d_nodes, d_verts_xyz, d_indices, d_rays,
+                       n_rays, d_out_dist, d_flag);
+    vd_time_end(ctx);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->host_pinned[0]) VD_FAIL(ctx, VD_ERR_STACK_OVERFLOW, "vd_traverse_iter: traversal stack (128 entries per ray) exceeded");
+    return VD_OK;
+}
+
 int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t n_rays, VdHit* out) {
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!scene_ok(scene)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: incomplete scene");
@@ -302,6 +441,45 @@ int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t 
     rc = launch_trace(ctx, &d, reinterpret_cast<const VdRay*>(base + off[6]), n_rays, d_out);
     if (rc) return rc;
     VD_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, sz[7], hipMemcpyDeviceToHost, ctx->stream));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VD_OK;
+}
+
+int vd_primary_rays(VdCtx* ctx, const VdCameraUniform* camera, uint32_t width, uint32_t height, VdRay* rays) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    const uint64_t n = (uint64_t)width * height;
+    if (n && !rays) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_primary_rays: null rays");
+    int rc = vd_ensure(ctx, &ctx->stage_out, &ctx->stage_out_bytes, (size_t)n * sizeof(VdRay));
+    if (rc) return rc;
+    rc = vd_primary_rays_dev(ctx, camera, width, height, reinterpret_cast<VdRay*>(ctx->stage_out));
+    if (rc || n == 0) return rc;
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(rays, ctx->stage_out, (size_t)n * sizeof(VdRay), hipMemcpyDeviceToHost, ctx->stream));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VD_OK;
+}
+
+int vd_traverse_iter(VdCtx* ctx, const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz, uint32_t n_vert,
+                     const uint32_t* indices, uint32_t n_tri, const VdRay* rays, uint32_t n_rays, float* out_dist) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!nodes || n_nodes == 0 || !verts_xyz || !indices) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse_iter: incomplete mesh");
+    if (n_rays == 0) return VD_OK;
+    if (!rays || !out_dist) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse_iter: null rays/out");
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t sz[5] = {(size_t)n_nodes * sizeof(VdBvhNode), (size_t)n_vert * 12, (size_t)n_tri * 12, (size_t)n_rays * sizeof(VdRay),
+                          (size_t)n_rays * 4};
+    const void* src[4] = {nodes, verts_xyz, indices, rays};
+    size_t off[5], total = 0;
+    for (int k = 0; k < 5; ++k) { off[k] = total; total += (sz[k] + 255) & ~(size_t)255; }
+    int rc = vd_ensure(ctx, &ctx->stage_in, &ctx->stage_in_bytes, total);
+    if (rc) return rc;
+    char* base = reinterpret_cast<char*>(ctx->stage_in);
+    for (int k = 0; k < 4; ++k)
+        if (sz[k]) VD_HIP_CHECK(ctx, hipMemcpyAsync(base + off[k], src[k], sz[k], hipMemcpyHostToDevice, ctx->stream));
+    float* d_out = reinterpret_cast<float*>(base + off[4]);
+    rc = vd_traverse_iter_dev(ctx, reinterpret_cast<const VdBvhNode*>(base + off[0]), n_nodes, reinterpret_cast<const float*>(base + off[1]),
+                              reinterpret_cast<const uint32_t*>(base + off[2]), reinterpret_cast<const VdRay*>(base + off[3]), n_rays, d_out);
+    if (rc) return rc;
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(out_dist, d_out, sz[4], hipMemcpyDeviceToHost, ctx->stream));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return VD_OK;
 }

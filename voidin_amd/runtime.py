@@ -233,6 +233,16 @@ class Context:
         lp = (C.c_float * 3)(*[float(x) for x in light_position])
         self._chk(self.lib.vd_shadow_rays_dev(self.h, abi.ptr(d_positions), abi.ptr(d_normals), n_points, lp, abi.ptr(d_rays)))
 
+    def primary_rays_dev(self, camera, width, height, d_rays):
+        """One ray per pixel from camera.clip_to_world (src/bin/bvh_cpu.rs:71-83); d_rays: width*height rays."""
+        cam = np.ascontiguousarray(camera, dtype=abi.CAMERA).reshape(1)
+        self._chk(self.lib.vd_primary_rays_dev(self.h, cam.ctypes.data, width, height, abi.ptr(d_rays)))
+
+    def traverse_iter_dev(self, d_nodes, n_nodes, d_verts, d_indices, d_rays, n_rays, d_out_dist):
+        """Bvh::traverse_iter (crates/bvh/src/blas.rs:247-295) for a batch of rays against one mesh; -1 = Miss."""
+        self._chk(self.lib.vd_traverse_iter_dev(self.h, abi.ptr(d_nodes), n_nodes, abi.ptr(d_verts), abi.ptr(d_indices),
+                                                abi.ptr(d_rays), n_rays, abi.ptr(d_out_dist)))
+
 
 # ------------------------------------------------------------------------------------------
 # Reference-shaped façade
