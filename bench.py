@@ -364,6 +364,28 @@ def main():
             ctx.set_timing(False)
             res[tag] = {"Mrays_per_s": round(w * w / min(tt) / 1e3, 1), "hit_fraction": round(float((d_t >= 0).float().mean()), 3)}
         extra["traverse_iter_cpu_harness"] = res
+        # EXTENSION, no reference counterpart: depth pyramid of a 1920 x 1080 buffer + occlusion refinement
+        # of the frustum mask of the headline's 10 M instances (a synthetic depth buffer: half the screen covered)
+        W, H = 1920, 1080
+        depth = np.zeros((H, W), dtype=np.float32)
+        depth[:, : W // 2] = np.float32(0.001 / 40.0)
+        Lz = ctx.hiz_layout(W, H)
+        d_depth, d_pyr = ctx.upload(depth), torch.zeros(Lz.total_texels, dtype=torch.float32, device=dev)
+        d_mask = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+        d_mask2 = torch.zeros_like(d_mask)
+        ctx.cull_mask_dev(cam, d_m, len(meshes), d_i, n, d_mask)
+        ctx.set_timing(True)
+        t_p, t_o = [], []
+        for _ in range(5):
+            ctx.hiz_build_dev(d_depth, W, H, d_pyr); t_p.append(ctx.last_gpu_ms())
+            ctx.occlusion_mask_dev(cam, d_m, len(meshes), d_i, n, d_pyr, W, H, d_mask, d_mask2); t_o.append(ctx.last_gpu_ms())
+        ctx.set_timing(False)
+        pop = lambda t: int(sum(bin(int(x) & 0xFFFFFFFFFFFFFFFF).count("1") for x in t.cpu().numpy()[:4096]))
+        extra["occlusion_extension"] = {"note": "extension, no reference counterpart", "depth": f"{W}x{H}",
+                                        "pyramid_build_ms": round(min(t_p), 4), "occlusion_mask_ms": round(min(t_o), 4),
+                                        "instances": n, "GBps_instances_read": round(n * 144 / min(t_o) / 1e6, 1),
+                                        "kept_of_first_262144_frustum_visible": [pop(d_mask2), pop(d_mask)]}
+        del d_depth, d_pyr, d_mask, d_mask2
 
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_cull_pmc.json")

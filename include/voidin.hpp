@@ -381,6 +381,29 @@ inline std::vector<VdHit> traverse_tlas(const Gpu& gpu, const VdTraceScene& scen
     return out;
 }
 
+// EXTENSION (no reference counterpart: README.md:33 only links "Two-Pass Occlusion Culling"): the second pass of that
+// scheme.  `build` turns the depth buffer the first pass rendered into a min pyramid; `refine` clears, in a frustum
+// mask made by vd_cull_mask_dev, the bits of instances hidden behind it; vd_expand_mask_dev then makes the draw list.
+class HizPyramid {
+   public:
+    HizPyramid(const Gpu& gpu, uint32_t width, uint32_t height) : gpu_(gpu) { gpu.check(vd_hiz_layout(width, height, &layout_)); }
+    const VdHizLayout& layout() const { return layout_; }
+    size_t bytes() const { return (size_t)layout_.total_texels * sizeof(float); }
+    // d_pyramid: bytes() of device memory owned by the caller
+    void build(const float* d_depth, float* d_pyramid) const {
+        gpu_.check(vd_hiz_build_dev(gpu_.ctx(), d_depth, layout_.width, layout_.height, d_pyramid));
+    }
+    void refine(const CameraUniform& camera, const MeshInfo* d_meshes, uint32_t n_meshes, const Instance* d_instances, uint32_t n_instances,
+                const float* d_pyramid, const uint64_t* d_mask_in, uint64_t* d_mask_out) const {
+        gpu_.check(vd_occlusion_mask_dev(gpu_.ctx(), &camera, d_meshes, n_meshes, d_instances, n_instances, d_pyramid, layout_.width,
+                                         layout_.height, d_mask_in, d_mask_out));
+    }
+
+   private:
+    const Gpu& gpu_;
+    VdHizLayout layout_{};
+};
+
 // The shadow pass's occlusion test (src/bin/raytraced_shadows.wgsl:90-102) for one point light: one ray per G-buffer
 // point, `occluded[i]` = traverse_tlas(ray).hit.  Scene pointers, positions and normals are device memory.
 inline void shadow_occlusion(const Gpu& gpu, const VdTraceScene& d_scene, const float* d_positions, const float* d_normals,

@@ -362,6 +362,52 @@ int vd_traverse_iter(VdCtx* ctx, const VdBvhNode* nodes, uint32_t n_nodes, const
                      uint32_t n_tri, const VdRay* rays, uint32_t n_rays, float* out_dist);
 
 /* ------------------------------------------------------------------------------------ */
+/* Occlusion culling  (SURVEY.md §8a C4 / §8f N4 — EXTENSION, no reference counterpart)     */
+/* ------------------------------------------------------------------------------------ */
+/* voidin has no occlusion culling: its README (README.md:33) only links "Two-Pass Occlusion
+ * Culling".  These entry points are the building blocks of that scheme on top of the cull
+ * path, defined here and nowhere else; they are OFF in every parity run (nothing in
+ * vd_cull_* calls them).  All device pointers.
+ *
+ * Depth convention: the reference's camera (perspective_infinite_reverse_rh, camera.rs:130-148):
+ * right-handed view space looking down -z, reverse Z — depth = ndc z, 1 at the near plane, 0 at
+ * infinity, cleared to 0; GREATER is nearer.  projection[11] must be -1 and projection[15] 0.
+ *
+ * Pyramid: level 0 = the depth buffer (width x height, row-major, row 0 = top = ndc y +1);
+ * level k texel (x, y) = MIN (= farthest) of the level k-1 texels (2x..2x+1, 2y..2y+1) that
+ * exist; level dims halve rounding up until 1 x 1.  vd_hiz_layout gives sizes and offsets
+ * (host only, no context); the pyramid buffer holds total_texels floats.
+ *
+ * vd_occlusion_mask_dev: mask_out = mask_in with the bit of every OCCLUDED instance cleared
+ * (bit i of word i/64 = instance i, as vd_cull_mask_dev writes them; in-place allowed).
+ * Instance i is occluded when all of this holds, in fp32, in this order, no FMA:
+ *   c  = ((view * transform) * vec4((mesh.min + mesh.max) / 2, 1)).xyz      (as emit_draws.wgsl:14-15)
+ *   r  = length(mesh.max - mesh.min) * 0.5 * max_scale(transform)  — a TRUE bounding radius
+ *        (emit_draws.wgsl:19's radius is kept bug-compatible in the frustum test; it is always
+ *        >= this one but usually reaches the camera, which would disable the test)
+ *   d = -c.z, dn = d - r;  dn > camera.znear            (whole sphere beyond the near plane)
+ *   tangent slopes of the sphere seen from the eye, per axis a in {x, y}, t = sqrt(c.a^2 + d^2 - r^2):
+ *     lo = (c.a t - r d) / (d t + c.a r),  hi = (c.a t + r d) / (d t - c.a r),  both divisors > 0
+ *   ndc = P[0] * slope_x - P[8],  P[5] * slope_y - P[9];  texel range = ndc -> pixels, widened by
+ *     half a texel each side, clipped to the screen (entirely off screen: not occluded)
+ *   level = number of bits of max(x1 - x0, y1 - y0) (so the range is <= 2 x 2 texels there)
+ *   hmin = min of the four corner texels of the range at that level
+ *   (P[14] - P[10] * dn) / dn  <  hmin                  (nearest point of the sphere is farther)
+ * Anything NaN fails a comparison and leaves the instance visible.                          */
+typedef struct VdHizLayout {
+    uint32_t width, height, n_levels, total_texels;
+    uint32_t level_offset[17], level_width[17], level_height[17];   /* in texels                */
+} VdHizLayout;
+int vd_hiz_layout(uint32_t width, uint32_t height, VdHizLayout* out);   /* width * height <= 2^30 */
+int vd_hiz_build_dev(VdCtx* ctx, const float* d_depth, uint32_t width, uint32_t height,
+                     float* d_pyramid);
+int vd_occlusion_mask_dev(VdCtx* ctx, const VdCameraUniform* camera /* host */,
+                          const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                          const VdInstance* d_instances, uint32_t n_inst,
+                          const float* d_pyramid, uint32_t width, uint32_t height,
+                          const uint64_t* d_mask_in, uint64_t* d_mask_out);
+
+/* ------------------------------------------------------------------------------------ */
 /* Instance animation  (SURVEY.md §8f N2 — the upstream mutator of the cull / TLAS input)  */
 /* ------------------------------------------------------------------------------------ */
 /* Replaces the `update` compute pass (shaders/compute_update.wgsl:10-28, recorded by

@@ -44,6 +44,9 @@ def load() -> C.CDLL:
             "vd_ref_traverse_iter": (_I, [_P, _U, _P, _P, _P, _U, _P]),
             "vd_ref_shadow_rays": (_I, [_P, _P, _U, _P, _P]),
             "vd_ref_primary_rays": (_I, [_P, _U, _U, _P]),
+            "vd_ref_hiz_layout": (_I, [_U, _U, _P]),
+            "vd_ref_hiz_build": (_I, [_P, _U, _U, _P]),
+            "vd_ref_occlusion_mask": (_I, [_P, _P, _U, _P, _U, _P, _U, _U, _P, _P]),
             "vd_ref_compute_update": (_I, [_P, _U, _P, _U, C.c_float, C.c_float, _I]),
             "vd_ref_version": (C.c_char_p, []),
         }
@@ -175,6 +178,29 @@ def primary_rays(camera, width, height):
     cam = _c(camera, abi.CAMERA).reshape(1)
     out = np.zeros(width * height, dtype=abi.RAY)
     _chk(load().vd_ref_primary_rays(cam.ctypes.data, width, height, out.ctypes.data))
+    return out
+
+
+def hiz_layout(width, height):
+    L = abi.HizLayout()
+    _chk(load().vd_ref_hiz_layout(width, height, C.byref(L)))
+    return L
+
+
+def hiz_build(depth):
+    depth = _c(depth, np.float32)
+    h, w = depth.shape
+    out = np.zeros(hiz_layout(w, h).total_texels, dtype=np.float32)
+    _chk(load().vd_ref_hiz_build(depth.ctypes.data, w, h, out.ctypes.data))
+    return out
+
+
+def occlusion_mask(camera, meshes, instances, pyramid, width, height, mask_in):
+    cam, meshes, instances = _c(camera, abi.CAMERA).reshape(1), _c(meshes, abi.MESH_INFO), _c(instances, abi.INSTANCE)
+    pyramid, mask_in = _c(pyramid, np.float32), _c(mask_in, np.uint64)
+    out = np.zeros_like(mask_in)
+    _chk(load().vd_ref_occlusion_mask(cam.ctypes.data, meshes.ctypes.data, len(meshes), instances.ctypes.data, len(instances),
+                                      pyramid.ctypes.data, width, height, mask_in.ctypes.data, out.ctypes.data))
     return out
 
 

@@ -73,6 +73,13 @@ int vd_ref_traverse_iter(const VdBvhNode* nodes, uint32_t n_nodes, const float* 
                          const uint32_t* indices, const VdRay* rays, uint32_t n_rays,
                          float* out_dist);
 
+/* CPU twin of the HiZ occlusion extension (no reference code exists: SURVEY.md 8a C4); definitions in voidin_abi.h */
+int vd_ref_hiz_layout(uint32_t width, uint32_t height, VdHizLayout* out);
+int vd_ref_hiz_build(const float* depth, uint32_t width, uint32_t height, float* pyramid);
+int vd_ref_occlusion_mask(const VdCameraUniform* camera, const VdMeshInfo* meshes, uint32_t n_mesh,
+                          const VdInstance* instances, uint32_t n_inst, const float* pyramid, uint32_t width,
+                          uint32_t height, const uint64_t* mask_in, uint64_t* mask_out);
+
 /* shaders/compute_update.wgsl:10-28 (+ fix-forward of inv_transform) */
 int vd_ref_compute_update(const uint32_t* indices, uint32_t n_indices, VdInstance* instances,
                           uint32_t n_instances, float time, float dt, int fix_inverse);

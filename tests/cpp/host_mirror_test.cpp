@@ -125,6 +125,36 @@ int main() {
     REQUIRE(vd_ref_compact(ref_draws.data(), (uint32_t)inst.size(), ref_comp.data(), &ref_count, 1) == VD_OK);
     REQUIRE(count == ref_count && std::memcmp(draws.data(), ref_comp.data(), draws.size() * sizeof(draws[0])) == 0);
 
+    // occlusion extension through the mirror: frustum mask -> pyramid of a near wall -> refined mask, against the twin
+    {
+        VdCameraUniform oc = cam;
+        oc.projection[0] = 0.8f; oc.projection[5] = 1.0f; oc.projection[11] = -1.0f; oc.projection[14] = 0.001f;
+        const uint32_t W = 320, H = 200;
+        voidin::HizPyramid hiz(gpu, W, H);
+        std::vector<float> depth((size_t)W * H, 0.0f);
+        for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W / 2; ++x) depth[(size_t)y * W + x] = 0.001f / 30.0f;   // wall 30 units away, left half
+        float *d_depth, *d_pyr; uint64_t* d_mask;
+        const size_t words = (inst.size() + 63) / 64;
+        REQUIRE(hipMalloc(&d_depth, depth.size() * 4) == hipSuccess && hipMalloc(&d_pyr, hiz.bytes()) == hipSuccess);
+        REQUIRE(hipMalloc(&d_mask, words * 8) == hipSuccess);
+        REQUIRE(hipMemcpy(d_depth, depth.data(), depth.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
+        REQUIRE(vd_cull_mask_dev(gpu.ctx(), &oc, d_mesh, 2, d_inst, (uint32_t)inst.size(), d_mask) == VD_OK);
+        std::vector<uint64_t> frustum(words), refined(words), ref_refined(words);
+        REQUIRE(hipMemcpy(frustum.data(), d_mask, words * 8, hipMemcpyDeviceToHost) == hipSuccess);
+        hiz.build(d_depth, d_pyr);
+        hiz.refine(oc, d_mesh, 2, d_inst, (uint32_t)inst.size(), d_pyr, d_mask, d_mask);
+        REQUIRE(hipMemcpy(refined.data(), d_mask, words * 8, hipMemcpyDeviceToHost) == hipSuccess);
+        std::vector<float> ref_pyr(hiz.layout().total_texels);
+        REQUIRE(vd_ref_hiz_build(depth.data(), W, H, ref_pyr.data()) == VD_OK);
+        REQUIRE(vd_ref_occlusion_mask(&oc, pool.mesh_info_cpu.data(), 2, inst.data(), (uint32_t)inst.size(), ref_pyr.data(), W, H,
+                                      frustum.data(), ref_refined.data()) == VD_OK);
+        REQUIRE(refined == ref_refined);
+        size_t a = 0, b = 0;
+        for (size_t w = 0; w < words; ++w) { a += __builtin_popcountll(frustum[w]); b += __builtin_popcountll(refined[w]); }
+        REQUIRE(b < a && b > 0);
+        hipFree(d_depth); hipFree(d_pyr); hipFree(d_mask);
+    }
+
     // the CPU harness (src/bin/bvh_cpu.rs:71-96): per-pixel rays from clip_to_world, Bvh::traverse_iter per ray.
     // clip_to_world here: eye = (x, y, 15), dir = normalize(x, y, -1)
     {

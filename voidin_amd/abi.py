@@ -71,6 +71,12 @@ class TraceScene(C.Structure):
                 ("indices", C.c_void_p), ("n_indices", C.c_uint32)]
 
 
+class HizLayout(C.Structure):
+    """VdHizLayout (include/voidin_abi.h, occlusion extension): sizes and texel offsets of the depth pyramid."""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("n_levels", C.c_uint32), ("total_texels", C.c_uint32),
+                ("level_offset", C.c_uint32 * 17), ("level_width", C.c_uint32 * 17), ("level_height", C.c_uint32 * 17)]
+
+
 _P = C.c_void_p
 _U = C.c_uint32
 _I = C.c_int
@@ -112,6 +118,9 @@ PROTOTYPES = {
     "vd_traverse_iter_dev": (_I, [_P, _P, _U, _P, _P, _P, _U, _P]),
     "vd_primary_rays": (_I, [_P, _P, _U, _U, _P]),
     "vd_traverse_iter": (_I, [_P, _P, _U, _P, _U, _P, _U, _P, _U, _P]),
+    "vd_hiz_layout": (_I, [_U, _U, _P]),
+    "vd_hiz_build_dev": (_I, [_P, _P, _U, _U, _P]),
+    "vd_occlusion_mask_dev": (_I, [_P, _P, _P, _U, _P, _U, _P, _U, _U, _P, _P]),
     "vd_compute_update_dev": (_I, [_P, _P, _U, _P, _U, C.c_float, C.c_float, _I]),
     "vd_ctx_set_timing": (_I, [_P, _I]),
     "vd_last_gpu_ms": (C.c_float, [_P]),

@@ -307,6 +307,93 @@ __global__ __launch_bounds__(kBlock, 3) void cull_mask_kernel(CullCamera cam, co
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Occlusion extension (no reference counterpart — definition in include/voidin_abi.h,
+// "Occlusion culling"; pyramid built by hiz.hip).  mask_out = mask_in minus the instances whose bounding sphere lies
+// behind the depth pyramid.  Words of mask_in that are 0 cost nothing: their 9 KB of instances are not read, which
+// is the common case in the second pass of the two-pass scheme.
+// ------------------------------------------------------------------------------------------
+struct OccCamera { float view[16]; float p00, p11, p20, p21, p22, p32, znear; };
+struct HizView { const float* base; unsigned width, height, n_levels; unsigned off[17]; };
+
+__device__ __forceinline__ bool is_occluded(const OccCamera& cam, const HizView& hz, const MeshRec& m, const float4 T0, const float4 T1,
+                                            const float4 T2, const float4 T3) {
+    const float* V = cam.view;
+    const float c0x = (m.mxx + m.mnx) / 2.0f, c0y = (m.mxy + m.mny) / 2.0f, c0z = (m.mxz + m.mnz) / 2.0f;
+    float c[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float v0 = V[r], v1 = V[4 + r], v2 = V[8 + r], v3 = V[12 + r];
+        const float m0 = ((v0 * T0.x + v1 * T0.y) + v2 * T0.z) + v3 * T0.w;
+        const float m1 = ((v0 * T1.x + v1 * T1.y) + v2 * T1.z) + v3 * T1.w;
+        const float m2 = ((v0 * T2.x + v1 * T2.y) + v2 * T2.z) + v3 * T2.w;
+        const float m3 = ((v0 * T3.x + v1 * T3.y) + v2 * T3.z) + v3 * T3.w;
+        c[r] = ((m0 * c0x + m1 * c0y) + m2 * c0z) + m3 * 1.0f;
+    }
+    const float sx = len3(T0.x, T0.y, T0.z), sy = len3(T1.x, T1.y, T1.z), sz = len3(T2.x, T2.y, T2.z);
+    const float max_scale = fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz));
+    const float r = (len3(m.mxx - m.mnx, m.mxy - m.mny, m.mxz - m.mnz) * 0.5f) * max_scale;
+    const float d = -c[2];
+    const float dn = d - r;
+    if (!(dn > cam.znear)) return false;
+    const float rr = r * r, dd = d * d, rd = r * d;
+    const float tx = sqrtf((c[0] * c[0] + dd) - rr), ty = sqrtf((c[1] * c[1] + dd) - rr);
+    const float dxm = d * tx + c[0] * r, dxp = d * tx - c[0] * r, dym = d * ty + c[1] * r, dyp = d * ty - c[1] * r;
+    if (!(dxm > 0.0f && dxp > 0.0f && dym > 0.0f && dyp > 0.0f)) return false;
+    const float sx0 = (c[0] * tx - rd) / dxm, sx1 = (c[0] * tx + rd) / dxp;
+    const float sy0 = (c[1] * ty - rd) / dym, sy1 = (c[1] * ty + rd) / dyp;
+    const float nxa = cam.p00 * sx0 - cam.p20, nxb = cam.p00 * sx1 - cam.p20, nya = cam.p11 * sy0 - cam.p21, nyb = cam.p11 * sy1 - cam.p21;
+    const float nx_lo = fminf(nxa, nxb), nx_hi = fmaxf(nxa, nxb), ny_lo = fminf(nya, nyb), ny_hi = fmaxf(nya, nyb);
+    const float W = (float)hz.width, H = (float)hz.height;
+    const float u0 = (nx_lo * 0.5f + 0.5f) * W - 0.5f, u1 = (nx_hi * 0.5f + 0.5f) * W + 0.5f;
+    const float v0 = (0.5f - ny_hi * 0.5f) * H - 0.5f, v1 = (0.5f - ny_lo * 0.5f) * H + 0.5f;
+    if (!(u1 >= 0.0f && v1 >= 0.0f && u0 < W && v0 < H)) return false;
+    const unsigned x0 = (unsigned)floorf(fmaxf(u0, 0.0f)), x1 = (unsigned)floorf(fminf(u1, W - 1.0f));
+    const unsigned y0 = (unsigned)floorf(fmaxf(v0, 0.0f)), y1 = (unsigned)floorf(fminf(v1, H - 1.0f));
+    const unsigned span = max(x1 - x0, y1 - y0);
+    const unsigned lvl = min(span ? 32u - (unsigned)__clz((int)span) : 0u, hz.n_levels - 1u);
+    const float* t = hz.base + hz.off[lvl];
+    const unsigned lw = ((hz.width - 1u) >> lvl) + 1u;
+    const unsigned ax = x0 >> lvl, bx = x1 >> lvl, ay = y0 >> lvl, by = y1 >> lvl;
+    const float h0 = fminf(t[(size_t)ay * lw + ax], t[(size_t)ay * lw + bx]);
+    const float h1 = fminf(t[(size_t)by * lw + ax], t[(size_t)by * lw + bx]);
+    const float hmin = fminf(h0, h1);
+    const float depth = (cam.p32 - cam.p22 * dn) / dn;
+    return depth < hmin;
+}
+
+__global__ __launch_bounds__(kBlock, 3) void occlusion_mask_kernel(OccCamera cam, HizView hz, const VdMeshInfo* __restrict__ meshes,
+                                                                   unsigned n_mesh, const VdInstance* __restrict__ inst, unsigned n_inst,
+                                                                   const vd_u64* __restrict__ mask_in, vd_u64* __restrict__ mask_out,
+                                                                   unsigned n_wave_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    char* slab = smem + wave * kSlabBytes;
+    const unsigned waves_total = gridDim.x * kWavesPerBlock;
+    u32x4 regs[kChunksPerLane];
+    for (unsigned wt = blockIdx.x * kWavesPerBlock + wave; wt < n_wave_tiles; wt += waves_total) {
+        const vd_u64 in = mask_in[wt];                       // wave-uniform
+        if (in == 0ull) {
+            if (lane == 0) mask_out[wt] = 0ull;
+            continue;
+        }
+        const size_t first = (size_t)wt * kWave;
+        const unsigned n_valid = min(64u, n_inst - (unsigned)first);
+        slab_fill<false>(inst, first, n_valid, lane, regs);
+        slab_store(slab, lane, regs);
+        vd_wave_lds_sync();
+        const LaneInst li = slab_read(slab, lane);
+        vd_wave_lds_sync();
+        bool keep = false;
+        if (lane < n_valid && ((in >> lane) & 1ull)) {
+            const MeshRec m = load_mesh(meshes, min(li.mesh, n_mesh - 1u));
+            keep = !is_occluded(cam, hz, m, li.T0, li.T1, li.T2, li.T3);
+        }
+        const unsigned long long b = __ballot(keep);
+        if (lane == 0) mask_out[wt] = b;
+    }
+}
+
 // Tiled form of pass 1: a wave owns kMaskRounds CONSECUTIVE rounds (1024 instances), keeps their
 // mesh ids and ballot words on chip and flushes them once per tile as wide stores, so the read
 // stream is interrupted by one 1-KB store per 147 KB read instead of a 64-B store per 9 KB.
@@ -1136,6 +1223,36 @@ int vd_cull_mask_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo
     vd_time_begin(ctx);
     hipLaunchKernelGGL(cull_mask_kernel<unsigned>, dim3(blocks), dim3(kBlock), kWavesPerBlock * kSlabBytes, ctx->stream, make_cam(camera),
                        d_meshes, n_mesh, d_instances, n_inst, reinterpret_cast<vd_u64*>(d_mask), (unsigned*)nullptr, n_wave_tiles);
+    vd_time_end(ctx);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    return VD_OK;
+}
+
+int vd_occlusion_mask_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                          const VdInstance* d_instances, uint32_t n_inst, const float* d_pyramid, uint32_t width, uint32_t height,
+                          const uint64_t* d_mask_in, uint64_t* d_mask_out) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!camera || !d_meshes || n_mesh == 0 || !d_pyramid) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_occlusion_mask: null camera/meshes/pyramid or n_mesh == 0");
+    VdHizLayout L;
+    if (vd_hiz_layout(width, height, &L)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_occlusion_mask: bad pyramid size");
+    if (!(camera->projection[11] == -1.0f && camera->projection[15] == 0.0f))
+        VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_occlusion_mask: projection is not a right-handed perspective matrix (projection[11] == -1, [15] == 0)");
+    if (n_inst == 0) return VD_OK;
+    if (!d_instances || !d_mask_in || !d_mask_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_occlusion_mask: null instances/masks");
+    OccCamera oc;
+    for (int k = 0; k < 16; ++k) oc.view[k] = camera->view[k];
+    const float* P = camera->projection;
+    oc.p00 = P[0]; oc.p11 = P[5]; oc.p20 = P[8]; oc.p21 = P[9]; oc.p22 = P[10]; oc.p32 = P[14]; oc.znear = camera->znear;
+    HizView hz;
+    hz.base = d_pyramid; hz.width = width; hz.height = height; hz.n_levels = L.n_levels;
+    for (int k = 0; k < 17; ++k) hz.off[k] = L.level_offset[k];
+    const unsigned n_wave_tiles = (n_inst + kWave - 1) / kWave;
+    unsigned blocks = (n_wave_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned cap = (unsigned)ctx->num_cus * 8u;
+    if (blocks > cap) blocks = cap;
+    vd_time_begin(ctx);
+    hipLaunchKernelGGL(occlusion_mask_kernel, dim3(blocks), dim3(kBlock), kWavesPerBlock * kSlabBytes, ctx->stream, oc, hz, d_meshes, n_mesh,
+                       d_instances, n_inst, reinterpret_cast<const vd_u64*>(d_mask_in), reinterpret_cast<vd_u64*>(d_mask_out), n_wave_tiles);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;

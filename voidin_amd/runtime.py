@@ -243,6 +243,20 @@ class Context:
         self._chk(self.lib.vd_traverse_iter_dev(self.h, abi.ptr(d_nodes), n_nodes, abi.ptr(d_verts), abi.ptr(d_indices),
                                                 abi.ptr(d_rays), n_rays, abi.ptr(d_out_dist)))
 
+    # -- occlusion extension (no reference counterpart; include/voidin_abi.h "Occlusion culling") ----------
+    def hiz_layout(self, width, height) -> "abi.HizLayout":
+        L = abi.HizLayout()
+        self._chk(self.lib.vd_hiz_layout(width, height, C.byref(L)))
+        return L
+
+    def hiz_build_dev(self, d_depth, width, height, d_pyramid):
+        self._chk(self.lib.vd_hiz_build_dev(self.h, abi.ptr(d_depth), width, height, abi.ptr(d_pyramid)))
+
+    def occlusion_mask_dev(self, camera, d_meshes, n_mesh, d_inst, n, d_pyramid, width, height, d_mask_in, d_mask_out):
+        cam = np.ascontiguousarray(camera, dtype=abi.CAMERA).reshape(1)
+        self._chk(self.lib.vd_occlusion_mask_dev(self.h, cam.ctypes.data, abi.ptr(d_meshes), n_mesh, abi.ptr(d_inst), n,
+                                                 abi.ptr(d_pyramid), width, height, abi.ptr(d_mask_in), abi.ptr(d_mask_out)))
+
 
 # ------------------------------------------------------------------------------------------
 # Reference-shaped façade
