@@ -74,3 +74,47 @@ def test_tlas_wide_64k_refit_is_idempotent(ctx):
     assert a.tobytes() == b.tobytes()
     w = a.view(abi.TLAS_NODE_WIDE)
     assert w["left"][0] == 2 * n - 1 and w["right"][0] == 2 * n - 1 and (w["instance_idx"][1:n + 1] == np.arange(n)).all()
+
+
+def test_frame_loop_replays_from_a_hip_graph(ctx, oracle):
+    """The per-frame entry points (compute_update -> TLAS refit -> cull + compaction, large-scene split form included)
+    enqueue only kernels and memsets on the context's stream - no allocation, no synchronisation, no host read-back
+    once the scratch buffers exist - so a frame can be captured into a HIP graph and replayed.  Scalars passed by
+    value (time, dt, the camera) are baked into the captured nodes: a replay is the same frame step again."""
+    import torch
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    for n in (3000, (1 << 20) + 777):
+        inst = synth.instances(n, seed=synth.SEED_BASE + 13, extent=400.0, scale_range=(0.02, 0.4))
+        n_t = min(n, 4096)                                   # TLAS over the first instances (build is O(n^2))
+        ids = np.arange(0, n, 2, dtype=np.uint32)
+        nodes = ctx.tlas_build(inst[:n_t], meshes)
+        d_m, d_i, d_ids, d_t = ctx.upload(meshes), ctx.upload(inst), ctx.upload(ids), ctx.upload(nodes)
+        d_out, d_cnt = ctx.empty(n * 20), torch.zeros(4, dtype=torch.int32, device="cuda")
+        t, dt = 0.7, 0.016
+
+        def frame():
+            ctx.compute_update_dev(d_ids, len(ids), d_i, n, t, dt, True)
+            ctx.tlas_refit_dev(d_i, n_t, d_m, len(meshes), d_t)
+            ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt)
+
+        frame()                                              # warm-up: sizes the context's scratch buffers
+        torch.cuda.synchronize()
+        ref_inst = oracle.compute_update(ids, inst, t, dt, True)
+        graph = torch.cuda.CUDAGraph()
+        main_stream = torch.cuda.current_stream().cuda_stream
+        try:
+            with torch.cuda.graph(graph):
+                ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                frame()
+        finally:
+            ctx.set_stream(main_stream)
+        for _ in range(3):
+            graph.replay()
+            ref_inst = oracle.compute_update(ids, ref_inst, t, dt, True)
+        torch.cuda.synchronize()
+        assert d_i.cpu().numpy().view(abi.INSTANCE).tobytes() == ref_inst.tobytes()
+        ref_nodes = oracle.tlas_refit(ref_inst[:n_t], meshes, nodes)
+        assert fields_equal(d_t.cpu().numpy()[: (2 * n_t + 1) * 32].view(abi.TLAS_NODE), ref_nodes)
+        want, wn = oracle.compact(oracle.cull_emit(cam, meshes, ref_inst, threads=8))
+        cnt = int(d_cnt[0].item())
+        assert cnt == wn and d_out.cpu().numpy()[: cnt * 20].tobytes() == want[:wn].tobytes()
