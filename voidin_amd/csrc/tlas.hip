@@ -237,12 +237,15 @@ __global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restr
 }
 
 // ---- refit -------------------------------------------------------------------------------
-// Launch 1: thread i < n recomputes leaf i+1; the same thread records the parent of the two children of interior node
-// n+1+i and clears its arrival counter.
+// The agglomerative tree is tall and thin (32 768 instances of the bench cloud: height 70, and about half the levels
+// of the longest path join a cluster with a single leaf), so a refit is one long dependent climb and what counts is
+// the number of memory-side round trips per level.
+// Launch 1: thread i < n recomputes leaf i+1; the same thread records, for the two children of interior node n+1+i,
+// {parent, sibling} and clears the node's handshake word.
 template <typename Node>
 __global__ __launch_bounds__(256) void tlas_refit_prep_kernel(const VdInstance* __restrict__ inst, unsigned n,
                                                               const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
-                                                              Node* __restrict__ nodes, unsigned* __restrict__ parent,
+                                                              Node* __restrict__ nodes, uint2* __restrict__ up,
                                                               unsigned* __restrict__ arrivals) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -252,48 +255,76 @@ __global__ __launch_bounds__(256) void tlas_refit_prep_kernel(const VdInstance* 
     const unsigned k = n + 1u + i;
     unsigned l, r;
     node_get_children(nodes[k], l, r);
-    parent[l] = k;
-    parent[r] = k;
+    up[l] = make_uint2(k, r);
+    up[r] = make_uint2(k, l);
     arrivals[k] = 0u;
 }
 
-// Launch 2: one lane per leaf climbs; the second arrival at a node owns it.  No fences: an agent-scope release
-// writes back the XCD's whole L2 (microseconds per hop).  Boxes travel as write-through agent-scope stores, which
-// have completed once vmcnt is 0, and are read back L1/L2-bypassing after the counter says both are there.
+template <typename Node> __device__ __forceinline__ Box load_box_plain(const Node* nodes, unsigned k) {
+    Box b;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { b.mn[c] = nodes[k].min[c]; b.mx[c] = nodes[k].max[c]; }
+    return b;
+}
+template <typename Node> __device__ __forceinline__ Box load_box_agent(Node* nodes, unsigned k) {
+    Box b;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        b.mn[c] = __hip_atomic_load(&nodes[k].min[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b.mx[c] = __hip_atomic_load(&nodes[k].max[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return b;
+}
+__device__ __forceinline__ Box box_union(const Box& a, const Box& b) {
+    Box u;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { u.mn[c] = vd_min_to(a.mn[c], b.mn[c]); u.mx[c] = vd_max_to(a.mx[c], b.mx[c]); }
+    return u;
+}
+
+// Launch 2: climbs start at the interior nodes whose children are both leaves (the lane of the smaller leaf) and
+// carry the box of the node just finished in registers.
+//  * sibling is a leaf: its box is final since launch 1 - plain load, no handshake, nothing to wait for.  A chain
+//    of such levels costs one L2 hit each ({parent, sibling} of the next level is fetched with the sibling's box).
+//  * sibling is an interior node: two climbers meet.  No fences (an agent-scope release writes back the XCD's
+//    whole L2); boxes travel as write-through agent-scope stores, complete once vmcnt is 0, and are read back L1/L2-
+//    bypassing.  The handshake word counts +1 "here" and +2 "my box is readable": a climber that finds the other
+//    side already readable (3) goes on after TWO round trips (announce, read) without waiting for its own stores;
+//    otherwise it publishes and the later of the two "readable" marks goes on (three round trips, as a plain
+//    arrival counter needs every time).  Nobody ever waits for another lane.
 template <typename Node>
-__global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigned n, const unsigned* __restrict__ parent,
+__global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigned n, const uint2* __restrict__ up,
                                                             unsigned* arrivals) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    unsigned k = parent[i + 1];
-    while (k != 0u) {
-        unsigned l, r;
-        node_get_children(nodes[k], l, r);
-        const unsigned need = l == r ? 1u : 2u;          // node 2n merges the true root with itself
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned seen = __hip_atomic_fetch_add(&arrivals[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen + 1u < need) return;                    // sibling subtree not finished yet
-        float mn[3], mx[3];
+    const unsigned c = i + 1u;
+    const uint2 u0 = up[c];
+    if (u0.y > n || c > u0.y) return;                     // sibling interior: its climber picks this leaf up; or the other leaf's lane
+    unsigned k = u0.x;
+    Box box = box_union(load_box_plain(nodes, c), load_box_plain(nodes, u0.y));
+    for (;;) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float lmn = __hip_atomic_load(&nodes[l].min[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float rmn = __hip_atomic_load(&nodes[r].min[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float lmx = __hip_atomic_load(&nodes[l].max[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float rmx = __hip_atomic_load(&nodes[r].max[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            mn[c] = vd_min_to(lmn, rmn);
-            mx[c] = vd_max_to(lmx, rmx);
+        for (int q = 0; q < 3; ++q) {
+            __hip_atomic_store(&nodes[k].min[q], box.mn[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&nodes[k].max[q], box.mx[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (k == 2u * n) {                                // tlas.rs:84: nodes[0] is a copy of the last node
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            __hip_atomic_store(&nodes[k].min[c], mn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&nodes[k].max[c], mx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (k == 2u * n) {                               // tlas.rs:84: nodes[0] is a copy of the last node
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { nodes[0].min[c] = mn[c]; nodes[0].max[c] = mx[c]; }
+            for (int q = 0; q < 3; ++q) { nodes[0].min[q] = box.mn[q]; nodes[0].max[q] = box.mx[q]; }
             return;
         }
-        k = parent[k];
+        const uint2 u = up[k];                            // {parent, sibling}
+        const unsigned p = u.x, s = u.y;
+        if (s == k) { k = p; continue; }                  // node 2n merges the true root with itself: same box
+        if (s <= n) { box = box_union(box, load_box_plain(nodes, s)); k = p; continue; }
+        const unsigned v = __hip_atomic_fetch_add(&arrivals[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != 3u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my box has reached memory
+            const unsigned w = __hip_atomic_fetch_add(&arrivals[p], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (w < 4u) return;                           // the other side is not readable yet: its climber goes on
+        }
+        box = box_union(box, load_box_agent(nodes, s));
+        k = p;
     }
 }
 
@@ -322,11 +353,11 @@ template <typename Node>
 int tlas_refit_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                     Node* d_nodes) {
     const size_t total = 2 * (size_t)n + 1;
-    const size_t need = total * 8 + 256;
+    const size_t need = total * 12 + 256;
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
     if (rc) return rc;
-    unsigned* parent = reinterpret_cast<unsigned*>(ctx->scratch);
-    unsigned* arrivals = parent + total;
+    uint2* parent = reinterpret_cast<uint2*>(ctx->scratch);                    // {parent, sibling} per node
+    unsigned* arrivals = reinterpret_cast<unsigned*>(parent + total);
     vd_time_begin(ctx);
     hipLaunchKernelGGL((tlas_refit_prep_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes, n_mesh,
                        d_nodes, parent, arrivals);
