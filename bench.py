@@ -130,6 +130,26 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     ms_per_step = wall * 1e3 / args.steps
+    breakdown = None
+    if distributed:
+        # where a step goes at this N (every rank runs every leg; max over ranks, like the headline): the local cull to a
+        # bitmask, the RCCL all-gather of the masks alone, and the expansion of ALL shards to the full draw list
+        def leg(fn):
+            fn(); barrier(); t = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            barrier()
+            tw = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            return round(float(tw.item()) * 1e3 / args.steps, 4)
+        breakdown = {
+            "cull_to_mask_ms": leg(lambda: ctx.cull_mask_dev(cam, d_m, len(meshes), d_i, n, sv.d_mask)),
+            "mask_allgather_ms": leg(lambda: dist.all_gather_into_tensor(sv.d_mask_all, sv.d_mask)),
+            "expand_all_shards_ms": leg(lambda: ctx.expand_mask_dev(sv.d_mask_all, n_total, sv.S, sv.d_mesh_ids, d_m, len(meshes), d_all, d_cnt_all)),
+            "mask_bytes_per_rank": int(sv.wps * 8), "draw_list_bytes_written_per_rank": int(d_cnt_all[0].item()) * 20,
+            "note": "every GPU materialises the whole list: the expansion leg writes N x the single-GPU output and is bound by the HBM write ceiling (DESIGN.md 6)"}
+        sv.step(cam, d_all, d_cnt_all)       # leave d_all / d_cnt_all as a full step leaves them
+        torch.cuda.synchronize()
     if distributed:   # also run the local fused kernel once so the roofline / verification legs have its output
         ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)
         torch.cuda.synchronize()
@@ -444,6 +464,8 @@ def main():
         }
         if extra:
             line["extra"] = extra
+        if breakdown:
+            line["step_breakdown"] = breakdown
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
