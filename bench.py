@@ -217,7 +217,23 @@ def main():
                              f"1-thread cull: {m / t1 / 1e6:.2f} M inst/s"}
 
     extra = {}
+
+    def pipelined(fn, reps=50):          # per-call time when calls are queued back to back (a frame loop does not sync per call)
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
     if not args.no_extra and rank == 0 and not distributed:   # single-GPU extras (they use no collective; N > 1 runs skip them)
+        # the smaller BASELINE configs (configs[0] 1 k, configs[1] 100 k instances; 1 M = the largest input of the fused
+        # single-launch form): cull + compaction per call, calls queued back to back; bit-exactness of these sizes is in tests/
+        small = {}
+        for m_ in (1000, 100_000, 1_000_000):
+            if m_ <= n:
+                t_ = pipelined(lambda: ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, m_, d_out, d_cnt, False, first), reps=200)
+                small[str(m_)] = {"us_per_call": round(t_ * 1e6, 2), "M_inst_per_s": round(m_ / t_ / 1e6, 1)}
+        extra["cull_compact_small_inputs"] = small
         d_emit = ctx.empty(n * 20)
         for _ in range(3):
             ctx.cull_emit_dev(cam, d_m, len(meshes), d_i, n, d_emit)
@@ -305,12 +321,6 @@ def main():
             torch.cuda.synchronize(); t = time.perf_counter()
             ctx.tlas_refit_dev(d_ti, n_tl, d_m, len(meshes), d_t)
             torch.cuda.synchronize(); t_refit = time.perf_counter() - t
-        def pipelined(fn, reps=50):          # per-call time when calls are queued back to back (a frame loop does not sync per call)
-            fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / reps
         t_pipe = pipelined(lambda: ctx.tlas_refit_dev(d_ti, n_tl, d_m, len(meshes), d_t))
         extra["tlas"] = {"n_instances": n_tl, "build_ms": round(t_build * 1e3, 1), "refit_ms": round(t_refit * 1e3, 3),
                          "refit_queued_ms": round(t_pipe * 1e3, 4)}

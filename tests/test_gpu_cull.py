@@ -203,7 +203,7 @@ def test_large_mesh_table(ctx, oracle):
 
 @pytest.mark.parametrize("n_mesh", [1, 257, 600, 66_000])
 def test_split_forms_with_every_id_width_and_table_size(ctx, oracle, n_mesh):
-    """Above 2^20 instances both vd_cull_emit and vd_cull_compact go through pass 1's bits + ids: 1-byte ids
+    """From abi.CULL_SPLIT_MIN (2 Mi) instances on both vd_cull_emit and vd_cull_compact go through pass 1's bits + ids: 1-byte ids
     (<= 256 meshes), 2-byte ids with the LDS table (<= 512) and without, 4-byte ids (> 65536 meshes)."""
     cam = synth.camera_uniform()
     meshes = synth.mesh_infos(n_mesh, seed=synth.SEED_BASE + 50)
@@ -211,7 +211,7 @@ def test_split_forms_with_every_id_width_and_table_size(ctx, oracle, n_mesh):
         meshes["index_count"] = 36
         meshes["base_index"] = np.arange(n_mesh, dtype=np.uint32) * 36
         meshes["vertex_offset"] = np.arange(n_mesh, dtype=np.int32) * 12
-    n = (1 << 20) + 12_345
+    n = abi.CULL_SPLIT_MIN + 12_345
     inst = synth.instances(n, n_mesh=n_mesh, seed=synth.SEED_BASE + 51, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
     want = oracle.cull_emit(cam, meshes, inst, threads=8)
     wc, wn = oracle.compact(want)
@@ -225,13 +225,13 @@ def test_id_table_follows_edited_instances(ctx, oracle):
     mesh ids differ everywhere / in a few rows / not at all (only transforms), and sizes that move the table."""
     import torch
     cam, meshes = synth.camera_uniform(), synth.mesh_infos()
-    n = (1 << 20) + 999
+    n = abi.CULL_SPLIT_MIN + 999
     a = synth.instances(n, seed=synth.SEED_BASE + 60, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
     b = a.copy(); b["mesh"] = (b["mesh"] + 5) % len(meshes)                      # every row differs
     c = a.copy(); c["mesh"][[3, 1024, 500_000, n - 1]] = [7, 7, 0, 11]           # four rows differ
     d = synth.instances(n, seed=synth.SEED_BASE + 61, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
     d["mesh"] = a["mesh"]                                                        # other transforms, same meshes
-    small = a[: (1 << 20) + 1]
+    small = a[: abi.CULL_SPLIT_MIN + 1]
     d_m = ctx.upload(meshes)
     d_out, d_cnt = ctx.empty(n * 20), torch.zeros(4, dtype=torch.int32, device="cuda")
     for name, inst in [("a", a), ("b", b), ("a", a), ("c", c), ("d", d), ("small", small), ("a", a)]:
@@ -242,10 +242,10 @@ def test_id_table_follows_edited_instances(ctx, oracle):
         assert d_out.cpu().numpy()[: wn * 20].tobytes() == want[:wn].tobytes(), name
 
 
-@pytest.mark.parametrize("n", [(1 << 20) - 1, 1 << 20, (1 << 20) + 77, 1_500_001])
+@pytest.mark.parametrize("n", [abi.CULL_SPLIT_MIN - 1, abi.CULL_SPLIT_MIN, abi.CULL_SPLIT_MIN + 77, 3_000_001])
 def test_split_and_fused_forms_agree_around_the_switch(ctx, oracle, n):
-    """vd_cull_compact runs the fused kernel below 2^20 instances and the split form (bitmask +
-    expansion) from 2^20 on: both must equal the oracle, including pad_tail and a shard offset."""
+    """vd_cull_compact runs the fused kernel below abi.CULL_SPLIT_MIN (2 Mi) instances and the split form (bitmask +
+    expansion) from there on: both must equal the oracle, including pad_tail and a shard offset."""
     import torch
     cam, meshes = synth.camera_uniform(), synth.mesh_infos()
     inst = synth.instances(n, seed=synth.SEED_BASE + 13, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)

@@ -83,7 +83,7 @@ def test_frame_loop_replays_from_a_hip_graph(ctx, oracle):
     value (time, dt, the camera) are baked into the captured nodes: a replay is the same frame step again."""
     import torch
     cam, meshes = synth.camera_uniform(), synth.mesh_infos()
-    for n in (3000, (1 << 20) + 777):
+    for n in (3000, abi.CULL_SPLIT_MIN + 777):
         inst = synth.instances(n, seed=synth.SEED_BASE + 13, extent=400.0, scale_range=(0.02, 0.4))
         n_t = min(n, 4096)                                   # TLAS over the first instances (build is O(n^2))
         ids = np.arange(0, n, 2, dtype=np.uint32)

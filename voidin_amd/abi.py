@@ -44,6 +44,7 @@ assert CAMERA.itemsize == 320 and BVH_NODE.itemsize == 32 and TLAS_NODE.itemsize
 assert TLAS_NODE_WIDE.itemsize == 48 and RAY.itemsize == 32 and HIT.itemsize == 16
 
 MAX_DIST = np.float32(1e30)
+CULL_SPLIT_MIN = 2 << 20   # VdCtx default: vd_cull_compact / vd_cull_emit run their split form from this many instances
 TLAS_MAX_INSTANCES = 32768
 
 VD_OK = 0

@@ -65,6 +65,7 @@ int vd_ctx_create(int device, VdCtx** out_ctx) {
     }
     ctx->stream = ctx->own_stream;
     if (const char* v = getenv("VD_CULL_VARIANT")) ctx->cull_variant = atoi(v);
+    if (const char* v = getenv("VD_SPLIT_MIN")) ctx->split_min = (unsigned)atoi(v);
     *out_ctx = ctx;
     return VD_OK;
 }

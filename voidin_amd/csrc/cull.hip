@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kBlock, 4) void emit_draws_kernel(CullCamera cam, c
 
 // ------------------------------------------------------------------------------------------
 // C1 + C3 fused: cull and emit survivors only, ascending instance order, single pass (used below
-// 2^20 instances; larger inputs run the split form: cull_mask_tiled_kernel + expand_mask_kernel).
+// VdCtx::split_min = 2 Mi instances; larger inputs run the split form: cull_mask_tiled_kernel + expand_mask_kernel).
 // ------------------------------------------------------------------------------------------
 template <int ROUNDS>
 __global__ __launch_bounds__(kBlock, 3)
@@ -1109,7 +1109,7 @@ int vd_cull_emit_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMe
     if (!camera || !d_meshes || n_mesh == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_emit: null camera/meshes or n_mesh == 0");
     if (n_inst == 0) return VD_OK;
     if (!d_instances || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_emit: null instances/out");
-    if (ctx->cull_variant <= 0 && ctx->cull_variant != -80 && n_inst >= (1u << 20)) {
+    if (ctx->cull_variant <= 0 && ctx->cull_variant != -80 && n_inst >= ctx->split_min) {
         // split form, as for the compacted list: the 20-byte stores leave the read stream
         vd_u64* d_mask; void* d_ids; unsigned id_bytes;
         int rc = launch_mask_pass(ctx, camera, d_meshes, n_mesh, d_instances, n_inst, &d_mask, &d_ids, &id_bytes);
@@ -1161,7 +1161,7 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
     int variant = ctx->cull_variant;
     vd_u64* ticket; vd_u64* states;
     int rc = VD_OK;
-    if ((variant <= 0) && n_inst >= (1u << 20)) {
+    if ((variant <= 0) && n_inst >= ctx->split_min) {
         // Split form (default for large inputs): pass 1 streams the instances and writes only one bit
         // + a compact mesh id per instance (reads run at ~6.4 TB/s when no 20-byte commands are stored
         // in the same kernel); pass 2 expands the bits into the ordered command list.  Mixing the
@@ -1193,7 +1193,7 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
     } while (0)
     // fused form: tile size grows with n so that ticket + two barriers + look-back amortise while
     // small inputs still spread over the chip.  variant > 0 forces a tile size (tools/ab_cull.py).
-    const int rounds = variant > 0 ? variant : (n_inst >= (4u << 20) ? 32 : (n_inst >= (1u << 20) ? 16 : (n_inst >= (1u << 18) ? 8 : 4)));
+    const int rounds = variant > 0 ? variant : (n_inst >= (4u << 20) ? 32 : (n_inst >= (5u << 18) ? 16 : (n_inst >= (1u << 18) ? 8 : 4)));
     switch (rounds) {
         case 4: VD_LAUNCH_COMPACT(4); break;
         case 8: VD_LAUNCH_COMPACT(8); break;

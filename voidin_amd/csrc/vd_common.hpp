@@ -23,6 +23,9 @@ struct VdCtx {
     char err[512] = {0};
     int num_cus = 256;
     int cull_variant = 0;               // kernel variant for A/B tuning (env VD_CULL_VARIANT)
+    unsigned split_min = 2u << 20;      // inputs of at least this many instances run the split form of the cull (env
+                                        // VD_SPLIT_MIN): below, the fused single launch is faster (tools/ab_split_min.py:
+                                        // 1 Mi 39 vs 47 us, 2 Mi 65 vs 65, 3 Mi 97 vs 93, 10 M 312 vs 256)
 
     // grow-only device scratch arenas
     void* scratch = nullptr;     size_t scratch_bytes = 0;     // general purpose
