@@ -32,6 +32,38 @@ def test_tlas_build_seeded_vs_oracle(ctx, oracle, n):
     assert np.array_equal(wide["min"], want["min"]) and np.array_equal(wide["instance_idx"], want["instance_idx"])
 
 
+def test_tlas_build_on_several_workgroups_vs_oracle(ctx, oracle):
+    """From 16384 instances on the chain runs on 16 workgroups that exchange their scan results through memory
+    (tlas.hip, "build, several workgroups"): same chain, same nodes - NaN-free fast arithmetic and, with a poisoned
+    instance, the total-order arithmetic; and the same bytes every time."""
+    meshes = synth.mesh_infos()
+    n = 16384 + 77
+    inst = synth.instances(n, seed=synth.SEED_BASE + 14, extent=700.0)
+    want = oracle.tlas_build(inst, meshes)
+    got = ctx.tlas_build(inst, meshes)
+    assert fields_equal(got, want)
+    wide = ctx.tlas_build(inst, meshes, wide=True)
+    assert np.array_equal(wide["left"] + (wide["right"] << 16), want["left_right"]) and np.array_equal(wide["max"], want["max"])
+    bad = inst.copy()
+    bad["transform"][4321][13] = np.float32("nan")
+    got_b, want_b = ctx.tlas_build(bad, meshes), oracle.tlas_build(bad, meshes)
+    for f in ("left_right", "instance_idx"):
+        assert np.array_equal(got_b[f], want_b[f])
+    for f in ("min", "max"):                          # NaN != NaN: compare bit patterns
+        assert np.array_equal(got_b[f].view(np.uint32), want_b[f].view(np.uint32))
+    # workgroups that do not hear from each other in time give up and the build is redone on one workgroup
+    import os
+    os.environ["VD_TLAS_SPIN_LIMIT"] = "0"
+    try:
+        assert fields_equal(ctx.tlas_build(inst, meshes), want)
+    finally:
+        del os.environ["VD_TLAS_SPIN_LIMIT"]
+    big = synth.instances(32768, seed=synth.SEED_BASE + 6, extent=300.0)
+    first = ctx.tlas_build(big, meshes).tobytes()
+    for _ in range(3):
+        assert ctx.tlas_build(big, meshes).tobytes() == first
+
+
 def test_cpu_harness_rays_and_traverse_iter(ctx, oracle):
     """The reference's CPU harness on the device: per-pixel rays (bvh_cpu.rs:71-83) bit-exact,
     Bvh::traverse_iter (blas.rs:247-295) bit-exact - same visit order, same arithmetic."""

@@ -18,8 +18,10 @@ inst = synth.instances(n, seed=synth.SEED_BASE + 6, extent=300.0)
 d_m, d_i = ctx.upload(meshes), ctx.upload(inst)
 wide = n > 32768
 d_t = ctx.empty((2 * n + 1) * (48 if wide else 32))
+torch.cuda.synchronize(); t0 = time.perf_counter()
 ctx.tlas_build_dev(d_i, n, d_m, len(meshes), d_t, wide=wide)
 torch.cuda.synchronize()
+print(f"n={n}: build {(time.perf_counter() - t0) * 1e3:.1f} ms (VD_TLAS_GROUPS={os.environ.get('VD_TLAS_GROUPS', 'default')})")
 for _ in range(3):
     ctx.tlas_refit_dev(d_i, n, d_m, len(meshes), d_t, wide=wide)
 torch.cuda.synchronize()

@@ -8,7 +8,8 @@
 //    object-space mesh box as seed (bug-compatible), total-order min/max;
 //  * build (tlas.rs:56-84): the reference is a sequential chain of ~2.5 N `find_best_match`
 //    scans whose tie-breaking depends on the slot order, so the chain itself cannot be
-//    reordered.  One 1024-lane workgroup runs the chain; each scan is data-parallel over the
+//    reordered.  One 1024-lane workgroup runs the chain (16 of them from 16384 instances on, see
+//    "build, several workgroups"); each scan is data-parallel over the
 //    active slots, which are kept as a compacted SoA (six float arrays + node ids) so a scan is
 //    a pure stream of 24 B per slot; the argmin is a 64-bit {area bits, slot} key reduced by
 //    wave shuffles + LDS, which reproduces "strict <, first slot wins";
@@ -236,6 +237,197 @@ __global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restr
     else tlas_build_chain<Node, true>(nodes, n, sb, slot_node, cap, s_red);
 }
 
+// ---- build, several workgroups ---------------------------------------------------------------
+// The same chain, the scans spread over W co-resident workgroups (one per CU).  Every workgroup runs the identical
+// control flow (a, b, c, cnt are functions of the scan results), scans a contiguous W-th of the active slots and
+// then takes part in one exchange: it stores its best {area bits, slot, tag} key into its own word of a two-deep ring
+// and one wave polls the W words of the scan until all carry the scan's tag - the data is the flag, so an exchange is
+// one write-through store and a few polling loads (~0.5 us; `tools/probe_exchange.hip`: an atomic-min + arrival-counter
+// exchange costs 1.4 - 2.2 us).  Entry (r % 2, w) is rewritten at scan r + 2, which w reaches only after every workgroup has
+// published r + 1, i.e. has finished reading r.  A merge is applied by workgroup 0 alone; the others wait for its
+// merge counter.  Slots are shared through memory: all reads and writes of them are agent-scope (L1/L2-bypassing
+// loads, write-through stores), no fences.  Spins are bounded: on a timeout every workgroup leaves, the host sees
+// the flag and falls back to the single-workgroup kernel.
+constexpr unsigned kMwMaxGroups = 32;
+#ifndef VD_MW_THREADS
+#define VD_MW_THREADS 1024
+#endif
+constexpr int kMwThreads = VD_MW_THREADS;
+constexpr unsigned kSpinLimit = 2000000u;   // polls before a workgroup gives up (~1 s; an exchange takes ~1 us)
+struct MwShared {
+    unsigned long long key[2][kMwMaxGroups];
+    unsigned merges;       // merge counter published by workgroup 0
+    unsigned fail;
+};
+
+// Workgroups are dealt to the 8 XCDs round-robin: the chain uses every 8th workgroup of the grid, i.e. CUs of ONE XCD,
+// whose shared L2 then serves the exchange and the slot traffic (correctness does not depend on it: all shared
+// accesses are agent-scope).
+__device__ __forceinline__ unsigned mw_group() { return blockIdx.x >> 3; }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one scan: returns the best slot for `target` (the same value in every thread of every workgroup), or ~0u on a timeout
+template <bool FAST>
+__device__ __forceinline__ unsigned mw_find_best_match(float* sb, unsigned cap, unsigned cnt, unsigned target, MwShared* sh,
+                                                       unsigned W, unsigned call, vd_u64* s_red, unsigned spin_limit) {
+    const unsigned tid = threadIdx.x, lane = tid & 63u, w = mw_group();
+    vd_u64 best = ~0ull;
+    if (target < cap) {
+        float t[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = ld_agent(sb + k * cap + target);
+        // contiguous slice of slot PAIRS per workgroup
+        const unsigned pairs = (cnt + 1u) >> 1, per = (pairs + W - 1u) / W;
+        const unsigned p_lo = w * per, p_hi = min(pairs, p_lo + per);
+        for (unsigned pr = p_lo + tid; pr < p_hi; pr += kMwThreads) {
+            const unsigned i0 = 2u * pr;
+            float v[6][2];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const vd_u64 q = __hip_atomic_load(reinterpret_cast<const vd_u64*>(sb + k * cap + i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[k][0] = __uint_as_float((unsigned)q); v[k][1] = __uint_as_float((unsigned)(q >> 32));
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned i = i0 + h;
+                float dx, dy, dz;
+                if (FAST) {
+                    dx = __builtin_fmaxf(t[3], v[3][h]) - __builtin_fminf(t[0], v[0][h]);
+                    dy = __builtin_fmaxf(t[4], v[4][h]) - __builtin_fminf(t[1], v[1][h]);
+                    dz = __builtin_fmaxf(t[5], v[5][h]) - __builtin_fminf(t[2], v[2][h]);
+                } else {
+                    dx = vd_max_to(t[3], v[3][h]) - vd_min_to(t[0], v[0][h]);
+                    dy = vd_max_to(t[4], v[4][h]) - vd_min_to(t[1], v[1][h]);
+                    dz = vd_max_to(t[5], v[5][h]) - vd_min_to(t[2], v[2][h]);
+                }
+                const float area = vd_area(dx, dy, dz);
+                if (i < cnt && i != target && area < 1e30f) {   // `surface_area < smallest` from 1e30, NaN never passes
+                    const vd_u64 kk = match_key(area, i);
+                    best = kk < best ? kk : best;
+                }
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    vd_u64* slot = s_red + (call % 3u);
+    if (lane == 0 && best != ~0ull) atomicMin(slot, best);
+    if (tid == 0) s_red[(call + 1u) % 3u] = ~0ull;
+    __syncthreads();
+    // exchange: {area bits : 32, slot : 20, tag : 12}; "nothing" = all ones above the tag
+    const unsigned ring = call & 1u;
+    const vd_u64 tag = (vd_u64)(((call >> 1) + 1u) & 0xfffu);
+    if (tid < 64u) {
+        if (tid == 0) {
+            const vd_u64 mine = *slot;
+            const vd_u64 packed = mine == ~0ull ? (~0ull << 12) : ((mine >> 32) << 32 | (mine & 0xfffffull) << 12);
+            __hip_atomic_store(&sh->key[ring][w], packed | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        vd_u64 got = ~0ull;
+        bool ok = true;
+        if (lane < W) {
+            unsigned spins = 0;
+            for (;;) {
+                got = __hip_atomic_load(&sh->key[ring][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((got & 0xfffull) == tag) break;
+                if (++spins > spin_limit || __hip_atomic_load(&sh->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = false; break; }
+            }
+            got >>= 12;
+        }
+        if (!__all(ok)) {
+            if (lane == 0) __hip_atomic_store(&sh->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            got = ~0ull - 1ull;                       // timeout marker
+        } else {
+            got = wave_min_u64(got);
+        }
+        if (lane == 0) s_red[3u + ring] = got;          // two-deep: the next scan writes the other word
+    }
+    __syncthreads();
+    const vd_u64 g = s_red[3u + ring];
+    if (g == ~0ull - 1ull) return ~0u;
+    if ((g >> 20) == 0xffffffffull) return target;     // nobody had a candidate
+    return (unsigned)(g & 0xfffffull);
+}
+
+template <typename Node, bool FAST>
+__device__ __forceinline__ void mw_build_chain(Node* __restrict__ nodes, unsigned n, float* sb, unsigned* slot_node, unsigned cap,
+                                               MwShared* sh, unsigned W, vd_u64* s_red, unsigned spin_limit) {
+    unsigned call = 0, merges = 0;
+    unsigned cnt = n, used = n + 1, a = 0;
+    unsigned b = mw_find_best_match<FAST>(sb, cap, cnt, a, sh, W, call++, s_red, spin_limit);
+    if (b == ~0u) return;
+    while (cnt > 0) {
+        const unsigned c = mw_find_best_match<FAST>(sb, cap, cnt, b, sh, W, call++, s_red, spin_limit);
+        if (c == ~0u) return;
+        if (a == c) {
+            merges += 1;
+            if (mw_group() == 0u) {
+                if (threadIdx.x == 0) {
+                    const unsigned idx_a = slot_node[a], idx_b = slot_node[b];
+                    Node nd;
+                    float u[6];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        u[k] = vd_min_to(ld_agent(sb + k * cap + a), ld_agent(sb + k * cap + b));
+                        u[3 + k] = vd_max_to(ld_agent(sb + (3 + k) * cap + a), ld_agent(sb + (3 + k) * cap + b));
+                        nd.min[k] = u[k];
+                        nd.max[k] = u[3 + k];
+                    }
+                    node_set_children(nd, idx_a, idx_b);
+                    nd.instance_idx = 0xffffffffu;
+                    nodes[used] = nd;
+                    // node_indices[a] = nodes_used; node_indices[b] = node_indices[cnt - 1]  (in this order)
+                    const unsigned last = cnt - 1;
+                    float mv[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) st_agent(sb + k * cap + a, u[k]);
+                    slot_node[a] = used;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) mv[k] = last == a ? u[k] : ld_agent(sb + k * cap + last);   // slot a as just rewritten
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) st_agent(sb + k * cap + b, mv[k]);
+                    slot_node[b] = slot_node[last];
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&sh->merges, merges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else if (threadIdx.x == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(&sh->merges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != merges) {
+                    if (++spins > spin_limit || __hip_atomic_load(&sh->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(&sh->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            used += 1;
+            cnt -= 1;
+            __syncthreads();
+            b = mw_find_best_match<FAST>(sb, cap, cnt, a, sh, W, call++, s_red, spin_limit);
+            if (b == ~0u) return;
+        } else {
+            a = b;
+            b = c;
+        }
+    }
+    if (mw_group() == 0u && threadIdx.x == 0) nodes[0] = nodes[slot_node[a]];   // tlas.rs:84
+}
+
+template <typename Node>
+__global__ __launch_bounds__(kMwThreads) void tlas_build_mw_kernel(Node* __restrict__ nodes, unsigned n, float* sb,
+                                                                      unsigned* slot_node, unsigned cap, MwShared* sh, unsigned spin_limit) {
+    __shared__ vd_u64 s_red[5];
+    if (threadIdx.x < 5) s_red[threadIdx.x] = ~0ull;
+    int nan = 0;
+    for (unsigned i = threadIdx.x; i < n; i += kMwThreads) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { const float v = sb[q * cap + i]; nan |= v != v; }
+    }
+    const bool any_nan = __syncthreads_or(nan) != 0;         // every workgroup sees the same leaves: same answer
+    if ((blockIdx.x & 7u) != 0u) return;                      // see mw_group()
+    if (any_nan) mw_build_chain<Node, false>(nodes, n, sb, slot_node, cap, sh, gridDim.x >> 3, s_red, spin_limit);
+    else mw_build_chain<Node, true>(nodes, n, sb, slot_node, cap, sh, gridDim.x >> 3, s_red, spin_limit);
+}
+
 // ---- refit -------------------------------------------------------------------------------
 // The agglomerative tree is tall and thin (32 768 instances of the bench cloud: height 70, and about half the levels
 // of the longest path join a cluster with a single leaf), so a refit is one long dependent climb and what counts is
@@ -333,17 +525,39 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
                     Node* d_nodes) {
     // scratch: 6 float slot arrays + slot node ids, capacity n
     const size_t cap = ((size_t)n + 7) & ~(size_t)3;   // multiple of 4 (+ slack): slot arrays are read 16 B at a time
-    const size_t need = cap * 7 * 4 + 256;
+    const size_t need = cap * 7 * 4 + 256 + sizeof(MwShared);
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
     if (rc) return rc;
     float* sb = reinterpret_cast<float*>(ctx->scratch);
     unsigned* slot_node = reinterpret_cast<unsigned*>(sb + 6 * cap);
+    MwShared* sh = reinterpret_cast<MwShared*>(reinterpret_cast<char*>(ctx->scratch) + ((cap * 7 * 4 + 255) & ~(size_t)255));
+    // several workgroups from a few thousand instances on (below, the exchange costs more than the shorter scans save);
+    // the slot field of the exchanged key holds 20 bits.  VD_TLAS_GROUPS = 1 forces the single-workgroup kernel.
+    const int env_groups = getenv("VD_TLAS_GROUPS") ? atoi(getenv("VD_TLAS_GROUPS")) : 0;
+    const unsigned spin_limit = getenv("VD_TLAS_SPIN_LIMIT") ? (unsigned)atoi(getenv("VD_TLAS_SPIN_LIMIT")) : kSpinLimit;   // tests: 0 forces the fallback
+    unsigned groups = env_groups > 0 ? (unsigned)env_groups : (n >= 16384u ? 16u : 1u);
+    if (groups > kMwMaxGroups) groups = kMwMaxGroups;
+    if (groups > (unsigned)ctx->num_cus) groups = (unsigned)ctx->num_cus;
+    if (n >= (1u << 20)) groups = 1u;
     vd_time_begin(ctx);
-    VD_HIP_CHECK(ctx, hipMemsetAsync(d_nodes, 0, sizeof(Node) * (2 * (size_t)n + 1), ctx->stream));   // TlasNode::default()
-    hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
-                       n_mesh, d_nodes, sb, slot_node, (unsigned)cap, 0);
-    hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
-                       (unsigned)cap);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        VD_HIP_CHECK(ctx, hipMemsetAsync(d_nodes, 0, sizeof(Node) * (2 * (size_t)n + 1), ctx->stream));   // TlasNode::default()
+        hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
+                           n_mesh, d_nodes, sb, slot_node, (unsigned)cap, 0);
+        if (groups <= 1u) {
+            hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
+                               (unsigned)cap);
+            break;
+        }
+        VD_HIP_CHECK(ctx, hipMemsetAsync(sh, 0, sizeof(MwShared), ctx->stream));
+        hipLaunchKernelGGL((tlas_build_mw_kernel<Node>), dim3(groups * 8u), dim3(kMwThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
+                           (unsigned)cap, sh, spin_limit);
+        VD_HIP_CHECK(ctx, hipGetLastError());
+        VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, &sh->fail, 4, hipMemcpyDeviceToHost, ctx->stream));
+        VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->host_pinned[0] == 0u) break;
+        groups = 1u;   // the workgroups were not co-resident in time (spin limit): run the chain on one
+    }
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;
