@@ -329,3 +329,164 @@ def trace(scene, rays):
                     st.append(a)
             out[ri]["dist"], out[ri]["hit"] = dist, hit
     return out
+
+
+# ---- the CPU harness: per-pixel rays + Bvh::traverse_iter (src/bin/bvh_cpu.rs:71-96, blas.rs:247-295) ----
+def primary_rays(cam, width, height):
+    """bvh_cpu.rs:71-83 in float32, glam operation order (Mat4 * Vec4 = ((c0*x + c1*y) + c2*z) + c3*w;
+    Vec3::normalize = v * (1 / sqrt((x*x + y*y) + z*z)))."""
+    M = np.asarray(cam["clip_to_world"], F).reshape(16)
+    n = width * height
+    i = np.arange(n, dtype=np.int64)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        x = ((i % width).astype(F) / F(width))
+        y = ((i // height).astype(F) / F(height)) if n else x
+        x = ((x - F(0.5)) * F(2.0)).astype(F)
+        y = ((y - F(0.5)) * F(-2.0)).astype(F)
+        p = [(((M[r] * x + M[4 + r] * y).astype(F) + M[8 + r] * F(1.0)).astype(F) + M[12 + r] * F(1.0)).astype(F) for r in range(4)]
+        t = [(((M[r] * x + M[4 + r] * y).astype(F) + M[8 + r] * F(0.0)).astype(F) + M[12 + r] * F(1.0)).astype(F) for r in range(4)]
+        rl = (F(1.0) / np.sqrt(((t[0] * t[0] + t[1] * t[1]).astype(F) + t[2] * t[2]).astype(F)).astype(F)).astype(F)
+        rays = np.zeros(n, dtype=abi.RAY)
+        for k in range(3):
+            rays["eye"][:, k] = (p[k] / p[3]).astype(F)
+            rays["dir"][:, k] = (t[k] * rl).astype(F)
+    return rays
+
+
+def _aabb_rs(orig, d, bmin, bmax, t):
+    """intersection.rs:47-55 -> (hit, tmin)."""
+    tx1 = ((bmin - orig) / d).astype(F)
+    tx2 = ((bmax - orig) / d).astype(F)
+    hi, lo = np.fmax(tx1, tx2), np.fmin(tx1, tx2)
+    tmax = np.fmin(hi[0], np.fmin(hi[1], hi[2]))
+    tmin = np.fmax(lo[0], np.fmax(lo[1], lo[2]))
+    return bool(tmax >= tmin and tmin < t and tmax > 0), F(tmin)
+
+
+def _tri_rs(orig, d, v0, v1, v2):
+    """intersection.rs:68-92 -> t or None."""
+    eps = F(0.0001)
+    e1, e2 = v1 - v0, v2 - v0
+    h = _cross(d, e2)
+    a = _dot(e1, h)
+    if -eps < a < eps:
+        return None
+    f = F(1.0) / a
+    s = orig - v0
+    u = F(f * _dot(s, h))
+    if not (F(0) <= u <= F(1)):
+        return None
+    q = _cross(s, e1)
+    v = F(f * _dot(d, q))
+    if v < 0 or F(u + v) > 1:
+        return None
+    t = F(f * _dot(e2, q))
+    return t if t > eps else None
+
+
+def traverse_iter(nodes, verts, indices, rays):
+    """Bvh::traverse_iter (blas.rs:247-295): -1 = Dist::Miss."""
+    verts = np.asarray(verts, F).reshape(-1, 3)
+    idx = np.asarray(indices, np.uint32).reshape(-1, 3)
+    out = np.zeros(len(rays), dtype=F)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for ri, ray in enumerate(rays):
+            orig, d = ray["eye"].astype(F), ray["dir"].astype(F)
+            st, hit = [0], None
+            while st:
+                nd = nodes[st.pop()]
+                if nd["count"] > 0:
+                    for i in range(int(nd["count"])):
+                        tri = idx[int(nd["left_first"]) + i]
+                        t = _tri_rs(orig, d, verts[tri[0]], verts[tri[1]], verts[tri[2]])
+                        if t is not None:
+                            hit = t if hit is None else F(min(hit, t))
+                else:
+                    a, b = int(nd["left_first"]), int(nd["left_first"]) + 1
+                    lim = hit if hit is not None else MAX_DIST
+                    ha, ta = _aabb_rs(orig, d, nodes[a]["min"], nodes[a]["max"], lim)
+                    hb, tb = _aabb_rs(orig, d, nodes[b]["min"], nodes[b]["max"], lim)
+                    # derive(PartialOrd) on enum Dist { Hit(f32), Miss }: Hit(x) < Miss
+                    gt = (not ha) if ha != hb else (ha and ta > tb)
+                    if gt:
+                        a, b, ha, hb = b, a, hb, ha
+                    if not ha:
+                        continue
+                    st.append(a)
+                    if hb:
+                        st.append(b)
+            out[ri] = F(-1.0) if hit is None else hit
+    return out
+
+
+# ---- occlusion extension (no reference counterpart; definition in include/voidin_abi.h) ----
+def hiz_build(depth):
+    depth = np.asarray(depth, F)
+    levels = [depth]
+    while levels[-1].shape != (1, 1):
+        s = levels[-1]
+        h, w = s.shape
+        dh, dw = (h + 1) // 2, (w + 1) // 2
+        ys = np.minimum(np.arange(dh)[:, None] * 2 + np.array([0, 1])[None, :], h - 1)     # clamped child rows
+        xs = np.minimum(np.arange(dw)[:, None] * 2 + np.array([0, 1])[None, :], w - 1)
+        levels.append(np.minimum.reduce([s[ys[:, a]][:, xs[:, b]] for a in (0, 1) for b in (0, 1)]))
+    return np.concatenate([l.reshape(-1) for l in levels]).astype(F), [l.shape for l in levels]
+
+
+def occlusion_mask(cam, meshes, inst, depth, mask_in):
+    """Per instance, in float32 and the operation order the header fixes."""
+    pyr, shapes = hiz_build(depth)
+    offs = np.concatenate([[0], np.cumsum([h * w for h, w in shapes])])
+    H, W = shapes[0]
+    V = np.asarray(cam["view"], F).reshape(16)
+    P = np.asarray(cam["projection"], F).reshape(16)
+    znear = F(cam["znear"])
+    n = len(inst)
+    bits = np.unpackbits(np.asarray(mask_in, np.uint64).view(np.uint8), bitorder="little")[:n].astype(bool)
+    keep = bits.copy()
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for i in np.flatnonzero(bits):
+            m = meshes[min(int(inst["mesh"][i]), len(meshes) - 1)]
+            T = inst["transform"][i].astype(F)
+            mn, mx = m["min"].astype(F), m["max"].astype(F)
+            c0 = ((mx + mn) / F(2.0)).astype(F)
+            c = []
+            for r in range(3):
+                col = [F(F(F(V[r] * T[4 * j] + V[4 + r] * T[4 * j + 1]) + V[8 + r] * T[4 * j + 2]) + V[12 + r] * T[4 * j + 3]) for j in range(4)]
+                c.append(F(F(F(col[0] * c0[0] + col[1] * c0[1]) + col[2] * c0[2]) + col[3] * F(1.0)))
+            ms = max(abs(_len3(T[0], T[1], T[2])), abs(_len3(T[4], T[5], T[6])), abs(_len3(T[8], T[9], T[10])))
+            e = (mx - mn).astype(F)
+            r_ = F(F(_len3(e[0], e[1], e[2]) * F(0.5)) * ms)
+            d = F(-c[2])
+            dn = F(d - r_)
+            if not (dn > znear):
+                continue
+            rr, dd, rd = F(r_ * r_), F(d * d), F(r_ * d)
+            tx = F(np.sqrt(F(F(c[0] * c[0] + dd) - rr)))
+            ty = F(np.sqrt(F(F(c[1] * c[1] + dd) - rr)))
+            dxm, dxp = F(d * tx + c[0] * r_), F(d * tx - c[0] * r_)
+            dym, dyp = F(d * ty + c[1] * r_), F(d * ty - c[1] * r_)
+            if not (dxm > 0 and dxp > 0 and dym > 0 and dyp > 0):
+                continue
+            sx0, sx1 = F(F(c[0] * tx - rd) / dxm), F(F(c[0] * tx + rd) / dxp)
+            sy0, sy1 = F(F(c[1] * ty - rd) / dym), F(F(c[1] * ty + rd) / dyp)
+            nxa, nxb = F(P[0] * sx0 - P[8]), F(P[0] * sx1 - P[8])
+            nya, nyb = F(P[5] * sy0 - P[9]), F(P[5] * sy1 - P[9])
+            nx_lo, nx_hi, ny_lo, ny_hi = np.fmin(nxa, nxb), np.fmax(nxa, nxb), np.fmin(nya, nyb), np.fmax(nya, nyb)
+            Wf, Hf = F(W), F(H)
+            u0 = F(F(F(nx_lo * F(0.5)) + F(0.5)) * Wf - F(0.5)); u1 = F(F(F(nx_hi * F(0.5)) + F(0.5)) * Wf + F(0.5))
+            v0 = F(F(F(0.5) - ny_hi * F(0.5)) * Hf - F(0.5)); v1 = F(F(F(0.5) - ny_lo * F(0.5)) * Hf + F(0.5))
+            if not (u1 >= 0 and v1 >= 0 and u0 < Wf and v0 < Hf):
+                continue
+            x0, x1 = int(np.floor(np.fmax(u0, F(0)))), int(np.floor(np.fmin(u1, F(Wf - F(1)))))
+            y0, y1 = int(np.floor(np.fmax(v0, F(0)))), int(np.floor(np.fmin(v1, F(Hf - F(1)))))
+            lvl = min(max(x1 - x0, y1 - y0).bit_length(), len(shapes) - 1)
+            lh, lw = shapes[lvl]
+            t = pyr[offs[lvl]: offs[lvl] + lh * lw].reshape(lh, lw)
+            hmin = min(t[y0 >> lvl, x0 >> lvl], t[y0 >> lvl, x1 >> lvl], t[y1 >> lvl, x0 >> lvl], t[y1 >> lvl, x1 >> lvl])
+            depth_s = F(F(P[14] - F(P[10] * dn)) / dn)
+            if depth_s < hmin:
+                keep[i] = False
+    out = np.zeros((n + 63) // 64 * 64, dtype=np.uint8)
+    out[:n] = keep
+    return np.packbits(out, bitorder="little").view(np.uint64)

@@ -99,10 +99,54 @@ def tlas_trace_cases():
     print("trace hits", int(h_np["hit"].sum()), "/", len(rays))
 
 
+def harness_case():
+    """src/bin/bvh_cpu.rs: camera (0, 0, 15), per-pixel rays, Bvh::traverse_iter over the 64-triangle soup."""
+    cam = synth.camera_uniform(eye=(0, 0, 15), pitch_deg=0)                 # bvh_cpu.rs:134
+    v, i = synth.triangle_soup(64)
+    nodes, idx = npr.bvh_build(v, i)
+    r_np, r_c = npr.primary_rays(cam, 48, 48), ref.primary_rays(cam, 48, 48)
+    assert r_np.tobytes() == r_c.tobytes()
+    d_np, d_c = npr.traverse_iter(nodes, v, idx, r_np), ref.traverse_iter(nodes, v, idx, r_c)
+    assert d_np.tobytes() == d_c.tobytes() and (d_np >= 0).sum() > 20
+    np.savez_compressed(os.path.join(OUT, "harness_soup64.npz"), camera=cam, width=np.uint32(48), height=np.uint32(48), rays=r_np,
+                        nodes=nodes, vertices=v, indices=idx, dist=d_np)
+    print("harness hits", int((d_np >= 0).sum()), "/", len(r_np))
+
+
+def occlusion_case():
+    """The occlusion extension (no reference counterpart): depth -> min pyramid -> refined mask."""
+    cam = synth.camera_uniform(eye=(0, 0, 50), pitch_deg=0, jitter=(0.003, -0.002))
+    meshes = synth.mesh_infos()
+    inst = synth.instances(1500, seed=synth.SEED_BASE + 42, extent=300.0, centre=(0.0, 0.0, -150.0), scale_range=(0.25, 4.0))
+    w, h = 100, 60
+    u = synth.uniform01(synth.SEED_BASE + 43, 0, 64 * 5).reshape(64, 5).astype(np.float64)
+    depth = np.zeros((h, w), dtype=np.float32)
+    for x, y, sx, sy, z in u:
+        x0, y0 = int(x * w), int(y * h)
+        depth[y0: y0 + 1 + int(sy * h / 3), x0: x0 + 1 + int(sx * w / 3)] = np.float32(0.001 / (20.0 + 300.0 * z))
+    p_np, _ = npr.hiz_build(depth)
+    p_c = ref.hiz_build(depth)
+    assert p_np.tobytes() == p_c.tobytes()
+    frustum = np.zeros((len(inst) + 63) // 64, dtype=np.uint64)
+    vis = ref.cull_emit(cam, meshes, inst)["instance_count"] == 1
+    padded = np.zeros(len(frustum) * 64, dtype=np.uint8)
+    padded[: len(inst)] = vis
+    frustum = np.packbits(padded, bitorder="little").view(np.uint64)
+    m_np = npr.occlusion_mask(cam, meshes, inst, depth, frustum)
+    m_c = ref.occlusion_mask(cam, meshes, inst, p_c, w, h, frustum)
+    assert np.array_equal(m_np, m_c)
+    np.savez_compressed(os.path.join(OUT, "occlusion_1500.npz"), camera=cam, meshes=meshes, instances=inst, depth=depth, pyramid=p_np,
+                        mask_in=frustum, mask_out=m_np)
+    pop = lambda m: int(np.unpackbits(m.view(np.uint8)).sum())
+    print("occlusion: frustum", pop(frustum), "-> kept", pop(m_np))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     cull_cases()
     blas_cases()
     tlas_trace_cases()
+    harness_case()
+    occlusion_case()
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes", sz)

@@ -77,6 +77,14 @@ def test_cpu_harness_rays_and_traverse_iter(ctx, oracle):
         assert d_rays.cpu().numpy().tobytes() == want.tobytes()
     ctx.primary_rays_dev(cam, 0, 0, None)                                       # nothing to do
     assert ctx.lib.vd_primary_rays_dev(ctx.h, None, 4, 4, None) == abi.VD_ERR_INVALID_ARG
+    g = golden("harness_soup64.npz")                                            # fixture from the numpy restatement
+    d_gr = torch.zeros(len(g["rays"]) * abi.RAY.itemsize, dtype=torch.uint8, device="cuda")
+    ctx.primary_rays_dev(g["camera"], int(g["width"]), int(g["height"]), d_gr)
+    assert d_gr.cpu().numpy().tobytes() == g["rays"].tobytes()
+    d_gd = torch.zeros(len(g["rays"]), dtype=torch.float32, device="cuda")
+    ctx.traverse_iter_dev(ctx.upload(g["nodes"]), len(g["nodes"]), ctx.upload(g["vertices"].astype(np.float32)),
+                          ctx.upload(g["indices"].astype(np.uint32)), d_gr, len(g["rays"]), d_gd)
+    assert d_gd.cpu().numpy().tobytes() == g["dist"].tobytes()
     rays = oracle.primary_rays(cam, 160, 160)
     for name in ("blas_soup64.npz", "blas_sphere_1_10.npz", "blas_knot_2k.npz", "blas_plane.npz"):
         g = golden(name)

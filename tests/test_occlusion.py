@@ -7,6 +7,7 @@ import math
 import numpy as np
 import pytest
 
+from conftest import golden
 from voidin_amd import abi, synth
 
 
@@ -80,6 +81,31 @@ def test_far_depth_culls_nothing_near_depth_culls_everything_in_front(oracle):
     bad["projection"][11] = 1.0
     with pytest.raises(oracle.OracleError):
         oracle.occlusion_mask(bad, meshes, inst, far, w, h, full)
+
+
+def test_twin_matches_golden(oracle):
+    """The C twin against the fixture written from the independent numpy statement (make_golden.py: occlusion_case)."""
+    g = golden("occlusion_1500.npz")
+    h, w = g["depth"].shape
+    pyr = oracle.hiz_build(g["depth"])
+    assert pyr.tobytes() == g["pyramid"].tobytes()
+    got = oracle.occlusion_mask(g["camera"], g["meshes"], g["instances"], pyr, w, h, g["mask_in"])
+    assert np.array_equal(got, g["mask_out"])
+
+
+@pytest.mark.gpu
+def test_gpu_matches_golden(ctx):
+    import torch
+    g = golden("occlusion_1500.npz")
+    h, w = g["depth"].shape
+    n = len(g["instances"])
+    d_pyr = torch.zeros(len(g["pyramid"]), dtype=torch.float32, device="cuda")
+    ctx.hiz_build_dev(ctx.upload(g["depth"]), w, h, d_pyr)
+    assert d_pyr.cpu().numpy().tobytes() == g["pyramid"].tobytes()
+    d_in = ctx.upload(g["mask_in"].view(np.int64))
+    d_out = torch.zeros_like(d_in)
+    ctx.occlusion_mask_dev(g["camera"], ctx.upload(g["meshes"]), len(g["meshes"]), ctx.upload(g["instances"]), n, d_pyr, w, h, d_in, d_out)
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), g["mask_out"])
 
 
 def _sphere_rect_f64(cam, mesh, T, w, h):

@@ -177,6 +177,16 @@ def test_primary_rays_follow_the_cpu_harness(oracle):
     assert len(oracle.primary_rays(cam, 0, 0)) == 0
 
 
+def test_cpu_harness_matches_golden(oracle):
+    """bvh_cpu.rs per-pixel rays + Bvh::traverse_iter: the C oracle against the fixture written from the independent
+    numpy restatement (tests/golden/make_golden.py: harness_case)."""
+    g = golden("harness_soup64.npz")
+    rays = oracle.primary_rays(g["camera"], int(g["width"]), int(g["height"]))
+    assert rays.tobytes() == g["rays"].tobytes()
+    d = oracle.traverse_iter(g["nodes"], g["vertices"], g["indices"], g["rays"])
+    assert d.tobytes() == g["dist"].tobytes()
+
+
 def test_rust_cpu_traversal_variant(oracle):
     # R2 (blas.rs:247-295): two-sided, divides by dir; agrees with R1 on front-facing hits
     g = golden("blas_soup64.npz")
