@@ -15,7 +15,7 @@ import numpy as np
 from voidin_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvd_oracle.so")
+LIB_PATH = os.environ.get("VD_ORACLE_LIB") or os.path.join(_HERE, "libvd_oracle.so")   # VD_ORACLE_LIB: e.g. the `make asan` build
 _lib = None
 _P, _U, _I = C.c_void_p, C.c_uint32, C.c_int
 
