@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, q):
+def _worker(rank, world, port, n, q, n_mesh=16):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,9 +33,9 @@ def _worker(rank, world, port, n, q):
         from voidin_amd.runtime import Context
         torch.cuda.set_device(0)
         ctx = Context(0)
-        cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+        cam, meshes = synth.camera_uniform(), synth.mesh_infos(n_mesh)
         lo, hi = vdist.shard_range(n, rank, world)
-        shard = synth.instances(hi - lo, seed=79, offset=lo, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+        shard = synth.instances(hi - lo, n_mesh=n_mesh, seed=79, offset=lo, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
         d_m, d_i = ctx.upload(meshes), ctx.upload(shard)
         sv = vdist.ShardedVisibility(ctx, n, d_m, len(meshes), d_i)
         d_out = ctx.empty(n * 20)
@@ -52,15 +52,16 @@ def _worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 200_003), (3, 64_000)])
-def test_sharded_visibility_two_ranks_one_gpu(oracle, world, n):
-    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
-    inst = synth.instances(n, seed=79, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+@pytest.mark.parametrize("world,n,n_mesh", [(2, 200_003, 16), (3, 64_000, 16), (2, 50_001, 300)])
+def test_sharded_visibility_two_ranks_one_gpu(oracle, world, n, n_mesh):
+    """n_mesh = 300: the replicated instance->mesh table holds 2-byte ids (gathered as bytes)."""
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos(n_mesh)
+    inst = synth.instances(n, n_mesh=n_mesh, seed=79, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
     want, wn = oracle.compact(oracle.cull_emit(cam, meshes, inst))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, n_mesh)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]

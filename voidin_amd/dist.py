@@ -65,7 +65,8 @@ class ShardedVisibility:
             ids[: self.n_local] = torch.clamp(col, 0, n_mesh - 1).to(id_dtype)
         self.d_mesh_ids = torch.empty(self.S * self.world, dtype=id_dtype, device=dev)
         if self.world > 1:
-            dist.all_gather_into_tensor(self.d_mesh_ids, ids, group=group)
+            # gathered as bytes: the RCCL backend has no 16-bit integer type
+            dist.all_gather_into_tensor(self.d_mesh_ids.view(torch.uint8), ids.view(torch.uint8), group=group)
         else:
             self.d_mesh_ids.copy_(ids)
 
