@@ -65,7 +65,9 @@ template <typename Node>
 __global__ __launch_bounds__(256) void tlas_leaves_kernel(const VdInstance* __restrict__ inst, unsigned n,
                                                           const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
                                                           Node* __restrict__ nodes, float* __restrict__ slot_box /* [6][cap] or null */,
-                                                          unsigned* __restrict__ slot_node, unsigned cap, int refit) {
+                                                          unsigned* __restrict__ slot_node, unsigned cap, int refit,
+                                                          const unsigned* __restrict__ only_if = nullptr) {
+    if (only_if && *only_if == 0u) return;                  // second attempt of a build: only when the first gave up
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const unsigned src = refit ? nodes[i + 1].instance_idx : i;
@@ -224,7 +226,8 @@ __device__ __forceinline__ void tlas_build_chain(Node* __restrict__ nodes, unsig
 template <typename Node>
 __global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restrict__ nodes, unsigned n,
                                                                    float* sb, unsigned* slot_node,
-                                                                   unsigned cap) {
+                                                                   unsigned cap, const unsigned* __restrict__ only_if) {
+    if (only_if && *only_if == 0u) return;                  // see tlas_build_impl
     __shared__ vd_u64 s_red[4];
     if (threadIdx.x < 4) s_red[threadIdx.x] = ~0ull;
     int nan = 0;
@@ -246,8 +249,8 @@ __global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restr
 // exchange costs 1.4 - 2.2 us).  Entry (r % 2, w) is rewritten at scan r + 2, which w reaches only after every workgroup has
 // published r + 1, i.e. has finished reading r.  A merge is applied by workgroup 0 alone; the others wait for its
 // merge counter.  Slots are shared through memory: all reads and writes of them are agent-scope (L1/L2-bypassing
-// loads, write-through stores), no fences.  Spins are bounded: on a timeout every workgroup leaves, the host sees
-// the flag and falls back to the single-workgroup kernel.
+// loads, write-through stores), no fences.  Spins are bounded: on a timeout every workgroup sets the flag and leaves,
+// and the single-workgroup kernel that is queued behind (it returns at once when the flag is clear) redoes the build.
 constexpr unsigned kMwMaxGroups = 32;
 #ifndef VD_MW_THREADS
 #define VD_MW_THREADS 1024
@@ -540,23 +543,23 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     if (groups > (unsigned)ctx->num_cus) groups = (unsigned)ctx->num_cus;
     if (n >= (1u << 20)) groups = 1u;
     vd_time_begin(ctx);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        VD_HIP_CHECK(ctx, hipMemsetAsync(d_nodes, 0, sizeof(Node) * (2 * (size_t)n + 1), ctx->stream));   // TlasNode::default()
-        hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
-                           n_mesh, d_nodes, sb, slot_node, (unsigned)cap, 0);
-        if (groups <= 1u) {
-            hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
-                               (unsigned)cap);
-            break;
-        }
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_nodes, 0, sizeof(Node) * (2 * (size_t)n + 1), ctx->stream));   // TlasNode::default()
+    hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
+                       n_mesh, d_nodes, sb, slot_node, (unsigned)cap, 0, (const unsigned*)nullptr);
+    if (groups <= 1u) {
+        hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
+                           (unsigned)cap, (const unsigned*)nullptr);
+    } else {
         VD_HIP_CHECK(ctx, hipMemsetAsync(sh, 0, sizeof(MwShared), ctx->stream));
         hipLaunchKernelGGL((tlas_build_mw_kernel<Node>), dim3(groups * 8u), dim3(kMwThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
                            (unsigned)cap, sh, spin_limit);
-        VD_HIP_CHECK(ctx, hipGetLastError());
-        VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, &sh->fail, 4, hipMemcpyDeviceToHost, ctx->stream));
-        VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->host_pinned[0] == 0u) break;
-        groups = 1u;   // the workgroups were not co-resident in time (spin limit): run the chain on one
+        // If the workgroups did not hear from each other in time (not co-resident: spin limit) they set sh->fail and
+        // leave; the two launches below then redo the build on one workgroup, and return at once otherwise - decided
+        // on the device, so the call stays asynchronous.  Every node a build writes is written again by the redo.
+        hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
+                           n_mesh, d_nodes, sb, slot_node, (unsigned)cap, 0, (const unsigned*)&sh->fail);
+        hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
+                           (unsigned)cap, (const unsigned*)&sh->fail);
     }
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
