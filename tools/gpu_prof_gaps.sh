@@ -26,6 +26,6 @@ for r in seq:
 for n,(c,t) in sorted(agg.items(),key=lambda kv:-kv[1][1])[:16]: print(f"  {n:32s} calls {c:5d} total {t/1e6:7.2f} ms avg {t/c/1e3:8.1f} us")
 big=[(g,seq[i]['Kernel_Name'][:40],seq[i+1]['Kernel_Name'][:40]) for i,g in enumerate(gaps) if g>30000]
 print("gaps > 30 us:",len(big), "sum %.2f ms"%(sum(b[0] for b in big)/1e6))
-for b in big[:8]: print("  %.1f us after %s before %s"%(b[0]/1e3,b[1],b[2]))
+for b in sorted(big, reverse=True)[:10]: print("  %.1f us after %s before %s"%(b[0]/1e3,b[1],b[2]))
 PY
 find $O -name "*kernel_trace.csv" -delete

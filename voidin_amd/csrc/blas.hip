@@ -1637,43 +1637,63 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         ctx->dbg_ptr = P.stack; ctx->dbg_count = 2 * n_small;
     }
     // ---- phase C: DFS numbering of the top tree on the host ----
-    std::vector<TopNode> h_top(n_top);
-    std::vector<unsigned> h_sub(n_small ? n_small : 1);
-    VD_HIP_CHECK(ctx, hipMemcpyAsync(h_top.data(), P.top, sizeof(TopNode) * n_top, hipMemcpyDeviceToHost, st));
-    if (n_small) VD_HIP_CHECK(ctx, hipMemcpyAsync(h_sub.data(), P.sub_interior, 4 * (size_t)n_small, hipMemcpyDeviceToHost, st));
-    VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
-    VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    if (h_ctl.err & ERR_DEGENERATE)
-        VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
-    std::vector<TopOut> h_out(n_top);
-    std::vector<unsigned> h_root_pair(n_small ? n_small : 1);
-    unsigned pool = 2;
+    // The top tree is final before phase B starts (the stream was synchronised after the last level / the mid tier), so
+    // it is fetched on a second stream and walked WHILE phase B runs; what depends on phase B - how many node pairs
+    // each small subtree takes - enters in one linear pass over the recorded pre-order afterwards.  Pinned staging:
+    // [TopNode n_top][TopOut n_top][order n_top][sub n_small][root_pair n_small]
+    const size_t off_out = sizeof(TopNode) * (size_t)n_top, off_ord = off_out + sizeof(TopOut) * (size_t)n_top;
+    const size_t off_sub = off_ord + 4 * (size_t)n_top, off_rp = off_sub + 4 * (size_t)(n_small ? n_small : 1);
+    int rc_h = vd_ensure_host(ctx, off_rp + 4 * (size_t)(n_small ? n_small : 1));
+    if (rc_h) return rc_h;
+    if (!ctx->aux_stream) VD_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    char* hs = reinterpret_cast<char*>(ctx->host_stage);
+    TopNode* h_top = reinterpret_cast<TopNode*>(hs);
+    TopOut* h_out = reinterpret_cast<TopOut*>(hs + off_out);
+    unsigned* h_ord = reinterpret_cast<unsigned*>(hs + off_ord);
+    unsigned* h_sub = reinterpret_cast<unsigned*>(hs + off_sub);
+    unsigned* h_root_pair = reinterpret_cast<unsigned*>(hs + off_rp);
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(h_top, P.top, sizeof(TopNode) * n_top, hipMemcpyDeviceToHost, ctx->aux_stream));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->aux_stream));
+    unsigned n_ord = 0;
     {
         // pre-order walk: an interior node takes the next pair when visited (blas.rs:110-112)
         std::vector<unsigned> stk;
         stk.push_back(0);
-        h_out[0].final_index = 0;
         while (!stk.empty()) {
             const unsigned v = stk.back(); stk.pop_back();
             const TopNode& t = h_top[v];
             if (t.kind == 0u) continue;
-            const unsigned pair = pool;
-            h_out[v].pair = pair;
-            if (t.kind == 2u) {
-                h_root_pair[t.small] = pair;
-                pool += 2u * h_sub[t.small];
-            } else {
-                pool += 2;
-                h_out[t.left].final_index = pair;
-                h_out[t.left + 1].final_index = pair + 1;
+            h_ord[n_ord++] = v;
+            if (t.kind == 1u) {
                 stk.push_back(t.left + 1);
                 stk.push_back(t.left);
             }
         }
     }
+    if (n_small) VD_HIP_CHECK(ctx, hipMemcpyAsync(h_sub, P.sub_interior, 4 * (size_t)n_small, hipMemcpyDeviceToHost, st));
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (h_ctl.err & ERR_DEGENERATE)
+        VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
+    unsigned pool = 2;
+    h_out[0].final_index = 0;
+    for (unsigned k = 0; k < n_ord; ++k) {
+        const unsigned v = h_ord[k];
+        const TopNode& t = h_top[v];
+        const unsigned pair = pool;
+        h_out[v].pair = pair;
+        if (t.kind == 2u) {
+            h_root_pair[t.small] = pair;
+            pool += 2u * h_sub[t.small];
+        } else {
+            pool += 2;
+            h_out[t.left].final_index = pair;
+            h_out[t.left + 1].final_index = pair + 1;
+        }
+    }
     if (pool > node_cap) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_bvh_build: node_cap too small");
-    VD_HIP_CHECK(ctx, hipMemcpyAsync(P.tout, h_out.data(), sizeof(TopOut) * n_top, hipMemcpyHostToDevice, st));
-    if (n_small) VD_HIP_CHECK(ctx, hipMemcpyAsync(P.root_pair, h_root_pair.data(), 4 * (size_t)n_small, hipMemcpyHostToDevice, st));
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(P.tout, h_out, sizeof(TopOut) * n_top, hipMemcpyHostToDevice, st));
+    if (n_small) VD_HIP_CHECK(ctx, hipMemcpyAsync(P.root_pair, h_root_pair, 4 * (size_t)n_small, hipMemcpyHostToDevice, st));
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_out, 0, sizeof(VdBvhNode) * 2, st));   // node 1 stays all-zero (blas.rs:52,90)
     hipLaunchKernelGGL(c_top_kernel, dim3((n_top + 63) / 64), dim3(64), 0, st, P.top, P.tout, n_top, d_out);
     if (n_small) hipLaunchKernelGGL(c_sub_kernel, dim3(n_small), dim3(256), 0, st, P.small, P.sub_interior, P.root_pair, n_small, P.subnodes, P.submap, d_out);
@@ -1681,7 +1701,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     hipLaunchKernelGGL(c_permute_kernel, dim3(tri_blocks), dim3(256), 0, st, P.final_ids, P.idx_copy, d_idx, n_tri);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
-    VD_HIP_CHECK(ctx, hipStreamSynchronize(st));   // h_out / h_root_pair go out of scope
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(st));   // the pinned staging is reused by the next build
     *out_n_nodes = pool;
     return VD_OK;
 }

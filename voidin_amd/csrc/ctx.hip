@@ -26,6 +26,26 @@ int vd_ensure(VdCtx* ctx, void** buf, size_t* cur, size_t need) {
     return VD_OK;
 }
 
+// grow-only pinned host staging
+int vd_ensure_host(VdCtx* ctx, size_t need) {
+    if (need <= ctx->host_stage_bytes && ctx->host_stage) return VD_OK;
+    size_t cap = ctx->host_stage_bytes ? ctx->host_stage_bytes : (size_t)1 << 16;
+    while (cap < need) cap *= 2;
+    if (ctx->host_stage) {
+        VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        VD_HIP_CHECK(ctx, hipHostFree(ctx->host_stage));
+        ctx->host_stage = nullptr; ctx->host_stage_bytes = 0;
+    }
+    hipError_t e = hipHostMalloc(&ctx->host_stage, cap);
+    if (e != hipSuccess) {
+        snprintf(ctx->err, sizeof(ctx->err), "hipHostMalloc(%zu) -> %s", cap, hipGetErrorString(e));
+        ctx->host_stage = nullptr;
+        return VD_ERR_OOM;
+    }
+    ctx->host_stage_bytes = cap;
+    return VD_OK;
+}
+
 int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer) {
     const size_t need = (16 + (size_t)n_tiles * 8 + 15) & ~(size_t)15;
     const bool periodic = (++ctx->scan_launches & ((1ull << 28) - 1)) == 0;   // epoch field is 30 bits: never let it lap
@@ -81,6 +101,8 @@ int vd_ctx_destroy(VdCtx* ctx) {
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
     if (ctx->stage_aux) (void)hipFree(ctx->stage_aux);
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
+    if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);

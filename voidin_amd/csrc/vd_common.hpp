@@ -37,6 +37,8 @@ struct VdCtx {
     void* stage_out = nullptr;   size_t stage_out_bytes = 0;
     void* stage_aux = nullptr;   size_t stage_aux_bytes = 0;
     uint32_t* host_pinned = nullptr;                           // 64 u32 of pinned host memory
+    void* host_stage = nullptr;  size_t host_stage_bytes = 0;  // grow-only pinned staging (BLAS top tree)
+    hipStream_t aux_stream = nullptr;                          // copies that overlap a kernel on `stream`
 };
 
 #define VD_HIP_CHECK(ctx, call)                                                              \
@@ -58,6 +60,7 @@ struct VdCtx {
 // Grow-only arena helper. Never called between a kernel's enqueue and its completion on the
 // same buffer without a stream sync (callers sync before growing).
 int vd_ensure(VdCtx* ctx, void** buf, size_t* cur, size_t need);
+int vd_ensure_host(VdCtx* ctx, size_t need);   // ctx->host_stage: grow-only pinned host memory
 // Look-back scan state for n_tiles tiles: *ticket = 64-bit {epoch | ticket} word, *states = granules.
 // Zeroed once when (re)allocated; the epoch tags make per-launch clearing unnecessary.
 int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer);
