@@ -63,7 +63,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct TriBox { float mn[3]; float pad0; float mx[3]; float pad1; };   // 32 B, by triangle id
 struct TmpNode { float mn[3]; unsigned left_first; float mx[3]; unsigned count; };   // == VdBvhNode layout
 
-enum : unsigned { ERR_DEGENERATE = 1u, ERR_BAD_INDEX = 2u };
+enum : unsigned { ERR_DEGENERATE = 1u, ERR_BAD_INDEX = 2u, ERR_INTERNAL = 4u };
 
 __device__ __forceinline__ float pay_c(const u32x4& v, int axis) {
     return __uint_as_float(axis == 0 ? v.y : (axis == 1 ? v.z : v.w));
@@ -200,6 +200,7 @@ struct WaveScratch {                              // per-wave: the node this wav
     unsigned short u_e[kCand + 3];
     unsigned short u_p[kCand + 3];
     int bin_min[3][8][3], bin_max[3][8][3];       // nodes > 64 prims: box keys of the non-`u` elements by (axis, bin)
+    unsigned next_ent;                            // the child this wave goes on with (0: none)
 };
 struct WaveLds {
     float cent[3][kSmallMax];
@@ -291,12 +292,14 @@ __device__ __forceinline__ void wave_shuffle_any(WaveLds& L, int src, unsigned s
 constexpr int kLaneMax = VD_LANE_MAX;   // nodes up to this size are built one-per-lane (literal sequential algorithm)
 constexpr int kQueue = kSmallMax / 4;   // a BFS level holds at most N/4 splittable nodes
 
-struct WaveQueues {                      // entry = node | start << 10 | count << 20
-    unsigned big[2][kQueue];             // BFS frontier of the wave-wide nodes
+struct WaveQueues {                      // entry = node | start << 10 | count << 20 (never 0: count > kLaneMax)
+    unsigned work[2 * kQueue];           // wave-wide nodes handed to other waves: append-only, 0 = not written yet
     unsigned small[kQueue];              // every node <= kLaneMax spawned by a wave-wide node
     unsigned lane_stack[2][64 * kSubWaves];   // per-lane DFS stack (<= kLaneMax/4 - 1 = 1 pending sibling)
     unsigned pool;                       // next free node pair
-    unsigned n_big_cnt[2], n_small, root_left, bad;   // n_big_cnt[q] counts the entries pushed into big[q]
+    unsigned head, tail;                 // work[head .. tail) is waiting for a wave
+    int pending;                         // wave-wide nodes queued or being split
+    unsigned n_small, root_left, bad;
 };
 
 // blas.rs:135-166 run literally by ONE lane on its own node [s, s+n), n <= 8, entirely in
@@ -437,23 +440,49 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     }
     // Wave-wide nodes ping-pong their own segment between the two perm buffers an even number of
     // times (22) and mirror the result, so both buffers agree outside the node being processed.
-    // The four waves split different nodes of one BFS level concurrently.  Nodes <= kLaneMax are
+    // The subtrees under a root are deep and thin (SAH splits are unbalanced): walked level by level, most levels hold
+    // fewer nodes than the workgroup has waves and still cost a full node pass of 22 dependent shuffles plus two
+    // barriers.  So there are no levels: a wave that has split a node goes straight on with one child and hands the
+    // other to whichever wave is idle (append-only list in LDS); `pending` counts the wave-wide nodes that are queued
+    // or being split, and a wave leaves when it finds nothing to take and pending is 0.  Nodes <= kLaneMax are
     // collected and built afterwards, one whole sub-subtree per lane.
+    for (unsigned x = tid; x < 2u * (unsigned)kQueue; x += 64u * kSubWaves) Q.work[x] = 0u;
+    const unsigned root_ent = 1023u | (N << 20);        // the root entry: node field unused; s = 0, n = N (no child has n = N)
     if (tid == 0) {
-        Q.pool = 0; Q.n_big_cnt[0] = 0; Q.n_big_cnt[1] = 0; Q.n_small = 0; Q.root_left = kNone; Q.bad = 0;
-        const unsigned ent = 1023u | (N << 20);     // the root entry: node field unused; s = 0, n = N
-        if (N > (unsigned)kLaneMax) Q.big[0][0] = ent; else { Q.small[0] = ent; Q.n_small = 1; }
+        Q.pool = 0; Q.n_small = 0; Q.root_left = kNone; Q.bad = 0; Q.head = 0; Q.tail = 0; Q.pending = 0;
+        if (N > (unsigned)kLaneMax) Q.pending = 1; else { Q.small[0] = root_ent; Q.n_small = 1; }
     }
     __syncthreads();
-    unsigned n_big = N > (unsigned)kLaneMax ? 1u : 0u;
-    bool root_level = true;
-    int qi = 0;
+    unsigned next_ent = (wave == 0u && N > (unsigned)kLaneMax) ? root_ent : 0u;   // wave-uniform; 0 = take one from the list
+    unsigned idle_polls = 0;
 
-    while (n_big > 0u) {
-        for (unsigned bi = wave; bi < n_big; bi += kSubWaves) {
-            const unsigned ent = Q.big[qi][bi];
+    for (;;) {
+        {
+            unsigned ent = next_ent;
+            if (ent == 0u) {
+                unsigned got = 0u;
+                if (lane == 0) {
+                    for (;;) {
+                        const unsigned h = *(volatile unsigned*)&Q.head, t = *(volatile unsigned*)&Q.tail;
+                        if (h >= t) break;
+                        if (atomicCAS(&Q.head, h, h + 1u) == h) {
+                            unsigned spins = 0;
+                            while ((got = *(volatile unsigned*)&Q.work[h]) == 0u && ++spins < (1u << 22)) {}   // claimed by its pusher, written next
+                            break;
+                        }
+                    }
+                }
+                ent = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+                if (ent == 0u) {
+                    if (*(volatile int*)&Q.pending <= 0 || *(volatile unsigned*)&Q.bad) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++idle_polls > (1u << 24)) { if (lane == 0) Q.bad = 2; break; }   // never expected: an error, not a hang
+                    continue;
+                }
+            }
+            next_ent = 0u;
             const unsigned node_id = ent & 1023u, s = (ent >> 10) & 1023u, n = ent >> 20;
-            const bool is_root = root_level;
+            const bool is_root = ent == root_ent;
             int cur = 0;
             int kmn[3] = {kBig, kBig, kBig}, kmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
             for (unsigned x = lane; x < n; x += 64u) {
@@ -614,7 +643,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             }
             }
             key = wave_min_u64(key);
-            if (key == ~0ull) { if (lane == 0) Q.bad = 1; continue; }
+            if (key == ~0ull) { if (lane == 0) { Q.bad = 1; atomicSub(&Q.pending, 1); } continue; }
             const int best = (int)(unsigned)key;
             const unsigned Lst = W.ttot[best] - W.u_p[best];             // stale optimal_pivot (blas.rs:159,165)
             {
@@ -648,21 +677,24 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 nodes[pair] = ln; nodes[pair + 1] = rn;
                 if (is_root) Q.root_left = pair;
                 else { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }   // creation-order link
+                unsigned keep = 0u;
+                int n_wide = 0;
                 for (int side = 0; side < 2; ++side) {
                     if (cn[side] > 3u) {
                         const unsigned e2 = (pair + side) | (cs[side] << 10) | (cn[side] << 20);
-                        if (cn[side] > (unsigned)kLaneMax) Q.big[qi ^ 1][atomicAdd(&Q.n_big_cnt[qi ^ 1], 1u)] = e2;
-                        else Q.small[atomicAdd(&Q.n_small, 1u)] = e2;
+                        if (cn[side] > (unsigned)kLaneMax) {
+                            n_wide += 1;
+                            if (keep == 0u) keep = e2;                      // this wave goes on with it
+                            else Q.work[atomicAdd(&Q.tail, 1u)] = e2;       // the other one is for whoever is idle
+                        } else Q.small[atomicAdd(&Q.n_small, 1u)] = e2;
                     }
                 }
+                if (n_wide != 1) atomicAdd(&Q.pending, n_wide - 1);         // this node is done, n_wide more exist
+                W.next_ent = keep;
             }
+            vd_wave_lds_sync();
+            next_ent = W.next_ent;
         }
-        __syncthreads();
-        n_big = Q.n_big_cnt[qi ^ 1];
-        if (tid == 0) Q.n_big_cnt[qi] = 0;     // big[qi] is the push target of the next level
-        root_level = false;
-        qi ^= 1;
-        __syncthreads();
     }
     __syncthreads();
 
@@ -702,7 +734,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     __threadfence_block();   // node records written by all lanes are re-read below, by this workgroup only (an agent-scope
                              // fence would write back the whole L2 of the XCD, once per subtree)
     __syncthreads();
-    if (Q.bad) { if (tid == 0) atomicOr(err, ERR_DEGENERATE); return; }
+    if (Q.bad) { if (tid == 0) atomicOr(err, Q.bad == 2u ? ERR_INTERNAL : ERR_DEGENERATE); return; }
     const unsigned pool = Q.pool, root_left = Q.root_left;
     const unsigned n_interior = pool / 2u;
 
@@ -1675,6 +1707,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
     if (h_ctl.err & ERR_DEGENERATE)
         VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
+    if (h_ctl.err & ERR_INTERNAL) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: phase B work list stalled");
     unsigned pool = 2;
     h_out[0].final_index = 0;
     for (unsigned k = 0; k < n_ord; ++k) {
