@@ -84,6 +84,19 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
+// min / max over the aligned group of 8 lanes a lane belongs to, on the VALU (DPP) - the LDS crossbar is what the
+// shuffles of the trials already saturate.  row_half_mirror pairs lane i with 7 - i, then each quad holds four
+// pairs that cover all eight lanes: quad_perm [1,0,3,2] and [2,3,0,1] finish the reduction.
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int group8_min_i(int v) {
+    v = min(v, dpp_i<0x141>(v)); v = min(v, dpp_i<0xB1>(v)); v = min(v, dpp_i<0x4E>(v));
+    return v;
+}
+__device__ __forceinline__ int group8_max_i(int v) {
+    v = max(v, dpp_i<0x141>(v)); v = max(v, dpp_i<0xB1>(v)); v = max(v, dpp_i<0x4E>(v));
+    return v;
+}
+
 // Split plane of candidate c (axis = c / 7, k = c % 7 + 1): glam lerp = min + (max - min) * (k/8)
 __device__ __forceinline__ float cand_pos(const float* cbmin, const float* cbmax, int c) {
     const int axis = c / 7, k = c % 7 + 1;
@@ -201,6 +214,9 @@ struct WaveScratch {                              // per-wave: the node this wav
     unsigned short u_p[kCand + 3];
     int bin_min[3][8][3], bin_max[3][8][3];       // nodes > 64 prims: box keys of the non-`u` elements by (axis, bin)
     unsigned next_ent;                            // the child this wave goes on with (0: none)
+    unsigned short g_ue[8][kCand + 3];            // group path: never-examined element of trial c, per lane group
+    unsigned char g_tt[8][kCand + 3];             // group path: trues of trial c | predicate of its u << 4
+    unsigned g_first, g_count;                    // group path: the batch of small nodes this wave took
 };
 struct WaveLds {
     float cent[3][kSmallMax];
@@ -291,15 +307,21 @@ __device__ __forceinline__ void wave_shuffle_any(WaveLds& L, int src, unsigned s
 
 constexpr int kLaneMax = VD_LANE_MAX;   // nodes up to this size are built one-per-lane (literal sequential algorithm)
 constexpr int kQueue = kSmallMax / 4;   // a BFS level holds at most N/4 splittable nodes
+constexpr int kSmallList = kSmallMax;   // nodes of 4..8 prims under one root: < 5/8 N (a chain 8,7,6,5,4 over 8 prims)
 
 struct WaveQueues {                      // entry = node | start << 10 | count << 20 (never 0: count > kLaneMax)
     unsigned work[2 * kQueue];           // wave-wide nodes handed to other waves: append-only, 0 = not written yet
-    unsigned small[kQueue];              // every node <= kLaneMax spawned by a wave-wide node
+    unsigned small[kSmallList];          // every node <= kLaneMax: spawned by a wave-wide node, or by another small node
     unsigned lane_stack[2][64 * kSubWaves];   // per-lane DFS stack (<= kLaneMax/4 - 1 = 1 pending sibling)
     unsigned pool;                       // next free node pair
     unsigned head, tail;                 // work[head .. tail) is waiting for a wave
     int pending;                         // wave-wide nodes queued or being split
+    unsigned s_head;                     // small[s_head .. n_small) is waiting for a lane group
+    int s_pending;                       // small nodes queued or being split
     unsigned n_small, root_left, bad;
+#ifdef VD_PHASEB_PROF
+    unsigned t_root, t_waves, n_wide_nodes, t_lane, t_renum, n_batches, busy0, n_smallnodes, idle0, t_small_begin, t_last_batch_end;
+#endif
 };
 
 // blas.rs:135-166 run literally by ONE lane on its own node [s, s+n), n <= 8, entirely in
@@ -447,9 +469,13 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     // or being split, and a wave leaves when it finds nothing to take and pending is 0.  Nodes <= kLaneMax are
     // collected and built afterwards, one whole sub-subtree per lane.
     for (unsigned x = tid; x < 2u * (unsigned)kQueue; x += 64u * kSubWaves) Q.work[x] = 0u;
+    for (unsigned x = tid; x < (unsigned)kSmallList; x += 64u * kSubWaves) Q.small[x] = 0u;
     const unsigned root_ent = 1023u | (N << 20);        // the root entry: node field unused; s = 0, n = N (no child has n = N)
     if (tid == 0) {
-        Q.pool = 0; Q.n_small = 0; Q.root_left = kNone; Q.bad = 0; Q.head = 0; Q.tail = 0; Q.pending = 0;
+        Q.pool = 0; Q.n_small = 0; Q.root_left = kNone; Q.bad = 0; Q.head = 0; Q.tail = 0; Q.pending = 0; Q.s_head = 0;
+#ifdef VD_PHASEB_PROF
+        Q.t_root = 0; Q.t_waves = 0; Q.n_wide_nodes = 0; Q.n_batches = 0; Q.busy0 = 0; Q.n_smallnodes = 0; Q.idle0 = 0; Q.t_small_begin = 0; Q.t_last_batch_end = 0;
+#endif
         if (N > (unsigned)kLaneMax) Q.pending = 1; else { Q.small[0] = root_ent; Q.n_small = 1; }
     }
     __syncthreads();
@@ -690,6 +716,10 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                     }
                 }
                 if (n_wide != 1) atomicAdd(&Q.pending, n_wide - 1);         // this node is done, n_wide more exist
+#ifdef VD_PHASEB_PROF
+                if (is_root) Q.t_root = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
+                atomicAdd(&Q.n_wide_nodes, 1u);
+#endif
                 W.next_ent = keep;
             }
             vd_wave_lds_sync();
@@ -698,43 +728,197 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     }
     __syncthreads();
 
-    // ---------------- lane-serial phase: one whole sub-subtree (<= kLaneMax prims) per lane ----------------
-    const unsigned n_small = Q.n_small;
-    for (unsigned b0 = 0; b0 < n_small; b0 += 64u * kSubWaves) {
-        if (b0 + tid < n_small) {
-            unsigned ent = Q.small[b0 + tid];
-            unsigned sp = 0;
-            bool is_root = N <= (unsigned)kLaneMax;      // then the single entry is the subtree root
-            for (;;) {
-                const unsigned node_id = ent & 1023u, s = (ent >> 10) & 1023u, n = ent >> 20;
-                int ck[12];
-                const unsigned piv = lane_partition(L, L.perm[0], s, n, ck);
-                if (piv == 0xffffffffu) { Q.bad = 1; break; }
-                const unsigned pair = atomicAdd(&Q.pool, 2u);
-                TmpNode ln, rn;
+#ifdef VD_PHASEB_PROF
+    if (tid == 0) Q.t_waves = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
+#endif
+    // ---------------- nodes of <= kLaneMax (8) prims: eight at a time per wave, one per 8-lane group ----------------
+    // (One whole sub-subtree per lane, the literal sequential loop in registers, was 56 % of this kernel: a lane that
+    // draws a chain 8 -> 7 -> 6 -> 5 -> 4 runs five splits of 22 trials one after the other while most of the
+    // workgroup idles.)  A group holds one position of its node per lane, keeps the arrangement in registers across
+    // the trials and moves it through the LDS crossbar exactly as the wave-wide path for <= 64 prims does; the costs
+    // of the 21 candidates are evaluated afterwards from the recorded `u` elements, with 8-lane reductions.  Children
+    // of 4..8 prims are appended to the same list; `s_pending` counts the small nodes not yet split.
+    if (tid == 0) Q.s_pending = (int)Q.n_small;
+    __syncthreads();
+#ifdef VD_PHASEB_PROF
+    if (tid == 0) Q.t_small_begin = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
+#endif
+    {
+        const unsigned gl = lane & 7u, gb = lane & ~7u, grp = lane >> 3;
+        unsigned idle2 = 0;
+        for (;;) {
+            if (lane == 0) {
+                unsigned first = 0, count = 0;
+                for (;;) {
+                    const unsigned h = *(volatile unsigned*)&Q.s_head, t = *(volatile unsigned*)&Q.n_small;
+                    if (h >= t) break;
+                    const unsigned k = min(8u, t - h);
+                    if (atomicCAS(&Q.s_head, h, h + k) == h) { first = h; count = k; break; }
+                }
+                W.g_first = first; W.g_count = count;
+            }
+            vd_wave_lds_sync();
+            const unsigned first = W.g_first, count = W.g_count;
+            vd_wave_lds_sync();
+            if (count == 0u) {
+                if (*(volatile int*)&Q.s_pending <= 0 || *(volatile unsigned*)&Q.bad) break;
+                __builtin_amdgcn_s_sleep(4);
+#ifdef VD_PHASEB_PROF
+                if (tid == 0) Q.idle0 += 1;
+#endif
+                if (++idle2 > (1u << 24)) { if (lane == 0) Q.bad = 2; break; }
+                continue;
+            }
+#ifdef VD_PHASEB_PROF
+            const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+            if (lane == 0) { atomicAdd(&Q.n_batches, 1u); atomicAdd(&Q.n_smallnodes, count); }
+#endif
+            unsigned ent = 0u;
+            if (grp < count) {
+                unsigned spins = 0;
+                while ((ent = *(volatile unsigned*)&Q.small[first + grp]) == 0u && ++spins < (1u << 22)) {}   // claimed by its pusher, written next
+            }
+            const bool have = ent != 0u;
+            const unsigned node_id = ent & 1023u, s = (ent >> 10) & 1023u, n = have ? ent >> 20 : 0u;
+            const bool valid = gl < n;
+            unsigned el = valid ? (unsigned)L.perm[0][s + gl] : 0u;
+            float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+            int bk[6] = {kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1};
+            if (valid) { cx = L.cent[0][el]; cy = L.cent[1][el]; cz = L.cent[2][el]; }
+            // centroid bounds of the node (blas.rs:139-143)
+            float cbmin[3], cbmax[3];
+            {
+                int kmn[3], kmx[3];
+                const float ce3[3] = {cx, cy, cz};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    kmn[k] = group8_min_i(valid ? vd_key(ce3[k]) : kBig); kmx[k] = group8_max_i(valid ? vd_key(ce3[k]) : -kBig - 1);
+                    cbmin[k] = box_lo(kmn[k]); cbmax[k] = box_hi(kmx[k]);
+                }
+            }
+            // one trial (blas.rs:168-182 in closed form, as the wave-wide register path): moves el / cx / cy / cz
+            auto trial = [&](int axis, float pos, unsigned& ttot_o, unsigned& ue_o, unsigned& up_o) {
+                const float ce = axis == 0 ? cx : (axis == 1 ? cy : cz);
+                const bool p = valid && ce < pos;
+                const unsigned gm = (unsigned)(__ballot(p) >> gb) & 0xffu;
+                const unsigned ttot = (unsigned)__popc(gm), ftot = n - ttot, tl = (unsigned)__popc(gm & ((1u << gl) - 1u)), x = gl;
+                const int tp_tab = __builtin_amdgcn_ds_permute((int)((gb + (p ? ttot - tl - 1u : 7u)) << 2), (int)x);
+                const int fp_tab = __builtin_amdgcn_ds_permute((int)((gb + ((valid && !p) ? x - tl : 7u)) << 2), (int)x);
+                const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
+                const int tp_at = __builtin_amdgcn_ds_bpermute((int)((gb + ((F - 1u) & 7u)) << 2), tp_tab);
+                const int fp_at = __builtin_amdgcn_ds_bpermute((int)((gb + (T & 7u)) << 2), fp_tab);
+                unsigned dest = gl;
+                bool is_u = false;
+                if (valid) {
+                    const int tF = F == 0u ? (int)n : (F <= ttot ? tp_at : -1);
+                    const bool left = (int)x < tF;
+                    const unsigned fj = (T + 1u <= ftot) ? (unsigned)fp_at : n;
+                    const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
+                    is_u = fetch == n - 1u;
+                    if (is_u) dest = ttot - (p ? 1u : 0u);
+                    else if (left) dest = p ? x : (unsigned)tF - 1u;
+                    else dest = p ? fj : x - 1u;
+                }
+                const unsigned um = (unsigned)(__ballot(is_u) >> gb) & 0xffu;
+                const int ul = um ? __builtin_ctz(um) : 0;
+                ue_o = (unsigned)__shfl((int)el, (int)gb + ul);
+                up_o = (unsigned)__shfl(p ? 1 : 0, (int)gb + ul);
+                ttot_o = ttot;
+                const int da = (int)((gb + dest) << 2);
+                el = (unsigned)__builtin_amdgcn_ds_permute(da, (int)el);
+                cx = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cx)));
+                cy = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cy)));
+                cz = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cz)));
+            };
+            for (int c = 0; c < kCand; ++c) {                                      // blas.rs:144-147
+                unsigned tt, ue, up;
+                trial(c / 7, cand_pos(cbmin, cbmax, c), tt, ue, up);
+                if (gl == 0u) { W.g_ue[grp][c] = (unsigned short)ue; W.g_tt[grp][c] = (unsigned char)(tt | (up << 4)); }
+            }
+            vd_wave_lds_sync();
+            // evaluate (blas.rs:149-161): left = examined trues = {e : p_c(e) and e != u_c}, right = the rest (incl. u_c)
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) bk[q] = L.box[q][el];
+            }
+            vd_u64 key = ~0ull;
+            for (int c = 0; c < kCand; ++c) {
+                const int axis = c / 7;
+                const float ce = axis == 0 ? cx : (axis == 1 ? cy : cz);
+                const unsigned ue = W.g_ue[grp][c], tu = W.g_tt[grp][c];
+                const bool inl = valid && ce < cand_pos(cbmin, cbmax, c) && el != ue, inr = valid && !inl;
+                int k12[12];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    ln.mn[q] = box_lo(ck[q]); ln.mx[q] = box_hi(ck[3 + q]);
-                    rn.mn[q] = box_lo(ck[6 + q]); rn.mx[q] = box_hi(ck[9 + q]);
+                    k12[q] = inl ? bk[q] : kBig; k12[3 + q] = inl ? bk[3 + q] : -kBig - 1;
+                    k12[6 + q] = inr ? bk[q] : kBig; k12[9 + q] = inr ? bk[3 + q] : -kBig - 1;
                 }
-                ln.left_first = base + s; ln.count = piv;
-                rn.left_first = base + s + piv; rn.count = n - piv;
-                nodes[pair] = ln; nodes[pair + 1] = rn;
-                if (is_root) { Q.root_left = pair; is_root = false; }
-                else { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }
-                const bool gl = piv > 3u, gr = (n - piv) > 3u;
-                if (gl && gr) { Q.lane_stack[sp][tid] = (pair + 1u) | ((s + piv) << 10) | ((n - piv) << 20); sp += 1; }
-                if (gl) ent = pair | (s << 10) | (piv << 20);
-                else if (gr) ent = (pair + 1u) | ((s + piv) << 10) | ((n - piv) << 20);
-                else if (sp > 0u) { sp -= 1; ent = Q.lane_stack[sp][tid]; }
-                else break;
+#pragma unroll
+                for (int i2 = 0; i2 < 12; ++i2) k12[i2] = (i2 % 6) < 3 ? group8_min_i(k12[i2]) : group8_max_i(k12[i2]);
+                const unsigned n1 = (tu & 15u) - (tu >> 4);
+                const float a1 = vd_area(box_hi(k12[3]) - box_lo(k12[0]), box_hi(k12[4]) - box_lo(k12[1]), box_hi(k12[5]) - box_lo(k12[2]));
+                const float a2 = vd_area(box_hi(k12[9]) - box_lo(k12[6]), box_hi(k12[10]) - box_lo(k12[7]), box_hi(k12[11]) - box_lo(k12[8]));
+                const vd_u64 kc = cost_key(a1 * (float)n1 + a2 * (float)(n - n1), (unsigned)c);
+                key = kc < key ? kc : key;
             }
+            const bool rejected = have && key == ~0ull;
+            const int best = rejected || !have ? 0 : (int)(unsigned)key;
+            const unsigned tb = W.g_tt[grp][best];
+            const unsigned Lst = (tb & 15u) - (tb >> 4);                            // stale optimal_pivot (blas.rs:159,165)
+            {
+                unsigned tt, ue, up;                                                // blas.rs:164
+                trial(best / 7, cand_pos(cbmin, cbmax, best), tt, ue, up);
+            }
+            if (valid) { L.perm[0][s + gl] = (unsigned short)el; L.perm[1][s + gl] = (unsigned short)el; }
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) bk[q] = L.box[q][el];
+            }
+            int ck[12];                                                             // children boxes (blas.rs:115-123)
+            {
+                const bool inl = valid && gl < Lst, inr = valid && !inl;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    ck[q] = inl ? bk[q] : kBig; ck[3 + q] = inl ? bk[3 + q] : -kBig - 1;
+                    ck[6 + q] = inr ? bk[q] : kBig; ck[9 + q] = inr ? bk[3 + q] : -kBig - 1;
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < 12; ++i2) ck[i2] = (i2 % 6) < 3 ? group8_min_i(ck[i2]) : group8_max_i(ck[i2]);
+            }
+            if (have && gl == 0u) {
+                if (rejected) { Q.bad = 1; atomicSub(&Q.s_pending, 1); }
+                else {
+                    const unsigned pair = atomicAdd(&Q.pool, 2u);
+                    TmpNode ln, rn;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        ln.mn[q] = box_lo(ck[q]); ln.mx[q] = box_hi(ck[3 + q]);
+                        rn.mn[q] = box_lo(ck[6 + q]); rn.mx[q] = box_hi(ck[9 + q]);
+                    }
+                    ln.left_first = base + s; ln.count = Lst;
+                    rn.left_first = base + s + Lst; rn.count = n - Lst;
+                    nodes[pair] = ln; nodes[pair + 1] = rn;
+                    if (ent == root_ent) Q.root_left = pair;                        // N <= kLaneMax: the subtree root itself
+                    else { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }
+                    int more = 0;
+                    if (Lst > 3u) { Q.small[atomicAdd(&Q.n_small, 1u)] = pair | (s << 10) | (Lst << 20); more += 1; }
+                    if (n - Lst > 3u) { Q.small[atomicAdd(&Q.n_small, 1u)] = (pair + 1u) | ((s + Lst) << 10) | ((n - Lst) << 20); more += 1; }
+                    if (more != 1) atomicAdd(&Q.s_pending, more - 1);
+                }
+            }
+#ifdef VD_PHASEB_PROF
+            if (tid == 0) Q.busy0 += (unsigned)(__builtin_amdgcn_s_memtime() - tb0);
+            if (lane == 0) atomicMax(&Q.t_last_batch_end, (unsigned)(__builtin_amdgcn_s_memtime() - t_begin));
+#endif
         }
     }
     __threadfence_block();   // node records written by all lanes are re-read below, by this workgroup only (an agent-scope
                              // fence would write back the whole L2 of the XCD, once per subtree)
     __syncthreads();
     if (Q.bad) { if (tid == 0) atomicOr(err, Q.bad == 2u ? ERR_INTERNAL : ERR_DEGENERATE); return; }
+#ifdef VD_PHASEB_PROF
+    if (tid == 0) Q.t_lane = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
+#endif
     const unsigned pool = Q.pool, root_left = Q.root_left;
     const unsigned n_interior = pool / 2u;
 
@@ -761,6 +945,9 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             if (LC[j] != 0xffffu) { const unsigned l = LC[j]; R[l] = (unsigned short)(R[j] + 1u); R[l + 1u] = (unsigned short)(R[j] + 1u + I[l]); }
     }
     __syncthreads();
+#ifdef VD_PHASEB_PROF
+    if (tid == 0) Q.t_renum = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
+#endif
     // new local index of node j = 2 * r(parent) + side; parent's rank = R[left sibling] - 1
     for (unsigned j = tid; j < n_nodes; j += 64u * kSubWaves) {
         const unsigned rl = R[j & ~1u];                    // rank of the left sibling = r(parent) + 1
@@ -770,7 +957,11 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     for (unsigned x = tid; x < N; x += 64u * kSubWaves) final_ids[base + x] = L.gid[L.perm[0][x]];
     if (tid == 0) {
         sub_interior[root_i] = n_interior;
+#ifdef VD_PHASEB_PROF
+        if (dbg_cycles) { dbg_cycles[2 * root_i] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin); dbg_cycles[2 * root_i + 1] = N | ((Q.t_lane >> 12) << 10) | ((Q.t_renum >> 12) << 20); dbg_cycles[2 * root_i + 1] = (Q.idle0 & 1023u) | ((Q.t_small_begin >> 12) << 10) | ((Q.t_last_batch_end >> 12) << 21); dbg_cycles[2 * root_i] = (dbg_cycles[2 * root_i] >> 8) | ((Q.t_root >> 12) << 16) | ((Q.t_waves >> 12) << 24); }
+#else
         if (dbg_cycles) { dbg_cycles[2 * root_i] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin); dbg_cycles[2 * root_i + 1] = N; }
+#endif
     }
 }
 
