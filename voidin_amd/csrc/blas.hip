@@ -96,6 +96,19 @@ __device__ __forceinline__ int group8_max_i(int v) {
     v = max(v, dpp_i<0x141>(v)); v = max(v, dpp_i<0xB1>(v)); v = max(v, dpp_i<0x4E>(v));
     return v;
 }
+// groups of gw = 8 / 16 / 32 lanes (wave-uniform gw): row_mirror joins the two 8-groups of a row, one shuffle the two rows
+__device__ __forceinline__ int group_min_i(int v, unsigned gw) {
+    v = group8_min_i(v);
+    if (gw >= 16u) v = min(v, dpp_i<0x140>(v));
+    if (gw >= 32u) v = min(v, __shfl_xor(v, 16));
+    return v;
+}
+__device__ __forceinline__ int group_max_i(int v, unsigned gw) {
+    v = group8_max_i(v);
+    if (gw >= 16u) v = max(v, dpp_i<0x140>(v));
+    if (gw >= 32u) v = max(v, __shfl_xor(v, 16));
+    return v;
+}
 
 // Split plane of candidate c (axis = c / 7, k = c % 7 + 1): glam lerp = min + (max - min) * (k/8)
 __device__ __forceinline__ float cand_pos(const float* cbmin, const float* cbmax, int c) {
@@ -215,7 +228,7 @@ struct WaveScratch {                              // per-wave: the node this wav
     int bin_min[3][8][3], bin_max[3][8][3];       // nodes > 64 prims: box keys of the non-`u` elements by (axis, bin)
     unsigned next_ent;                            // the child this wave goes on with (0: none)
     unsigned short g_ue[8][kCand + 3];            // group path: never-examined element of trial c, per lane group
-    unsigned char g_tt[8][kCand + 3];             // group path: trues of trial c | predicate of its u << 4
+    unsigned char g_tt[8][kCand + 3];             // group path: trues of trial c | predicate of its u << 7
     unsigned g_first, g_count;                    // group path: the batch of small nodes this wave took
 };
 struct WaveLds {
@@ -305,124 +318,26 @@ __device__ __forceinline__ void wave_shuffle_any(WaveLds& L, int src, unsigned s
     else wave_shuffle<kChunks>(L, src, s, n, axis, pos, tt, ue, up);
 }
 
-constexpr int kLaneMax = VD_LANE_MAX;   // nodes up to this size are built one-per-lane (literal sequential algorithm)
+constexpr int kLaneMax = VD_LANE_MAX;   // a subtree root of at most this many prims starts in the group path (8 lanes)
 constexpr int kQueue = kSmallMax / 4;   // a BFS level holds at most N/4 splittable nodes
 constexpr int kSmallList = kSmallMax;   // nodes of 4..8 prims under one root: < 5/8 N (a chain 8,7,6,5,4 over 8 prims)
+constexpr int kC16 = kSmallMax, kC32 = kSmallMax / 2;   // 9..16: <= 8/16 N (chain 16..9); 17..32: <= 16/32 N; never reached in practice, checked
 
-struct WaveQueues {                      // entry = node | start << 10 | count << 20 (never 0: count > kLaneMax)
+struct WaveQueues {                      // entry = node | start << 10 | count << 20 (never 0: count > 3)
     unsigned work[2 * kQueue];           // wave-wide nodes handed to other waves: append-only, 0 = not written yet
-    unsigned small[kSmallList];          // every node <= kLaneMax: spawned by a wave-wide node, or by another small node
-    unsigned lane_stack[2][64 * kSubWaves];   // per-lane DFS stack (<= kLaneMax/4 - 1 = 1 pending sibling)
+    unsigned small[kSmallList];          // nodes of 4..8 prims: eight per wave
     unsigned pool;                       // next free node pair
     unsigned head, tail;                 // work[head .. tail) is waiting for a wave
     int pending;                         // wave-wide nodes queued or being split
     unsigned s_head;                     // small[s_head .. n_small) is waiting for a lane group
-    int s_pending;                       // small nodes queued or being split
+    int s_pending;                       // nodes of <= 32 prims queued or being split
+    unsigned c16[kC16], c32[kC32];       // nodes of 9..16 / 17..32 prims: four / two per wave
+    unsigned h16, t16, h32, t32;
     unsigned n_small, root_left, bad;
-#ifdef VD_PHASEB_PROF
-    unsigned t_root, t_waves, n_wide_nodes, t_lane, t_renum, n_batches, busy0, n_smallnodes, idle0, t_small_begin, t_last_batch_end;
+#ifdef VD_PROF_SEL
+    unsigned prof[8];   // 0 root node done, 1 wave loop done, 2 lists drained, 3 renumber scan done, 4 group batches, 5 listed nodes, 6 wide nodes
 #endif
 };
-
-// blas.rs:135-166 run literally by ONE lane on its own node [s, s+n), n <= 8, entirely in
-// registers: the node's elements sit in 8 fixed register slots (centroids + box keys, static
-// indexing), the arrangement is a packed word of 4-bit slot ids, and partition_shuffle
-// (blas.rs:168-182) is simulated on that word with the predicates as an 8-bit mask.  Returns the
-// stale pivot (relative) or 0xffffffff when every candidate is rejected; writes the children box
-// keys (left min/max, right min/max) and the final arrangement back to `perm`.
-static_assert(kLaneMax <= 8, "the register-resident lane path holds at most 8 elements");
-__device__ __forceinline__ unsigned lane_partition(WaveLds& L, unsigned short* perm, unsigned s, unsigned n, int (&ck)[12]) {
-    unsigned el[8];
-    float cx[8], cy[8], cz[8];
-    int bk[6][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        el[j] = 0; cx[j] = cy[j] = cz[j] = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) bk[q][j] = q < 3 ? kBig : -kBig - 1;
-        if ((unsigned)j < n) {
-            el[j] = perm[s + j];
-            cx[j] = L.cent[0][el[j]]; cy[j] = L.cent[1][el[j]]; cz[j] = L.cent[2][el[j]];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) bk[q][j] = L.box[q][el[j]];
-        }
-    }
-    int kmn[3] = {kBig, kBig, kBig}, kmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if ((unsigned)j < n) {
-            const int k0 = vd_key(cx[j]), k1 = vd_key(cy[j]), k2 = vd_key(cz[j]);
-            kmn[0] = min(kmn[0], k0); kmx[0] = max(kmx[0], k0);
-            kmn[1] = min(kmn[1], k1); kmx[1] = max(kmx[1], k1);
-            kmn[2] = min(kmn[2], k2); kmx[2] = max(kmx[2], k2);
-        }
-    }
-    float cbmin[3], cbmax[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(kmn[k]); cbmax[k] = box_hi(kmx[k]); }
-    float best_cost = 3.40282347e+38f, best_pos = 0.0f;
-    int best_axis = -1;
-    unsigned best_piv = 0;
-    unsigned arr = 0x76543210u;           // position x holds slot (arr >> 4x) & 15
-    for (int c = 0; c <= kCand; ++c) {
-        int axis; float pos;
-        if (c < kCand) { axis = c / 7; pos = cand_pos(cbmin, cbmax, c); }
-        else { if (best_axis < 0) return 0xffffffffu; axis = best_axis; pos = best_pos; }
-        unsigned pmask = 0;               // predicate per slot
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float ce = axis == 0 ? cx[j] : (axis == 1 ? cy[j] : cz[j]);
-            pmask |= (ce < pos ? 1u : 0u) << j;
-        }
-        // partition_shuffle (blas.rs:168-182) on the packed arrangement
-        unsigned i = 0, e = n - 1u;
-        while (i < e) {
-            const unsigned a = (arr >> (4u * i)) & 15u;
-            if ((pmask >> a) & 1u) { i += 1u; }
-            else {
-                const unsigned bb = (arr >> (4u * e)) & 15u, x = a ^ bb;
-                arr ^= (x << (4u * i)) | (x << (4u * e));
-                e -= 1u;
-            }
-        }
-        const unsigned piv = c < kCand ? i : best_piv;   // final pass: the stale pivot splits the children
-        unsigned leftmask = 0;            // slots at positions < piv
-        for (unsigned x = 0; x < piv; ++x) leftmask |= 1u << ((arr >> (4u * x)) & 15u);
-        int k12[12];
-#pragma unroll
-        for (int q = 0; q < 12; ++q) k12[q] = (q % 6) < 3 ? kBig : -kBig - 1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool valid = (unsigned)j < n, inl = (leftmask >> j) & 1u;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int lo = bk[q][j], hi = bk[3 + q][j];
-                k12[q] = min(k12[q], (valid && inl) ? lo : kBig);
-                k12[3 + q] = max(k12[3 + q], (valid && inl) ? hi : -kBig - 1);
-                k12[6 + q] = min(k12[6 + q], (valid && !inl) ? lo : kBig);
-                k12[9 + q] = max(k12[9 + q], (valid && !inl) ? hi : -kBig - 1);
-            }
-        }
-        if (c == kCand) {
-#pragma unroll
-            for (int q = 0; q < 12; ++q) ck[q] = k12[q];
-            break;
-        }
-        const float a1 = vd_area(box_hi(k12[3]) - box_lo(k12[0]), box_hi(k12[4]) - box_lo(k12[1]), box_hi(k12[5]) - box_lo(k12[2]));
-        const float a2 = vd_area(box_hi(k12[9]) - box_lo(k12[6]), box_hi(k12[10]) - box_lo(k12[7]), box_hi(k12[11]) - box_lo(k12[8]));
-        const float cost = a1 * (float)piv + a2 * (float)(n - piv);
-        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_pos = pos; best_piv = piv; }
-    }
-    // write the final arrangement back
-    for (unsigned x = 0; x < n; ++x) {
-        const unsigned slot = (arr >> (4u * x)) & 15u;
-        unsigned v = el[0];
-#pragma unroll
-        for (int j = 1; j < 8; ++j) v = slot == (unsigned)j ? el[j] : v;
-        perm[s + x] = (unsigned short)v;
-    }
-    return best_piv;
-}
 
 __global__ __launch_bounds__(64 * kSubWaves, 4)
 void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
@@ -466,19 +381,196 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     // fewer nodes than the workgroup has waves and still cost a full node pass of 22 dependent shuffles plus two
     // barriers.  So there are no levels: a wave that has split a node goes straight on with one child and hands the
     // other to whichever wave is idle (append-only list in LDS); `pending` counts the wave-wide nodes that are queued
-    // or being split, and a wave leaves when it finds nothing to take and pending is 0.  Nodes <= kLaneMax are
-    // collected and built afterwards, one whole sub-subtree per lane.
+    // or being split, and a wave leaves when it finds nothing to take and pending is 0.  Nodes of <= 32 prims go to
+    // per-size lists and are split several per wave (try_group), by whichever wave has nothing wave-wide to do.
     for (unsigned x = tid; x < 2u * (unsigned)kQueue; x += 64u * kSubWaves) Q.work[x] = 0u;
     for (unsigned x = tid; x < (unsigned)kSmallList; x += 64u * kSubWaves) Q.small[x] = 0u;
+    for (unsigned x = tid; x < (unsigned)kC16; x += 64u * kSubWaves) Q.c16[x] = 0u;
+    for (unsigned x = tid; x < (unsigned)kC32; x += 64u * kSubWaves) Q.c32[x] = 0u;
     const unsigned root_ent = 1023u | (N << 20);        // the root entry: node field unused; s = 0, n = N (no child has n = N)
     if (tid == 0) {
         Q.pool = 0; Q.n_small = 0; Q.root_left = kNone; Q.bad = 0; Q.head = 0; Q.tail = 0; Q.pending = 0; Q.s_head = 0;
-#ifdef VD_PHASEB_PROF
-        Q.t_root = 0; Q.t_waves = 0; Q.n_wide_nodes = 0; Q.n_batches = 0; Q.busy0 = 0; Q.n_smallnodes = 0; Q.idle0 = 0; Q.t_small_begin = 0; Q.t_last_batch_end = 0;
+        Q.s_pending = 0; Q.h16 = 0; Q.t16 = 0; Q.h32 = 0; Q.t32 = 0;
+#ifdef VD_PROF_SEL
+        for (int q = 0; q < 8; ++q) Q.prof[q] = 0;
 #endif
-        if (N > (unsigned)kLaneMax) Q.pending = 1; else { Q.small[0] = root_ent; Q.n_small = 1; }
+        if (N > (unsigned)kLaneMax) Q.pending = 1; else { Q.small[0] = root_ent; Q.n_small = 1; Q.s_pending = 1; }
     }
     __syncthreads();
+    // ---------------- nodes of <= 32 prims: several at a time per wave, one per lane group ----------------
+    // A wave takes eight nodes of <= 8 prims, four of 9..16 or two of 17..32 and gives each a group of 8 / 16 / 32
+    // lanes: one position per lane, the arrangement kept in registers across the trials and moved through the LDS
+    // crossbar exactly as the wave-wide path for <= 64 prims does; the costs of the 21 candidates are evaluated
+    // afterwards from the recorded `u` elements, with group reductions on the VALU (DPP).  (One node per wave made the
+    // ~60 nodes of 9..175 prims under a root 58 % of this kernel, and one whole sub-subtree of <= 8 prims per lane -
+    // the literal loop in registers, a chain 8 -> 7 -> 6 -> 5 -> 4 being five splits of 22 trials in a row - 12 %.)
+    // Children of 4..32 prims go to the list of their class; `s_pending` counts the listed nodes not yet split.
+    auto push_class = [&](unsigned e2, unsigned cn) {                              // called by one lane
+        atomicAdd(&Q.s_pending, 1);
+        if (cn <= 8u) { const unsigned k = atomicAdd(&Q.n_small, 1u); if (k < (unsigned)kSmallList) Q.small[k] = e2; else Q.bad = 2; }
+        else if (cn <= 16u) { const unsigned k = atomicAdd(&Q.t16, 1u); if (k < (unsigned)kC16) Q.c16[k] = e2; else Q.bad = 2; }
+        else { const unsigned k = atomicAdd(&Q.t32, 1u); if (k < (unsigned)kC32) Q.c32[k] = e2; else Q.bad = 2; }
+    };
+    auto try_group = [&]() -> bool {
+        if (lane == 0) {
+            unsigned first = 0, count = 0, cls = 0;
+            for (int c3 = 2; c3 >= 0 && count == 0u; --c3) {                       // the larger nodes first
+                unsigned* hp = c3 == 2 ? &Q.h32 : (c3 == 1 ? &Q.h16 : &Q.s_head);
+                unsigned* tp = c3 == 2 ? &Q.t32 : (c3 == 1 ? &Q.t16 : &Q.n_small);
+                for (;;) {
+                    const unsigned h = *(volatile unsigned*)hp, t = *(volatile unsigned*)tp;
+                    if (h >= t) break;
+                    const unsigned k = min(8u >> c3, t - h);
+                    if (atomicCAS(hp, h, h + k) == h) { first = h; count = k; cls = (unsigned)c3; break; }
+                }
+            }
+            W.g_first = first; W.g_count = count | (cls << 8);
+        }
+        vd_wave_lds_sync();
+        const unsigned first = W.g_first, count = W.g_count & 255u, cls = W.g_count >> 8;
+        vd_wave_lds_sync();
+        if (count == 0u) return false;
+#ifdef VD_PROF_SEL
+        if (lane == 0) { atomicAdd(&Q.prof[4], 1u); atomicAdd(&Q.prof[5], count); }
+#endif
+        const unsigned gw = 8u << cls, gmask = gw == 32u ? 0xffffffffu : (1u << gw) - 1u;
+        const unsigned* list = cls == 2u ? Q.c32 : (cls == 1u ? Q.c16 : Q.small);
+        const unsigned gl = lane & (gw - 1u), gb = lane & ~(gw - 1u), grp = lane >> (3u + cls);
+            unsigned ent = 0u;
+            if (grp < count) {
+                unsigned spins = 0;
+                while ((ent = *(volatile unsigned*)&list[first + grp]) == 0u && ++spins < (1u << 22)) {}   // claimed by its pusher, written next
+            }
+            const bool have = ent != 0u;
+            const unsigned node_id = ent & 1023u, s = (ent >> 10) & 1023u, n = have ? ent >> 20 : 0u;
+            const bool valid = gl < n;
+            unsigned el = valid ? (unsigned)L.perm[0][s + gl] : 0u;
+            float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+            int bk[6] = {kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1};
+            if (valid) { cx = L.cent[0][el]; cy = L.cent[1][el]; cz = L.cent[2][el]; }
+            // centroid bounds of the node (blas.rs:139-143)
+            float cbmin[3], cbmax[3];
+            {
+                int kmn[3], kmx[3];
+                const float ce3[3] = {cx, cy, cz};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    kmn[k] = group_min_i(valid ? vd_key(ce3[k]) : kBig, gw); kmx[k] = group_max_i(valid ? vd_key(ce3[k]) : -kBig - 1, gw);
+                    cbmin[k] = box_lo(kmn[k]); cbmax[k] = box_hi(kmx[k]);
+                }
+            }
+            // one trial (blas.rs:168-182 in closed form, as the wave-wide register path): moves el / cx / cy / cz
+            auto trial = [&](int axis, float pos, unsigned& ttot_o, unsigned& ue_o, unsigned& up_o) {
+                const float ce = axis == 0 ? cx : (axis == 1 ? cy : cz);
+                const bool p = valid && ce < pos;
+                const unsigned gm = (unsigned)(__ballot(p) >> gb) & gmask;
+                const unsigned ttot = (unsigned)__popc(gm), ftot = n - ttot, tl = (unsigned)__popc(gm & ((1u << gl) - 1u)), x = gl;
+                const int tp_tab = __builtin_amdgcn_ds_permute((int)((gb + (p ? ttot - tl - 1u : gw - 1u)) << 2), (int)x);
+                const int fp_tab = __builtin_amdgcn_ds_permute((int)((gb + ((valid && !p) ? x - tl : gw - 1u)) << 2), (int)x);
+                const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
+                const int tp_at = __builtin_amdgcn_ds_bpermute((int)((gb + ((F - 1u) & (gw - 1u))) << 2), tp_tab);
+                const int fp_at = __builtin_amdgcn_ds_bpermute((int)((gb + (T & (gw - 1u))) << 2), fp_tab);
+                unsigned dest = gl;
+                bool is_u = false;
+                if (valid) {
+                    const int tF = F == 0u ? (int)n : (F <= ttot ? tp_at : -1);
+                    const bool left = (int)x < tF;
+                    const unsigned fj = (T + 1u <= ftot) ? (unsigned)fp_at : n;
+                    const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
+                    is_u = fetch == n - 1u;
+                    if (is_u) dest = ttot - (p ? 1u : 0u);
+                    else if (left) dest = p ? x : (unsigned)tF - 1u;
+                    else dest = p ? fj : x - 1u;
+                }
+                const unsigned um = (unsigned)(__ballot(is_u) >> gb) & gmask;
+                const int ul = um ? __builtin_ctz(um) : 0;
+                ue_o = (unsigned)__shfl((int)el, (int)gb + ul);
+                up_o = (unsigned)__shfl(p ? 1 : 0, (int)gb + ul);
+                ttot_o = ttot;
+                const int da = (int)((gb + dest) << 2);
+                el = (unsigned)__builtin_amdgcn_ds_permute(da, (int)el);
+                cx = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cx)));
+                cy = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cy)));
+                cz = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cz)));
+            };
+            for (int c = 0; c < kCand; ++c) {                                      // blas.rs:144-147
+                unsigned tt, ue, up;
+                trial(c / 7, cand_pos(cbmin, cbmax, c), tt, ue, up);
+                if (gl == 0u) { W.g_ue[grp][c] = (unsigned short)ue; W.g_tt[grp][c] = (unsigned char)(tt | (up << 7)); }
+            }
+            vd_wave_lds_sync();
+            // evaluate (blas.rs:149-161): left = examined trues = {e : p_c(e) and e != u_c}, right = the rest (incl. u_c)
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) bk[q] = L.box[q][el];
+            }
+            vd_u64 key = ~0ull;
+            for (int c = 0; c < kCand; ++c) {
+                const int axis = c / 7;
+                const float ce = axis == 0 ? cx : (axis == 1 ? cy : cz);
+                const unsigned ue = W.g_ue[grp][c], tu = W.g_tt[grp][c];
+                const bool inl = valid && ce < cand_pos(cbmin, cbmax, c) && el != ue, inr = valid && !inl;
+                int k12[12];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    k12[q] = inl ? bk[q] : kBig; k12[3 + q] = inl ? bk[3 + q] : -kBig - 1;
+                    k12[6 + q] = inr ? bk[q] : kBig; k12[9 + q] = inr ? bk[3 + q] : -kBig - 1;
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < 12; ++i2) k12[i2] = (i2 % 6) < 3 ? group_min_i(k12[i2], gw) : group_max_i(k12[i2], gw);
+                const unsigned n1 = (tu & 127u) - (tu >> 7);
+                const float a1 = vd_area(box_hi(k12[3]) - box_lo(k12[0]), box_hi(k12[4]) - box_lo(k12[1]), box_hi(k12[5]) - box_lo(k12[2]));
+                const float a2 = vd_area(box_hi(k12[9]) - box_lo(k12[6]), box_hi(k12[10]) - box_lo(k12[7]), box_hi(k12[11]) - box_lo(k12[8]));
+                const vd_u64 kc = cost_key(a1 * (float)n1 + a2 * (float)(n - n1), (unsigned)c);
+                key = kc < key ? kc : key;
+            }
+            const bool rejected = have && key == ~0ull;                              // SURVEY.md §8a B7
+            const int best = rejected || !have ? 0 : (int)(unsigned)key;
+            const unsigned tb = W.g_tt[grp][best];
+            const unsigned Lst = (tb & 127u) - (tb >> 7);                            // stale optimal_pivot (blas.rs:159,165)
+            {
+                unsigned tt, ue, up;                                                // blas.rs:164
+                trial(best / 7, cand_pos(cbmin, cbmax, best), tt, ue, up);
+            }
+            if (valid) { L.perm[0][s + gl] = (unsigned short)el; L.perm[1][s + gl] = (unsigned short)el; }
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) bk[q] = L.box[q][el];
+            }
+            int ck[12];                                                             // children boxes (blas.rs:115-123)
+            {
+                const bool inl = valid && gl < Lst, inr = valid && !inl;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    ck[q] = inl ? bk[q] : kBig; ck[3 + q] = inl ? bk[3 + q] : -kBig - 1;
+                    ck[6 + q] = inr ? bk[q] : kBig; ck[9 + q] = inr ? bk[3 + q] : -kBig - 1;
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < 12; ++i2) ck[i2] = (i2 % 6) < 3 ? group_min_i(ck[i2], gw) : group_max_i(ck[i2], gw);
+            }
+            if (have && gl == 0u) {
+                if (rejected) { Q.bad = 1; atomicSub(&Q.s_pending, 1); }
+                else {
+                    const unsigned pair = atomicAdd(&Q.pool, 2u);
+                    TmpNode ln, rn;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        ln.mn[q] = box_lo(ck[q]); ln.mx[q] = box_hi(ck[3 + q]);
+                        rn.mn[q] = box_lo(ck[6 + q]); rn.mx[q] = box_hi(ck[9 + q]);
+                    }
+                    ln.left_first = base + s; ln.count = Lst;
+                    rn.left_first = base + s + Lst; rn.count = n - Lst;
+                    nodes[pair] = ln; nodes[pair + 1] = rn;
+                    if (ent == root_ent) Q.root_left = pair;                        // N <= kLaneMax: the subtree root itself
+                    else { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }
+                    if (Lst > 3u) push_class(pair | (s << 10) | (Lst << 20), Lst);
+                    if (n - Lst > 3u) push_class((pair + 1u) | ((s + Lst) << 10) | ((n - Lst) << 20), n - Lst);
+                    atomicSub(&Q.s_pending, 1);                                     // after the children were counted
+                }
+            }
+        return true;
+    };
+
     unsigned next_ent = (wave == 0u && N > (unsigned)kLaneMax) ? root_ent : 0u;   // wave-uniform; 0 = take one from the list
     unsigned idle_polls = 0;
 
@@ -500,6 +592,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 }
                 ent = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
                 if (ent == 0u) {
+                    if (try_group()) { idle_polls = 0; continue; }                  // nothing wave-wide to take: split listed nodes meanwhile
                     if (*(volatile int*)&Q.pending <= 0 || *(volatile unsigned*)&Q.bad) break;
                     __builtin_amdgcn_s_sleep(4);
                     if (++idle_polls > (1u << 24)) { if (lane == 0) Q.bad = 2; break; }   // never expected: an error, not a hang
@@ -708,17 +801,17 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 for (int side = 0; side < 2; ++side) {
                     if (cn[side] > 3u) {
                         const unsigned e2 = (pair + side) | (cs[side] << 10) | (cn[side] << 20);
-                        if (cn[side] > (unsigned)kLaneMax) {
+                        if (cn[side] > 32u) {
                             n_wide += 1;
                             if (keep == 0u) keep = e2;                      // this wave goes on with it
                             else Q.work[atomicAdd(&Q.tail, 1u)] = e2;       // the other one is for whoever is idle
-                        } else Q.small[atomicAdd(&Q.n_small, 1u)] = e2;
+                        } else push_class(e2, cn[side]);
                     }
                 }
                 if (n_wide != 1) atomicAdd(&Q.pending, n_wide - 1);         // this node is done, n_wide more exist
-#ifdef VD_PHASEB_PROF
-                if (is_root) Q.t_root = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
-                atomicAdd(&Q.n_wide_nodes, 1u);
+#ifdef VD_PROF_SEL
+                if (is_root) Q.prof[0] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
+                atomicAdd(&Q.prof[6], 1u);
 #endif
                 W.next_ent = keep;
             }
@@ -728,196 +821,25 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     }
     __syncthreads();
 
-#ifdef VD_PHASEB_PROF
-    if (tid == 0) Q.t_waves = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
+#ifdef VD_PROF_SEL
+    if (tid == 0) Q.prof[1] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
 #endif
-    // ---------------- nodes of <= kLaneMax (8) prims: eight at a time per wave, one per 8-lane group ----------------
-    // (One whole sub-subtree per lane, the literal sequential loop in registers, was 56 % of this kernel: a lane that
-    // draws a chain 8 -> 7 -> 6 -> 5 -> 4 runs five splits of 22 trials one after the other while most of the
-    // workgroup idles.)  A group holds one position of its node per lane, keeps the arrangement in registers across
-    // the trials and moves it through the LDS crossbar exactly as the wave-wide path for <= 64 prims does; the costs
-    // of the 21 candidates are evaluated afterwards from the recorded `u` elements, with 8-lane reductions.  Children
-    // of 4..8 prims are appended to the same list; `s_pending` counts the small nodes not yet split.
-    if (tid == 0) Q.s_pending = (int)Q.n_small;
-    __syncthreads();
-#ifdef VD_PHASEB_PROF
-    if (tid == 0) Q.t_small_begin = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
-#endif
+    // ---------------- drain the lists ----------------
     {
-        const unsigned gl = lane & 7u, gb = lane & ~7u, grp = lane >> 3;
         unsigned idle2 = 0;
         for (;;) {
-            if (lane == 0) {
-                unsigned first = 0, count = 0;
-                for (;;) {
-                    const unsigned h = *(volatile unsigned*)&Q.s_head, t = *(volatile unsigned*)&Q.n_small;
-                    if (h >= t) break;
-                    const unsigned k = min(8u, t - h);
-                    if (atomicCAS(&Q.s_head, h, h + k) == h) { first = h; count = k; break; }
-                }
-                W.g_first = first; W.g_count = count;
-            }
-            vd_wave_lds_sync();
-            const unsigned first = W.g_first, count = W.g_count;
-            vd_wave_lds_sync();
-            if (count == 0u) {
-                if (*(volatile int*)&Q.s_pending <= 0 || *(volatile unsigned*)&Q.bad) break;
-                __builtin_amdgcn_s_sleep(4);
-#ifdef VD_PHASEB_PROF
-                if (tid == 0) Q.idle0 += 1;
-#endif
-                if (++idle2 > (1u << 24)) { if (lane == 0) Q.bad = 2; break; }
-                continue;
-            }
-#ifdef VD_PHASEB_PROF
-            const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
-            if (lane == 0) { atomicAdd(&Q.n_batches, 1u); atomicAdd(&Q.n_smallnodes, count); }
-#endif
-            unsigned ent = 0u;
-            if (grp < count) {
-                unsigned spins = 0;
-                while ((ent = *(volatile unsigned*)&Q.small[first + grp]) == 0u && ++spins < (1u << 22)) {}   // claimed by its pusher, written next
-            }
-            const bool have = ent != 0u;
-            const unsigned node_id = ent & 1023u, s = (ent >> 10) & 1023u, n = have ? ent >> 20 : 0u;
-            const bool valid = gl < n;
-            unsigned el = valid ? (unsigned)L.perm[0][s + gl] : 0u;
-            float cx = 0.0f, cy = 0.0f, cz = 0.0f;
-            int bk[6] = {kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1};
-            if (valid) { cx = L.cent[0][el]; cy = L.cent[1][el]; cz = L.cent[2][el]; }
-            // centroid bounds of the node (blas.rs:139-143)
-            float cbmin[3], cbmax[3];
-            {
-                int kmn[3], kmx[3];
-                const float ce3[3] = {cx, cy, cz};
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    kmn[k] = group8_min_i(valid ? vd_key(ce3[k]) : kBig); kmx[k] = group8_max_i(valid ? vd_key(ce3[k]) : -kBig - 1);
-                    cbmin[k] = box_lo(kmn[k]); cbmax[k] = box_hi(kmx[k]);
-                }
-            }
-            // one trial (blas.rs:168-182 in closed form, as the wave-wide register path): moves el / cx / cy / cz
-            auto trial = [&](int axis, float pos, unsigned& ttot_o, unsigned& ue_o, unsigned& up_o) {
-                const float ce = axis == 0 ? cx : (axis == 1 ? cy : cz);
-                const bool p = valid && ce < pos;
-                const unsigned gm = (unsigned)(__ballot(p) >> gb) & 0xffu;
-                const unsigned ttot = (unsigned)__popc(gm), ftot = n - ttot, tl = (unsigned)__popc(gm & ((1u << gl) - 1u)), x = gl;
-                const int tp_tab = __builtin_amdgcn_ds_permute((int)((gb + (p ? ttot - tl - 1u : 7u)) << 2), (int)x);
-                const int fp_tab = __builtin_amdgcn_ds_permute((int)((gb + ((valid && !p) ? x - tl : 7u)) << 2), (int)x);
-                const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
-                const int tp_at = __builtin_amdgcn_ds_bpermute((int)((gb + ((F - 1u) & 7u)) << 2), tp_tab);
-                const int fp_at = __builtin_amdgcn_ds_bpermute((int)((gb + (T & 7u)) << 2), fp_tab);
-                unsigned dest = gl;
-                bool is_u = false;
-                if (valid) {
-                    const int tF = F == 0u ? (int)n : (F <= ttot ? tp_at : -1);
-                    const bool left = (int)x < tF;
-                    const unsigned fj = (T + 1u <= ftot) ? (unsigned)fp_at : n;
-                    const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
-                    is_u = fetch == n - 1u;
-                    if (is_u) dest = ttot - (p ? 1u : 0u);
-                    else if (left) dest = p ? x : (unsigned)tF - 1u;
-                    else dest = p ? fj : x - 1u;
-                }
-                const unsigned um = (unsigned)(__ballot(is_u) >> gb) & 0xffu;
-                const int ul = um ? __builtin_ctz(um) : 0;
-                ue_o = (unsigned)__shfl((int)el, (int)gb + ul);
-                up_o = (unsigned)__shfl(p ? 1 : 0, (int)gb + ul);
-                ttot_o = ttot;
-                const int da = (int)((gb + dest) << 2);
-                el = (unsigned)__builtin_amdgcn_ds_permute(da, (int)el);
-                cx = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cx)));
-                cy = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cy)));
-                cz = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cz)));
-            };
-            for (int c = 0; c < kCand; ++c) {                                      // blas.rs:144-147
-                unsigned tt, ue, up;
-                trial(c / 7, cand_pos(cbmin, cbmax, c), tt, ue, up);
-                if (gl == 0u) { W.g_ue[grp][c] = (unsigned short)ue; W.g_tt[grp][c] = (unsigned char)(tt | (up << 4)); }
-            }
-            vd_wave_lds_sync();
-            // evaluate (blas.rs:149-161): left = examined trues = {e : p_c(e) and e != u_c}, right = the rest (incl. u_c)
-            if (valid) {
-#pragma unroll
-                for (int q = 0; q < 6; ++q) bk[q] = L.box[q][el];
-            }
-            vd_u64 key = ~0ull;
-            for (int c = 0; c < kCand; ++c) {
-                const int axis = c / 7;
-                const float ce = axis == 0 ? cx : (axis == 1 ? cy : cz);
-                const unsigned ue = W.g_ue[grp][c], tu = W.g_tt[grp][c];
-                const bool inl = valid && ce < cand_pos(cbmin, cbmax, c) && el != ue, inr = valid && !inl;
-                int k12[12];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    k12[q] = inl ? bk[q] : kBig; k12[3 + q] = inl ? bk[3 + q] : -kBig - 1;
-                    k12[6 + q] = inr ? bk[q] : kBig; k12[9 + q] = inr ? bk[3 + q] : -kBig - 1;
-                }
-#pragma unroll
-                for (int i2 = 0; i2 < 12; ++i2) k12[i2] = (i2 % 6) < 3 ? group8_min_i(k12[i2]) : group8_max_i(k12[i2]);
-                const unsigned n1 = (tu & 15u) - (tu >> 4);
-                const float a1 = vd_area(box_hi(k12[3]) - box_lo(k12[0]), box_hi(k12[4]) - box_lo(k12[1]), box_hi(k12[5]) - box_lo(k12[2]));
-                const float a2 = vd_area(box_hi(k12[9]) - box_lo(k12[6]), box_hi(k12[10]) - box_lo(k12[7]), box_hi(k12[11]) - box_lo(k12[8]));
-                const vd_u64 kc = cost_key(a1 * (float)n1 + a2 * (float)(n - n1), (unsigned)c);
-                key = kc < key ? kc : key;
-            }
-            const bool rejected = have && key == ~0ull;                              // SURVEY.md §8a B7
-            const int best = rejected || !have ? 0 : (int)(unsigned)key;
-            const unsigned tb = W.g_tt[grp][best];
-            const unsigned Lst = (tb & 15u) - (tb >> 4);                            // stale optimal_pivot (blas.rs:159,165)
-            {
-                unsigned tt, ue, up;                                                // blas.rs:164
-                trial(best / 7, cand_pos(cbmin, cbmax, best), tt, ue, up);
-            }
-            if (valid) { L.perm[0][s + gl] = (unsigned short)el; L.perm[1][s + gl] = (unsigned short)el; }
-            if (valid) {
-#pragma unroll
-                for (int q = 0; q < 6; ++q) bk[q] = L.box[q][el];
-            }
-            int ck[12];                                                             // children boxes (blas.rs:115-123)
-            {
-                const bool inl = valid && gl < Lst, inr = valid && !inl;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    ck[q] = inl ? bk[q] : kBig; ck[3 + q] = inl ? bk[3 + q] : -kBig - 1;
-                    ck[6 + q] = inr ? bk[q] : kBig; ck[9 + q] = inr ? bk[3 + q] : -kBig - 1;
-                }
-#pragma unroll
-                for (int i2 = 0; i2 < 12; ++i2) ck[i2] = (i2 % 6) < 3 ? group8_min_i(ck[i2]) : group8_max_i(ck[i2]);
-            }
-            if (have && gl == 0u) {
-                if (rejected) { Q.bad = 1; atomicSub(&Q.s_pending, 1); }
-                else {
-                    const unsigned pair = atomicAdd(&Q.pool, 2u);
-                    TmpNode ln, rn;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        ln.mn[q] = box_lo(ck[q]); ln.mx[q] = box_hi(ck[3 + q]);
-                        rn.mn[q] = box_lo(ck[6 + q]); rn.mx[q] = box_hi(ck[9 + q]);
-                    }
-                    ln.left_first = base + s; ln.count = Lst;
-                    rn.left_first = base + s + Lst; rn.count = n - Lst;
-                    nodes[pair] = ln; nodes[pair + 1] = rn;
-                    if (ent == root_ent) Q.root_left = pair;                        // N <= kLaneMax: the subtree root itself
-                    else { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }
-                    int more = 0;
-                    if (Lst > 3u) { Q.small[atomicAdd(&Q.n_small, 1u)] = pair | (s << 10) | (Lst << 20); more += 1; }
-                    if (n - Lst > 3u) { Q.small[atomicAdd(&Q.n_small, 1u)] = (pair + 1u) | ((s + Lst) << 10) | ((n - Lst) << 20); more += 1; }
-                    if (more != 1) atomicAdd(&Q.s_pending, more - 1);
-                }
-            }
-#ifdef VD_PHASEB_PROF
-            if (tid == 0) Q.busy0 += (unsigned)(__builtin_amdgcn_s_memtime() - tb0);
-            if (lane == 0) atomicMax(&Q.t_last_batch_end, (unsigned)(__builtin_amdgcn_s_memtime() - t_begin));
-#endif
+            if (try_group()) { idle2 = 0; continue; }
+            if (*(volatile int*)&Q.s_pending <= 0 || *(volatile unsigned*)&Q.bad) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (++idle2 > (1u << 24)) { if (lane == 0) Q.bad = 2; break; }
         }
     }
     __threadfence_block();   // node records written by all lanes are re-read below, by this workgroup only (an agent-scope
                              // fence would write back the whole L2 of the XCD, once per subtree)
     __syncthreads();
     if (Q.bad) { if (tid == 0) atomicOr(err, Q.bad == 2u ? ERR_INTERNAL : ERR_DEGENERATE); return; }
-#ifdef VD_PHASEB_PROF
-    if (tid == 0) Q.t_lane = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
+#ifdef VD_PROF_SEL
+    if (tid == 0) Q.prof[2] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
 #endif
     const unsigned pool = Q.pool, root_left = Q.root_left;
     const unsigned n_interior = pool / 2u;
@@ -945,8 +867,8 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             if (LC[j] != 0xffffu) { const unsigned l = LC[j]; R[l] = (unsigned short)(R[j] + 1u); R[l + 1u] = (unsigned short)(R[j] + 1u + I[l]); }
     }
     __syncthreads();
-#ifdef VD_PHASEB_PROF
-    if (tid == 0) Q.t_renum = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
+#ifdef VD_PROF_SEL
+    if (tid == 0) Q.prof[3] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
 #endif
     // new local index of node j = 2 * r(parent) + side; parent's rank = R[left sibling] - 1
     for (unsigned j = tid; j < n_nodes; j += 64u * kSubWaves) {
@@ -957,8 +879,8 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     for (unsigned x = tid; x < N; x += 64u * kSubWaves) final_ids[base + x] = L.gid[L.perm[0][x]];
     if (tid == 0) {
         sub_interior[root_i] = n_interior;
-#ifdef VD_PHASEB_PROF
-        if (dbg_cycles) { dbg_cycles[2 * root_i] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin); dbg_cycles[2 * root_i + 1] = N | ((Q.t_lane >> 12) << 10) | ((Q.t_renum >> 12) << 20); dbg_cycles[2 * root_i + 1] = (Q.idle0 & 1023u) | ((Q.t_small_begin >> 12) << 10) | ((Q.t_last_batch_end >> 12) << 21); dbg_cycles[2 * root_i] = (dbg_cycles[2 * root_i] >> 8) | ((Q.t_root >> 12) << 16) | ((Q.t_waves >> 12) << 24); }
+#ifdef VD_PROF_SEL
+        if (dbg_cycles) { dbg_cycles[2 * root_i] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin); dbg_cycles[2 * root_i + 1] = Q.prof[VD_PROF_SEL]; }
 #else
         if (dbg_cycles) { dbg_cycles[2 * root_i] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin); dbg_cycles[2 * root_i + 1] = N; }
 #endif
