@@ -332,12 +332,103 @@ struct WaveQueues {                      // entry = node | start << 10 | count <
     unsigned s_head;                     // small[s_head .. n_small) is waiting for a lane group
     int s_pending;                       // nodes of <= 32 prims queued or being split
     unsigned c16[kC16], c32[kC32];       // nodes of 9..16 / 17..32 prims: four / two per wave
+    unsigned r_cnt[kChunks];             // block-wide shuffle of the subtree root: trues per 64-position chunk
+    unsigned r_src, r_axis, r_active, r_ue, r_up;
+    float r_pos;
     unsigned h16, t16, h32, t32;
     unsigned n_small, root_left, bad;
 #ifdef VD_PROF_SEL
     unsigned prof[8];   // 0 root node done, 1 wave loop done, 2 lists drained, 3 renumber scan done, 4 group batches, 5 listed nodes, 6 wide nodes
 #endif
 };
+
+// The same shuffle for the subtree root [0, n), by all waves of the workgroup: wave w owns the 64-position chunks
+// w, w + kSubWaves, ...  The root is split while nothing else can run (it is 20 % of a subtree's time on one wave),
+// so the other waves serve as helpers: the leader (wave 0, inside its ordinary node body) posts {src, axis, pos} and
+// everyone meets at four workgroup barriers per shuffle; r_active = 0 releases the helpers.
+constexpr int kOwnChunks = (kChunks + kSubWaves - 1) / kSubWaves;
+__device__ __forceinline__ void block_shuffle_part(WaveLds& L, WaveQueues& Q, unsigned n, unsigned wave) {
+    const unsigned lane = vd_lane();
+    const int src = (int)Q.r_src;
+    const unsigned short* pin = L.perm[src];
+    unsigned short* pout = L.perm[src ^ 1];
+    const float* cen = L.cent[Q.r_axis];
+    const float pos = Q.r_pos;
+    unsigned long long masks[kOwnChunks];
+    unsigned short el[kOwnChunks];
+#pragma unroll
+    for (int k = 0; k < kOwnChunks; ++k) {
+        const unsigned ch = wave + (unsigned)k * kSubWaves, x = ch * 64u + lane;
+        bool p = false;
+        el[k] = 0;
+        if (ch < (unsigned)kChunks && x < n) { el[k] = pin[x]; p = cen[el[k]] < pos; }
+        masks[k] = __ballot(p);
+        if (lane == 0 && ch < (unsigned)kChunks) Q.r_cnt[ch] = (unsigned)__popcll(masks[k]);
+    }
+    __syncthreads();                                                     // B1: chunk counts are in
+    unsigned ttot = 0, run[kOwnChunks];
+#pragma unroll
+    for (int k = 0; k < kOwnChunks; ++k) run[k] = 0;
+#pragma unroll
+    for (int ch = 0; ch < kChunks; ++ch) {
+        const unsigned cnt = Q.r_cnt[ch];
+#pragma unroll
+        for (int k = 0; k < kOwnChunks; ++k) if ((unsigned)ch < wave + (unsigned)k * kSubWaves) run[k] += cnt;
+        ttot += cnt;
+    }
+    const unsigned ftot = n - ttot;
+#pragma unroll
+    for (int k = 0; k < kOwnChunks; ++k) {
+        const unsigned ch = wave + (unsigned)k * kSubWaves, x = ch * 64u + lane;
+        if (ch < (unsigned)kChunks && x < n) {
+            const bool p = (masks[k] >> lane) & 1ull;
+            const unsigned tl = run[k] + vd_mbcnt(masks[k]);
+            if (p) L.truepos[ttot - tl] = (unsigned short)x;             // (T+1)-th true from the right
+            else L.falsepos[x - tl + 1u] = (unsigned short)x;            // (F+1)-th false from the left
+        }
+    }
+    __syncthreads();                                                     // B2: rank -> position tables are complete
+#pragma unroll
+    for (int k = 0; k < kOwnChunks; ++k) {
+        const unsigned ch = wave + (unsigned)k * kSubWaves, x = ch * 64u + lane;
+        bool is_u = false, p = false;
+        if (ch < (unsigned)kChunks && x < n) {
+            p = (masks[k] >> lane) & 1ull;
+            const unsigned tl = run[k] + vd_mbcnt(masks[k]);
+            const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
+            const int tF = F == 0u ? (int)n : (F <= ttot ? (int)L.truepos[F] : -1);
+            const bool left = (int)x < tF;
+            const unsigned fj = (T + 1u <= ftot) ? (unsigned)L.falsepos[T + 1u] : n;
+            const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
+            is_u = fetch == n - 1u;
+            unsigned dest;
+            if (is_u) dest = ttot - (p ? 1u : 0u);
+            else if (left) dest = p ? x : (unsigned)tF - 1u;
+            else dest = p ? fj : x - 1u;
+            pout[dest] = el[k];
+            if (is_u) { Q.r_ue = el[k]; Q.r_up = p ? 1u : 0u; }
+        }
+    }
+    __syncthreads();                                                     // B3: the new arrangement and u are in
+}
+// leader side (wave 0): same out parameters as wave_shuffle
+__device__ __forceinline__ void block_shuffle_leader(WaveLds& L, WaveQueues& Q, int src, unsigned n, int axis, float pos,
+                                                     unsigned& tt, unsigned& ue, unsigned& up) {
+    if (vd_lane() == 0) { Q.r_src = (unsigned)src; Q.r_axis = (unsigned)axis; Q.r_pos = pos; Q.r_active = 1u; }
+    __syncthreads();                                                     // B0: the command is posted
+    block_shuffle_part(L, Q, n, 0u);
+    unsigned t = 0;
+#pragma unroll
+    for (int ch = 0; ch < kChunks; ++ch) t += Q.r_cnt[ch];
+    tt = t; ue = Q.r_ue; up = Q.r_up;
+}
+__device__ __forceinline__ void block_shuffle_helpers(WaveLds& L, WaveQueues& Q, unsigned n, unsigned wave) {
+    for (;;) {
+        __syncthreads();                                                 // B0
+        if (Q.r_active == 0u) break;
+        block_shuffle_part(L, Q, n, wave);
+    }
+}
 
 __global__ __launch_bounds__(64 * kSubWaves, 4)
 void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
@@ -573,6 +664,8 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
 
     unsigned next_ent = (wave == 0u && N > (unsigned)kLaneMax) ? root_ent : 0u;   // wave-uniform; 0 = take one from the list
     unsigned idle_polls = 0;
+    const bool root_by_block = N > 128u;                 // the subtree root is shuffled by all waves (block_shuffle_*)
+    if (root_by_block && wave != 0u) block_shuffle_helpers(L, Q, N, wave);
 
     for (;;) {
         {
@@ -664,7 +757,8 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             } else {
                 for (int c = 0; c < kCand; ++c) {                                     // blas.rs:144-147
                     unsigned tt, ue, up;
-                    wave_shuffle_any(L, cur, s, n, c / 7, W.pos[c], tt, ue, up);
+                    if (is_root && root_by_block) block_shuffle_leader(L, Q, cur, n, c / 7, W.pos[c], tt, ue, up);
+                    else wave_shuffle_any(L, cur, s, n, c / 7, W.pos[c], tt, ue, up);
                     cur ^= 1;
                     if (lane == 0) { W.u_e[c] = (unsigned short)ue; W.u_p[c] = (unsigned short)up; W.ttot[c] = tt; }
                 }
@@ -762,12 +856,20 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             }
             }
             key = wave_min_u64(key);
-            if (key == ~0ull) { if (lane == 0) { Q.bad = 1; atomicSub(&Q.pending, 1); } continue; }
+            if (key == ~0ull) {
+                if (lane == 0) { Q.bad = 1; atomicSub(&Q.pending, 1); }
+                if (is_root && root_by_block) { if (lane == 0) Q.r_active = 0u; __syncthreads(); }   // release the helpers
+                continue;
+            }
             const int best = (int)(unsigned)key;
             const unsigned Lst = W.ttot[best] - W.u_p[best];             // stale optimal_pivot (blas.rs:159,165)
             {
                 unsigned tt, ue, up;                                     // blas.rs:164
-                wave_shuffle_any(L, cur, s, n, best / 7, W.pos[best], tt, ue, up);
+                if (is_root && root_by_block) {
+                    block_shuffle_leader(L, Q, cur, n, best / 7, W.pos[best], tt, ue, up);
+                    if (lane == 0) Q.r_active = 0u;
+                    __syncthreads();                                     // B0 with r_active = 0: the helpers leave
+                } else wave_shuffle_any(L, cur, s, n, best / 7, W.pos[best], tt, ue, up);
                 cur ^= 1;                                                // 22 flips: back in buffer 0
             }
             int k12[12];                                                 // children boxes (blas.rs:115-123)
