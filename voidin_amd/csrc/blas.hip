@@ -550,17 +550,27 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                     cbmin[k] = box_lo(kmn[k]); cbmax[k] = box_hi(kmx[k]);
                 }
             }
-            // one trial (blas.rs:168-182 in closed form, as the wave-wide register path): moves el / cx / cy / cz
-            auto trial = [&](int axis, float pos, unsigned& ttot_o, unsigned& ue_o, unsigned& up_o) {
-                const float ce = axis == 0 ? cx : (axis == 1 ? cy : cz);
-                const bool p = valid && ce < pos;
+            // the 21 predicates of an element do not depend on where it sits: one bit each, computed once, and the word
+            // travels with the element id (two crossbar moves per trial instead of four)
+            unsigned pb = 0u;
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < kCand; ++c) {
+                    const float ce = c < 7 ? cx : (c < 14 ? cy : cz);
+                    pb |= (ce < cand_pos(cbmin, cbmax, c) ? 1u : 0u) << c;
+                }
+            }
+            // one trial (blas.rs:168-182 in closed form, as the wave-wide register path): moves el / pb
+            auto trial = [&](int c, bool record) {
+                const bool p = valid && ((pb >> c) & 1u);
                 const unsigned gm = (unsigned)(__ballot(p) >> gb) & gmask;
                 const unsigned ttot = (unsigned)__popc(gm), ftot = n - ttot, tl = (unsigned)__popc(gm & ((1u << gl) - 1u)), x = gl;
-                const int tp_tab = __builtin_amdgcn_ds_permute((int)((gb + (p ? ttot - tl - 1u : gw - 1u)) << 2), (int)x);
-                const int fp_tab = __builtin_amdgcn_ds_permute((int)((gb + ((valid && !p) ? x - tl : gw - 1u)) << 2), (int)x);
+                // both rank -> position tables in ONE crossbar move: truepos[k + 1] in lane k < ttot, falsepos[k + 1] in lane
+                // ttot + k (ttot + ftot = n <= gw); lanes without an element aim at lane gw - 1, which is free when n < gw
+                const int tab = __builtin_amdgcn_ds_permute((int)((gb + (p ? ttot - tl - 1u : (valid ? ttot + x - tl : gw - 1u))) << 2), (int)x);
                 const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
-                const int tp_at = __builtin_amdgcn_ds_bpermute((int)((gb + ((F - 1u) & (gw - 1u))) << 2), tp_tab);
-                const int fp_at = __builtin_amdgcn_ds_bpermute((int)((gb + (T & (gw - 1u))) << 2), fp_tab);
+                const int tp_at = __builtin_amdgcn_ds_bpermute((int)((gb + ((F - 1u) & (gw - 1u))) << 2), tab);
+                const int fp_at = __builtin_amdgcn_ds_bpermute((int)((gb + ((ttot + T) & (gw - 1u))) << 2), tab);
                 unsigned dest = gl;
                 bool is_u = false;
                 if (valid) {
@@ -573,22 +583,14 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                     else if (left) dest = p ? x : (unsigned)tF - 1u;
                     else dest = p ? fj : x - 1u;
                 }
-                const unsigned um = (unsigned)(__ballot(is_u) >> gb) & gmask;
-                const int ul = um ? __builtin_ctz(um) : 0;
-                ue_o = (unsigned)__shfl((int)el, (int)gb + ul);
-                up_o = (unsigned)__shfl(p ? 1 : 0, (int)gb + ul);
-                ttot_o = ttot;
+                if (record && is_u) {                  // the one never-examined element of the node writes its own record
+                    W.g_ue[grp][c] = (unsigned short)el; W.g_tt[grp][c] = (unsigned char)(ttot | ((p ? 1u : 0u) << 7));
+                }
                 const int da = (int)((gb + dest) << 2);
                 el = (unsigned)__builtin_amdgcn_ds_permute(da, (int)el);
-                cx = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cx)));
-                cy = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cy)));
-                cz = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cz)));
+                pb = (unsigned)__builtin_amdgcn_ds_permute(da, (int)pb);
             };
-            for (int c = 0; c < kCand; ++c) {                                      // blas.rs:144-147
-                unsigned tt, ue, up;
-                trial(c / 7, cand_pos(cbmin, cbmax, c), tt, ue, up);
-                if (gl == 0u) { W.g_ue[grp][c] = (unsigned short)ue; W.g_tt[grp][c] = (unsigned char)(tt | (up << 7)); }
-            }
+            for (int c = 0; c < kCand; ++c) trial(c, true);                        // blas.rs:144-147
             vd_wave_lds_sync();
             // evaluate (blas.rs:149-161): left = examined trues = {e : p_c(e) and e != u_c}, right = the rest (incl. u_c)
             if (valid) {
@@ -597,10 +599,8 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             }
             vd_u64 key = ~0ull;
             for (int c = 0; c < kCand; ++c) {
-                const int axis = c / 7;
-                const float ce = axis == 0 ? cx : (axis == 1 ? cy : cz);
                 const unsigned ue = W.g_ue[grp][c], tu = W.g_tt[grp][c];
-                const bool inl = valid && ce < cand_pos(cbmin, cbmax, c) && el != ue, inr = valid && !inl;
+                const bool inl = valid && ((pb >> c) & 1u) && el != ue, inr = valid && !inl;
                 int k12[12];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -619,10 +619,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             const int best = rejected || !have ? 0 : (int)(unsigned)key;
             const unsigned tb = W.g_tt[grp][best];
             const unsigned Lst = (tb & 127u) - (tb >> 7);                            // stale optimal_pivot (blas.rs:159,165)
-            {
-                unsigned tt, ue, up;                                                // blas.rs:164
-                trial(best / 7, cand_pos(cbmin, cbmax, best), tt, ue, up);
-            }
+            trial(best, false);                                                     // blas.rs:164
             if (valid) { L.perm[0][s + gl] = (unsigned short)el; L.perm[1][s + gl] = (unsigned short)el; }
             if (valid) {
 #pragma unroll
@@ -708,28 +705,28 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             if (lane < (unsigned)kCand) W.pos[lane] = cand_pos(cbmin, cbmax, (int)lane);
             vd_wave_lds_sync();
             if (n <= 64u) {
-                // One position per lane: the arrangement (element id + its centroid) stays in registers across the 21
-                // trials and moves through the LDS crossbar (ds_permute / ds_bpermute), the rank -> position tables
-                // likewise.  A trial is then three dependent crossbar hops instead of five dependent LDS accesses -
-                // and the many levels that hold only a few small nodes cost exactly that chain, 22 times each.
+                // One position per lane: the arrangement (element id + the element's 21 predicate bits) stays in registers
+                // across the 21 trials and moves through the LDS crossbar (ds_permute / ds_bpermute), the rank ->
+                // position tables likewise.  A trial is then three dependent crossbar hops (five moves in all) instead of
+                // five dependent LDS accesses.
                 const bool valid = lane < n;
                 unsigned el = valid ? (unsigned)L.perm[cur][s + lane] : 0u;
-                float cx = 0.0f, cy = 0.0f, cz = 0.0f;
-                if (valid) { cx = L.cent[0][el]; cy = L.cent[1][el]; cz = L.cent[2][el]; }
+                unsigned pb = 0u;                      // the element's 21 predicates: they travel with it
+                if (valid) {
+                    const float cx = L.cent[0][el], cy = L.cent[1][el], cz = L.cent[2][el];
+#pragma unroll
+                    for (int c = 0; c < kCand; ++c) pb |= ((c < 7 ? cx : (c < 14 ? cy : cz)) < W.pos[c] ? 1u : 0u) << c;
+                }
                 for (int c = 0; c < kCand; ++c) {                                     // blas.rs:144-147
-                    const int axis = c / 7;
-                    const float pos = W.pos[c];
-                    const float ce = axis == 0 ? cx : (axis == 1 ? cy : cz);
-                    const bool p = valid && ce < pos;
+                    const bool p = valid && ((pb >> c) & 1u);
                     const unsigned long long mask = __ballot(p);
                     const unsigned ttot = (unsigned)__popcll(mask), ftot = n - ttot, tl = vd_mbcnt(mask), x = lane;
-                    // lane k receives truepos[k + 1] resp. falsepos[k + 1] (0-based here); lane 63 is the dump slot (a table
-                    // that needs all 64 lanes has no lane left over to dump)
-                    const int tp_tab = __builtin_amdgcn_ds_permute((int)((p ? ttot - tl - 1u : 63u) << 2), (int)x);
-                    const int fp_tab = __builtin_amdgcn_ds_permute((int)(((valid && !p) ? x - tl : 63u) << 2), (int)x);
+                    // both rank -> position tables in one crossbar move: lane k < ttot receives truepos[k + 1], lane ttot + k
+                    // falsepos[k + 1] (0-based here); lanes without an element aim at lane 63, which is free when n < 64
+                    const int tab = __builtin_amdgcn_ds_permute((int)((p ? ttot - tl - 1u : (valid ? ttot + x - tl : 63u)) << 2), (int)x);
                     const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
-                    const int tp_at = __builtin_amdgcn_ds_bpermute((int)(((F - 1u) & 63u) << 2), tp_tab);
-                    const int fp_at = __builtin_amdgcn_ds_bpermute((int)((T & 63u) << 2), fp_tab);
+                    const int tp_at = __builtin_amdgcn_ds_bpermute((int)(((F - 1u) & 63u) << 2), tab);
+                    const int fp_at = __builtin_amdgcn_ds_bpermute((int)(((ttot + T) & 63u) << 2), tab);
                     unsigned dest = lane;
                     bool is_u = false;
                     if (valid) {
@@ -742,15 +739,10 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                         else if (left) dest = p ? x : (unsigned)tF - 1u;
                         else dest = p ? fj : x - 1u;
                     }
-                    const unsigned long long um = __ballot(is_u);
-                    const int ul = um ? __builtin_ctzll(um) : 0;
-                    const unsigned ue = (unsigned)__shfl((int)el, ul), up = (unsigned)__shfl(p ? 1 : 0, ul);
-                    if (lane == 0) { W.u_e[c] = (unsigned short)ue; W.u_p[c] = (unsigned short)up; W.ttot[c] = ttot; }
+                    if (is_u) { W.u_e[c] = (unsigned short)el; W.u_p[c] = p ? 1 : 0; W.ttot[c] = ttot; }   // the never-examined element records itself
                     const int da = (int)(dest << 2);
                     el = (unsigned)__builtin_amdgcn_ds_permute(da, (int)el);
-                    cx = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cx)));
-                    cy = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cy)));
-                    cz = __int_as_float(__builtin_amdgcn_ds_permute(da, __float_as_int(cz)));
+                    pb = (unsigned)__builtin_amdgcn_ds_permute(da, (int)pb);
                 }
                 cur ^= 1;                                                             // 21 flips
                 if (valid) L.perm[cur][s + lane] = (unsigned short)el;
