@@ -587,8 +587,8 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                     W.g_ue[grp][c] = (unsigned short)el; W.g_tt[grp][c] = (unsigned char)(ttot | ((p ? 1u : 0u) << 7));
                 }
                 const int da = (int)((gb + dest) << 2);
-                el = (unsigned)__builtin_amdgcn_ds_permute(da, (int)el);
-                pb = (unsigned)__builtin_amdgcn_ds_permute(da, (int)pb);
+                const unsigned ep = (unsigned)__builtin_amdgcn_ds_permute(da, (int)(el | (pb << 10)));   // el < 1024, 21 predicate bits
+                el = ep & 1023u; pb = ep >> 10;
             };
             for (int c = 0; c < kCand; ++c) trial(c, true);                        // blas.rs:144-147
             vd_wave_lds_sync();
@@ -741,8 +741,8 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                     }
                     if (is_u) { W.u_e[c] = (unsigned short)el; W.u_p[c] = p ? 1 : 0; W.ttot[c] = ttot; }   // the never-examined element records itself
                     const int da = (int)(dest << 2);
-                    el = (unsigned)__builtin_amdgcn_ds_permute(da, (int)el);
-                    pb = (unsigned)__builtin_amdgcn_ds_permute(da, (int)pb);
+                    const unsigned ep = (unsigned)__builtin_amdgcn_ds_permute(da, (int)(el | (pb << 10)));   // el < 1024, 21 predicate bits
+                    el = ep & 1023u; pb = ep >> 10;
                 }
                 cur ^= 1;                                                             // 21 flips
                 if (valid) L.perm[cur][s + lane] = (unsigned short)el;
