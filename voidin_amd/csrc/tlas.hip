@@ -94,11 +94,24 @@ __device__ __forceinline__ vd_u64 match_key(float area, unsigned slot) {
     return ((vd_u64)k << 32) | slot;
 }
 
+// min over the wave of a 64-bit key.  Within a 16-lane row on the VALU (DPP: quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror), across the four rows through the LDS crossbar - 4 crossbar moves instead of 12: the reduction sits
+// on the critical path of every scan.
+template <int CTRL> __device__ __forceinline__ vd_u64 dpp_u64(vd_u64 v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)v, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, true);
+    return ((vd_u64)hi << 32) | lo;
+}
 __device__ __forceinline__ vd_u64 wave_min_u64(vd_u64 v) {
+    vd_u64 o;
+    o = dpp_u64<0xB1>(v); v = o < v ? o : v;
+    o = dpp_u64<0x4E>(v); v = o < v ? o : v;
+    o = dpp_u64<0x141>(v); v = o < v ? o : v;
+    o = dpp_u64<0x140>(v); v = o < v ? o : v;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 16; off <= 32; off <<= 1) {
         const unsigned lo = __shfl_xor((unsigned)v, off), hi = __shfl_xor((unsigned)(v >> 32), off);
-        const vd_u64 o = ((vd_u64)hi << 32) | lo;
+        o = ((vd_u64)hi << 32) | lo;
         v = o < v ? o : v;
     }
     return v;
