@@ -28,6 +28,7 @@
 // the reference's pre-order node numbering locally.  C: DFS numbering of the (small) top tree on
 // the host, parallel copy-out.
 #include "vd_common.hpp"
+#include <type_traits>
 
 #include <vector>
 
@@ -73,21 +74,23 @@ __device__ __forceinline__ float pay_c(const u32x4& v, int axis) {
 __device__ __forceinline__ float box_lo(int key) { return vd_unkey(min(key, vd_key(1e30f))); }
 __device__ __forceinline__ float box_hi(int key) { return vd_unkey(max(key, vd_key(-1e30f))); }
 
+// Wave-wide min / max: inside a 16-lane row on the VALU (DPP), across the four rows through the LDS crossbar - two
+// crossbar moves instead of six (the crossbar is what phase B's shuffles saturate).
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    v = min(v, dpp_i<0xB1>(v)); v = min(v, dpp_i<0x4E>(v)); v = min(v, dpp_i<0x141>(v)); v = min(v, dpp_i<0x140>(v));
+    v = min(v, __shfl_xor(v, 16)); v = min(v, __shfl_xor(v, 32));
     return v;
 }
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    v = max(v, dpp_i<0xB1>(v)); v = max(v, dpp_i<0x4E>(v)); v = max(v, dpp_i<0x141>(v)); v = max(v, dpp_i<0x140>(v));
+    v = max(v, __shfl_xor(v, 16)); v = max(v, __shfl_xor(v, 32));
     return v;
 }
 
 // min / max over the aligned group of 8 lanes a lane belongs to, on the VALU (DPP) - the LDS crossbar is what the
 // shuffles of the trials already saturate.  row_half_mirror pairs lane i with 7 - i, then each quad holds four
 // pairs that cover all eight lanes: quad_perm [1,0,3,2] and [2,3,0,1] finish the reduction.
-template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
 __device__ __forceinline__ int group8_min_i(int v) {
     v = min(v, dpp_i<0x141>(v)); v = min(v, dpp_i<0xB1>(v)); v = min(v, dpp_i<0x4E>(v));
     return v;
@@ -203,11 +206,18 @@ __device__ __forceinline__ vd_u64 cost_key(float cost, unsigned c) {
     return ((vd_u64)k << 32) | c;
 }
 __device__ __forceinline__ vd_u64 wave_min_u64(vd_u64 v) {
+    auto step = [&](vd_u64 o) { v = o < v ? o : v; };
+    auto dpp = [&](auto ctrl) {
+        constexpr int C = decltype(ctrl)::value;
+        const unsigned lo = (unsigned)dpp_i<C>((int)(unsigned)v), hi = (unsigned)dpp_i<C>((int)(unsigned)(v >> 32));
+        return ((vd_u64)hi << 32) | lo;
+    };
+    step(dpp(std::integral_constant<int, 0xB1>{})); step(dpp(std::integral_constant<int, 0x4E>{}));
+    step(dpp(std::integral_constant<int, 0x141>{})); step(dpp(std::integral_constant<int, 0x140>{}));
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 16; off <= 32; off <<= 1) {
         const unsigned lo = __shfl_xor((unsigned)v, off), hi = __shfl_xor((unsigned)(v >> 32), off);
-        const vd_u64 o = ((vd_u64)hi << 32) | lo;
-        v = o < v ? o : v;
+        step(((vd_u64)hi << 32) | lo);
     }
     return v;
 }
