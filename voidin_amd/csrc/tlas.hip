@@ -326,16 +326,21 @@ __device__ __forceinline__ unsigned mw_find_best_match(float* sb, unsigned cap, 
         }
     }
     best = wave_min_u64(best);
-    vd_u64* slot = s_red + (call % 3u);
-    if (lane == 0 && best != ~0ull) atomicMin(slot, best);
-    if (tid == 0) s_red[(call + 1u) % 3u] = ~0ull;
+    // workgroup minimum: every wave leaves its key in its own word (two-deep by scan parity: no second barrier), wave 0
+    // reduces the <= 16 words inside one DPP row - no LDS atomics on one address
+    const unsigned ring = call & 1u;
+    constexpr unsigned kWaves = kMwThreads / 64;
+    static_assert(kWaves <= 16, "one DPP row");
+    if (lane == 0) s_red[ring * 16u + (tid >> 6)] = best;
     __syncthreads();
     // exchange: {area bits : 32, slot : 20, tag : 12}; "nothing" = all ones above the tag
-    const unsigned ring = call & 1u;
     const vd_u64 tag = (vd_u64)(((call >> 1) + 1u) & 0xfffu);
     if (tid < 64u) {
+        vd_u64 wg = lane < kWaves ? s_red[ring * 16u + lane] : ~0ull;
+        { vd_u64 o; o = dpp_u64<0xB1>(wg); wg = o < wg ? o : wg; o = dpp_u64<0x4E>(wg); wg = o < wg ? o : wg;
+          o = dpp_u64<0x141>(wg); wg = o < wg ? o : wg; o = dpp_u64<0x140>(wg); wg = o < wg ? o : wg; }   // lanes 0..15 hold the minimum
         if (tid == 0) {
-            const vd_u64 mine = *slot;
+            const vd_u64 mine = wg;
             const vd_u64 packed = mine == ~0ull ? (~0ull << 12) : ((mine >> 32) << 32 | (mine & 0xfffffull) << 12);
             __hip_atomic_store(&sh->key[ring][w], packed | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -356,10 +361,10 @@ __device__ __forceinline__ unsigned mw_find_best_match(float* sb, unsigned cap, 
         } else {
             got = wave_min_u64(got);
         }
-        if (lane == 0) s_red[3u + ring] = got;          // two-deep: the next scan writes the other word
+        if (lane == 0) s_red[32u + ring] = got;         // two-deep: the next scan writes the other word
     }
     __syncthreads();
-    const vd_u64 g = s_red[3u + ring];
+    const vd_u64 g = s_red[32u + ring];
     if (g == ~0ull - 1ull) return ~0u;
     if ((g >> 20) == 0xffffffffull) return target;     // nobody had a candidate
     return (unsigned)(g & 0xfffffull);
@@ -431,8 +436,8 @@ __device__ __forceinline__ void mw_build_chain(Node* __restrict__ nodes, unsigne
 template <typename Node>
 __global__ __launch_bounds__(kMwThreads) void tlas_build_mw_kernel(Node* __restrict__ nodes, unsigned n, float* sb,
                                                                       unsigned* slot_node, unsigned cap, MwShared* sh, unsigned spin_limit) {
-    __shared__ vd_u64 s_red[5];
-    if (threadIdx.x < 5) s_red[threadIdx.x] = ~0ull;
+    __shared__ vd_u64 s_red[34];   // [2][16] per-wave keys by scan parity, [32 + parity] the exchanged result
+    if (threadIdx.x < 34) s_red[threadIdx.x] = ~0ull;
     int nan = 0;
     for (unsigned i = threadIdx.x; i < n; i += kMwThreads) {
 #pragma unroll
