@@ -12,8 +12,8 @@
 //    "build, several workgroups"); each scan is data-parallel over the
 //    active slots, which are kept as a compacted SoA (six float arrays + node ids) so a scan is
 //    a pure stream of 24 B per slot; the argmin is a 64-bit {area bits, slot} key reduced by
-//    wave shuffles + LDS, which reproduces "strict <, first slot wins";
-//  * refit: leaves recomputed, interior boxes by a bottom-up walk with per-node arrival counters
+//    DPP / wave shuffles + per-wave LDS words, which reproduces "strict <, first slot wins";
+//  * refit: leaves recomputed, interior boxes by a bottom-up walk with per-node handshake counters
 //    (write-through agent-scope stores, no fences; boxes re-read L1/L2-bypassing).
 #include "vd_common.hpp"
 
@@ -179,16 +179,18 @@ __device__ __forceinline__ unsigned find_best_match(const float* sb, unsigned ca
             }
         }
     }
-    // one barrier per scan: waves fold their best key into a rotating LDS slot with a 64-bit atomic
-    // min; the slot two scans ahead is re-armed by thread 0 while nobody can be reading it
+    // one barrier per scan: every wave leaves its key in its own word (two-deep by scan parity, so the words of this
+    // scan are not rewritten before everybody has read them) and every wave reduces the 16 words itself, in one DPP row
     if (FAST && fbits != 0xffffffffu) best = match_key(__uint_as_float(fbits), fslot);
     best = wave_min_u64(best);
-    vd_u64* slot = s_red + (call % 3u);
-    if (lane == 0 && best != ~0ull) atomicMin(slot, best);
-    if (tid == 0) s_red[(call + 1u) % 3u] = ~0ull;
+    vd_u64* words = s_red + (call & 1u) * 16u;
+    if (lane == 0) words[tid >> 6] = best;
     __syncthreads();
-    const vd_u64 v = *slot;
-    return v == ~0ull ? target : (unsigned)v;
+    vd_u64 v = lane < (unsigned)(kBuildThreads / 64) ? words[lane] : ~0ull;
+    { vd_u64 o; o = dpp_u64<0xB1>(v); v = o < v ? o : v; o = dpp_u64<0x4E>(v); v = o < v ? o : v;
+      o = dpp_u64<0x141>(v); v = o < v ? o : v; o = dpp_u64<0x140>(v); v = o < v ? o : v; }        // lanes 0..15 hold the minimum
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (lo & hi) == 0xffffffffu ? target : lo;
 }
 
 // tlas.rs:56-84 — one workgroup runs the whole chain.
@@ -241,8 +243,8 @@ __global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restr
                                                                    float* sb, unsigned* slot_node,
                                                                    unsigned cap, const unsigned* __restrict__ only_if) {
     if (only_if && *only_if == 0u) return;                  // see tlas_build_impl
-    __shared__ vd_u64 s_red[4];
-    if (threadIdx.x < 4) s_red[threadIdx.x] = ~0ull;
+    __shared__ vd_u64 s_red[32];   // [2][16] per-wave keys by scan parity
+    if (threadIdx.x < 32) s_red[threadIdx.x] = ~0ull;
     int nan = 0;
     for (unsigned i = threadIdx.x; i < n; i += kBuildThreads) {
 #pragma unroll
