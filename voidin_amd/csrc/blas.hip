@@ -65,6 +65,7 @@ struct TriBox { float mn[3]; float pad0; float mx[3]; float pad1; };   // 32 B, 
 struct TmpNode { float mn[3]; unsigned left_first; float mx[3]; unsigned count; };   // == VdBvhNode layout
 
 enum : unsigned { ERR_DEGENERATE = 1u, ERR_BAD_INDEX = 2u, ERR_INTERNAL = 4u };
+constexpr unsigned kInteriorMark = 0x80000000u;   // phase B: TmpNode.count of a split node until the renumber (n stays in the low bits)
 
 __device__ __forceinline__ float pay_c(const u32x4& v, int axis) {
     return __uint_as_float(axis == 0 ? v.y : (axis == 1 ? v.z : v.w));
@@ -659,8 +660,9 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                     ln.left_first = base + s; ln.count = Lst;
                     rn.left_first = base + s + Lst; rn.count = n - Lst;
                     nodes[pair] = ln; nodes[pair + 1] = rn;
+                    nmap[pair] = (unsigned short)s; nmap[pair + 1u] = (unsigned short)(s + Lst);   // start positions: renumber keys
                     if (ent == root_ent) Q.root_left = pair;                        // N <= kLaneMax: the subtree root itself
-                    else { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }
+                    else { nodes[node_id].left_first = pair; nodes[node_id].count = n | kInteriorMark; }
                     if (Lst > 3u) push_class(pair | (s << 10) | (Lst << 20), Lst);
                     if (n - Lst > 3u) push_class((pair + 1u) | ((s + Lst) << 10) | ((n - Lst) << 20), n - Lst);
                     atomicSub(&Q.s_pending, 1);                                     // after the children were counted
@@ -898,8 +900,9 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 ln.left_first = base + cs[0]; ln.count = cn[0];          // leaf form; interior nodes are patched when split
                 rn.left_first = base + cs[1]; rn.count = cn[1];
                 nodes[pair] = ln; nodes[pair + 1] = rn;
+                nmap[pair] = (unsigned short)cs[0]; nmap[pair + 1u] = (unsigned short)cs[1];   // start positions: renumber keys
                 if (is_root) Q.root_left = pair;
-                else { nodes[node_id].left_first = pair; nodes[node_id].count = 0u; }   // creation-order link
+                else { nodes[node_id].left_first = pair; nodes[node_id].count = n | kInteriorMark; }   // creation-order link; n kept for the renumber
                 unsigned keep = 0u;
                 int n_wide = 0;
                 for (int side = 0; side < 2; ++side) {
@@ -945,30 +948,28 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
 #ifdef VD_PROF_SEL
     if (tid == 0) Q.prof[2] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin);
 #endif
-    const unsigned pool = Q.pool, root_left = Q.root_left;
+    const unsigned pool = Q.pool;
     const unsigned n_interior = pool / 2u;
 
     // ---- restore the reference's DFS pre-order numbering (blas.rs:110-112,125-126) ----
-    // creation order: children have larger ids than their parent.  I[j] = interior nodes in j's
-    // subtree; rank r(j) = interior nodes before j in pre-order (the subtree root has rank 0 and
-    // owns local pair 0).  Work arrays alias the (now dead) box keys.
-    unsigned short* I = reinterpret_cast<unsigned short*>(&L.box[0][0]);          // [2N]
-    unsigned short* R = I + 2 * kSmallMax;                                          // [2N]
-    unsigned short* LC = R + 2 * kSmallMax;                                         // [2N] left child pair (creation id), 0xffff = leaf
+    // A node covers the positions [s, s + n) of the final arrangement and its children split that range, so pre-order
+    // is the order of the keys (s ascending, n descending): rank r(j) = 1 (the subtree root, local pair 0) + the number of
+    // interior nodes whose key is smaller - counted by every thread for its own nodes, all at once (two serial passes
+    // over the creation order by one thread were 9 % of this kernel).  Work arrays alias the (now dead) box keys.
+    unsigned* IK = reinterpret_cast<unsigned*>(&L.box[0][0]);                      // [2N] key of an interior node, ~0 for a leaf
+    unsigned short* R = reinterpret_cast<unsigned short*>(IK + 2 * kSmallMax);      // [2N]
     const unsigned n_nodes = pool;
     for (unsigned j = tid; j < n_nodes; j += 64u * kSubWaves) {
-        const TmpNode t = nodes[j];
-        LC[j] = t.count == 0u ? (unsigned short)t.left_first : (unsigned short)0xffffu;
-        I[j] = 0;
+        const unsigned cnt = nodes[j].count;
+        IK[j] = (cnt & kInteriorMark) ? ((unsigned)nmap[j] << 10) | (1023u - (cnt & ~kInteriorMark)) : 0xffffffffu;
     }
     __syncthreads();
-    if (tid == 0) {
-        for (int j = (int)n_nodes - 1; j >= 0; --j)
-            if (LC[j] != 0xffffu) I[j] = (unsigned short)(1u + I[LC[j]] + I[LC[j] + 1u]);
-        // forward: parents first
-        if (root_left != kNone) { R[root_left] = 1; R[root_left + 1u] = (unsigned short)(1u + I[root_left]); }
-        for (unsigned j = 0; j < n_nodes; ++j)
-            if (LC[j] != 0xffffu) { const unsigned l = LC[j]; R[l] = (unsigned short)(R[j] + 1u); R[l + 1u] = (unsigned short)(R[j] + 1u + I[l]); }
+    for (unsigned j = tid; j < n_nodes; j += 64u * kSubWaves) {
+        const unsigned cnt = nodes[j].count;
+        const unsigned key = ((unsigned)nmap[j] << 10) | (1023u - (cnt & ~kInteriorMark));
+        unsigned r = 1u;
+        for (unsigned k = 0; k < n_nodes; ++k) r += IK[k] < key ? 1u : 0u;
+        R[j] = (unsigned short)r;
     }
     __syncthreads();
 #ifdef VD_PROF_SEL
@@ -978,7 +979,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     for (unsigned j = tid; j < n_nodes; j += 64u * kSubWaves) {
         const unsigned rl = R[j & ~1u];                    // rank of the left sibling = r(parent) + 1
         nmap[j] = (unsigned short)(2u * (rl - 1u) + (j & 1u));
-        if (LC[j] != 0xffffu) nodes[j].left_first = 2u * R[j];   // interior: its own pair in DFS numbering
+        if (IK[j] != 0xffffffffu) { nodes[j].left_first = 2u * R[j]; nodes[j].count = 0u; }   // interior: its own pair in DFS numbering
     }
     for (unsigned x = tid; x < N; x += 64u * kSubWaves) final_ids[base + x] = L.gid[L.perm[0][x]];
     if (tid == 0) {
