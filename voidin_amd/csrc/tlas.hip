@@ -360,6 +360,9 @@ __device__ __forceinline__ unsigned mw_find_best_match(float* sb, unsigned cap, 
         if (!__all(ok)) {
             if (lane == 0) __hip_atomic_store(&sh->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             got = ~0ull - 1ull;                       // timeout marker
+        } else if (W <= 16u) {                          // the W words sit in one DPP row
+            vd_u64 o; o = dpp_u64<0xB1>(got); got = o < got ? o : got; o = dpp_u64<0x4E>(got); got = o < got ? o : got;
+            o = dpp_u64<0x141>(got); got = o < got ? o : got; o = dpp_u64<0x140>(got); got = o < got ? o : got;
         } else {
             got = wave_min_u64(got);
         }
