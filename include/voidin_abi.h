@@ -281,7 +281,7 @@ int vd_bvh_build_dev(VdCtx* ctx, const float* d_verts_xyz, uint32_t n_vert,
  * (crates/bvh/src/tlas.rs:31-105), called from MeshPool::generate_tlas
  * (crates/pools/src/mesh/mod.rs:279-286). out_nodes holds 2*n+1 nodes.
  * n > 32768 => VD_ERR_TLAS_OVERFLOW (use the *_wide variant).  The *_dev forms only enqueue
- * work (from 16384 instances on the chain is shared by 16 workgroups; whether they stayed in
+ * work (from 12288 instances on the chain is shared by 16 workgroups; whether they stayed in
  * step, and the redo on one workgroup if not, is decided on the device).                  */
 int vd_tlas_build(VdCtx* ctx, const VdInstance* instances, uint32_t n,
                   const VdMeshInfo* meshes, uint32_t n_mesh, VdTlasNode* out_nodes);

@@ -33,7 +33,7 @@ def test_tlas_build_seeded_vs_oracle(ctx, oracle, n):
 
 
 def test_tlas_build_on_several_workgroups_vs_oracle(ctx, oracle):
-    """From 16384 instances on the chain runs on 16 workgroups that exchange their scan results through memory
+    """From 12288 instances on the chain runs on 16 workgroups that exchange their scan results through memory
     (tlas.hip, "build, several workgroups"): same chain, same nodes - NaN-free fast arithmetic and, with a poisoned
     instance, the total-order arithmetic; and the same bytes every time."""
     meshes = synth.mesh_infos()

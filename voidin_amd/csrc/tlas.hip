@@ -8,7 +8,7 @@
 //    object-space mesh box as seed (bug-compatible), total-order min/max;
 //  * build (tlas.rs:56-84): the reference is a sequential chain of ~2.5 N `find_best_match`
 //    scans whose tie-breaking depends on the slot order, so the chain itself cannot be
-//    reordered.  One 1024-lane workgroup runs the chain (16 of them from 16384 instances on, see
+//    reordered.  One 1024-lane workgroup runs the chain (16 of them from 12288 instances on, see
 //    "build, several workgroups"); each scan is data-parallel over the
 //    active slots, which are kept as a compacted SoA (six float arrays + node ids) so a scan is
 //    a pure stream of 24 B per slot; the argmin is a 64-bit {area bits, slot} key reduced by
@@ -561,7 +561,7 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     // the slot field of the exchanged key holds 20 bits.  VD_TLAS_GROUPS = 1 forces the single-workgroup kernel.
     const int env_groups = getenv("VD_TLAS_GROUPS") ? atoi(getenv("VD_TLAS_GROUPS")) : 0;
     const unsigned spin_limit = getenv("VD_TLAS_SPIN_LIMIT") ? (unsigned)atoi(getenv("VD_TLAS_SPIN_LIMIT")) : kSpinLimit;   // tests: 0 forces the fallback
-    unsigned groups = env_groups > 0 ? (unsigned)env_groups : (n >= 16384u ? 16u : 1u);
+    unsigned groups = env_groups > 0 ? (unsigned)env_groups : (n >= 12288u ? 16u : 1u);
     if (groups > kMwMaxGroups) groups = kMwMaxGroups;
     if (groups > (unsigned)ctx->num_cus) groups = (unsigned)ctx->num_cus;
     if (n >= (1u << 20)) groups = 1u;
