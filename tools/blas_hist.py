@@ -14,7 +14,7 @@ ctx.lib.vd_debug_blas_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 n = ctx.lib.vd_debug_blas_cycles(ctx.h, buf.ctypes.data, len(buf))
 d = buf[:n].reshape(-1,2); cyc = d[:,0].astype(np.float64); N = d[:,1]
 print('roots', len(d), 'prims mean', N.mean(), 'min', N.min(), 'max', N.max())
-us = cyc/100.0   # s_memtime ticks at 100 MHz
+us = cyc/2100.0  # s_memtime ticks: ~2.1 GHz on this part (a subtree takes ~0.6 ms: 1.2 M ticks)
 print('block time us: mean %.1f median %.1f p90 %.1f p99 %.1f max %.1f sum(ms) %.1f' % (us.mean(), np.median(us), np.percentile(us,90), np.percentile(us,99), us.max(), us.sum()/1e3))
 for lo,hi in [(0,64),(64,128),(128,256),(256,384),(384,513)]:
     m=(N>=lo)&(N<hi)
