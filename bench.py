@@ -334,6 +334,23 @@ def main():
         t_pipe = pipelined(lambda: ctx.tlas_refit_dev(d_ti, n_tl, d_m, len(meshes), d_t))
         extra["tlas"] = {"n_instances": n_tl, "build_ms": round(t_build * 1e3, 1), "refit_ms": round(t_refit * 1e3, 3),
                          "refit_queued_ms": round(t_pipe * 1e3, 4)}
+        # the dynamic-scene frame: animate 10 % of the instances (compute_update, inverse kept in step), refit
+        # the TLAS of the first 32768, cull + compact all of them - queued back to back as a frame loop does
+        if n >= n_tl:
+            d_dyn = d_i.clone()
+            d_mov = torch.arange(0, n, 10, dtype=torch.int32, device=dev)
+            d_t2 = ctx.empty((2 * n_tl + 1) * 32)
+            ctx.tlas_build_dev(d_dyn, n_tl, d_m, len(meshes), d_t2)
+
+            def frame():
+                ctx.compute_update_dev(d_mov, d_mov.numel(), d_dyn, n, 1.0, 0.016, True)
+                ctx.tlas_refit_dev(d_dyn, n_tl, d_m, len(meshes), d_t2)
+                ctx.cull_compact_dev(cam, d_m, len(meshes), d_dyn, n, d_out, d_cnt, False, first)
+            t_frame = pipelined(frame, reps=30)
+            extra["dynamic_frame"] = {"instances": n, "moving": int(d_mov.numel()), "tlas_instances": n_tl,
+                                      "ms_per_frame": round(t_frame * 1e3, 4), "fps_equivalent": round(1.0 / t_frame, 1)}
+            del d_dyn, d_mov, d_t2
+            ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, False, first)   # leave d_out / the id table as the later legs expect
         # BASELINE config 5 names a 64k-instance refit: beyond the reference's 16-bit child ids (tlas.rs:71), so in
         # the wide layout; timed with HIP events by the library (wall clock of a 0.1 ms call is mostly launch latency)
         n_w = 65536
