@@ -24,9 +24,11 @@
 // predicates of a level are evaluated once and the arrangement ping-pongs between two 8-byte
 // {triangle id, predicate bits} arrays in HBM.  Mid tier (kSmallMax < n <= kMidMax): one workgroup
 // per segment, the same rounds with the arrangement in LDS (barriers instead of launches).
-// B (<= kSmallMax): one workgroup builds the whole subtree in DFS order out of LDS, which yields
-// the reference's pre-order node numbering locally.  C: DFS numbering of the (small) top tree on
-// the host, parallel copy-out.
+// B (<= kSmallMax): one workgroup builds the whole subtree out of LDS - no levels: a wave that has split a
+// node goes on with one child and hands the other to an idle wave; nodes of <= 32 prims are split
+// several per wave in lane groups of 8 / 16 / 32; the subtree root's shuffles are shared by all waves - and
+// restores the reference's pre-order node numbering locally from (start, -count) keys.  C: DFS numbering of
+// the (small) top tree on the host while phase B runs, parallel copy-out.
 #include "vd_common.hpp"
 #include <type_traits>
 
