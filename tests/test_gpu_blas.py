@@ -50,6 +50,27 @@ def test_knot_meshes_vs_oracle(ctx, oracle, shape):
     assert np.array_equal(idx, want_idx)
 
 
+@pytest.mark.parametrize("n_tri,ratio", [(60, 3.0), (300, 1.25), (512, 1.14), (1500, 1.045), (5000, 1.012)])   # x stays below 1e30
+def test_chain_like_trees_vs_oracle(ctx, oracle, n_tri, ratio):
+    """Triangles at geometrically growing distances: every split peels a few prims off the far end, so the tree is one
+    long chain - the worst case for the builder's work lists (nodes of one size class nest instead of sitting side by
+    side) and for the depth of everything that walks the tree."""
+    x = (ratio ** np.arange(n_tri, dtype=np.float64)).astype(np.float32)
+    v = np.zeros((3 * n_tri, 3), dtype=np.float32)
+    v[0::3, 0] = x; v[1::3, 0] = x * np.float32(1.01); v[2::3, 0] = x
+    v[1::3, 1] = 0.5; v[2::3, 2] = 0.5
+    i = np.arange(3 * n_tri, dtype=np.uint32)
+    want_nodes, want_idx = oracle.bvh_build(v, i)
+    depth = np.zeros(len(want_nodes), dtype=np.int64)
+    for k in range(len(want_nodes)):                           # children come after their parent in pre-order
+        if want_nodes["count"][k] == 0 and k != 1:
+            l = int(want_nodes["left_first"][k]); depth[l] = depth[l + 1] = depth[k] + 1
+    assert depth.max() > 25                                    # really a chain, not a bushy tree
+    nodes, idx = ctx.bvh_build(v, i)
+    assert fields_equal(nodes, want_nodes), diff_report(nodes, want_nodes)
+    assert np.array_equal(idx, want_idx)
+
+
 def test_builder_api_permutes_callers_indices(ctx):
     # BvhBuilder::new(&[Vec3], &mut [UVec3]).build() -> Bvh{nodes}; caller's slice permuted (blas.rs:95-100)
     g = golden("blas_soup64.npz")

@@ -333,8 +333,10 @@ __device__ __forceinline__ void wave_shuffle_any(WaveLds& L, int src, unsigned s
 
 constexpr int kLaneMax = VD_LANE_MAX;   // a subtree root of at most this many prims starts in the group path (8 lanes)
 constexpr int kQueue = kSmallMax / 4;   // a BFS level holds at most N/4 splittable nodes
-constexpr int kSmallList = kSmallMax;   // nodes of 4..8 prims under one root: < 5/8 N (a chain 8,7,6,5,4 over 8 prims)
-constexpr int kC16 = kSmallMax, kC32 = kSmallMax / 2;   // 9..16: <= 8/16 N (chain 16..9); 17..32: <= 16/32 N; never reached in practice, checked
+// List capacities that cannot overflow: the maximal nodes of a class are disjoint, and below one of them the class
+// nodes form a single chain (two children of the same class do not fit, except 8 -> 4 + 4):
+//   4..8 prims: <= 5 nodes per 8 prims -> 5/8 N;  9..16: <= 8 per 9 prims -> 8/9 N;  17..32: <= 16 per 17 -> 16/17 N
+constexpr int kSmallList = kSmallMax, kC16 = kSmallMax, kC32 = kSmallMax;
 
 struct WaveQueues {                      // entry = node | start << 10 | count << 20 (never 0: count > 3)
     unsigned work[2 * kQueue];           // wave-wide nodes handed to other waves: append-only, 0 = not written yet
