@@ -111,6 +111,29 @@ def test_cpu_harness_rays_and_traverse_iter(ctx, oracle):
     ctx.traverse_iter_dev(ctx.upload(nodes), len(nodes), ctx.upload(v.astype(np.float32)), ctx.upload(idx), ctx.upload(rs), len(rs), d_out)
     assert d_out.cpu().numpy().tobytes() == want.tobytes()
     assert ctx.lib.vd_traverse_iter_dev(ctx.h, None, 0, None, None, None, 4, None) == abi.VD_ERR_INVALID_ARG
+    # axis-aligned rays (zero direction components: the slab test divides by them - inf and NaN must flow through min / max
+    # exactly as in the restated loop), rays that start inside the mesh, and degenerate rays
+    g = golden("blas_sphere_1_10.npz")
+    k = 3000
+    u = synth.uniform01(synth.SEED_BASE + 32, 0, 3 * k).reshape(k, 3).astype(np.float64)
+    ar = np.zeros(6 * k + 3, dtype=abi.RAY)
+    for a in range(3):
+        for sgn in (0, 1):
+            blk = ar[(2 * a + sgn) * k: (2 * a + sgn + 1) * k]
+            e = (u * 2 - 1) * 1.2
+            e[:, a] = -3.0 if sgn == 0 else 0.0          # outside along the axis / inside the sphere
+            blk["eye"] = e
+            blk["dir"][:, a] = 1.0 if sgn == 0 else -1.0
+    ar["dir"][-3] = (0, 0, 0)                            # no direction at all
+    ar["dir"][-2] = (np.nan, 1, 0)
+    ar["eye"][-1] = (np.inf, 0, 0); ar["dir"][-1] = (-1, 0, 0)
+    want = oracle.traverse_iter(g["nodes"], g["vertices"], g["indices_out"], ar)
+    d_out = torch.zeros(len(ar), dtype=torch.float32, device="cuda")
+    ctx.traverse_iter_dev(ctx.upload(g["nodes"]), len(g["nodes"]), ctx.upload(g["vertices"].astype(np.float32)),
+                          ctx.upload(g["indices_out"].astype(np.uint32)), ctx.upload(ar), len(ar), d_out)
+    got = d_out.cpu().numpy()
+    assert got.view(np.uint32).tobytes() == want.view(np.uint32).tobytes()
+    assert (got[: 6 * k] >= 0).sum() > k
 
 
 def test_tlas_build_with_nan_and_inf_boxes(ctx, oracle):

@@ -223,6 +223,36 @@ def test_gpu_occlusion_mask_bit_exact(ctx, oracle, n, w, h):
 
 
 @pytest.mark.gpu
+def test_gpu_occlusion_with_poisoned_and_near_plane_instances(ctx, oracle):
+    """NaN / inf transforms, zero scale, instances around and behind the camera: every comparison with NaN fails and
+    leaves the instance visible; the kernel and the twin agree bit for bit."""
+    import torch
+    cam = synth.camera_uniform(eye=(0, 0, 50), pitch_deg=0)
+    meshes, inst = _cloud(4000, synth.SEED_BASE + 48)
+    inst["transform"][10, 12] = np.nan
+    inst["transform"][11, 0] = np.inf
+    inst["transform"][12, :12] = 0.0                       # zero scale: radius 0
+    inst["transform"][13, 14] = 50.0                       # at the eye
+    inst["transform"][14, 14] = 500.0                      # far behind the camera
+    inst["transform"][15:400, 14] = 50.0 - synth.uniform01(synth.SEED_BASE + 49, 0, 385).astype(np.float32) * 3.0   # straddling the near plane
+    w, h = 160, 120
+    depth = np.full((h, w), np.float32(0.001 / 5.0), dtype=np.float32)     # a wall 5 units away: hides whatever is wholly behind it
+    pyr = oracle.hiz_build(depth)
+    full = _all_bits(len(inst))
+    want = oracle.occlusion_mask(cam, meshes, inst, pyr, w, h, full)
+    d_pyr = torch.zeros(len(pyr), dtype=torch.float32, device="cuda")
+    ctx.hiz_build_dev(ctx.upload(depth), w, h, d_pyr)
+    d_in = ctx.upload(full.view(np.int64))
+    d_out = torch.zeros_like(d_in)
+    ctx.occlusion_mask_dev(cam, ctx.upload(meshes), len(meshes), ctx.upload(inst), len(inst), d_pyr, w, h, d_in, d_out)
+    got = d_out.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+    keep = _bits(got, len(inst))
+    assert keep[10] and keep[11] and keep[13] and keep[14]         # NaN, inf, at / behind the eye: never culled
+    assert 0 < keep.sum() < len(inst)
+
+
+@pytest.mark.gpu
 def test_gpu_occlusion_bad_arguments(ctx):
     import torch
     cam = synth.camera_uniform()
