@@ -261,3 +261,36 @@ def test_trace_seeded_scene_vs_oracle(ctx, oracle):
     occ_want, _ = oracle.trace(scene, want_rays, threads=8)
     assert np.array_equal(d_occ.cpu().numpy().astype(np.uint32), occ_want["hit"])
     assert 0 < occ_want["hit"].sum() < len(pts)
+
+
+def test_trace_axis_aligned_and_degenerate_rays(ctx, oracle):
+    """The WGSL walk multiplies by inv_dir = 1 / dir: rays with zero direction components give inf and 0 * inf = NaN
+    in the slab test, which must flow through min / max as in the restated shader (WGSL min / max = IEEE minNum /
+    maxNum, SURVEY 8a C2'); plus rays that start inside boxes, a ray with no direction, NaN and inf origins."""
+    v, i = synth.uv_sphere(1.0, 6)
+    nodes, idx = oracle.bvh_build(v, i)
+    infos = np.zeros(1, dtype=abi.MESH_INFO)
+    infos["min"], infos["max"], infos["index_count"] = *synth.mesh_bounds(v), len(idx)
+    inst = synth.instances(60, n_mesh=1, seed=synth.SEED_BASE + 33, extent=12.0, scale_range=(0.8, 2.5))
+    tl = ctx.tlas_build(inst, infos)
+    k = 2000
+    u = synth.uniform01(synth.SEED_BASE + 34, 0, 3 * k).reshape(k, 3).astype(np.float64)
+    rays = np.zeros(6 * k + 4, dtype=abi.RAY)
+    for a in range(3):
+        for sgn in (0, 1):
+            blk = rays[(2 * a + sgn) * k: (2 * a + sgn + 1) * k]
+            e = (u * 2 - 1) * 7.0
+            e[:, a] = -20.0 if sgn == 0 else 20.0
+            blk["eye"] = e
+            blk["dir"][:, a] = 1.0 if sgn == 0 else -1.0
+    rays["dir"][-4] = (0, 0, 0)
+    rays["dir"][-3] = (np.nan, 1, 0)
+    rays["eye"][-2] = (np.inf, 0, 0); rays["dir"][-2] = (-1, 0, 0)
+    rays["eye"][-1] = inst["transform"][0][12:15]; rays["dir"][-1] = (0, 1, 0)      # from the centre of an instance
+    scene = (tl, inst, infos, nodes, v, idx)
+    want, _ = oracle.trace(scene, rays, threads=8)
+    got = ctx.trace(scene, rays)
+    assert np.array_equal(got["hit"], want["hit"]) and want["hit"].sum() > 500
+    hit = want["hit"] == 1
+    assert np.all(np.abs(got["dist"][hit] - want["dist"][hit]) <= REL_TOL * np.abs(want["dist"][hit]))
+    assert got["dist"].view(np.uint32).tobytes() == want["dist"].view(np.uint32).tobytes()      # in fact bit for bit, NaN-free or not
