@@ -71,6 +71,28 @@ def test_chain_like_trees_vs_oracle(ctx, oracle, n_tri, ratio):
     assert np.array_equal(idx, want_idx)
 
 
+@pytest.mark.parametrize("n_tri", [40, 700, 5000])
+def test_extreme_vertex_values_agree_with_oracle(ctx, oracle, n_tri):
+    """NaN / inf vertices make every split candidate of some node NaN: the reference would crash (blas.rs:137-140), the
+    oracle and the library both answer VD_ERR_DEGENERATE; a coordinate beyond the 1e30 bound seeds (blas.rs:185-186)
+    and heavily duplicated vertices still build - the same tree, bit for bit."""
+    v, i = synth.triangle_soup(n_tri, seed=77)
+    for val in (np.nan, np.inf, -np.inf):
+        v2 = v.copy(); v2[5, 1] = val
+        with pytest.raises(oracle.OracleError):
+            oracle.bvh_build(v2, i)
+        with pytest.raises(VoidinError) as e:
+            ctx.bvh_build(v2, i)
+        assert e.value.code == abi.VD_ERR_DEGENERATE
+    big = v.copy(); big[5, 1] = 1e31
+    dup = v.copy(); dup[::7] = dup[0]
+    for vv in (big, dup):
+        want_nodes, want_idx = oracle.bvh_build(vv, i)
+        nodes, idx = ctx.bvh_build(vv, i)
+        assert fields_equal(nodes, want_nodes), diff_report(nodes, want_nodes)
+        assert np.array_equal(idx, want_idx)
+
+
 def test_builder_api_permutes_callers_indices(ctx):
     # BvhBuilder::new(&[Vec3], &mut [UVec3]).build() -> Bvh{nodes}; caller's slice permuted (blas.rs:95-100)
     g = golden("blas_soup64.npz")
