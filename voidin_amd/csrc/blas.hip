@@ -258,9 +258,17 @@ struct WaveScratch {                              // per-wave: the node this wav
     unsigned char g_tt[8][kCand + 3];             // group path: trues of trial c | predicate of its u << 7
     unsigned g_first, g_count;                    // group path: the batch of small nodes this wave took
 };
+// box keys (min xyz, max xyz) of a local element come from the per-triangle boxes in global memory (L2-resident for
+// the few hundred triangles of a subtree): keeping them in LDS cost 12 KB of the image and one root per CU
+#ifndef VD_BOX_IN_LDS
+#define VD_BOX_IN_LDS 0
+#endif
+struct BoxKeys { int k[6]; };
 struct WaveLds {
     float cent[3][kSmallMax];
+#if VD_BOX_IN_LDS
     int box[6][kSmallMax];                        // order-preserving keys: min xyz, max xyz
+#endif
     unsigned gid[kSmallMax];                      // local element -> triangle id
     unsigned short perm[2][kSmallMax];            // arrangement ping-pong (position -> local element)
     unsigned short falsepos[kSmallMax + 2];       // indexed by ABSOLUTE position s + j: segments are disjoint,
@@ -268,6 +276,20 @@ struct WaveLds {
     unsigned char uflag[kSmallMax];               // marks the <= 21 never-examined elements of the node being evaluated
     WaveScratch w[kSubWaves];
 };
+__device__ __forceinline__ BoxKeys box_keys(const WaveLds& L, const TriBox* __restrict__ boxes, unsigned e) {
+    BoxKeys r;
+#if VD_BOX_IN_LDS
+#pragma unroll
+    for (int q = 0; q < 6; ++q) r.k[q] = L.box[q][e];
+#else
+    const f32x4* p = reinterpret_cast<const f32x4*>(boxes + L.gid[e]);
+    const f32x4 a = p[0], b = p[1];
+    r.k[0] = vd_key(a.x); r.k[1] = vd_key(a.y); r.k[2] = vd_key(a.z);
+    r.k[3] = vd_key(b.x); r.k[4] = vd_key(b.y); r.k[5] = vd_key(b.z);
+#endif
+    return r;
+}
+
 
 // One closed-form shuffle of segment [s, s+n) with predicate cent[axis] < pos: reads perm[src],
 // writes perm[src^1].  NCH = number of 64-position chunks compiled in (1 = the n <= 64 fast path).
@@ -459,7 +481,10 @@ __device__ __forceinline__ void block_shuffle_helpers(WaveLds& L, WaveQueues& Q,
     }
 }
 
-__global__ __launch_bounds__(64 * kSubWaves, 4)
+#ifndef VD_SMALL_OCC
+#define VD_SMALL_OCC 6
+#endif
+__global__ __launch_bounds__(64 * kSubWaves, VD_SMALL_OCC)
 void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
                        const u32x2* __restrict__ slim, const f32x4* __restrict__ cent, const TriBox* __restrict__ boxes,
                        TmpNode* __restrict__ subnodes, unsigned short* __restrict__ submap,
@@ -481,7 +506,9 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
 
     for (unsigned x = tid; x < N; x += 64u * kSubWaves) {
         const unsigned id = slim[base + x].x;
+#if VD_BOX_IN_LDS
         const TriBox bx = boxes[id];
+#endif
         const f32x4 c4 = cent[id];
         const float ce[3] = {c4.x, c4.y, c4.z};
         L.gid[x] = id;
@@ -491,8 +518,10 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             L.cent[k][x] = ce[k];
+#if VD_BOX_IN_LDS
             L.box[k][x] = vd_key(bx.mn[k]);
             L.box[3 + k][x] = vd_key(bx.mx[k]);
+#endif
         }
     }
     // Wave-wide nodes ping-pong their own segment between the two perm buffers an even number of
@@ -623,8 +652,9 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             vd_wave_lds_sync();
             // evaluate (blas.rs:149-161): left = examined trues = {e : p_c(e) and e != u_c}, right = the rest (incl. u_c)
             if (valid) {
+                { const BoxKeys bb = box_keys(L, boxes, el);
 #pragma unroll
-                for (int q = 0; q < 6; ++q) bk[q] = L.box[q][el];
+                  for (int q = 0; q < 6; ++q) bk[q] = bb.k[q]; }
             }
             vd_u64 key = ~0ull;
             for (int c = 0; c < kCand; ++c) {
@@ -651,8 +681,9 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             trial(best, false);                                                     // blas.rs:164
             if (valid) { L.perm[0][s + gl] = (unsigned short)el; L.perm[1][s + gl] = (unsigned short)el; }
             if (valid) {
+                { const BoxKeys bb = box_keys(L, boxes, el);
 #pragma unroll
-                for (int q = 0; q < 6; ++q) bk[q] = L.box[q][el];
+                  for (int q = 0; q < 6; ++q) bk[q] = bb.k[q]; }
             }
             int ck[12];                                                             // children boxes (blas.rs:115-123)
             {
@@ -799,6 +830,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 for (unsigned x = lane; x < n; x += 64u) {
                     const unsigned e = L.perm[cur][s + x];
                     if (L.uflag[e]) continue;
+                    const BoxKeys ebk = box_keys(L, boxes, e);
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
                         const float ce = L.cent[a][e];
@@ -806,7 +838,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
 #pragma unroll
                         for (int k = 0; k < 7; ++k) b += !(ce < W.pos[a * 7 + k]);
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) { atomicMin(&W.bin_min[a][b][q], L.box[q][e]); atomicMax(&W.bin_max[a][b][q], L.box[3 + q][e]); }
+                        for (int q = 0; q < 3; ++q) { atomicMin(&W.bin_min[a][b][q], ebk.k[q]); atomicMax(&W.bin_max[a][b][q], ebk.k[3 + q]); }
                     }
                 }
                 vd_wave_lds_sync();
@@ -830,9 +862,10 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                         for (int i = 0; i < j; ++i) dup |= W.u_e[i] == e;
                         if (dup) continue;
                         const bool to_left = e != own_u && L.cent[a][e] < pos;   // left = examined trues; u itself goes right
+                        const BoxKeys ubk = box_keys(L, boxes, e);
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
-                            const int lo = L.box[q][e], hi = L.box[3 + q][e];
+                            const int lo = ubk.k[q], hi = ubk.k[3 + q];
                             if (to_left) { tmn[q] = min(tmn[q], lo); tmx[q] = max(tmx[q], hi); }
                             else { fmn[q] = min(fmn[q], lo); fmx[q] = max(fmx[q], hi); }
                         }
@@ -860,8 +893,9 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                     for (unsigned i = part; i < n; i += 3u) {
                         const unsigned e = L.perm[cur][s + i];
                         const int o = (cen[e] < pos && e != ue) ? 0 : 6;
+                        { const BoxKeys kb = box_keys(L, boxes, e);
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) { k12[o + q] = min(k12[o + q], L.box[q][e]); k12[o + 3 + q] = max(k12[o + 3 + q], L.box[3 + q][e]); }
+                        for (int q = 0; q < 3; ++q) { k12[o + q] = min(k12[o + q], kb.k[q]); k12[o + 3 + q] = max(k12[o + 3 + q], kb.k[3 + q]); } }
                     }
                 }
 #pragma unroll
@@ -901,8 +935,9 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 const unsigned short e = L.perm[0][s + x];
                 L.perm[1][s + x] = e;                                    // keep both buffers in step
                 const int o = x < Lst ? 0 : 6;
+                { const BoxKeys kb = box_keys(L, boxes, e);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { k12[o + q] = min(k12[o + q], L.box[q][e]); k12[o + 3 + q] = max(k12[o + 3 + q], L.box[3 + q][e]); }
+                for (int q = 0; q < 3; ++q) { k12[o + q] = min(k12[o + q], kb.k[q]); k12[o + 3 + q] = max(k12[o + 3 + q], kb.k[3 + q]); } }
             }
 #pragma unroll
             for (int i = 0; i < 12; ++i) k12[i] = (i % 6) < 3 ? wave_min_i(k12[i]) : wave_max_i(k12[i]);
@@ -973,8 +1008,8 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     // A node covers the positions [s, s + n) of the final arrangement and its children split that range, so pre-order
     // is the order of the keys (s ascending, n descending): rank r(j) = 1 (the subtree root, local pair 0) + the number of
     // interior nodes whose key is smaller - counted by every thread for its own nodes, all at once (two serial passes
-    // over the creation order by one thread were 9 % of this kernel).  Work arrays alias the (now dead) box keys.
-    unsigned* IK = reinterpret_cast<unsigned*>(&L.box[0][0]);                      // [2N] key of an interior node, ~0 for a leaf
+    // over the creation order by one thread were 9 % of this kernel).  Work arrays alias the (now dead) centroids.
+    unsigned* IK = reinterpret_cast<unsigned*>(&L.cent[0][0]);                     // [2N] key of an interior node, ~0 for a leaf (the centroids: 3 x N floats = exactly IK + R)
     unsigned short* R = reinterpret_cast<unsigned short*>(IK + 2 * kSmallMax);      // [2N]
     const unsigned n_nodes = pool;
     for (unsigned j = tid; j < n_nodes; j += 64u * kSubWaves) {
