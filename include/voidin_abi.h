@@ -252,6 +252,21 @@ int vd_expand_mask_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_total, uin
                        const void* d_mesh_ids, uint32_t id_bytes, const VdMeshInfo* d_meshes,
                        uint32_t n_mesh, VdDrawIndexedIndirect* d_out, uint32_t* d_out_count);
 
+/* Indices-only wire format (NEW; SURVEY.md §8e "gather only survivor indices (4 B each) and rebuild
+ * commands locally from replicated mesh_ids"): pays off against the bitmask when fewer than 1 instance
+ * in 32 survives.
+ *   vd_mask_to_indices_dev  ascending list of the set bits of a shard mask (ceil(n_inst/64) words) as
+ *                           GLOBAL instance indices first_instance + i; *d_out_count = their number.
+ *   vd_indices_to_draws_dev d_out[k] = the command emit_draws writes for instance d_indices[k] with
+ *                           instance_count = 1 (mesh fields through d_mesh_ids, as vd_expand_mask_dev).
+ * vd_indices_to_draws(concat over shards of vd_mask_to_indices(vd_cull_mask(shard))) == vd_cull_compact
+ * on the whole scene, bit for bit.                                                                  */
+int vd_mask_to_indices_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_inst, uint32_t first_instance,
+                           uint32_t* d_out_indices, uint32_t* d_out_count);
+int vd_indices_to_draws_dev(VdCtx* ctx, const uint32_t* d_indices, uint32_t n_indices, const void* d_mesh_ids,
+                            uint32_t id_bytes, uint32_t n_total, const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                            VdDrawIndexedIndirect* d_out);
+
 /* C3 alone — ordered compaction of an existing emit_draws output (same definition).     */
 int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t n,
                          VdDrawIndexedIndirect* d_out, uint32_t* d_out_count);
@@ -436,6 +451,16 @@ float vd_last_gpu_ms(VdCtx* ctx);
 /* For calls that run two passes (vd_cull_compact* on large inputs: cull-to-bitmask, then
  * expansion): milliseconds of pass `stage` (0 or 1); negative when the call had one pass.  */
 float vd_last_gpu_ms_stage(VdCtx* ctx, int stage);
+/* Where the most recent vd_bvh_build[_dev] on this ctx spent its time: host wall clock between the
+ * synchronisation points the builder has anyway (after the precompute, after the level loop of the
+ * large segments, after the mid tier, after the small subtrees, after copy-out + index permute).   */
+typedef struct VdBvhBuildStats {
+    float    ms_precompute, ms_phase_a, ms_mid, ms_phase_b, ms_phase_c;
+    uint32_t levels_phase_a;      /* level-synchronous rounds over segments > 2048 prims */
+    uint32_t n_top_nodes, n_mid_roots, n_small_roots;
+    uint32_t kernel_launches;     /* kernels enqueued by the build */
+} VdBvhBuildStats;
+int vd_bvh_last_build_stats(const VdCtx* ctx, VdBvhBuildStats* out);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,26 @@ def golden(name):
 
 
 def fields_equal(a, b):
-    return a.dtype == b.dtype and len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
+    """BIT equality of two structured arrays, field by field: -0.0 != +0.0 and a NaN equals the same NaN, so the
+    total-order min/max of the box reductions (vd_key / vd_min_to) and NaN boxes are compared, not skipped."""
+    if a.dtype != b.dtype or len(a) != len(b):
+        return False
+    for f in a.dtype.names:
+        x, y = np.ascontiguousarray(a[f]), np.ascontiguousarray(b[f])
+        if x.view(np.uint8).tobytes() != y.view(np.uint8).tobytes():
+            return False
+    return True
+
+
+def first_difference(a, b):
+    """(field, index) of the first bitwise difference, for assertion messages."""
+    for f in a.dtype.names:
+        x = np.ascontiguousarray(a[f]).view(np.uint32).reshape(len(a), -1)
+        y = np.ascontiguousarray(b[f]).view(np.uint32).reshape(len(b), -1)
+        d = np.nonzero((x != y).any(axis=1))[0]
+        if d.size:
+            return f, int(d[0])
+    return None
 
 
 @pytest.fixture(scope="session")

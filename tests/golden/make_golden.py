@@ -46,9 +46,30 @@ def cull_cases():
             print("cull", name, tag, "visible", cnt, "/ 1000")
 
 
+def cube_obj():
+    """tests/golden/cube.obj is a byte copy of /root/reference/assets/cube/cube.obj - the only mesh asset the reference
+    still ships (216 v / 218 mixed quad + triangle faces): ObjModel::load's fan triangulation + single-index vertices."""
+    from voidin_amd.obj import ObjModel
+    src = "/root/reference/assets/cube/cube.obj"
+    if os.path.exists(src):
+        assert open(src, "rb").read() == open(os.path.join(OUT, "cube.obj"), "rb").read(), "fixture differs from the reference asset"
+    (m,) = ObjModel.load(os.path.join(OUT, "cube.obj"))
+    return m.arrays()
+
+
+def builtin_pool_case():
+    """MeshPool::new (mesh/mod.rs:266-274): plane, rotated plane, uv_sphere(1, 1), uv_sphere(1, 10) added in that order;
+    MeshPool::add (mesh/mod.rs:309-351) bookkeeping: vertex_offset / base_index / bvh_index are running sums."""
+    infos, V, I, B = pool([synth.plane_mesh(), synth.plane_mesh_rot_x(), synth.uv_sphere(1.0, 1), synth.uv_sphere(1.0, 10)])
+    np.savez_compressed(os.path.join(OUT, "pool_builtin.npz"), meshes=infos, vertices=V, indices=I, bvh_nodes=B)
+    print("builtin pool", infos["bvh_index"], infos["base_index"], infos["vertex_offset"])
+
+
 def blas_cases():
     cases = {
         "plane": synth.plane_mesh(),                   # crates/pools/src/mesh/plane.rs:5-38
+        "plane_rot": synth.plane_mesh_rot_x(),         # mesh/mod.rs:269-272: the plane rotated by Mat3::from_rotation_x(-PI/2)
+        "cube_obj": cube_obj(),                        # the reference's own asset, assets/cube/cube.obj (copied: data, not source)
         "sphere_1_1": synth.uv_sphere(1.0, 1),         # mesh/mod.rs:273
         "sphere_1_10": synth.uv_sphere(1.0, 10),       # mesh/mod.rs:274 (6320 tris)
         "soup64": synth.triangle_soup(64),             # src/bin/bvh_cpu.rs:39-52 distribution
@@ -145,6 +166,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     cull_cases()
     blas_cases()
+    builtin_pool_case()
     tlas_trace_cases()
     harness_case()
     occlusion_case()

@@ -28,7 +28,9 @@ def test_mirror_header_compiles_and_links():
 def _build_cpp(name):
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
     exe = os.path.join(ROOT, "tests", "cpp", name)
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "voidin.hpp")),
+                 os.path.getmtime(os.path.join(ROOT, "include", "voidin_abi.h")))
+    if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), src,
                "-L", os.path.join(ROOT, "voidin_amd", "csrc"), "-lvoidin_hip", f"-Wl,-rpath,{os.path.join(ROOT, 'voidin_amd', 'csrc')}",
                "-o", exe]
@@ -46,6 +48,56 @@ def test_obj_reader_restates_tobj_gpu_load_options():
     subprocess.run(cmd, check=True, capture_output=True, timeout=300)
     out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "two_objects.obj")], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "obj_reader_test OK" in out.stdout, out.stdout + out.stderr
+
+
+def _blocks(path):
+    import struct
+    raw = open(path, "rb").read()
+    n = struct.unpack_from("<Q", raw, 0)[0]
+    off, out = 8, []
+    while off < len(raw):
+        (b,) = struct.unpack_from("<Q", raw, off)
+        out.append(raw[off + 8: off + 8 + b])
+        off += 8 + b
+    return n, out
+
+
+def test_cpp_and_python_obj_readers_agree_on_the_reference_cube(tmp_path):
+    """The reference's own asset (assets/cube/cube.obj, copied to tests/golden/): C++ ObjModel::load == voidin_amd.obj."""
+    import numpy as np
+    from voidin_amd.obj import ObjModel
+    exe = _build_cpp("obj_reader_test")
+    for name in ("cube.obj", "two_objects.obj"):
+        obj = os.path.join(ROOT, "tests", "golden", name)
+        out = str(tmp_path / (name + ".bin"))
+        r = subprocess.run([exe, "dump", obj, out], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stdout + r.stderr
+        n, blocks = _blocks(out)
+        want = ObjModel.load(obj)
+        assert n == len(want) and len(blocks) == 2 * n
+        for k, m in enumerate(want):
+            v, i = m.arrays()
+            assert blocks[2 * k] == v.tobytes() and blocks[2 * k + 1] == i.tobytes(), (name, k)
+
+
+@pytest.mark.gpu
+def test_obj_import_into_mesh_pool_builds_the_cube_blas_bit_exact(tmp_path):
+    """ObjModel::import -> MeshPool::add -> BvhBuilder on the GPU (models/mod.rs:40-53, mesh/mod.rs:309-351) for the
+    reference's cube asset: nodes and permuted indices equal the golden fixture (oracle == numpy restatement)."""
+    import numpy as np
+    from conftest import golden
+    from voidin_amd import abi
+    exe = _build_cpp("obj_reader_test")
+    out = str(tmp_path / "pool.bin")
+    r = subprocess.run([exe, "pool", os.path.join(ROOT, "tests", "golden", "cube.obj"), out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    n, (infos, nodes, idx) = _blocks(out)
+    g = golden("blas_cube_obj.npz")
+    assert n == 1
+    assert nodes == g["nodes"].tobytes() and idx == g["indices_out"].tobytes()
+    info = np.frombuffer(infos, dtype=abi.MESH_INFO)[0]
+    assert (info["index_count"], info["base_index"], info["vertex_offset"], info["bvh_index"]) == (len(g["indices"]), 0, 0, 0)
+    assert np.array_equal(info["min"], g["vertices"].min(axis=0)) and np.array_equal(info["max"], g["vertices"].max(axis=0))
 
 
 @pytest.mark.gpu

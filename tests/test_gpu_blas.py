@@ -9,7 +9,8 @@ from voidin_amd.runtime import BvhBuilder, VoidinError
 
 pytestmark = pytest.mark.gpu
 
-BLAS = ["blas_plane.npz", "blas_sphere_1_1.npz", "blas_soup64.npz", "blas_knot_2k.npz", "blas_sphere_1_10.npz"]
+BLAS = ["blas_plane.npz", "blas_sphere_1_1.npz", "blas_soup64.npz", "blas_knot_2k.npz", "blas_sphere_1_10.npz",
+        "blas_plane_rot.npz", "blas_cube_obj.npz"]   # reference-held inputs: mesh/mod.rs:269-272, assets/cube/cube.obj
 
 
 def diff_report(got, want):

@@ -7,7 +7,9 @@ from conftest import fields_equal, golden
 from oracle import np_restate as npr
 from voidin_amd import abi, synth
 
-BLAS = ["blas_plane.npz", "blas_sphere_1_1.npz", "blas_sphere_1_10.npz", "blas_soup64.npz", "blas_knot_2k.npz"]
+BLAS = ["blas_plane.npz", "blas_sphere_1_1.npz", "blas_sphere_1_10.npz", "blas_soup64.npz", "blas_knot_2k.npz",
+        "blas_plane_rot.npz",    # the X-rotated built-in plane, crates/pools/src/mesh/mod.rs:269-272
+        "blas_cube_obj.npz"]     # the reference's own asset assets/cube/cube.obj through ObjModel::load
 
 
 @pytest.mark.parametrize("name", BLAS)
@@ -194,3 +196,39 @@ def test_rust_cpu_traversal_variant(oracle):
     rays = synth.primary_rays(cam, 48, 48)
     d = oracle.traverse_iter(g["nodes"], g["vertices"], g["indices_out"], rays)
     assert (d >= 0).sum() > 20 and d[d >= 0].min() > 5.0
+
+
+def test_reference_cube_asset_through_both_obj_readers():
+    """tests/golden/cube.obj = the reference's assets/cube/cube.obj (216 v, 218 mixed quad + triangle faces): the Python
+    and the C++ ObjModel::load agree, the counts match an independent parse, and the fixture's inputs are what they read."""
+    import os
+    from conftest import GOLDEN
+    from voidin_amd.obj import ObjModel
+    path = os.path.join(GOLDEN, "cube.obj")
+    (m,) = ObjModel.load(path)
+    faces = [l.split()[1:] for l in open(path) if l.startswith("f ")]
+    assert len(faces) == 218 and sum(1 for l in open(path) if l.startswith("v ")) == 216
+    assert len(m.indices) // 3 == sum(len(f) - 2 for f in faces) == 428          # fan triangulation of quads
+    assert len(m.positions) == len({t for f in faces for t in f}) == 277          # single_index: one vertex per distinct v/vt/vn
+    v, i = m.arrays()
+    g = golden("blas_cube_obj.npz")
+    assert v.tobytes() == g["vertices"].tobytes() and np.array_equal(i, g["indices"])
+    assert m.name == "Cube_Finished_Cube.001" and m.material_id == 0 and len(m.normals) == len(m.texcoords) // 2 == 277
+
+
+def test_builtin_pool_bookkeeping(oracle):
+    """MeshPool::new's four built-in meshes (mesh/mod.rs:266-274) through MeshPool::add's bookkeeping (mesh/mod.rs:309-351):
+    the fixture's MeshInfo offsets are running sums and its BLAS blocks are the oracle's."""
+    g = golden("pool_builtin.npz")
+    meshes = [synth.plane_mesh(), synth.plane_mesh_rot_x(), synth.uv_sphere(1.0, 1), synth.uv_sphere(1.0, 10)]
+    vo = bo = no = 0
+    for k, (v, i) in enumerate(meshes):
+        nodes, idx = oracle.bvh_build(v, i)
+        info = g["meshes"][k]
+        assert (info["vertex_offset"], info["base_index"], info["bvh_index"], info["index_count"]) == (vo, bo, no, len(i))
+        assert fields_equal(g["bvh_nodes"][no: no + len(nodes)], nodes) and np.array_equal(g["indices"][bo: bo + len(idx)], idx)
+        assert np.array_equal(info["min"], v.min(axis=0)) and np.array_equal(info["max"], v.max(axis=0))
+        vo += len(v); bo += len(idx); no += len(nodes)
+    # the rotated plane stands up: y spans [-0.5, 0.5], z is +-2.2e-8 (cos(-PI/2 as f32) != 0)
+    r = synth.plane_mesh_rot_x()[0]
+    assert np.array_equal(np.abs(r[:, 1]), np.full(4, 0.5, np.float32)) and np.all(np.abs(r[:, 2]) == np.float32(2.1855694e-08))

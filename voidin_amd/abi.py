@@ -78,6 +78,13 @@ class HizLayout(C.Structure):
                 ("level_offset", C.c_uint32 * 17), ("level_width", C.c_uint32 * 17), ("level_height", C.c_uint32 * 17)]
 
 
+class BvhBuildStats(C.Structure):
+    """VdBvhBuildStats (include/voidin_abi.h, instrumentation)."""
+    _fields_ = [("ms_precompute", C.c_float), ("ms_phase_a", C.c_float), ("ms_mid", C.c_float), ("ms_phase_b", C.c_float),
+                ("ms_phase_c", C.c_float), ("levels_phase_a", C.c_uint32), ("n_top_nodes", C.c_uint32),
+                ("n_mid_roots", C.c_uint32), ("n_small_roots", C.c_uint32), ("kernel_launches", C.c_uint32)]
+
+
 _P = C.c_void_p
 _U = C.c_uint32
 _I = C.c_int
@@ -99,6 +106,8 @@ PROTOTYPES = {
     "vd_cull_compact_shard_dev": (_I, [_P, _P, _P, _U, _P, _U, _U, _P, _P, _I]),
     "vd_cull_mask_dev": (_I, [_P, _P, _P, _U, _P, _U, _P]),
     "vd_expand_mask_dev": (_I, [_P, _P, _U, _U, _P, _U, _P, _U, _P, _P]),
+    "vd_mask_to_indices_dev": (_I, [_P, _P, _U, _U, _P, _P]),
+    "vd_indices_to_draws_dev": (_I, [_P, _P, _U, _P, _U, _U, _P, _U, _P]),
     "vd_compact_draws_dev": (_I, [_P, _P, _U, _P, _P]),
     "vd_bvh_build": (_I, [_P, _P, _U, _P, _U, _P, _U, _P]),
     "vd_bvh_build_dev": (_I, [_P, _P, _U, _P, _U, _P, _U, _P]),
@@ -126,6 +135,7 @@ PROTOTYPES = {
     "vd_ctx_set_timing": (_I, [_P, _I]),
     "vd_last_gpu_ms": (C.c_float, [_P]),
     "vd_last_gpu_ms_stage": (C.c_float, [_P, _I]),
+    "vd_bvh_last_build_stats": (_I, [_P, C.POINTER(BvhBuildStats)]),
 }
 
 _lib = None

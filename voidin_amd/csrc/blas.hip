@@ -30,6 +30,8 @@
 // restores the reference's pre-order node numbering locally from (start, -count) keys.  C: DFS numbering of
 // the (small) top tree on the host while phase B runs, parallel copy-out.
 #include "vd_common.hpp"
+
+#include <chrono>
 #include <type_traits>
 
 #include <vector>
@@ -1856,6 +1858,14 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     Arena arena{reinterpret_cast<char*>(ctx->scratch), 0};
     auto P = layout(arena, true);
     hipStream_t st = ctx->stream;
+    VdBvhBuildStats& stats = ctx->bvh_stats;
+    stats = VdBvhBuildStats{};
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&](float& slot) {
+        const auto now = std::chrono::steady_clock::now();
+        slot += std::chrono::duration<float, std::milli>(now - t_mark).count();
+        t_mark = now;
+    };
 
     vd_time_begin(ctx);
     {
@@ -1878,6 +1888,8 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     if (h_ctl.err & ERR_BAD_INDEX) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_bvh_build: index >= n_vert");
     unsigned n_seg = h_ctl.n_seg;
     int levels = 0;
+    stats.kernel_launches = 2;
+    lap(stats.ms_precompute);
     while (n_seg > 0) {
         const unsigned seg_blocks = (n_seg + 63) / 64;
         // upper bound of items this level: sum ceil(count/kItem) <= T/kItem + n_seg
@@ -1914,15 +1926,17 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
         n_seg = h_ctl.n_seg;
         Seg* t = seg_cur; seg_cur = seg_next; seg_next = t;
+        stats.kernel_launches += 9 + 4 * (kCand + 1);
         if (++levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
     }
+    stats.levels_phase_a = (uint32_t)levels;
+    lap(stats.ms_phase_a);
 
     // ---- mid tier: segments of kSmallMax < n <= kMidMax, one workgroup each, down to small roots ----
     if (h_ctl.n_mid) {
-        static bool lds_opt_in = false;
-        if (!lds_opt_in) {
+        if (!ctx->mid_lds_opt_in) {   // per context (= per device), not per process
             VD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(blas_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds)));
-            lds_opt_in = true;
+            ctx->mid_lds_opt_in = true;
         }
         hipLaunchKernelGGL(blas_mid_kernel, dim3(h_ctl.n_mid), dim3(kMidThreads), sizeof(MidLds), st, P.mid, &P.ctl->n_mid, P.pay0, P.cent, P.boxes,
                            P.ctl, P.top, P.small, top_cap, small_cap);
@@ -1931,9 +1945,12 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         if (h_ctl.err & ERR_DEGENERATE)
             VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
         if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
+        stats.kernel_launches += 1;
     }
+    lap(stats.ms_mid);
     // ---- phase B ----
     const unsigned n_small = h_ctl.n_small, n_top = h_ctl.n_top;
+    stats.n_top_nodes = n_top; stats.n_small_roots = n_small; stats.n_mid_roots = h_ctl.n_mid;
     if (n_small) {
         hipLaunchKernelGGL(blas_small_kernel, dim3(n_small), dim3(64 * kSubWaves), sizeof(WaveLds) + sizeof(WaveQueues), st, P.small, &P.ctl->n_small, P.pay0,
                            P.cent, P.boxes, P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err, P.stack);
@@ -1979,6 +1996,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     if (h_ctl.err & ERR_DEGENERATE)
         VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
     if (h_ctl.err & ERR_INTERNAL) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: phase B work list stalled");
+    lap(stats.ms_phase_b);
     unsigned pool = 2;
     h_out[0].final_index = 0;
     for (unsigned k = 0; k < n_ord; ++k) {
@@ -2006,6 +2024,8 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     VD_HIP_CHECK(ctx, hipStreamSynchronize(st));   // the pinned staging is reused by the next build
+    stats.kernel_launches += (n_small ? 2 : 0) + 3;
+    lap(stats.ms_phase_c);
     *out_n_nodes = pool;
     return VD_OK;
 }
@@ -2022,8 +2042,15 @@ int check_build_args(VdCtx* ctx, const void* verts, uint32_t n_vert, const void*
 
 extern "C" {
 
+int vd_bvh_last_build_stats(const VdCtx* ctx, VdBvhBuildStats* out) {
+    if (!ctx || !out) return VD_ERR_INVALID_ARG;
+    *out = ctx->bvh_stats;
+    return VD_OK;
+}
+
 // Tuning hook: per-subtree {cycles, prims} pairs of the last phase B run.
 int vd_debug_blas_cycles(VdCtx* ctx, uint32_t* out, uint32_t cap) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx || !ctx->dbg_ptr) return 0;
     const uint32_t n = ctx->dbg_count < cap ? ctx->dbg_count : cap;
     if (hipMemcpy(out, ctx->dbg_ptr, 4 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
@@ -2032,12 +2059,14 @@ int vd_debug_blas_cycles(VdCtx* ctx, uint32_t* out, uint32_t cap) {
 
 int vd_bvh_build_dev(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32_t* d_idx, uint32_t n_tri, VdBvhNode* d_out,
                      uint32_t node_cap, uint32_t* out_n_nodes) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_build_args(ctx, d_verts, n_vert, d_idx, n_tri, d_out, node_cap, out_n_nodes);
     return rc ? rc : bvh_build_dev_impl(ctx, d_verts, n_vert, d_idx, n_tri, d_out, node_cap, out_n_nodes);
 }
 
 int vd_bvh_build(VdCtx* ctx, const float* verts, uint32_t n_vert, uint32_t* idx, uint32_t n_tri, VdBvhNode* out,
                  uint32_t node_cap, uint32_t* out_n_nodes) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_build_args(ctx, verts, n_vert, idx, n_tri, out, node_cap, out_n_nodes);
     if (rc) return rc;
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

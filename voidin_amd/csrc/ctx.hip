@@ -112,6 +112,7 @@ int vd_ctx_destroy(VdCtx* ctx) {
 }
 
 int vd_ctx_set_stream(VdCtx* ctx, void* hip_stream) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);   // NULL = the HIP default stream
@@ -119,6 +120,7 @@ int vd_ctx_set_stream(VdCtx* ctx, void* hip_stream) {
 }
 
 int vd_ctx_reset_stream(VdCtx* ctx) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = ctx->own_stream;
@@ -126,6 +128,7 @@ int vd_ctx_reset_stream(VdCtx* ctx) {
 }
 
 int vd_ctx_synchronize(VdCtx* ctx) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return VD_OK;
@@ -137,6 +140,7 @@ const char* vd_last_error(const VdCtx* ctx) { return ctx ? ctx->err : "null ctx"
 struct VdExternalBuffer { hipExternalMemory_t mem; void* ptr; };
 
 int vd_import_external_buffer(VdCtx* ctx, int opaque_fd, uint64_t size_bytes, VdExternalBuffer** out_handle, void** out_device_ptr) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (opaque_fd < 0 || size_bytes == 0 || !out_handle || !out_device_ptr) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_import_external_buffer: bad fd/size/out pointer");
     *out_handle = nullptr; *out_device_ptr = nullptr;
@@ -164,6 +168,7 @@ int vd_import_external_buffer(VdCtx* ctx, int opaque_fd, uint64_t size_bytes, Vd
 }
 
 int vd_release_external_buffer(VdCtx* ctx, VdExternalBuffer* handle) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx || !handle) return VD_ERR_INVALID_ARG;
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     hipError_t e = hipDestroyExternalMemory(handle->mem);
@@ -186,6 +191,7 @@ int vd_ctx_set_timing(VdCtx* ctx, int enabled) {
 }
 
 float vd_last_gpu_ms_stage(VdCtx* ctx, int stage) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx || !ctx->timed || !ctx->timed_mid || stage < 0 || stage > 1) return -1.0f;
     if (hipEventSynchronize(ctx->ev_stop) != hipSuccess) return -1.0f;
     float ms = -1.0f;
@@ -194,6 +200,7 @@ float vd_last_gpu_ms_stage(VdCtx* ctx, int stage) {
 }
 
 float vd_last_gpu_ms(VdCtx* ctx) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx || !ctx->timed) return -1.0f;
     if (hipEventSynchronize(ctx->ev_stop) != hipSuccess) return -1.0f;
     float ms = -1.0f;

@@ -13,12 +13,14 @@
 //   * emit path (reference format): the 20-byte commands of a wave (1280 contiguous bytes) go
 //     through the same slab and leave as 16-B-per-lane stores;
 //   * compact path, large inputs (split form): pass 1 `cull_mask_tiled_kernel` writes only one
-//     ballot bit + a compact mesh id per instance, so the read stream runs at ~6.3 TB/s; pass 2
-//     `expand_mask_kernel` turns the bits into the ordered command list with a single-pass
-//     decoupled look-back over 8-byte {epoch,status,value} granules and LDS-staged 16-B stores.
+//     ballot bit + a compact mesh id per instance, so the read stream runs at ~6.3 TB/s; pass 2 =
+//     `mask_scan_kernel` (survivors per 8192-instance chunk, scanned by the last workgroup to
+//     arrive) + `expand_mask_u8_kernel` / `expand_mask_kernel` (workgroup c expands chunk c to
+//     out[offset[c]...): no ticket, no look-back, every load issued before the first store).
 //     (Storing the 20-byte commands from inside the read stream costs ~3x per byte: DESIGN.md §3.1);
-//   * compact path, small inputs (fused form): `cull_compact_kernel<ROUNDS>`, one launch, the same
-//     look-back ranks the tiles while per-round (mesh id | visible) words wait in LDS;
+//   * compact path, small inputs (fused form): `cull_compact_kernel<ROUNDS>`, one launch, a
+//     decoupled look-back over 8-byte {epoch,status,value} granules ranks the tiles while
+//     per-round (mesh id | visible) words wait in LDS;
 //   * multi-GPU: the same pass 1 / pass 2 pair with the bitmask all-gathered in between
 //     (vd_cull_mask_dev / vd_expand_mask_dev, voidin_amd/dist.py).
 #include "vd_common.hpp"
@@ -481,38 +483,53 @@ constexpr int kChunkWords = kWavesPerBlock * kExpandWords;   // per workgroup: 1
 // scan in place and the total.  Keeping the scan out of pass 2b leaves that kernel without tickets, look-back or
 // any other load that depends on another workgroup: under a saturated store stream every dependent load costs
 // microseconds (on gfx950 loads and stores share vmcnt and the same queue), and 2b had four of them in a chain.
+//
+// Hand-off between workgroups without fences (an agent-scope release writes back the whole L2 of the XCD, ~100 ns per
+// workgroup while the previous frame's command list is still dirty in it) and without a data race: a chunk's count
+// travels as ONE naturally aligned 8-byte {launch epoch, count} word, written by one agent-scope atomic store and
+// read by agent-scope atomic loads - the datum is its own flag, as in the look-back granules of vd_common.hpp.  The
+// arrival counter only ELECTS the workgroup that scans; that workgroup accepts an entry when its tag is this
+// launch's epoch (and polls the few that are still in flight), so nothing is inferred from the order of accesses to
+// different addresses.  The epoch word is read at the start of every workgroup and advanced by the elected one after
+// everybody has arrived, i.e. it is stable for the whole launch; launches on one stream are ordered by the stream.
 constexpr int kScanBlock = 1024;                     // 16 waves: the last workgroup's scan is one round trip even at 80 M
+struct ScanState { unsigned done, epoch, pad[2]; };  // followed by one vd_u64 entry per chunk: {epoch : 32 | value : 32}
 __global__ __launch_bounds__(kScanBlock) void mask_scan_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned n_chunks,
-                                                           unsigned* chunk_offset, unsigned* done_counter,
+                                                           vd_u64* chunk_entry, ScanState* state,
                                                            unsigned* __restrict__ out_count) {
     constexpr int kScanWaves = kScanBlock / kWave;
     __shared__ unsigned s_last, s_wave_sum[kScanWaves];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned ep = __hip_atomic_load(&state->epoch, VD_RLX_AGENT);
+    const vd_u64 tag = (vd_u64)ep << 32;
     for (unsigned c = blockIdx.x * kScanWaves + wave; c < n_chunks; c += gridDim.x * kScanWaves) {
         const unsigned w = c * kChunkWords + lane;
         unsigned v = (w < n_words ? (unsigned)__popcll(mask[w]) : 0u) + (w + 64u < n_words ? (unsigned)__popcll(mask[w + 64u]) : 0u);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) __hip_atomic_store(&chunk_offset[c], v, VD_RLX_AGENT);   // write-through, like the look-back granules
+        if (lane == 0) __hip_atomic_store(&chunk_entry[c], tag | v, VD_RLX_AGENT);   // write-through: the datum is its own flag
     }
-    // No fence (an agent-scope release writes back the whole L2 of the XCD, ~100 ns per workgroup while the previous
-    // frame's command list is still dirty in it): the write-through stores above have completed at agent scope once
-    // vmcnt is 0, and the workgroup's arrival is only counted after every wave got there.
+    // not needed for correctness (entries are self-validating): arriving only after this workgroup's stores have
+    // completed means the elected workgroup almost never has to poll
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done_counter, 1u, VD_RLX_AGENT) == gridDim.x - 1u;
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&state->done, 1u, VD_RLX_AGENT) == gridDim.x - 1u;
     __syncthreads();
     if (!s_last) return;
     // thread t scans the contiguous range [t*per, (t+1)*per): all its loads are independent (one round trip) and
-    // read at agent scope (other XCDs wrote the sums)
-    const unsigned per = ((n_chunks + kScanBlock - 1) / kScanBlock + 1u) & ~1u;     // even: 8-byte loads
+    // read at agent scope (other XCDs wrote the counts)
+    const unsigned per = (n_chunks + kScanBlock - 1) / kScanBlock;
     const unsigned begin = min(threadIdx.x * per, n_chunks), end = min(begin + per, n_chunks);
-    vd_u64* pairs = reinterpret_cast<vd_u64*>(chunk_offset);
+    auto entry = [&](unsigned c) -> unsigned {
+        vd_u64 e = __hip_atomic_load(&chunk_entry[c], VD_RLX_AGENT);
+        while ((e >> 32) != (vd_u64)ep) {                    // still in flight: its writer has arrived, the store lands shortly
+            __builtin_amdgcn_s_sleep(1);
+            e = __hip_atomic_load(&chunk_entry[c], VD_RLX_AGENT);
+        }
+        return (unsigned)e;
+    };
     unsigned sum = 0;
-    for (unsigned c = begin; c < end; c += 2u) {
-        if (c + 2u <= end) { const vd_u64 v = __hip_atomic_load(&pairs[c >> 1], VD_RLX_AGENT); sum += (unsigned)v + (unsigned)(v >> 32); }
-        else sum += __hip_atomic_load(&chunk_offset[c], VD_RLX_AGENT);
-    }
+    for (unsigned c = begin; c < end; ++c) sum += entry(c);
     unsigned incl = sum;                                   // inclusive scan of the per-thread sums
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -523,20 +540,15 @@ __global__ __launch_bounds__(kScanBlock) void mask_scan_kernel(const vd_u64* __r
     __syncthreads();
     unsigned run = incl - sum;
     for (unsigned w = 0; w < wave; ++w) run += s_wave_sum[w];
-    for (unsigned c = begin; c < end; c += 2u) {
-        if (c + 2u <= end) {
-            const vd_u64 v = __hip_atomic_load(&pairs[c >> 1], VD_RLX_AGENT);
-            pairs[c >> 1] = (vd_u64)run | ((vd_u64)(run + (unsigned)v) << 32);
-            run += (unsigned)v + (unsigned)(v >> 32);
-        } else {
-            const unsigned v = __hip_atomic_load(&chunk_offset[c], VD_RLX_AGENT);
-            chunk_offset[c] = run;
-            run += v;
-        }
+    for (unsigned c = begin; c < end; ++c) {
+        const unsigned v = entry(c);
+        chunk_entry[c] = tag | run;                        // read by pass 2b, a later launch on this stream
+        run += v;
     }
     if (threadIdx.x == kScanBlock - 1u) {
         *out_count = run;
-        __hip_atomic_store(done_counter, 0u, VD_RLX_AGENT);   // re-armed for the next launch on this stream
+        __hip_atomic_store(&state->done, 0u, VD_RLX_AGENT);        // re-armed for the next launch on this stream
+        __hip_atomic_store(&state->epoch, ep + 1u, VD_RLX_AGENT);  // every workgroup of this launch has read it (all arrived)
     }
 }
 
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
                                                              const IdT* __restrict__ mesh_ids,
                                                              const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
                                                              VdDrawIndexedIndirect* __restrict__ out,
-                                                             const unsigned* __restrict__ chunk_offset) {
+                                                             const vd_u64* __restrict__ chunk_entry) {
     constexpr int kGroups = kExpandWords / kExpandGroup;
     constexpr unsigned kTab = TAB ? 512 : 1;              // mesh tables up to 512 entries are served from LDS
     __shared__ unsigned s_tab[kTab][3];                   // {index_count, base_index, vertex_offset}
@@ -561,7 +573,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
     const unsigned chunk = blockIdx.x;
     const unsigned cw0 = chunk * kChunkWords;
     const unsigned w0 = __builtin_amdgcn_readfirstlane(cw0 + wave * kExpandWords);   // wave-uniform: scalar index math
-    unsigned base = chunk_offset[chunk];
+    unsigned base = (unsigned)chunk_entry[chunk];
     // survivors of the chunk's earlier waves: lane l looks at words cw0 + l and cw0 + 64 + l
     unsigned before = 0;
     if (lane < wave * kExpandWords && cw0 + lane < n_words) before = (unsigned)__popcll(mask[cw0 + lane]);
@@ -667,7 +679,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_u8_kernel(const vd_u64* __
                                                                 const unsigned char* __restrict__ mesh_ids,
                                                                 const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
                                                                 VdDrawIndexedIndirect* __restrict__ out,
-                                                                const unsigned* __restrict__ chunk_offset) {
+                                                                const vd_u64* __restrict__ chunk_entry) {
     constexpr int kGroups = kExpandWords / kExpandGroup;
     __shared__ __attribute__((aligned(16))) unsigned s_tab[256][4];
     constexpr int kStageBytes = DIRECT ? 16 : kExpandGroup * 1280 + 32;
@@ -677,7 +689,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_u8_kernel(const vd_u64* __
     const unsigned chunk = blockIdx.x;
     const unsigned cw0 = chunk * kChunkWords;
     const unsigned w0 = cw0 + wave * kExpandWords;
-    unsigned base = chunk_offset[chunk];
+    unsigned base = (unsigned)chunk_entry[chunk];
     // survivors of the chunk's earlier waves: lane l looks at words cw0 + l and cw0 + 64 + l
     unsigned before = 0;
     if (lane < wave * kExpandWords && cw0 + lane < n_words) before = (unsigned)__popcll(mask[cw0 + lane]);
@@ -892,23 +904,90 @@ __global__ __launch_bounds__(kBlock) void emit_all_u8_kernel(const vd_u64* __res
     }
 }
 
+// Indices-only wire format: the set bits of a shard mask as an ascending list of global instance
+// indices (4 B per survivor on the wire instead of 1 bit per instance: smaller below 1 survivor in 32), and the
+// commands rebuilt from such a list.  Workgroup c owns mask chunk c as in pass 2b; no inter-workgroup dependency.
+__global__ __launch_bounds__(kBlock) void mask_to_indices_kernel(const vd_u64* __restrict__ mask, unsigned n_words, unsigned first_instance,
+                                                                 unsigned* __restrict__ out, const vd_u64* __restrict__ chunk_entry) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned cw0 = blockIdx.x * kChunkWords;
+    const unsigned w0 = cw0 + wave * kExpandWords;
+    unsigned base = (unsigned)chunk_entry[blockIdx.x];
+    unsigned before = 0;
+    if (lane < wave * kExpandWords && cw0 + lane < n_words) before = (unsigned)__popcll(mask[cw0 + lane]);
+    if (lane + 64u < wave * kExpandWords && cw0 + 64u + lane < n_words) before += (unsigned)__popcll(mask[cw0 + 64u + lane]);
+    vd_u64 my_word = 0;                                   // lane l < 32 holds mask word w0 + l
+    if (lane < (unsigned)kExpandWords && w0 + lane < n_words) my_word = mask[w0 + lane];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    base = __builtin_amdgcn_readfirstlane(base + before);
+    const unsigned inst_lane = first_instance + 64u * w0 + lane;
+#pragma unroll
+    for (int k = 0; k < kExpandWords; ++k) {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)my_word, k), hi = __builtin_amdgcn_readlane((unsigned)(my_word >> 32), k);
+        const vd_u64 m = ((vd_u64)hi << 32) | lo;
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) out[base + vd_mbcnt(m)] = inst_lane + 64u * (unsigned)k;
+        base += (unsigned)__popcll(m);
+    }
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(kBlock) void indices_to_draws_kernel(const unsigned* __restrict__ indices, unsigned n_indices,
+                                                                  const IdT* __restrict__ mesh_ids, unsigned n_total,
+                                                                  const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
+                                                                  VdDrawIndexedIndirect* __restrict__ out) {
+    constexpr unsigned kTab = 512;
+    __shared__ __attribute__((aligned(16))) unsigned s_tab[kTab][4];     // ready-made {index_count, 1, base_index, vertex_offset}
+    const bool tab = n_mesh <= kTab;
+    if (tab)
+        for (unsigned i = threadIdx.x; i < n_mesh; i += kBlock) {
+            s_tab[i][0] = meshes[i].index_count; s_tab[i][1] = 1u;
+            s_tab[i][2] = meshes[i].base_index;  s_tab[i][3] = (unsigned)meshes[i].vertex_offset;
+        }
+    __syncthreads();
+    for (unsigned k = blockIdx.x * kBlock + threadIdx.x; k < n_indices; k += gridDim.x * kBlock) {
+        const unsigned i = indices[k];
+        const unsigned mid = min((unsigned)mesh_ids[min(i, n_total - 1u)], n_mesh - 1u);
+        u32x4 c;
+        if (tab) c = *reinterpret_cast<const u32x4*>(s_tab[mid]);
+        else { c.x = meshes[mid].index_count; c.y = 1u; c.z = meshes[mid].base_index; c.w = (unsigned)meshes[mid].vertex_offset; }
+        unsigned* o = reinterpret_cast<unsigned*>(out + k);
+        typedef u32x4 __attribute__((aligned(4))) u32x4_a4;
+        *reinterpret_cast<u32x4_a4*>(o) = c;
+        o[4] = i;
+    }
+}
+
 // Host side of pass 2 (shared by vd_cull_compact* and vd_expand_mask_dev).
+// Pass 2a: per-chunk survivor counts -> exclusive offsets (ctx->expand_state) and the total (*d_out_count).
+static int launch_mask_scan(VdCtx* ctx, const vd_u64* d_mask, unsigned n_words, unsigned* d_out_count, vd_u64** out_entries) {
+    const unsigned n_chunks = (n_words + kChunkWords - 1) / kChunkWords;
+    const size_t need = sizeof(ScanState) + (size_t)n_chunks * 8;
+    if (need > ctx->expand_state_bytes || !ctx->expand_state) {
+        int rc = vd_ensure(ctx, &ctx->expand_state, &ctx->expand_state_bytes, need);
+        if (rc) return rc;
+        // entries zeroed = tagged with epoch 0; the first launch runs in epoch 1
+        VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->expand_state, 0, ctx->expand_state_bytes, ctx->stream));
+        VD_HIP_CHECK(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<char*>(ctx->expand_state) + offsetof(ScanState, epoch)), 1, 1, ctx->stream));
+    }
+    ScanState* state = reinterpret_cast<ScanState*>(ctx->expand_state);
+    vd_u64* entries = reinterpret_cast<vd_u64*>(reinterpret_cast<char*>(ctx->expand_state) + sizeof(ScanState));
+    unsigned sblocks = (n_chunks + 15u) / 16u;                                // one wave per chunk, grid-stride beyond 2 per CU
+    if (sblocks > (unsigned)ctx->num_cus * 2u) sblocks = (unsigned)ctx->num_cus * 2u;
+    hipLaunchKernelGGL(mask_scan_kernel, dim3(sblocks), dim3(kScanBlock), 0, ctx->stream, d_mask, n_words, n_chunks, entries, state,
+                       d_out_count);
+    *out_entries = entries;
+    return VD_OK;
+}
+
 static int launch_expand(VdCtx* ctx, const vd_u64* d_mask, unsigned n_words, unsigned wps, unsigned shard_size,
                          unsigned n_total, unsigned first_instance, const void* d_ids, unsigned id_bytes,
                          const VdMeshInfo* d_meshes, unsigned n_mesh, VdDrawIndexedIndirect* d_out, unsigned* d_out_count) {
     const unsigned n_chunks = (n_words + kChunkWords - 1) / kChunkWords;
-    const size_t need = 16 + (((size_t)n_chunks * 4 + 15) & ~(size_t)15);
-    if (need > ctx->expand_state_bytes || !ctx->expand_state) {
-        int rc = vd_ensure(ctx, &ctx->expand_state, &ctx->expand_state_bytes, need);
-        if (rc) return rc;
-        VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->expand_state, 0, 16, ctx->stream));   // the done counter
-    }
-    unsigned* done = reinterpret_cast<unsigned*>(ctx->expand_state);
-    unsigned* offsets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->expand_state) + 16);
-    unsigned sblocks = (n_chunks + 15u) / 16u;                                // one wave per chunk, grid-stride beyond 2 per CU
-    if (sblocks > (unsigned)ctx->num_cus * 2u) sblocks = (unsigned)ctx->num_cus * 2u;
-    hipLaunchKernelGGL(mask_scan_kernel, dim3(sblocks), dim3(kScanBlock), 0, ctx->stream, d_mask, n_words, n_chunks, offsets, done,
-                       d_out_count);
+    vd_u64* offsets;
+    int rc_scan = launch_mask_scan(ctx, d_mask, n_words, d_out_count, &offsets);
+    if (rc_scan) return rc_scan;
     const bool one_shard = wps >= n_words;
     const bool tab = n_mesh <= 512u;
     // fast path: 1-byte ids that can be fetched as aligned dwords (every word's first instance is a multiple of 4)
@@ -1068,6 +1147,7 @@ extern "C" {
 
 int vd_cull_emit_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                      const VdInstance* d_instances, uint32_t n_inst, VdDrawIndexedIndirect* d_out) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     return vd_cull_emit_shard_dev(ctx, camera, d_meshes, n_mesh, d_instances, n_inst, 0u, d_out);
 }
 
@@ -1114,6 +1194,7 @@ static int launch_mask_pass(VdCtx* ctx, const VdCameraUniform* camera, const VdM
 int vd_cull_emit_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                            const VdInstance* d_instances, uint32_t n_inst, uint32_t first_instance,
                            VdDrawIndexedIndirect* d_out) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!camera || !d_meshes || n_mesh == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_emit: null camera/meshes or n_mesh == 0");
     if (n_inst == 0) return VD_OK;
@@ -1153,12 +1234,14 @@ int vd_cull_emit_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMe
 int vd_cull_compact_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                         const VdInstance* d_instances, uint32_t n_inst, VdDrawIndexedIndirect* d_out,
                         uint32_t* d_out_count, int pad_tail) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     return vd_cull_compact_shard_dev(ctx, camera, d_meshes, n_mesh, d_instances, n_inst, 0u, d_out, d_out_count, pad_tail);
 }
 
 int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                               const VdInstance* d_instances, uint32_t n_inst, uint32_t first_instance,
                               VdDrawIndexedIndirect* d_out, uint32_t* d_out_count, int pad_tail) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!camera || !d_meshes || n_mesh == 0 || !d_out_count)
         VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_compact: null camera/meshes/count or n_mesh == 0");
@@ -1221,6 +1304,7 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
 
 int vd_cull_mask_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                      const VdInstance* d_instances, uint32_t n_inst, uint64_t* d_mask) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!camera || !d_meshes || n_mesh == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_mask: null camera/meshes or n_mesh == 0");
     if (n_inst == 0) return VD_OK;
@@ -1240,6 +1324,7 @@ int vd_cull_mask_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo
 int vd_occlusion_mask_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                           const VdInstance* d_instances, uint32_t n_inst, const float* d_pyramid, uint32_t width, uint32_t height,
                           const uint64_t* d_mask_in, uint64_t* d_mask_out) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!camera || !d_meshes || n_mesh == 0 || !d_pyramid) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_occlusion_mask: null camera/meshes/pyramid or n_mesh == 0");
     VdHizLayout L;
@@ -1270,6 +1355,7 @@ int vd_occlusion_mask_dev(VdCtx* ctx, const VdCameraUniform* camera, const VdMes
 int vd_expand_mask_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_total, uint32_t shard_size, const void* d_mesh_ids,
                        uint32_t id_bytes, const VdMeshInfo* d_meshes, uint32_t n_mesh, VdDrawIndexedIndirect* d_out,
                        uint32_t* d_out_count) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!d_out_count || !d_meshes || n_mesh == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_expand_mask: null count/meshes");
     if (n_total == 0) {
@@ -1290,8 +1376,51 @@ int vd_expand_mask_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_total, uin
     return VD_OK;
 }
 
+int vd_mask_to_indices_dev(VdCtx* ctx, const uint64_t* d_mask, uint32_t n_inst, uint32_t first_instance, uint32_t* d_out_indices,
+                           uint32_t* d_out_count) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!d_out_count) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_mask_to_indices: null count");
+    if (n_inst == 0) {
+        VD_HIP_CHECK(ctx, hipMemsetAsync(d_out_count, 0, 4, ctx->stream));
+        return VD_OK;
+    }
+    if (!d_mask || !d_out_indices) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_mask_to_indices: null mask/out");
+    const unsigned n_words = (n_inst + 63u) / 64u;
+    vd_time_begin(ctx);
+    vd_u64* offsets;
+    int rc = launch_mask_scan(ctx, reinterpret_cast<const vd_u64*>(d_mask), n_words, d_out_count, &offsets);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mask_to_indices_kernel, dim3((n_words + kChunkWords - 1) / kChunkWords), dim3(kBlock), 0, ctx->stream,
+                       reinterpret_cast<const vd_u64*>(d_mask), n_words, first_instance, d_out_indices, offsets);
+    vd_time_end(ctx);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    return VD_OK;
+}
+
+int vd_indices_to_draws_dev(VdCtx* ctx, const uint32_t* d_indices, uint32_t n_indices, const void* d_mesh_ids, uint32_t id_bytes,
+                            uint32_t n_total, const VdMeshInfo* d_meshes, uint32_t n_mesh, VdDrawIndexedIndirect* d_out) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!d_meshes || n_mesh == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_indices_to_draws: null meshes or n_mesh == 0");
+    if (n_indices == 0) return VD_OK;
+    if (!d_indices || !d_mesh_ids || !d_out || n_total == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_indices_to_draws: null indices/ids/out or n_total == 0");
+    if (id_bytes != 1u && id_bytes != 2u && id_bytes != 4u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_indices_to_draws: id_bytes must be 1, 2 or 4");
+    unsigned blocks = (n_indices + kBlock - 1) / kBlock;
+    if (blocks > (unsigned)ctx->num_cus * 16u) blocks = (unsigned)ctx->num_cus * 16u;
+    vd_time_begin(ctx);
+#define VD_I2D(IdT) hipLaunchKernelGGL(indices_to_draws_kernel<IdT>, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_indices, n_indices,   \
+                                       reinterpret_cast<const IdT*>(d_mesh_ids), n_total, d_meshes, n_mesh, d_out)
+    if (id_bytes == 1u) VD_I2D(unsigned char); else if (id_bytes == 2u) VD_I2D(unsigned short); else VD_I2D(unsigned);
+#undef VD_I2D
+    vd_time_end(ctx);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    return VD_OK;
+}
+
 int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t n, VdDrawIndexedIndirect* d_out,
                          uint32_t* d_out_count) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!d_out_count) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_compact_draws: null count");
     if (n == 0) {
@@ -1312,6 +1441,7 @@ int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t
 
 int vd_compute_update_dev(VdCtx* ctx, const uint32_t* d_indices, uint32_t n_indices, VdInstance* d_instances,
                           uint32_t n_instances, float time, float dt, int fix_inverse) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (n_indices == 0) return VD_OK;
     if (!d_indices || !d_instances) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_compute_update: null indices/instances");
@@ -1347,6 +1477,7 @@ static int stage_cull_inputs(VdCtx* ctx, const VdMeshInfo* meshes, uint32_t n_me
 
 int vd_cull_emit(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* meshes, uint32_t n_mesh,
                  const VdInstance* instances, uint32_t n_inst, VdDrawIndexedIndirect* out) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!camera || !meshes || n_mesh == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_emit: null camera/meshes or n_mesh == 0");
     if (n_inst == 0) return VD_OK;
@@ -1364,6 +1495,7 @@ int vd_cull_emit(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* me
 int vd_cull_compact(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo* meshes, uint32_t n_mesh,
                     const VdInstance* instances, uint32_t n_inst, VdDrawIndexedIndirect* out, uint32_t* out_count,
                     int pad_tail) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!camera || !meshes || n_mesh == 0 || !out_count)
         VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_compact: null camera/meshes/count or n_mesh == 0");

@@ -67,6 +67,7 @@ extern "C" {
 int vd_hiz_layout(uint32_t width, uint32_t height, VdHizLayout* out) { return layout(width, height, out); }
 
 int vd_hiz_build_dev(VdCtx* ctx, const float* d_depth, uint32_t width, uint32_t height, float* d_pyramid) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     VdHizLayout L;
     if (layout(width, height, &L)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_hiz_build: width, height must be 1..65536 and width * height <= 2^30");

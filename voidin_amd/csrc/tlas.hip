@@ -645,26 +645,31 @@ extern "C" {
 
 int vd_tlas_build_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                       VdTlasNode* d_nodes) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, false);
     return rc ? rc : tlas_build_impl<VdTlasNode>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
 }
 int vd_tlas_build_wide_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                            VdTlasNodeWide* d_nodes) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, true);
     return rc ? rc : tlas_build_impl<VdTlasNodeWide>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
 }
 int vd_tlas_refit_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                       VdTlasNode* d_nodes) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, false);
     return rc ? rc : tlas_refit_impl<VdTlasNode>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
 }
 int vd_tlas_refit_wide_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                            VdTlasNodeWide* d_nodes) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, true);
     return rc ? rc : tlas_refit_impl<VdTlasNodeWide>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
 }
 
 int vd_tlas_build(VdCtx* ctx, const VdInstance* inst, uint32_t n, const VdMeshInfo* meshes, uint32_t n_mesh, VdTlasNode* nodes) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_args(ctx, inst, n, meshes, n_mesh, nodes, false);
     if (rc) return rc;
     return tlas_host<VdTlasNode>(ctx, inst, n, meshes, n_mesh, nodes, false, [&](const VdInstance* di, const VdMeshInfo* dm, VdTlasNode* dn) {
@@ -673,6 +678,7 @@ int vd_tlas_build(VdCtx* ctx, const VdInstance* inst, uint32_t n, const VdMeshIn
 }
 int vd_tlas_build_wide(VdCtx* ctx, const VdInstance* inst, uint32_t n, const VdMeshInfo* meshes, uint32_t n_mesh,
                        VdTlasNodeWide* nodes) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_args(ctx, inst, n, meshes, n_mesh, nodes, true);
     if (rc) return rc;
     return tlas_host<VdTlasNodeWide>(ctx, inst, n, meshes, n_mesh, nodes, false, [&](const VdInstance* di, const VdMeshInfo* dm, VdTlasNodeWide* dn) {
@@ -680,6 +686,7 @@ int vd_tlas_build_wide(VdCtx* ctx, const VdInstance* inst, uint32_t n, const VdM
     });
 }
 int vd_tlas_refit(VdCtx* ctx, const VdInstance* inst, uint32_t n, const VdMeshInfo* meshes, uint32_t n_mesh, VdTlasNode* nodes) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_args(ctx, inst, n, meshes, n_mesh, nodes, false);
     if (rc) return rc;
     return tlas_host<VdTlasNode>(ctx, inst, n, meshes, n_mesh, nodes, true, [&](const VdInstance* di, const VdMeshInfo* dm, VdTlasNode* dn) {

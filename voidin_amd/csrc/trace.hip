@@ -350,6 +350,7 @@ bool scene_ok(const VdTraceScene* s) {
 extern "C" {
 
 int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!scene_ok(d_scene)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: incomplete scene");
     if (n_rays == 0) return VD_OK;
@@ -358,6 +359,7 @@ int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_rays, u
 }
 
 int vd_trace_any_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_rays, uint32_t n_rays, uint32_t* d_out_hit) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!scene_ok(d_scene)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_any: incomplete scene");
     if (n_rays == 0) return VD_OK;
@@ -367,6 +369,7 @@ int vd_trace_any_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_ray
 
 int vd_shadow_rays_dev(VdCtx* ctx, const float* d_positions, const float* d_normals, uint32_t n_points, const float* light_position,
                        VdRay* d_rays) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (n_points == 0) return VD_OK;
     if (!d_positions || !d_normals || !light_position || !d_rays) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_shadow_rays: null pointer");
@@ -377,6 +380,7 @@ int vd_shadow_rays_dev(VdCtx* ctx, const float* d_positions, const float* d_norm
 }
 
 int vd_primary_rays_dev(VdCtx* ctx, const VdCameraUniform* camera, uint32_t width, uint32_t height, VdRay* d_rays) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!camera) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_primary_rays: null camera");
     const uint64_t n = (uint64_t)width * height;
@@ -392,6 +396,7 @@ int vd_primary_rays_dev(VdCtx* ctx, const VdCameraUniform* camera, uint32_t widt
 
 int vd_traverse_iter_dev(VdCtx* ctx, const VdBvhNode* d_nodes, uint32_t n_nodes, const float* d_verts_xyz, const uint32_t* d_indices,
                          const VdRay* d_rays, uint32_t n_rays, float* d_out_dist) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!d_nodes || n_nodes == 0 || !d_verts_xyz || !d_indices) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse_iter: incomplete mesh");
     if (n_rays == 0) return VD_OK;
@@ -412,6 +417,7 @@ int vd_traverse_iter_dev(VdCtx* ctx, const VdBvhNode* d_nodes, uint32_t n_nodes,
 }
 
 int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t n_rays, VdHit* out) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!scene_ok(scene)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: incomplete scene");
     if (n_rays == 0) return VD_OK;
@@ -446,6 +452,7 @@ int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t 
 }
 
 int vd_primary_rays(VdCtx* ctx, const VdCameraUniform* camera, uint32_t width, uint32_t height, VdRay* rays) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     const uint64_t n = (uint64_t)width * height;
     if (n && !rays) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_primary_rays: null rays");
@@ -460,6 +467,7 @@ int vd_primary_rays(VdCtx* ctx, const VdCameraUniform* camera, uint32_t width, u
 
 int vd_traverse_iter(VdCtx* ctx, const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz, uint32_t n_vert,
                      const uint32_t* indices, uint32_t n_tri, const VdRay* rays, uint32_t n_rays, float* out_dist) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (!nodes || n_nodes == 0 || !verts_xyz || !indices) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse_iter: incomplete mesh");
     if (n_rays == 0) return VD_OK;

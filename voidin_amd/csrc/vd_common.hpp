@@ -39,6 +39,22 @@ struct VdCtx {
     uint32_t* host_pinned = nullptr;                           // 64 u32 of pinned host memory
     void* host_stage = nullptr;  size_t host_stage_bytes = 0;  // grow-only pinned staging (BLAS top tree)
     hipStream_t aux_stream = nullptr;                          // copies that overlap a kernel on `stream`
+    VdBvhBuildStats bvh_stats = {};                            // vd_bvh_last_build_stats
+    bool mid_lds_opt_in = false;                               // blas_mid_kernel's dynamic-LDS attribute set on this device
+};
+
+// Every extern "C" entry point runs on the context's device: allocations, event records and launches otherwise go to
+// the calling thread's CURRENT device (another thread, or torch.cuda.set_device(j) after the ctx was made for k).
+struct VdDeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit VdDeviceGuard(const VdCtx* ctx) {
+        if (!ctx) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~VdDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    VdDeviceGuard(const VdDeviceGuard&) = delete;
+    VdDeviceGuard& operator=(const VdDeviceGuard&) = delete;
 };
 
 #define VD_HIP_CHECK(ctx, call)                                                              \

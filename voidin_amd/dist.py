@@ -39,8 +39,31 @@ def mask_words(shard: int) -> int:
     return (shard + 63) // 64
 
 
+def id_width(n_mesh: int) -> int:
+    """Bytes per entry of the instance -> mesh table: the rule of launch_mask_pass (voidin_amd/csrc/cull.hip)."""
+    return 1 if n_mesh <= 256 else (2 if n_mesh <= 65536 else 4)
+
+
+def mesh_id_table(d_inst_u8: torch.Tensor, n_local: int, n_mesh: int, rows: int) -> torch.Tensor:
+    """`rows` table entries of id_width(n_mesh) bytes each (flat uint8): min(u32 instance.mesh, n_mesh - 1) for the
+    first n_local instances of the shard, 0 beyond.  The clamp is UNSIGNED, as in the kernels and the oracle
+    (emit path: `min(li.mesh, n_mesh - 1u)`): ids >= 2^31 clamp to n_mesh - 1, not to 0."""
+    w = id_width(n_mesh)
+    ids = torch.zeros(rows, dtype=torch.int64, device=d_inst_u8.device)
+    if n_local:
+        col = d_inst_u8[: n_local * 144].view(torch.int32).view(-1, 36)[:, 32]
+        ids[:n_local] = (col.to(torch.int64) & 0xFFFFFFFF).clamp(max=n_mesh - 1)
+    return ids.to(torch.int32).view(torch.uint8).view(-1, 4)[:, :w].contiguous().view(-1)
+
+
 class ShardedVisibility:
-    """Per-frame: local cull -> bitmask all-gather -> local expansion to the full draw list."""
+    """Per-frame visibility of a scene whose instances are sharded by rank.  Four consumers (bench.py --gather):
+
+      step          full list on every rank; wire = 1 bit per instance (bitmask all-gather + local expansion)
+      step_indices  full list on every rank; wire = 4 B per survivor (SURVEY.md 8e option) + local rebuild
+      step_draws    full list on every rank; wire = the 20-byte commands themselves (the literal north-star exchange)
+      step_shard    every rank keeps the compacted list of ITS shard only (global base_instance): no exchange
+    """
 
     def __init__(self, ctx, n_total: int, d_meshes, n_mesh: int, d_inst_shard, group=None):
         self.ctx, self.group = ctx, group
@@ -56,19 +79,18 @@ class ShardedVisibility:
         # local mask (zero padded to wps words) and the gathered masks of all shards
         self.d_mask = torch.zeros(self.wps, dtype=torch.int64, device=dev)
         self.d_mask_all = torch.zeros(self.wps * self.world, dtype=torch.int64, device=dev)
-        # replicated instance -> mesh table: column 32 of the 36-dword instance records, gathered once,
-        # stored at the narrowest width the mesh table allows (the expansion pass reads it every frame)
-        id_dtype = torch.uint8 if n_mesh <= 256 else (torch.int16 if n_mesh <= 32768 else torch.int32)
-        ids = torch.zeros(self.S, dtype=id_dtype, device=dev)
-        if self.n_local:
-            col = d_inst_shard[: self.n_local * 144].view(torch.int32).view(-1, 36)[:, 32]
-            ids[: self.n_local] = torch.clamp(col, 0, n_mesh - 1).to(id_dtype)
-        self.d_mesh_ids = torch.empty(self.S * self.world, dtype=id_dtype, device=dev)
+        # replicated instance -> mesh table: column 32 of the 36-dword instance records, gathered once (as bytes: the
+        # RCCL backend has no 16-bit integer type), stored at the narrowest width the mesh table allows (the expansion
+        # pass reads it every frame); global instance i sits at row i (shards are S rows each)
+        self.id_bytes = id_width(n_mesh)
+        ids = mesh_id_table(d_inst_shard, self.n_local, n_mesh, self.S)
+        self.d_mesh_ids = torch.empty(self.S * self.world * self.id_bytes, dtype=torch.uint8, device=dev)
         if self.world > 1:
-            # gathered as bytes: the RCCL backend has no 16-bit integer type
-            dist.all_gather_into_tensor(self.d_mesh_ids.view(torch.uint8), ids.view(torch.uint8), group=group)
+            dist.all_gather_into_tensor(self.d_mesh_ids, ids, group=group)
         else:
             self.d_mesh_ids.copy_(ids)
+        self.d_idx = self.d_idx_all = self.d_local = None
+        self.d_cnt = torch.zeros(4, dtype=torch.int32, device=dev)
 
     def step(self, camera, d_out, d_count):
         """d_out: n_total * 20 bytes; d_count: int32[>=1].  Enqueues on the ctx stream."""
@@ -78,7 +100,46 @@ class ShardedVisibility:
             masks = self.d_mask_all
         else:
             masks = self.d_mask
-        self.ctx.expand_mask_dev(masks, self.n_total, self.S, self.d_mesh_ids, self.d_meshes, self.n_mesh, d_out, d_count)
+        self.ctx.expand_mask_dev(masks, self.n_total, self.S, self.d_mesh_ids, self.d_meshes, self.n_mesh, d_out, d_count,
+                                 id_bytes=self.id_bytes)
+
+    def step_shard(self, camera, d_out_local, d_count_local):
+        """Own shard only: d_out_local holds n_local commands with GLOBAL base_instance.  No exchange."""
+        self.ctx.cull_compact_dev(camera, self.d_meshes, self.n_mesh, self.d_inst, self.n_local, d_out_local, d_count_local,
+                                  False, self.lo)
+
+    def step_indices(self, camera, d_out, d_count):
+        """Survivor indices (4 B each) are exchanged, every rank rebuilds all commands.  The sizes are data dependent,
+        so the step reads the counts back (one host round trip)."""
+        dev = self.d_inst.device
+        if self.d_idx is None:
+            self.d_idx = torch.empty(max(self.S, 4), dtype=torch.int32, device=dev)
+            self.d_idx_all = torch.empty(max(self.S * self.world, 4), dtype=torch.int32, device=dev)
+        self.ctx.cull_mask_dev(camera, self.d_meshes, self.n_mesh, self.d_inst, self.n_local, self.d_mask)
+        self.ctx.mask_to_indices_dev(self.d_mask, self.n_local, self.lo, self.d_idx, self.d_cnt)
+        if self.world > 1:
+            counts = allgather_counts(self.d_cnt[:1], self.group)
+            total = allgather_records(self.d_idx.view(torch.uint8), counts, self.d_idx_all.view(torch.uint8), 4, self.group)
+            src = self.d_idx_all
+        else:
+            total, src = int(self.d_cnt[0].item()), self.d_idx
+        self.ctx.indices_to_draws_dev(src, total, self.d_mesh_ids, self.S * self.world, self.d_meshes, self.n_mesh, d_out,
+                                      id_bytes=self.id_bytes)
+        d_count[:1].fill_(total)
+
+    def step_draws(self, camera, d_out, d_count):
+        """The literal exchange: every rank compacts its shard to 20-byte commands and they are all-gathered."""
+        dev = self.d_inst.device
+        if self.d_local is None:
+            self.d_local = torch.empty(max(self.S, 1) * DRAW_BYTES, dtype=torch.uint8, device=dev)
+        self.step_shard(camera, self.d_local, self.d_cnt)
+        if self.world > 1:
+            counts = allgather_counts(self.d_cnt[:1], self.group)
+            total = allgather_records(self.d_local, counts, d_out, DRAW_BYTES, self.group)
+        else:
+            total = int(self.d_cnt[0].item())
+            d_out[: total * DRAW_BYTES].copy_(self.d_local[: total * DRAW_BYTES])
+        d_count[:1].fill_(total)
 
 
 def allgather_counts(local_count: torch.Tensor, group=None) -> torch.Tensor:
@@ -90,33 +151,47 @@ def allgather_counts(local_count: torch.Tensor, group=None) -> torch.Tensor:
     return out.cpu()
 
 
-def allgather_draws(local_draws_u8: torch.Tensor, counts: torch.Tensor, out_u8: torch.Tensor, group=None):
-    """Place rank q's first counts[q] commands at byte offset 20*sum(counts[:q]) of out_u8 on
-    every rank.  local_draws_u8 / out_u8 are flat uint8 tensors on the compute device."""
+def allgather_records(local_u8: torch.Tensor, counts: torch.Tensor, out_u8: torch.Tensor, record_bytes: int, group=None):
+    """Place rank q's first counts[q] records at byte offset record_bytes*sum(counts[:q]) of out_u8 on every rank:
+    exact-size one-shot direct all-gather (every rank sends its list straight into every peer's final buffer, one
+    xGMI link per peer).  local_u8 / out_u8 are flat uint8 tensors on the compute device."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [int(c) for c in counts]
     offs = [0]
     for c in counts:
         offs.append(offs[-1] + c)
     total = offs[-1]
-    assert out_u8.numel() >= total * DRAW_BYTES
-    mine = local_draws_u8[: counts[rank] * DRAW_BYTES]
-    out_u8[offs[rank] * DRAW_BYTES: offs[rank + 1] * DRAW_BYTES].copy_(mine)
+    assert out_u8.numel() >= total * record_bytes
+    mine = local_u8[: counts[rank] * record_bytes]
+    out_u8[offs[rank] * record_bytes: offs[rank + 1] * record_bytes].copy_(mine)
     if world == 1:
         return total
-    ops = []
+    # gloo has no device-tensor send/recv: ranks that share a GPU in the functional tests stage through the host
+    staged = mine.is_cuda and dist.get_backend(group) == "gloo"
+    send_buf = mine.cpu() if staged else mine
+    ops, landed = [], []
     for step in range(1, world):
         dst = (rank + step) % world
         src = (rank - step) % world
         if counts[rank]:
-            ops.append(dist.P2POp(dist.isend, mine, dist.get_global_rank(group, dst) if group else dst, group))
+            ops.append(dist.P2POp(dist.isend, send_buf, dist.get_global_rank(group, dst) if group else dst, group))
         if counts[src]:
-            view = out_u8[offs[src] * DRAW_BYTES: offs[src + 1] * DRAW_BYTES]
-            ops.append(dist.P2POp(dist.irecv, view, dist.get_global_rank(group, src) if group else src, group))
+            view = out_u8[offs[src] * record_bytes: offs[src + 1] * record_bytes]
+            buf = torch.empty(view.numel(), dtype=torch.uint8) if staged else view
+            if staged:
+                landed.append((view, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, dist.get_global_rank(group, src) if group else src, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    for view, buf in landed:
+        view.copy_(buf)
     return total
+
+
+def allgather_draws(local_draws_u8: torch.Tensor, counts: torch.Tensor, out_u8: torch.Tensor, group=None):
+    """allgather_records for 20-byte DrawIndexedIndirect commands."""
+    return allgather_records(local_draws_u8, counts, out_u8, DRAW_BYTES, group)
 
 
 def build_blas_batch(build_fn, meshes, group=None, device=None):

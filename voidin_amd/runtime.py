@@ -113,6 +113,15 @@ class Context:
         self._chk(self.lib.vd_expand_mask_dev(self.h, abi.ptr(d_mask), n_total, shard_size, abi.ptr(d_mesh_ids), id_bytes,
                                               abi.ptr(d_meshes), n_mesh, abi.ptr(d_out), abi.ptr(d_count)))
 
+    def mask_to_indices_dev(self, d_mask, n_inst, first_instance, d_out_indices, d_count):
+        self._chk(self.lib.vd_mask_to_indices_dev(self.h, abi.ptr(d_mask), n_inst, first_instance, abi.ptr(d_out_indices), abi.ptr(d_count)))
+
+    def indices_to_draws_dev(self, d_indices, n_indices, d_mesh_ids, n_total, d_meshes, n_mesh, d_out, id_bytes=None):
+        if id_bytes is None:
+            id_bytes = d_mesh_ids.element_size() if hasattr(d_mesh_ids, "element_size") else 4
+        self._chk(self.lib.vd_indices_to_draws_dev(self.h, abi.ptr(d_indices), n_indices, abi.ptr(d_mesh_ids), id_bytes, n_total,
+                                                   abi.ptr(d_meshes), n_mesh, abi.ptr(d_out)))
+
     def compact_draws_dev(self, d_in, n, d_out, d_count):
         self._chk(self.lib.vd_compact_draws_dev(self.h, abi.ptr(d_in), n, abi.ptr(d_out), abi.ptr(d_count)))
 
@@ -158,6 +167,11 @@ class Context:
         self._chk(self.lib.vd_bvh_build_dev(self.h, abi.ptr(d_verts), n_vert, abi.ptr(d_indices), n_tri,
                                             abi.ptr(d_nodes), node_cap, C.addressof(n_nodes)))
         return n_nodes.value
+
+    def bvh_last_build_stats(self) -> dict:
+        st = abi.BvhBuildStats()
+        self._chk(self.lib.vd_bvh_last_build_stats(self.h, C.byref(st)))
+        return {k: (round(getattr(st, k), 3) if t is C.c_float else int(getattr(st, k))) for k, t in st._fields_}
 
     # -- TLAS -------------------------------------------------------------------------------
     def tlas_build(self, instances, meshes, wide=False) -> np.ndarray:

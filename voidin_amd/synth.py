@@ -204,6 +204,23 @@ def plane_mesh(width=1.0, height=1.0):
     return v, i
 
 
+def plane_mesh_rot_x(width=1.0, height=1.0):
+    """The second built-in mesh of MeshPool::new (crates/pools/src/mesh/mod.rs:269-272): the plane with every vertex
+    multiplied by glam Mat3::from_rotation_x(-PI/2) = columns X, (0, cos, sin), (0, -sin, cos); Mat3 * v =
+    (X*v.x + Y*v.y) + Z*v.z in f32 (glam 0.24 scalar/SSE2 order, from memory - unpinned like the other glam choices).
+    sin/cos of the f32 angle are taken in f64 and rounded (cos(-PI/2 as f32) = -4.371139e-08, sin = -1)."""
+    v, i = plane_mesh(width, height)
+    a = np.float32(-np.pi / 2)
+    c, s = np.float32(np.cos(np.float64(a))), np.float32(np.sin(np.float64(a)))
+    X = np.array([1, 0, 0], dtype=np.float32)
+    Y = np.array([0, c, s], dtype=np.float32)
+    Z = np.array([0, -s, c], dtype=np.float32)
+    out = np.empty_like(v)
+    for k in range(len(v)):
+        out[k] = (X * v[k, 0] + Y * v[k, 1]) + Z * v[k, 2]
+    return out, i
+
+
 def uv_sphere(radius=1.0, resolution=10):
     """make_uv_sphere (crates/pools/src/mesh/sphere.rs:6-66).  Vertices use libm sin/cos in
     f32 there; here they are computed in f64 and rounded, and the arrays are committed as
