@@ -1,0 +1,129 @@
+"""The algorithm of the indexed TLAS build (lower-bound pruning over a spatial index, strict nearest-neighbour cache,
+slot relabelling incl. the stale-slot quirk) restated on the CPU (tests/cpp/tlas_index_model.cpp) and checked against
+the literal oracle: same node arrays on random clouds and on inputs made of ties (nested, identical, lattice boxes)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from voidin_amd import abi, synth
+
+SRC = os.path.join(ROOT, "tests", "cpp", "tlas_index_model.cpp")
+LIB = os.path.join(ROOT, "tests", "cpp", "libtlas_index_model.so")
+
+
+@pytest.fixture(scope="module")
+def model():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", SRC, "-o", LIB], check=True)
+    lib = C.CDLL(LIB)
+    lib.tlas_index_model.restype = C.c_int
+    lib.tlas_index_model.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def run(leaf_boxes, slice_=16, block=64, super_slices=32, phase2=0, cache=0, refresh=0):
+        lb = np.ascontiguousarray(leaf_boxes, dtype=np.float32).reshape(-1, 6)
+        n = len(lb)
+        params = np.array([slice_, block, super_slices, phase2, cache, refresh], dtype=np.uint32)
+        box = np.zeros((2 * n + 1, 6), np.float32)
+        l, r, ii = (np.zeros(2 * n + 1, np.uint32) for _ in range(3))
+        st = np.zeros(8, np.uint64)
+        rc = lib.tlas_index_model(lb.ctypes.data, n, params.ctypes.data, box.ctypes.data, l.ctypes.data, r.ctypes.data, ii.ctypes.data, st.ctypes.data)
+        return rc, box, l, r, ii, dict(zip(["full", "cached", "cand", "slices", "phase2", "nonstrict", "lb", "ownblock"], (int(x) for x in st)))
+    return run
+
+
+def oracle_from_boxes(oracle, boxes):
+    """The oracle builds from instances; identity transforms + one MeshInfo per box give exactly these leaf boxes
+    (the fold seed is the object-space box, and the 8 transformed corners are its corners)."""
+    boxes = np.asarray(boxes, dtype=np.float32).reshape(-1, 6)
+    n = len(boxes)
+    meshes = np.zeros(n, dtype=abi.MESH_INFO)
+    meshes["min"], meshes["max"] = boxes[:, :3], boxes[:, 3:]
+    inst = np.zeros(n, dtype=abi.INSTANCE)
+    eye = np.eye(4, dtype=np.float32).reshape(16)
+    inst["transform"], inst["inv_transform"] = eye, eye
+    inst["mesh"] = np.arange(n, dtype=np.uint32)
+    return oracle.tlas_build(inst, meshes, wide=True)
+
+
+def same(want, box, l, r, ii):
+    return (want["left"].tobytes() == l.tobytes() and want["right"].tobytes() == r.tobytes() and want["instance_idx"].tobytes() == ii.tobytes()
+            and np.ascontiguousarray(want["min"]).tobytes() == np.ascontiguousarray(box[:, :3]).tobytes()
+            and np.ascontiguousarray(want["max"]).tobytes() == np.ascontiguousarray(box[:, 3:]).tobytes())
+
+
+def cloud(n, seed, extent=60.0, size=4.0):
+    u = synth.uniform01(seed, 0, 6 * n).reshape(n, 6).astype(np.float32)
+    c = (u[:, :3] - 0.5) * np.float32(extent)
+    h = u[:, 3:] * np.float32(size) * np.float32(0.5)
+    return np.concatenate([c - h, c + h], axis=1)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 64, 65, 200, 1000, 3000])
+@pytest.mark.parametrize("cfg", [dict(slice_=4, block=8, super_slices=4, phase2=0), dict(slice_=4, block=8, super_slices=4, phase2=7),
+                                 dict(slice_=16, block=64, super_slices=32, phase2=0), dict(slice_=16, block=64, super_slices=32, phase2=256, cache=1, refresh=50),
+                                 dict(slice_=4, block=8, super_slices=4, phase2=3, cache=1), dict(slice_=4, block=8, super_slices=4, phase2=0, refresh=7)])
+def test_random_clouds(model, oracle, n, cfg):
+    boxes = cloud(n, 1000 + n)
+    want = oracle_from_boxes(oracle, boxes)
+    rc, box, l, r, ii, st = model(boxes, **cfg)
+    assert rc == 0 and same(want, box, l, r, ii), st
+
+
+def test_scene_instances_like_the_bench(model, oracle):
+    """Leaf boxes of real instances (rotations, anisotropic scale, the object-space seed quirk) taken from the oracle's own
+    leaves; the sequential part shrinks to ~1.2 full queries per instance, the rest is served by the cache."""
+    meshes = synth.mesh_infos()
+    n = 6000
+    inst = synth.instances(n, seed=synth.SEED_BASE + 6, extent=170.0)
+    want = oracle.tlas_build(inst, meshes, wide=True)
+    boxes = np.concatenate([want["min"][1:n + 1], want["max"][1:n + 1]], axis=1)
+    rc, box, l, r, ii, st = model(boxes, phase2=512, refresh=256)
+    assert rc == 0 and same(want, box, l, r, ii), st
+    assert st["cand"] < 400 * st["full"], st          # the index prunes: a query looks at a few hundred of the 6000 clusters
+
+
+def test_ties_everywhere(model, oracle):
+    rng = np.random.default_rng(5)
+    cases = []
+    # identical boxes; nested boxes (a big box makes every union area equal: first slot wins); integer lattice
+    cases.append(np.tile(np.array([[0, 0, 0, 1, 1, 1]], np.float32), (40, 1)))
+    big = np.array([[-50, -50, -50, 50, 50, 50]], np.float32)
+    cases.append(np.concatenate([cloud(60, 7, 40.0, 2.0), big, cloud(60, 8, 40.0, 2.0), big * np.float32(0.5)]))
+    g = np.stack(np.meshgrid(np.arange(6), np.arange(5), np.arange(4), indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float32) * 3
+    cases.append(np.concatenate([g, g + 1], axis=1))
+    cases.append(np.concatenate([g, g + 1], axis=1)[rng.permutation(len(g))])
+    line = np.zeros((97, 6), np.float32); line[:, 0] = np.arange(97); line[:, 3] = np.arange(97) + 0.5; line[:, 4:] = 0.5
+    cases.append(line)
+    cases.append(np.concatenate([cloud(100, 9), cloud(100, 9)]))                    # every box twice
+    flat = cloud(150, 11); flat[:, 2] = 0; flat[:, 5] = 0                           # zero extents: areas with zero factors
+    cases.append(flat)
+    for k, boxes in enumerate(cases):
+        want = oracle_from_boxes(oracle, boxes)
+        for cfg in (dict(slice_=4, block=8, super_slices=4, phase2=0), dict(slice_=4, block=8, super_slices=2, phase2=5, cache=1),
+                    dict(slice_=16, block=64, super_slices=32, phase2=0, refresh=9), dict(slice_=4, block=8, super_slices=4, phase2=0, cache=1, refresh=3)):
+            rc, box, l, r, ii, st = model(boxes, **cfg)
+            assert rc == 0 and same(want, box, l, r, ii), (k, cfg, st)
+
+
+def test_last_slot_merges_leave_a_stale_index(model, oracle):
+    """Clusters arranged so that the chain ends on the last slot again and again (descending spacing from the end)."""
+    n = 300
+    x = np.cumsum(1.0 + 0.01 * np.arange(n))[::-1].astype(np.float32)          # slot n-1 and n-2 are the closest pair
+    boxes = np.zeros((n, 6), np.float32)
+    boxes[:, 0], boxes[:, 3] = x, x + np.float32(0.25)
+    boxes[:, 4:] = 0.25
+    want = oracle_from_boxes(oracle, boxes)
+    for cfg in (dict(slice_=4, block=8, super_slices=4, phase2=0), dict(slice_=16, block=64, super_slices=32, phase2=40)):
+        rc, box, l, r, ii, st = model(boxes, **cfg)
+        assert rc == 0 and same(want, box, l, r, ii), (cfg, st)
+
+
+def test_precondition_rejects_what_the_fast_arithmetic_cannot_order(model):
+    b = cloud(10, 3)
+    for bad in (np.nan, np.inf, 1e19):
+        c = b.copy(); c[4, 3] = bad
+        assert model(c)[0] == -1

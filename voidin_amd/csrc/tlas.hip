@@ -17,6 +17,9 @@
 //    (write-through agent-scope stores, no fences; boxes re-read L1/L2-bypassing).
 #include "vd_common.hpp"
 
+#include <stdlib.h>
+#include <type_traits>
+
 namespace {
 
 constexpr int kBuildThreads = 1024;
@@ -124,7 +127,7 @@ __device__ __forceinline__ vd_u64 wave_min_u64(vd_u64 v) {
 // v_min/v_max instead of the total-order min/max.  Only the sign of a zero extent can differ, the area is then the
 // same +0/-0-normalised value, so the argmin is unchanged; the boxes written to the nodes always use the total order.
 // Per thread the slots come in increasing order, so `strictly smaller area` alone keeps the first slot.
-template <bool FAST>
+template <bool FAST, int THREADS = kBuildThreads>
 __device__ __forceinline__ unsigned find_best_match(const float* sb, unsigned cap, unsigned cnt,
                                                     unsigned target, vd_u64* s_red, unsigned call) {
     const unsigned tid = threadIdx.x, lane = tid & 63u;
@@ -135,7 +138,7 @@ __device__ __forceinline__ unsigned find_best_match(const float* sb, unsigned ca
         const float t3 = sb[3 * cap + target], t4 = sb[4 * cap + target], t5 = sb[5 * cap + target];
         // four consecutive slots per lane per step: six independent 16-B loads in flight (issuing the next step's
         // loads before this step's arithmetic was measured: 20 % slower)
-        for (unsigned i0 = tid * 4u; i0 < cnt; i0 += kBuildThreads * 4u) {
+        for (unsigned i0 = tid * 4u; i0 < cnt; i0 += THREADS * 4u) {
             const float4 a0 = *reinterpret_cast<const float4*>(sb + i0), a1 = *reinterpret_cast<const float4*>(sb + cap + i0);
             const float4 a2 = *reinterpret_cast<const float4*>(sb + 2 * cap + i0), a3 = *reinterpret_cast<const float4*>(sb + 3 * cap + i0);
             const float4 a4 = *reinterpret_cast<const float4*>(sb + 4 * cap + i0), a5 = *reinterpret_cast<const float4*>(sb + 5 * cap + i0);
@@ -186,22 +189,24 @@ __device__ __forceinline__ unsigned find_best_match(const float* sb, unsigned ca
     vd_u64* words = s_red + (call & 1u) * 16u;
     if (lane == 0) words[tid >> 6] = best;
     __syncthreads();
-    vd_u64 v = lane < (unsigned)(kBuildThreads / 64) ? words[lane] : ~0ull;
+    vd_u64 v = lane < (unsigned)(THREADS / 64) ? words[lane] : ~0ull;
     { vd_u64 o; o = dpp_u64<0xB1>(v); v = o < v ? o : v; o = dpp_u64<0x4E>(v); v = o < v ? o : v;
       o = dpp_u64<0x141>(v); v = o < v ? o : v; o = dpp_u64<0x140>(v); v = o < v ? o : v; }        // lanes 0..15 hold the minimum
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return (lo & hi) == 0xffffffffu ? target : lo;
 }
 
-// tlas.rs:56-84 — one workgroup runs the whole chain.
-template <typename Node, bool FAST>
-__device__ __forceinline__ void tlas_build_chain(Node* __restrict__ nodes, unsigned n, float* sb, unsigned* slot_node,
-                                                 unsigned cap, vd_u64* s_red) {
+// tlas.rs:56-84 — one workgroup runs the whole chain.  Resumable: the indexed build hands over in the middle of the
+// chain with {cnt, used, a, b} (b already found); a fresh build starts at {n, n + 1, 0, none}.
+struct ChainState { unsigned cnt, used, a, b; bool have_b; };
+template <typename Node, bool FAST, int THREADS = kBuildThreads>
+__device__ __forceinline__ void tlas_build_chain(Node* __restrict__ nodes, float* sb, unsigned* slot_node,
+                                                 unsigned cap, vd_u64* s_red, ChainState st) {
     unsigned call = 0;
-    unsigned cnt = n, used = n + 1, a = 0;
-    unsigned b = find_best_match<FAST>(sb, cap, cnt, a, s_red, call++);
+    unsigned cnt = st.cnt, used = st.used, a = st.a;
+    unsigned b = st.have_b ? st.b : find_best_match<FAST, THREADS>(sb, cap, cnt, a, s_red, call++);
     while (cnt > 0) {
-        const unsigned c = find_best_match<FAST>(sb, cap, cnt, b, s_red, call++);
+        const unsigned c = find_best_match<FAST, THREADS>(sb, cap, cnt, b, s_red, call++);
         if (a == c) {
             if (threadIdx.x == 0) {
                 const unsigned idx_a = slot_node[a], idx_b = slot_node[b];
@@ -229,7 +234,7 @@ __device__ __forceinline__ void tlas_build_chain(Node* __restrict__ nodes, unsig
             used += 1;
             cnt -= 1;
             __syncthreads();
-            b = find_best_match<FAST>(sb, cap, cnt, a, s_red, call++);
+            b = find_best_match<FAST, THREADS>(sb, cap, cnt, a, s_red, call++);
         } else {
             a = b;
             b = c;
@@ -251,8 +256,9 @@ __global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restr
         for (int q = 0; q < 6; ++q) { const float v = sb[q * cap + i]; nan |= v != v; }
     }
     const bool any_nan = __syncthreads_or(nan) != 0;         // also orders the s_red initialisation
-    if (any_nan) tlas_build_chain<Node, false>(nodes, n, sb, slot_node, cap, s_red);
-    else tlas_build_chain<Node, true>(nodes, n, sb, slot_node, cap, s_red);
+    const ChainState fresh{n, n + 1u, 0u, 0u, false};
+    if (any_nan) tlas_build_chain<Node, false>(nodes, sb, slot_node, cap, s_red, fresh);
+    else tlas_build_chain<Node, true>(nodes, sb, slot_node, cap, s_red, fresh);
 }
 
 // ---- build, several workgroups ---------------------------------------------------------------
@@ -454,6 +460,473 @@ __global__ __launch_bounds__(kMwThreads) void tlas_build_mw_kernel(Node* __restr
     else mw_build_chain<Node, true>(nodes, n, sb, slot_node, cap, sh, gridDim.x >> 3, s_red, spin_limit);
 }
 
+// ---- build, indexed ---------------------------------------------------------------------------
+// The chain of tlas.rs:56-84 is sequential (~3 N dependent find_best_match calls), so what can shrink is the cost of
+// ONE call.  A call is an exact nearest-neighbour query under the metric area(union(t, o)) with the slot index as the
+// tie-break; here it is answered through an index instead of a scan of all cnt clusters:
+//
+//  * clusters are ENTRIES {box, slot, node} in a fixed order (sorted once by the Morton code of the 6-D point (mn, mx):
+//    the reference's leaf boxes all reach back to the object-space mesh box, tlas.rs:39, so two boxes are near when BOTH
+//    corners are); 16 consecutive entries form a slice, 16 slices a super-slice;
+//  * every group keeps its INNER corner I = {max of the members' mn, min of their mx}.  Every member o has o.mn <= I.mn
+//    and o.mx >= I.mx, so the box {min(t.mn, I.mn), max(t.mx, I.mx)} lies inside union(t, o), and the f32 evaluation of
+//    Aabb::area (subtract, multiply, add: each monotone under round-to-nearest for non-negative extents) is monotone
+//    under inclusion: area of that box <= area(union(t, o)) in f32 for EVERY member.  A group whose lower bound exceeds
+//    the union area with any known candidate cannot hold the answer (an equal bound may: the slot index decides);
+//  * a merged cluster replaces one of its two parts in that part's entry and only grows, dead entries only loosen a
+//    corner: the corners stay valid without updates and are re-tightened every few hundred merges;
+//  * the chain supplies the known candidate for free: for c = best(b) it is a (b = best(a) a moment ago), right after a
+//    merge it is the chain element before a (never merged while remembered).  Without one, the target's own block of 64
+//    entries is scanned first;
+//  * slots are an attribute of an entry; idx[b] = idx[cnt-1] relabels one entry, and the stale index a that the
+//    reference keeps using when a was the last slot (the merged cluster then sits in slot b and is a candidate of
+//    best(a)) falls out of "exclude by slot".
+// Precondition: every leaf coordinate finite, |x| < 1e18 (no overflow, hence no inf * 0 = NaN anywhere) and mn <= mx;
+// otherwise the plain chain above runs.  tests/cpp/tlas_index_model.cpp restates this algorithm on the CPU and
+// tests/test_tlas_index_model.py checks it against the literal oracle, ties, nesting and stale slots included.
+//
+// One 256-lane workgroup (a wave per SIMD) runs the chain; a query is three barriers: super-slice bounds -> slice
+// bounds -> surviving entries -> minimum.  When cnt falls to kIxPhase2 the plain scan takes over (few, large clusters:
+// every group overlaps every target).
+constexpr int kIxThreads = 256;
+constexpr unsigned kIxSlice = 16u, kIxSuper = 16u, kIxBlock = 64u, kIxDead = 0xffffffffu;
+constexpr unsigned kIxMaxInstances = 65536u;         // slice corners of 65536 entries fill 128 KB of the 160 KB LDS
+constexpr int kSortThreads = 512;
+
+struct __attribute__((aligned(16))) IxEntry { float mn[3]; unsigned slot; float mx[3]; unsigned node; };   // two 16-byte loads
+struct IxCtl { unsigned ok, fallback, pad[2]; };
+
+__device__ __forceinline__ unsigned ix_spread6(unsigned x) {   // 5 bits -> every sixth bit
+    return (x & 1u) | ((x & 2u) << 5) | ((x & 4u) << 10) | ((x & 8u) << 15) | ((x & 16u) << 20);
+}
+
+// One workgroup: precondition check, Morton codes, stable LSD radix sort (4 bits a pass, a thread owns a contiguous chunk:
+// counts[digit][thread] in LDS, one scan of the flattened matrix per pass), then the entries and the slot -> entry map.
+__global__ __launch_bounds__(kSortThreads) void tlas_index_kernel(const float* __restrict__ sb, unsigned cap, unsigned n, unsigned E,
+                                                                  unsigned* key0, unsigned* val0, unsigned* key1, unsigned* val1,
+                                                                  IxEntry* __restrict__ entries, unsigned* __restrict__ slot_ent, IxCtl* ctl) {
+    constexpr unsigned T = kSortThreads, W = kSortThreads / 64;
+    __shared__ unsigned s_cnt[16 * kSortThreads];
+    __shared__ float s_lo[W][3], s_hi[W][3];
+    __shared__ unsigned s_wsum[W];
+    const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    int bad = 0;
+    for (unsigned i = t; i < n; i += T) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float mn = sb[k * cap + i], mx = sb[(3 + k) * cap + i];
+            bad |= !(fabsf(mn) < 1e18f) || !(fabsf(mx) < 1e18f) || !(mn <= mx);
+            lo[k] = __builtin_fminf(lo[k], mn); hi[k] = __builtin_fmaxf(hi[k], mx);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = __builtin_fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = __builtin_fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+        if (lane == 0) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
+    }
+    if (__syncthreads_or(bad)) {                          // the fast arithmetic cannot order this input: plain chain
+        if (t == 0) { ctl->ok = 0u; ctl->fallback = 1u; }
+        return;
+    }
+    if (t == 0) { ctl->ok = 1u; ctl->fallback = 0u; }
+    float scale[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float l = s_lo[0][k], h = s_hi[0][k];
+        for (unsigned w = 1; w < W; ++w) { l = __builtin_fminf(l, s_lo[w][k]); h = __builtin_fmaxf(h, s_hi[w][k]); }
+        lo[k] = l;
+        scale[k] = h > l ? 32.0f / (h - l) : 0.0f;
+    }
+    for (unsigned i = t; i < n; i += T) {
+        unsigned c = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float q0 = __builtin_fminf(__builtin_fmaxf((sb[k * cap + i] - lo[k]) * scale[k], 0.0f), 31.0f);
+            const float q1 = __builtin_fminf(__builtin_fmaxf((sb[(3 + k) * cap + i] - lo[k]) * scale[k], 0.0f), 31.0f);
+            c |= ix_spread6((unsigned)q0) << k;
+            c |= ix_spread6((unsigned)q1) << (3 + k);
+        }
+        key0[i] = c; val0[i] = i;
+    }
+    __syncthreads();
+    const unsigned chunk = (n + T - 1) / T;
+    const unsigned begin = min(n, t * chunk), end = min(n, begin + chunk);
+    unsigned *kin = key0, *vin = val0, *kout = key1, *vout = val1;
+    for (unsigned shift = 0; shift < 32u; shift += 4u) {          // 8 passes: the result is back in key0 / val0
+#pragma unroll
+        for (unsigned d = 0; d < 16u; ++d) s_cnt[d * T + t] = 0u;
+        for (unsigned i = begin; i < end; ++i) s_cnt[((kin[i] >> shift) & 15u) * T + t] += 1u;
+        __syncthreads();
+        unsigned v[16], run = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const unsigned c = s_cnt[16u * t + j]; v[j] = run; run += c; }
+        unsigned incl = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(incl, off); if (lane >= (unsigned)off) incl += o; }
+        if (lane == 63u) s_wsum[wave] = incl;
+        __syncthreads();
+        unsigned base = incl - run;
+        for (unsigned w = 0; w < wave; ++w) base += s_wsum[w];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s_cnt[16u * t + j] = base + v[j];
+        __syncthreads();
+        for (unsigned i = begin; i < end; ++i) {
+            const unsigned k = kin[i];
+            const unsigned pos = s_cnt[((k >> shift) & 15u) * T + t]++;
+            kout[pos] = k; vout[pos] = vin[i];
+        }
+        __syncthreads();
+        unsigned* x = kin; kin = kout; kout = x;
+        x = vin; vin = vout; vout = x;
+    }
+    for (unsigned e = t; e < E; e += T) {
+        IxEntry en;
+        if (e < n) {
+            const unsigned i = vin[e];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { en.mn[k] = sb[k * cap + i]; en.mx[k] = sb[(3 + k) * cap + i]; }
+            en.slot = i; en.node = i + 1u;
+            slot_ent[i] = e;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { en.mn[k] = 1e30f; en.mx[k] = -1e30f; }
+            en.slot = kIxDead; en.node = 0u;
+        }
+        entries[e] = en;
+    }
+}
+
+struct IxShared {
+    vd_u64 res_key[2][4];                                // by query parity: a wave may start the next query before the
+    unsigned res_e[2][4], res_node[2][4];                // others have read this one's result
+    float res_box[2][4][6];
+    vd_u64 red[32];                                      // s_red of the plain chain (phase 2)
+};
+struct IxHit { vd_u64 key; unsigned e, node; float box[6]; };
+// list1 / list2: per-wave survivor lists (every wave owns a quarter of each array)
+struct IxLds { IxShared* sh; float4* slice; float4* super; unsigned short* list1; unsigned short* list2; unsigned n_slices, n_super, cap1, cap2; };
+struct IxProf { unsigned long long t_bounds, t_entries, t_reduce, t_merge, t_refresh, queries, own, n1, n2; };
+
+__device__ __forceinline__ float ix_union_area(const float (&t)[6], const float (&o)[6]) {
+    const float dx = __builtin_fmaxf(t[3], o[3]) - __builtin_fminf(t[0], o[0]);
+    const float dy = __builtin_fmaxf(t[4], o[4]) - __builtin_fminf(t[1], o[1]);
+    const float dz = __builtin_fmaxf(t[5], o[5]) - __builtin_fminf(t[2], o[2]);
+    return vd_area(dx, dy, dz) + 0.0f;
+}
+__device__ __forceinline__ float ix_lower_bound(const float (&t)[6], const float4 lo, const float4 hi) {
+    const float dx = __builtin_fmaxf(t[3], hi.x) - __builtin_fminf(t[0], lo.x);
+    const float dy = __builtin_fmaxf(t[4], hi.y) - __builtin_fminf(t[1], lo.y);
+    const float dz = __builtin_fmaxf(t[5], hi.z) - __builtin_fminf(t[2], lo.z);
+    return vd_area(dx, dy, dz) + 0.0f;
+}
+
+// per-lane running minimum over the entries it evaluates
+struct IxLane { vd_u64 key; unsigned e; float4 lo, hi; };
+__device__ __forceinline__ void ix_eval(IxLane& L, const IxEntry* entries, unsigned e, unsigned t_slot, const float (&tb)[6]) {
+    const float4 lo = reinterpret_cast<const float4*>(entries + e)[0], hi = reinterpret_cast<const float4*>(entries + e)[1];
+    const unsigned slot = __float_as_uint(lo.w);
+    const float o[6] = {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z};
+    const float area = ix_union_area(tb, o);
+    const bool ok = slot != kIxDead && slot != t_slot && area < 1e30f;   // tlas.rs:88,98: from 1e30, never the target
+    const vd_u64 key = ok ? (((vd_u64)__float_as_uint(area) << 32) | slot) : ~0ull;
+    if (key < L.key) { L.key = key; L.e = e; L.lo = lo; L.hi = hi; }
+}
+
+// survivors among the super-slices into a wave-private list; R rounds of 64 evaluated side by side
+template <int R>
+__device__ __forceinline__ unsigned ix_supers(const IxLds& L, const float (&tb)[6], bool have, float bound, unsigned short* my1, unsigned lane) {
+    unsigned n1 = 0;
+    for (unsigned base = 0; base < L.n_super; base += 64u * R) {
+        float lb[R];
+        bool in[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned s = base + 64u * r + lane;
+            in[r] = s < L.n_super;
+            const unsigned sc = in[r] ? s : 0u;
+            lb[r] = ix_lower_bound(tb, L.super[2u * sc], L.super[2u * sc + 1u]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool keep = in[r] && (!have || lb[r] <= bound);
+            const unsigned long long mask = __ballot(keep);
+            if (keep) my1[n1 + vd_mbcnt(mask)] = (unsigned short)(base + 64u * r + lane);
+            n1 += (unsigned)__popcll(mask);
+        }
+    }
+    return n1;
+}
+
+// find_best_match through the index.  Every thread of the workgroup calls it with the same arguments and gets the same
+// answer.  bound: union area with a known candidate, NaN = none.  q: running query number (parity of the result slots).
+// ONE workgroup barrier per query: every wave works out the surviving super-slices by itself (their corners sit in LDS:
+// the same few reads in all four waves), then takes a quarter of their slices, then the entries of the slices ITS
+// quarter left over - through wave-private lists, no cross-wave hand-off until the four minima meet.
+__device__ __forceinline__ IxHit ix_query(const IxEntry* entries, const IxLds& L, unsigned q, unsigned t_slot, const float (&tb)[6],
+                                          unsigned e_t, float bound, IxProf* prof) {
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    IxShared* sh = L.sh;
+    const unsigned p = q & 1u;
+    long long t0 = 0;
+    if (prof) t0 = clock64();
+    IxLane mine{~0ull, 0u, float4{0, 0, 0, 0}, float4{0, 0, 0, 0}};
+    if (!(bound == bound)) {                              // no candidate known: the target's own block supplies one
+        ix_eval(mine, entries, (e_t / kIxBlock) * kIxBlock + lane, t_slot, tb);
+        const vd_u64 m = wave_min_u64(mine.key);
+        bound = __uint_as_float((unsigned)(m >> 32));     // 0xffffffff reads back as NaN: still none
+        if (prof && tid == 0u) prof->own += 1;
+    }
+    const bool have = bound == bound;
+    unsigned short* my1 = L.list1 + wave * L.cap1;
+    unsigned short* my2 = L.list2 + wave * L.cap2;
+    // One wave per SIMD: nothing hides latency but the wave's own independent instructions, so every stage first issues
+    // all its loads and evaluates up to four items per lane side by side, and only then does the (serial) bookkeeping.
+    const unsigned n1 = L.n_super <= 64u ? ix_supers<1>(L, tb, have, bound, my1, lane)
+                      : (L.n_super <= 128u ? ix_supers<2>(L, tb, have, bound, my1, lane) : ix_supers<4>(L, tb, have, bound, my1, lane));
+    vd_wave_lds_sync();
+    // slices of the surviving super-slices: item i is dealt to wave i % 4 (neighbouring slices survive together)
+    const unsigned items1 = n1 * kIxSuper;
+    unsigned n2 = 0;
+    for (unsigned base = 0; base < items1; base += 512u) {
+        float lb[2];
+        bool in[2];
+        unsigned sl[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned item = base + (64u * r + lane) * 4u + wave;
+            in[r] = item < items1;
+            sl[r] = in[r] ? (unsigned)my1[item / kIxSuper] * kIxSuper + (item % kIxSuper) : 0u;
+            in[r] = in[r] && sl[r] < L.n_slices;
+            const unsigned sc = in[r] ? sl[r] : 0u;
+            lb[r] = ix_lower_bound(tb, L.slice[2u * sc], L.slice[2u * sc + 1u]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const bool keep = in[r] && (!have || lb[r] <= bound);
+            const unsigned long long mask = __ballot(keep);
+            if (keep) my2[n2 + vd_mbcnt(mask)] = (unsigned short)sl[r];
+            n2 += (unsigned)__popcll(mask);
+        }
+    }
+    vd_wave_lds_sync();
+    long long t1 = 0;
+    if (prof) t1 = clock64();
+    const unsigned items2 = n2 * kIxSlice;
+    for (unsigned base = 0; base < items2; base += 128u) {
+        float4 lo[2], hi[2];
+        unsigned e[2];
+        bool in[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned item = base + 64u * r + lane;
+            in[r] = item < items2;
+            e[r] = in[r] ? (unsigned)my2[item / kIxSlice] * kIxSlice + (item % kIxSlice) : 0u;
+            lo[r] = reinterpret_cast<const float4*>(entries + e[r])[0];
+            hi[r] = reinterpret_cast<const float4*>(entries + e[r])[1];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned slot = __float_as_uint(lo[r].w);
+            const float o[6] = {lo[r].x, lo[r].y, lo[r].z, hi[r].x, hi[r].y, hi[r].z};
+            const float area = ix_union_area(tb, o);
+            const bool ok = in[r] && slot != kIxDead && slot != t_slot && area < 1e30f;
+            const vd_u64 key = ok ? (((vd_u64)__float_as_uint(area) << 32) | slot) : ~0ull;
+            if (key < mine.key) { mine.key = key; mine.e = e[r]; mine.lo = lo[r]; mine.hi = hi[r]; }
+        }
+    }
+    long long t2 = 0;
+    if (prof) { t2 = clock64(); }
+    const vd_u64 m = wave_min_u64(mine.key);
+    if (m == ~0ull) {
+        if (lane == 0u) sh->res_key[p][wave] = ~0ull;
+    } else if (mine.key == m) {                           // slots are unique: exactly one lane
+        sh->res_key[p][wave] = m; sh->res_e[p][wave] = mine.e; sh->res_node[p][wave] = __float_as_uint(mine.hi.w);
+        sh->res_box[p][wave][0] = mine.lo.x; sh->res_box[p][wave][1] = mine.lo.y; sh->res_box[p][wave][2] = mine.lo.z;
+        sh->res_box[p][wave][3] = mine.hi.x; sh->res_box[p][wave][4] = mine.hi.y; sh->res_box[p][wave][5] = mine.hi.z;
+    }
+    __syncthreads();
+    unsigned w = 0;
+    vd_u64 best = sh->res_key[p][0];
+#pragma unroll
+    for (unsigned k = 1; k < 4u; ++k) { const vd_u64 o = sh->res_key[p][k]; if (o < best) { best = o; w = k; } }
+    IxHit h;
+    h.key = best; h.e = sh->res_e[p][w]; h.node = sh->res_node[p][w];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) h.box[k] = sh->res_box[p][w][k];
+    if (prof && tid == 0u) {
+        const long long t3 = clock64();
+        prof->t_bounds += (unsigned long long)(t1 - t0); prof->t_entries += (unsigned long long)(t2 - t1); prof->t_reduce += (unsigned long long)(t3 - t2);
+        prof->queries += 1; prof->n1 += n1; prof->n2 += n2;
+    }
+    return h;
+}
+
+// inner corners of all groups from the live entries (a slice per thread, then a super-slice per thread)
+__device__ __forceinline__ void ix_refresh(const IxEntry* entries, const IxLds& L) {
+    for (unsigned sl = threadIdx.x; sl < L.n_slices; sl += kIxThreads) {
+        float4 lo{-1e30f, -1e30f, -1e30f, 0.0f}, hi{1e30f, 1e30f, 1e30f, 0.0f};      // empty group: every bound overflows to +inf
+        for (unsigned j = 0; j < kIxSlice; ++j) {
+            const float4 a = reinterpret_cast<const float4*>(entries + sl * kIxSlice + j)[0];
+            const float4 b = reinterpret_cast<const float4*>(entries + sl * kIxSlice + j)[1];
+            if (__float_as_uint(a.w) != kIxDead) {
+                lo.x = __builtin_fmaxf(lo.x, a.x); lo.y = __builtin_fmaxf(lo.y, a.y); lo.z = __builtin_fmaxf(lo.z, a.z);
+                hi.x = __builtin_fminf(hi.x, b.x); hi.y = __builtin_fminf(hi.y, b.y); hi.z = __builtin_fminf(hi.z, b.z);
+            }
+        }
+        L.slice[2u * sl] = lo; L.slice[2u * sl + 1u] = hi;
+    }
+    __syncthreads();
+    for (unsigned sp = threadIdx.x; sp < L.n_super; sp += kIxThreads) {
+        float4 lo{-1e30f, -1e30f, -1e30f, 0.0f}, hi{1e30f, 1e30f, 1e30f, 0.0f};
+        for (unsigned j = 0; j < kIxSuper && sp * kIxSuper + j < L.n_slices; ++j) {
+            const float4 a = L.slice[2u * (sp * kIxSuper + j)], b = L.slice[2u * (sp * kIxSuper + j) + 1u];
+            lo.x = __builtin_fmaxf(lo.x, a.x); lo.y = __builtin_fmaxf(lo.y, a.y); lo.z = __builtin_fmaxf(lo.z, a.z);
+            hi.x = __builtin_fminf(hi.x, b.x); hi.y = __builtin_fminf(hi.y, b.y); hi.z = __builtin_fminf(hi.z, b.z);
+        }
+        L.super[2u * sp] = lo; L.super[2u * sp + 1u] = hi;
+    }
+    __syncthreads();
+}
+
+// wave-private survivor lists: every wave may keep all super-slices, and of the slices its quarter (+ one round of slack)
+static __host__ __device__ unsigned ix_cap1(unsigned n_super) { return (n_super + 7u) & ~7u; }
+static __host__ __device__ unsigned ix_cap2(unsigned n_slices) { return ((n_slices + 3u) / 4u + 64u + 7u) & ~7u; }
+static size_t ix_lds_bytes(unsigned n_slices, unsigned n_super) {
+    return ((sizeof(IxShared) + 15) & ~(size_t)15) + (size_t)n_slices * 32 + (size_t)n_super * 32 + (size_t)ix_cap1(n_super) * 8 +
+           (size_t)ix_cap2(n_slices) * 8 + 16;
+}
+
+template <typename Node>
+__global__ __launch_bounds__(kIxThreads) void tlas_build_indexed_kernel(Node* __restrict__ nodes, unsigned n, IxEntry* entries, unsigned* slot_ent,
+                                                                        unsigned E, float* sb, unsigned* slot_node, unsigned cap,
+                                                                        const IxCtl* ctl, unsigned phase2_cnt, unsigned refresh_every, int profile) {
+    if (ctl->ok == 0u) return;                            // precondition failed: the plain chain is queued behind
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    IxLds L;
+    L.n_slices = E / kIxSlice;
+    L.n_super = (L.n_slices + kIxSuper - 1u) / kIxSuper;
+    char* p = smem;
+    L.sh = reinterpret_cast<IxShared*>(p); p += (sizeof(IxShared) + 15) & ~(size_t)15;
+    L.slice = reinterpret_cast<float4*>(p); p += (size_t)L.n_slices * 32;
+    L.super = reinterpret_cast<float4*>(p); p += (size_t)L.n_super * 32;
+    L.cap1 = ix_cap1(L.n_super); L.cap2 = ix_cap2(L.n_slices);
+    L.list1 = reinterpret_cast<unsigned short*>(p); p += (size_t)L.cap1 * 8;
+    L.list2 = reinterpret_cast<unsigned short*>(p);
+    const unsigned tid = threadIdx.x;
+    if (tid < 32u) L.sh->red[tid] = ~0ull;
+    IxProf prof_data{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    IxProf* prof = profile ? &prof_data : nullptr;
+    ix_refresh(entries, L);                               // ends with a barrier
+
+    // chain state: the same values in every thread
+    unsigned cnt = n, used = n + 1u, q = 0, since_refresh = 0;
+    unsigned a = 0u, ea = slot_ent[0], node_a = 1u, b, eb, node_b;
+    float box_a[6], box_b[6], box_prev[6] = {0, 0, 0, 0, 0, 0};
+    bool a_stale = false, have_prev = false;
+    unsigned e_prev = 0u;
+    unsigned el_last = slot_ent[n - 1u];                  // entry of the last slot: used by thread 0 at the next merge
+    {
+        const float4 lo = reinterpret_cast<const float4*>(entries + ea)[0], hi = reinterpret_cast<const float4*>(entries + ea)[1];
+        box_a[0] = lo.x; box_a[1] = lo.y; box_a[2] = lo.z; box_a[3] = hi.x; box_a[4] = hi.y; box_a[5] = hi.z;
+    }
+    const float kNone = __uint_as_float(0x7fc00000u);
+    auto take = [&](const IxHit& h, unsigned t_slot, unsigned e_t, unsigned node_t, const float (&tb)[6], unsigned& o_slot, unsigned& o_e,
+                    unsigned& o_node, float (&o_box)[6]) {
+        if (h.key == ~0ull) {                             // nothing: find_best_match returns the target (tlas.rs:89)
+            o_slot = t_slot; o_e = e_t; o_node = node_t;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o_box[k] = tb[k];
+        } else {
+            o_slot = (unsigned)h.key; o_e = h.e; o_node = h.node;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o_box[k] = h.box[k];
+        }
+    };
+    take(ix_query(entries, L, q++, a, box_a, ea, kNone, prof), a, ea, node_a, box_a, b, eb, node_b, box_b);
+    while (cnt > phase2_cnt) {
+        float bound = kNone;
+        if (!a_stale) bound = ix_union_area(box_b, box_a);                        // a is a live candidate of best(b)
+        else if (have_prev && e_prev != eb) bound = ix_union_area(box_b, box_prev);
+        unsigned c, ec, node_c;
+        float box_c[6];
+        take(ix_query(entries, L, q++, b, box_b, eb, bound, prof), b, eb, node_b, box_b, c, ec, node_c, box_c);
+        if (a == c) {
+            float u[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { u[k] = vd_min_to(box_a[k], box_b[k]); u[3 + k] = vd_max_to(box_a[3 + k], box_b[3 + k]); }
+            const unsigned last = cnt - 1u;
+            long long tm = 0;
+            if (prof) tm = clock64();
+            if (tid == 0u) {
+                Node nd;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { nd.min[k] = u[k]; nd.max[k] = u[3 + k]; }
+                node_set_children(nd, node_a, node_b);
+                nd.instance_idx = 0xffffffffu;
+                nodes[used] = nd;
+                // node_indices[a] = nodes_used; node_indices[b] = node_indices[cnt - 1]  (tlas.rs:72-75, in this order)
+                float4* ma = reinterpret_cast<float4*>(entries + ea);
+                ma[0] = float4{u[0], u[1], u[2], __uint_as_float(last == a ? b : a)};
+                ma[1] = float4{u[3], u[4], u[5], __uint_as_float(used)};
+                entries[eb].slot = kIxDead;
+                if (last == a) slot_ent[b] = ea;                                  // the merged cluster lands in slot b, a goes stale
+                else if (last != b) { entries[el_last].slot = b; slot_ent[b] = el_last; }
+                if (last >= 1u) el_last = slot_ent[last - 1u];                    // the next merge's last slot; after my own stores (same-thread order)
+            }
+            if (have_prev && (e_prev == eb || e_prev == ea)) have_prev = false;   // prev is consumed (or names the merged entry)
+            a_stale = last == a;
+            node_a = used;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) box_a[k] = u[k];
+            used += 1u; cnt -= 1u;
+            __syncthreads();                              // thread 0's entry stores are complete and visible to the other waves
+            if (prof && tid == 0u) prof->t_merge += (unsigned long long)(clock64() - tm);
+            if (refresh_every && ++since_refresh >= refresh_every) {
+                if (prof) tm = clock64();
+                ix_refresh(entries, L);
+                since_refresh = 0u;
+                if (prof && tid == 0u) prof->t_refresh += (unsigned long long)(clock64() - tm);
+            }
+            const float bnd = have_prev ? ix_union_area(box_a, box_prev) : kNone;
+            take(ix_query(entries, L, q++, a, box_a, ea, bnd, prof), a, ea, node_a, box_a, b, eb, node_b, box_b);
+        } else {
+            have_prev = true; e_prev = ea;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { box_prev[k] = box_a[k]; box_a[k] = box_b[k]; box_b[k] = box_c[k]; }
+            a = b; ea = eb; node_a = node_b; a_stale = false;
+            b = c; eb = ec; node_b = node_c;
+        }
+    }
+    if (prof && tid == 0u)
+        printf("tlas indexed build n=%u: %llu queries (%llu with an own-block bound), survivors per query: %.1f super-slices, %.1f slices; "
+               "cycles per query: bounds %.0f, entries %.0f, reduce+barrier %.0f; per merge %.0f; refresh total %llu\n",
+               n, prof->queries, prof->own, (double)prof->n1 / prof->queries, 4.0 * prof->n2 / prof->queries, (double)prof->t_bounds / prof->queries,
+               (double)prof->t_entries / prof->queries, (double)prof->t_reduce / prof->queries, (double)prof->t_merge / (n - cnt), prof->t_refresh);
+    // ---- hand over to the plain scan: slot arrays from the live entries (+ the stale slot a the chain may still name) ----
+    __syncthreads();
+    for (unsigned e = tid; e < E; e += kIxThreads) {
+        const float4 lo = reinterpret_cast<const float4*>(entries + e)[0], hi = reinterpret_cast<const float4*>(entries + e)[1];
+        const unsigned slot = __float_as_uint(lo.w);
+        if (slot != kIxDead) {
+            sb[slot] = lo.x; sb[cap + slot] = lo.y; sb[2 * cap + slot] = lo.z;
+            sb[3 * cap + slot] = hi.x; sb[4 * cap + slot] = hi.y; sb[5 * cap + slot] = hi.z;
+            slot_node[slot] = __float_as_uint(hi.w);
+        }
+    }
+    __syncthreads();
+    if (a_stale && tid == 0u) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sb[k * cap + a] = box_a[k];
+        slot_node[a] = node_a;
+    }
+    __syncthreads();
+    tlas_build_chain<Node, true, kIxThreads>(nodes, sb, slot_node, cap, L.sh->red, ChainState{cnt, used, a, b, true});
+}
+
 // ---- refit -------------------------------------------------------------------------------
 // The agglomerative tree is tall and thin (32 768 instances of the bench cloud: height 70, and about half the levels
 // of the longest path join a cluster with a single leaf), so a refit is one long dependent climb and what counts is
@@ -549,14 +1022,32 @@ __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigne
 template <typename Node>
 int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                     Node* d_nodes) {
-    // scratch: 6 float slot arrays + slot node ids, capacity n
+    // scratch: 6 float slot arrays + slot node ids (capacity n), the several-workgroup exchange words, and for the indexed
+    // build the entries, the slot -> entry map, two key / value pairs of the sort and the control words
     const size_t cap = ((size_t)n + 7) & ~(size_t)3;   // multiple of 4 (+ slack): slot arrays are read 16 B at a time
-    const size_t need = cap * 7 * 4 + 256 + sizeof(MwShared);
+    const size_t off_sh = (cap * 7 * 4 + 255) & ~(size_t)255;
+    const unsigned E = (n + kIxBlock - 1u) / kIxBlock * kIxBlock;
+    const size_t off_ent = (off_sh + sizeof(MwShared) + 255) & ~(size_t)255;
+    const size_t off_map = off_ent + (size_t)E * sizeof(IxEntry);
+    const size_t off_sort = off_map + (((size_t)n * 4 + 255) & ~(size_t)255);
+    const size_t sort_stride = ((size_t)n * 4 + 255) & ~(size_t)255;
+    const size_t off_ctl = off_sort + 4 * sort_stride;
+    const size_t need = off_ctl + 256;
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
     if (rc) return rc;
-    float* sb = reinterpret_cast<float*>(ctx->scratch);
+    char* base = reinterpret_cast<char*>(ctx->scratch);
+    float* sb = reinterpret_cast<float*>(base);
     unsigned* slot_node = reinterpret_cast<unsigned*>(sb + 6 * cap);
-    MwShared* sh = reinterpret_cast<MwShared*>(reinterpret_cast<char*>(ctx->scratch) + ((cap * 7 * 4 + 255) & ~(size_t)255));
+    MwShared* sh = reinterpret_cast<MwShared*>(base + off_sh);
+    // The indexed build (one workgroup, exact pruning) from a few thousand instances up to what its corner table fits in
+    // LDS; above that the scans are spread over several workgroups.  VD_TLAS_INDEX=0 switches it off (A/B),
+    // VD_TLAS_INDEX_MIN / VD_TLAS_PHASE2 / VD_TLAS_REFRESH tune it.
+    const int env_index = getenv("VD_TLAS_INDEX") ? atoi(getenv("VD_TLAS_INDEX")) : 1;
+    const unsigned ix_min = getenv("VD_TLAS_INDEX_MIN") ? (unsigned)atoi(getenv("VD_TLAS_INDEX_MIN")) : 4096u;
+    unsigned phase2 = getenv("VD_TLAS_PHASE2") ? (unsigned)atoi(getenv("VD_TLAS_PHASE2")) : 2048u;
+    const unsigned refresh = getenv("VD_TLAS_REFRESH") ? (unsigned)atoi(getenv("VD_TLAS_REFRESH")) : 1024u;
+    if (phase2 < 64u) phase2 = 64u;
+    const bool indexed = env_index != 0 && n >= ix_min && n > phase2 && n <= kIxMaxInstances;
     // several workgroups from a few thousand instances on (below, the exchange costs more than the shorter scans save);
     // the slot field of the exchanged key holds 20 bits.  VD_TLAS_GROUPS = 1 forces the single-workgroup kernel.
     const int env_groups = getenv("VD_TLAS_GROUPS") ? atoi(getenv("VD_TLAS_GROUPS")) : 0;
@@ -569,7 +1060,29 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_nodes, 0, sizeof(Node) * (2 * (size_t)n + 1), ctx->stream));   // TlasNode::default()
     hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
                        n_mesh, d_nodes, sb, slot_node, (unsigned)cap, 0, (const unsigned*)nullptr);
-    if (groups <= 1u) {
+    if (indexed) {
+        IxEntry* entries = reinterpret_cast<IxEntry*>(base + off_ent);
+        unsigned* slot_ent = reinterpret_cast<unsigned*>(base + off_map);
+        unsigned* keys[4];
+        for (int k = 0; k < 4; ++k) keys[k] = reinterpret_cast<unsigned*>(base + off_sort + k * sort_stride);
+        IxCtl* ctl = reinterpret_cast<IxCtl*>(base + off_ctl);
+        const unsigned n_slices = E / kIxSlice, n_super = (n_slices + kIxSuper - 1u) / kIxSuper;
+        const size_t lds = ix_lds_bytes(n_slices, n_super);
+        constexpr int which = std::is_same<Node, VdTlasNode>::value ? 0 : 1;
+        if (!ctx->tlas_ix_lds_opt_in[which]) {            // per context (= per device): up to 160 KB of dynamic LDS
+            VD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tlas_build_indexed_kernel<Node>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ix_lds_bytes(kIxMaxInstances / kIxSlice, kIxMaxInstances / kIxSlice / kIxSuper)));
+            ctx->tlas_ix_lds_opt_in[which] = true;
+        }
+        hipLaunchKernelGGL(tlas_index_kernel, dim3(1), dim3(kSortThreads), 0, ctx->stream, sb, (unsigned)cap, n, E, keys[0], keys[1], keys[2], keys[3],
+                           entries, slot_ent, ctl);
+        hipLaunchKernelGGL((tlas_build_indexed_kernel<Node>), dim3(1), dim3(kIxThreads), lds, ctx->stream, d_nodes, n, entries, slot_ent, E, sb,
+                           slot_node, (unsigned)cap, ctl, phase2, refresh, getenv("VD_TLAS_PROFILE") ? 1 : 0);
+        // leaf coordinates the fast arithmetic cannot order (NaN, inf, |x| >= 1e18): decided on the device, the plain chain
+        // runs instead (the indexed kernel returned at once and left the slot arrays as the leaves kernel wrote them)
+        hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
+                           (unsigned)cap, (const unsigned*)&ctl->fallback);
+    } else if (groups <= 1u) {
         hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
                            (unsigned)cap, (const unsigned*)nullptr);
     } else {
