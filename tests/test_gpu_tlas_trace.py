@@ -294,3 +294,63 @@ def test_trace_axis_aligned_and_degenerate_rays(ctx, oracle):
     hit = want["hit"] == 1
     assert np.all(np.abs(got["dist"][hit] - want["dist"][hit]) <= REL_TOL * np.abs(want["dist"][hit]))
     assert got["dist"].view(np.uint32).tobytes() == want["dist"].view(np.uint32).tobytes()      # in fact bit for bit, NaN-free or not
+
+
+def _boxes_as_scene(boxes):
+    """Identity transforms + one MeshInfo per box: the leaf boxes are exactly `boxes` (tests/test_tlas_index_model.py)."""
+    boxes = np.asarray(boxes, dtype=np.float32).reshape(-1, 6)
+    n = len(boxes)
+    meshes = np.zeros(n, dtype=abi.MESH_INFO)
+    meshes["min"], meshes["max"] = boxes[:, :3], boxes[:, 3:]
+    inst = np.zeros(n, dtype=abi.INSTANCE)
+    eye = np.eye(4, dtype=np.float32).reshape(16)
+    inst["transform"], inst["inv_transform"] = eye, eye
+    inst["mesh"] = np.arange(n, dtype=np.uint32)
+    return inst, meshes
+
+
+def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, monkeypatch):
+    """The indexed build (tlas.hip, "build, indexed": pruned queries, two at a time - the one the chain needs and the one a
+    merge would need) forced onto small inputs made of what can break it: identical and nested boxes (every union area
+    ties: the slot index decides), lattices, zero extents, chains that keep ending on the last slot (the stale index of
+    tlas.rs:72-75), and ordinary clouds; and inputs it must hand to the plain chain (NaN, inf, huge)."""
+    monkeypatch.setenv("VD_TLAS_INDEX_MIN", "65")
+    monkeypatch.setenv("VD_TLAS_PHASE2", "64")
+    monkeypatch.setenv("VD_TLAS_REFRESH", "37")
+
+    def cloud(n, seed, extent=60.0, size=4.0):
+        u = synth.uniform01(seed, 0, 6 * n).reshape(n, 6).astype(np.float32)
+        c = (u[:, :3] - 0.5) * np.float32(extent)
+        h = u[:, 3:] * np.float32(size) * np.float32(0.5)
+        return np.concatenate([c - h, c + h], axis=1)
+    rng = np.random.default_rng(5)
+    cases = [cloud(n, 100 + n) for n in (65, 100, 257, 700, 1500, 3000)]
+    cases.append(np.tile(np.array([[0, 0, 0, 1, 1, 1]], np.float32), (90, 1)))
+    big = np.array([[-50, -50, -50, 50, 50, 50]], np.float32)
+    cases.append(np.concatenate([cloud(160, 7, 40.0, 2.0), big, cloud(160, 8, 40.0, 2.0), big * np.float32(0.5)]))
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(7), np.arange(6), indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float32) * 3
+    cases.append(np.concatenate([g, g + 1], axis=1))
+    cases.append(np.concatenate([g, g + 1], axis=1)[rng.permutation(len(g))])
+    line = np.zeros((297, 6), np.float32); line[:, 0] = np.arange(297); line[:, 3] = np.arange(297) + 0.5; line[:, 4:] = 0.5
+    cases.append(line)
+    cases.append(np.concatenate([cloud(200, 9), cloud(200, 9)]))
+    flat = cloud(350, 11); flat[:, 2] = 0; flat[:, 5] = 0
+    cases.append(flat)
+    n = 400
+    x = np.cumsum(1.0 + 0.01 * np.arange(n))[::-1].astype(np.float32)          # the closest pair is always the last two slots
+    stale = np.zeros((n, 6), np.float32); stale[:, 0], stale[:, 3] = x, x + np.float32(0.25); stale[:, 4:] = 0.25
+    cases.append(stale)
+    for k, boxes in enumerate(cases):
+        inst, meshes = _boxes_as_scene(boxes)
+        want = oracle.tlas_build(inst, meshes)
+        got = ctx.tlas_build(inst, meshes)
+        assert fields_equal(got, want), f"case {k} ({len(boxes)} boxes)"
+        wide = ctx.tlas_build(inst, meshes, wide=True)
+        assert np.array_equal(wide["left"] + (wide["right"] << 16), want["left_right"]) and wide["min"].tobytes() == want["min"].tobytes()
+    for bad in (np.nan, np.inf, 1e19):                                          # precondition fails -> plain chain, same answer
+        boxes = cloud(300, 3)
+        boxes[41, 3] = bad
+        inst, meshes = _boxes_as_scene(boxes)
+        want, got = oracle.tlas_build(inst, meshes), ctx.tlas_build(inst, meshes)
+        assert got["left_right"].tobytes() == want["left_right"].tobytes()
+        assert got["min"].view(np.uint32).tobytes() == want["min"].view(np.uint32).tobytes() and got["max"].view(np.uint32).tobytes() == want["max"].view(np.uint32).tobytes()

@@ -611,16 +611,21 @@ struct IxHit { vd_u64 key; unsigned e, node; float box[6]; };
 struct IxLds { IxShared* sh; float4* slice; float4* super; unsigned short* list1; unsigned short* list2; unsigned n_slices, n_super, cap1, cap2; };
 struct IxProf { unsigned long long t_bounds, t_entries, t_reduce, t_merge, t_refresh, queries, own, n1, n2; };
 
+// v_max_f32 / v_min_f32 as single instructions: under the precondition no operand is a NaN, so the canonicalising
+// v_max x, x the compiler puts in front of every IEEE maxnum / minnum operand (three instructions per min or max) buys
+// nothing here, and the chain is bound by the instructions one wave issues per query.
+__device__ __forceinline__ float ix_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float ix_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float ix_union_area(const float (&t)[6], const float (&o)[6]) {
-    const float dx = __builtin_fmaxf(t[3], o[3]) - __builtin_fminf(t[0], o[0]);
-    const float dy = __builtin_fmaxf(t[4], o[4]) - __builtin_fminf(t[1], o[1]);
-    const float dz = __builtin_fmaxf(t[5], o[5]) - __builtin_fminf(t[2], o[2]);
+    const float dx = ix_max(t[3], o[3]) - ix_min(t[0], o[0]);
+    const float dy = ix_max(t[4], o[4]) - ix_min(t[1], o[1]);
+    const float dz = ix_max(t[5], o[5]) - ix_min(t[2], o[2]);
     return vd_area(dx, dy, dz) + 0.0f;
 }
 __device__ __forceinline__ float ix_lower_bound(const float (&t)[6], const float4 lo, const float4 hi) {
-    const float dx = __builtin_fmaxf(t[3], hi.x) - __builtin_fminf(t[0], lo.x);
-    const float dy = __builtin_fmaxf(t[4], hi.y) - __builtin_fminf(t[1], lo.y);
-    const float dz = __builtin_fmaxf(t[5], hi.z) - __builtin_fminf(t[2], lo.z);
+    const float dx = ix_max(t[3], hi.x) - ix_min(t[0], lo.x);
+    const float dy = ix_max(t[4], hi.y) - ix_min(t[1], lo.y);
+    const float dz = ix_max(t[5], hi.z) - ix_min(t[2], lo.z);
     return vd_area(dx, dy, dz) + 0.0f;
 }
 
