@@ -42,6 +42,7 @@ def load() -> C.CDLL:
             "vd_ref_tlas_refit_wide": (_I, [_P, _U, _P, _U, _P]),
             "vd_ref_trace": (_I, [C.POINTER(abi.TraceScene), _P, _U, _P, _P, _I]),
             "vd_ref_traverse_iter": (_I, [_P, _U, _P, _P, _P, _U, _P]),
+            "vd_ref_traverse": (_I, [_P, _U, _P, _P, _P, _U, C.c_float, _P]),
             "vd_ref_shadow_rays": (_I, [_P, _P, _U, _P, _P]),
             "vd_ref_primary_rays": (_I, [_P, _U, _U, _P]),
             "vd_ref_hiz_layout": (_I, [_U, _U, _P]),
@@ -210,4 +211,14 @@ def traverse_iter(nodes, verts, indices, rays):
     out = np.zeros(len(rays), dtype=np.float32)
     _chk(load().vd_ref_traverse_iter(nodes.ctypes.data, len(nodes), verts.ctypes.data,
                                      indices.ctypes.data, rays.ctypes.data, len(rays), out.ctypes.data))
+    return out
+
+
+def traverse_recursive(nodes, verts, indices, rays, t0=1e30):
+    """Bvh::traverse (blas.rs:211-245, R3; dead code in the reference): Hit(t) -> t (t0 itself if nothing nearer), Miss -> -1."""
+    nodes, verts = _c(nodes, abi.BVH_NODE), _c(verts, np.float32).reshape(-1)
+    indices, rays = _c(indices, np.uint32).reshape(-1), _c(rays, abi.RAY)
+    out = np.zeros(len(rays), dtype=np.float32)
+    _chk(load().vd_ref_traverse(nodes.ctypes.data, len(nodes), verts.ctypes.data, indices.ctypes.data, rays.ctypes.data, len(rays),
+                                float(t0), out.ctypes.data))
     return out

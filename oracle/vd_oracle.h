@@ -73,6 +73,11 @@ int vd_ref_traverse_iter(const VdBvhNode* nodes, uint32_t n_nodes, const float* 
                          const uint32_t* indices, const VdRay* rays, uint32_t n_rays,
                          float* out_dist);
 
+/* crates/bvh/src/blas.rs:211-245 (R3): the recursive Bvh::traverse, unused in the reference (bvh_cpu.rs:86 is commented
+ * out).  out_dist[i] = t of Hit(t) - which is t0 itself when the root box is entered and no triangle is nearer - or -1 for Miss. */
+int vd_ref_traverse(const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz,
+                    const uint32_t* indices, const VdRay* rays, uint32_t n_rays, float t0, float* out_dist);
+
 /* CPU twin of the HiZ occlusion extension (no reference code exists: SURVEY.md 8a C4); definitions in voidin_abi.h */
 int vd_ref_hiz_layout(uint32_t width, uint32_t height, VdHizLayout* out);
 int vd_ref_hiz_build(const float* depth, uint32_t width, uint32_t height, float* pyramid);

@@ -288,6 +288,48 @@ int vd_ref_traverse_iter(const VdBvhNode* nodes, uint32_t n_nodes, const float* 
     return VD_OK;
 }
 
+/* ---------------- R3: Bvh::traverse, the recursive walk (crates/bvh/src/blas.rs:211-245) ----------------
+ * Dead code in the reference (its only call is commented out: src/bin/bvh_cpu.rs:86 `self.bvh.traverse(.., ray, 0, 1e30)`);
+ * restated for completeness of SURVEY.md 8a.  It takes Vec4 / UVec4 arrays there (xyz used); the arrays here are the
+ * Vec3 / UVec3 ones of traverse_iter.  Quirk kept: once a node's box is hit the call returns Hit(t) with the t it was
+ * GIVEN when nothing closer was found, so the top-level call returns Hit(1e30) for a ray that enters the root box and
+ * hits no triangle, and Miss only when the root box itself is missed.                                               */
+static dist_t traverse_rec(const VdBvhNode* nodes, const float* verts_xyz, const uint32_t* indices, v3 orig, v3 dir,
+                           uint32_t node_idx, float t, uint32_t depth, int* overflow) {
+    dist_t miss = {0, 0.0f};
+    if (depth > 4096u) { *overflow = 1; return miss; }
+    const VdBvhNode* node = &nodes[node_idx];
+    dist_t box = intersect_aabb_rs(orig, dir, v3_load(node->min), v3_load(node->max), t);
+    if (!box.hit) return miss;                                   /* blas.rs:220-222 */
+    if (node->count > 0) {                                       /* blas.rs:223-235 */
+        for (uint32_t i = 0; i < node->count; ++i) {
+            const uint32_t* idx = indices + 3u * (size_t)(node->left_first + i);
+            float d = ray_intersect_rs(orig, dir, v3_load(verts_xyz + 3u * (size_t)idx[0]), v3_load(verts_xyz + 3u * (size_t)idx[1]),
+                                       v3_load(verts_xyz + 3u * (size_t)idx[2]));
+            if (d >= 0.0f) t = fminf(t, d);
+        }
+    } else {                                                     /* blas.rs:236-243 */
+        dist_t l = traverse_rec(nodes, verts_xyz, indices, orig, dir, node->left_first, t, depth + 1u, overflow);
+        if (l.hit) t = fminf(t, l.t);
+        dist_t r = traverse_rec(nodes, verts_xyz, indices, orig, dir, node->left_first + 1u, t, depth + 1u, overflow);
+        if (r.hit) t = fminf(t, r.t);
+    }
+    dist_t h = {1, t};
+    return h;                                                    /* blas.rs:244 */
+}
+
+int vd_ref_traverse(const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz, const uint32_t* indices,
+                    const VdRay* rays, uint32_t n_rays, float t0, float* out_dist) {
+    if (!nodes || !verts_xyz || !indices || (n_rays && (!rays || !out_dist)) || n_nodes == 0) return VD_ERR_INVALID_ARG;
+    for (uint32_t r = 0; r < n_rays; ++r) {
+        int overflow = 0;
+        dist_t d = traverse_rec(nodes, verts_xyz, indices, v3_load(rays[r].eye), v3_load(rays[r].dir), 0u, t0, 0u, &overflow);
+        if (overflow) return VD_ERR_STACK_OVERFLOW;
+        out_dist[r] = d.hit ? d.t : -1.0f;
+    }
+    return VD_OK;
+}
+
 /* Per-pixel primary rays of the CPU harness (src/bin/bvh_cpu.rs:71-83):
  *   x = (i % WIDTH) / WIDTH; y = (i / HEIGHT) / HEIGHT; (x, y) = ((x, y) - 0.5) * (2, -2);
  *   view_pos = clip_to_world * (x, y, 1, 1); view_tang = clip_to_world * (x, y, 0, 1);

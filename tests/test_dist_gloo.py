@@ -163,3 +163,63 @@ def test_blas_batch_is_partitioned_by_mesh_and_replicated(oracle):
         assert n_built == 2, "each rank builds its own half of the meshes"
         for (nb, ib), (wn, wi) in zip(blobs, want):
             assert nb == wn.tobytes() and ib == wi.tobytes(), f"rank {rank}"
+
+
+def _records_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ref
+        cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+        lo, hi = vdist.shard_range(n, rank, world)
+        shard = synth.instances(hi - lo, seed=81, offset=lo, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+        vis = ref.cull_emit(cam, meshes, shard)["instance_count"] == 1
+        idx = (np.nonzero(vis)[0] + lo).astype(np.uint32)                 # what vd_mask_to_indices_dev writes for this shard
+        counts = vdist.allgather_counts(torch.tensor([len(idx)], dtype=torch.int32))
+        out = torch.zeros(int(counts.sum()) * 4 + 16, dtype=torch.uint8)
+        total = vdist.allgather_records(torch.from_numpy(idx.view(np.uint8).copy()), counts, out, 4)
+        # the replicated instance -> mesh table, as ShardedVisibility builds it (unsigned clamp, narrowest width)
+        table = vdist.mesh_id_table(torch.from_numpy(shard.view(np.uint8).reshape(-1).copy()), hi - lo, len(meshes), vdist.shard_size(n, world))
+        all_ids = torch.zeros(table.numel() * world, dtype=torch.uint8)
+        dist.all_gather_into_tensor(all_ids, table)
+        q.put((rank, total, out[: total * 4].numpy().tobytes(), all_ids.numpy().tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_indices_wire_format_reconstructs_the_scene(oracle):
+    """--gather indices on CPU (gloo, world 3): exact-size exchange of u32 survivor indices + the replicated mesh-id
+    table give every rank what vd_indices_to_draws_dev needs; rebuilt here in numpy == single-rank compaction."""
+    world, n = 3, 12_345
+    cam, meshes = synth.camera_uniform(), synth.mesh_infos()
+    inst = synth.instances(n, seed=81, scale_range=(0.02, 0.6), extent=600.0, with_inverse=False)
+    want, wn = oracle.compact(oracle.cull_emit(cam, meshes, inst))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_records_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, total, iblob, tblob in res:
+        idx = np.frombuffer(iblob, np.uint32)
+        assert total == wn and np.array_equal(idx, want["base_instance"][:wn]), f"rank {rank}"
+        ids = np.frombuffer(tblob, np.uint8)                                # 16 meshes: one byte per instance, row = global index
+        assert np.array_equal(meshes["index_count"][ids[idx]], want["vertex_count"][:wn])
+
+
+def test_mesh_id_table_clamps_unsigned():
+    """ids >= 2^31 must clamp to n_mesh - 1 like `min(u32 id, n_mesh - 1)` in the kernels, not to 0."""
+    inst = synth.instances(7, seed=3, with_inverse=False)
+    inst["mesh"] = np.array([0, 5, 15, 16, 0x7fffffff, 0x80000000, 0xffffffff], dtype=np.uint32)
+    raw = torch.from_numpy(inst.view(np.uint8).reshape(-1).copy())
+    for n_mesh, width in ((16, 1), (300, 2), (70000, 4)):
+        t = vdist.mesh_id_table(raw, 7, n_mesh, 8).numpy()
+        assert vdist.id_width(n_mesh) == width and t.size == 8 * width
+        got = t.view({1: np.uint8, 2: np.uint16, 4: np.uint32}[width])
+        want = np.minimum(inst["mesh"].astype(np.uint64), n_mesh - 1)
+        assert np.array_equal(got[:7].astype(np.uint64), want) and got[7] == 0

@@ -232,3 +232,29 @@ def test_builtin_pool_bookkeeping(oracle):
     # the rotated plane stands up: y spans [-0.5, 0.5], z is +-2.2e-8 (cos(-PI/2 as f32) != 0)
     r = synth.plane_mesh_rot_x()[0]
     assert np.array_equal(np.abs(r[:, 1]), np.full(4, 0.5, np.float32)) and np.all(np.abs(r[:, 2]) == np.float32(2.1855694e-08))
+
+
+def test_recursive_traverse_agrees_with_the_iterative_walk(oracle):
+    """R3 (blas.rs:211-245), dead code in the reference: restated for completeness.  Where a triangle is hit it reports
+    the same distance as Bvh::traverse_iter (both take the minimum over the triangles their box tests let through, and a
+    box test only ever prunes with the current best); where none is hit it returns Hit(t0) if the root box is entered
+    (the quirk of blas.rs:244) and Miss otherwise."""
+    g = golden("harness_soup64.npz")
+    it = oracle.traverse_iter(g["nodes"], g["vertices"], g["indices"], g["rays"])
+    rec = oracle.traverse_recursive(g["nodes"], g["vertices"], g["indices"], g["rays"], 1e30)
+    hit = it >= 0
+    assert hit.sum() > 20 and np.array_equal(rec[hit], it[hit])
+    assert set(np.unique(rec[~hit])) <= {np.float32(-1.0), np.float32(1e30)}
+    # the root box test decides between Miss and Hit(t0)
+    root_min, root_max = g["nodes"]["min"][0], g["nodes"]["max"][0]
+    o, d = g["rays"]["eye"][~hit].astype(np.float32), g["rays"]["dir"][~hit].astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t1, t2 = (root_min - o) / d, (root_max - o) / d
+    tmax, tmin = np.maximum(t1, t2).min(axis=1), np.minimum(t1, t2).max(axis=1)
+    enters = (tmax >= tmin) & (tmin < np.float32(1e30)) & (tmax > 0)
+    assert np.array_equal(rec[~hit] == np.float32(1e30), enters)
+    v, i = synth.knot_mesh(48, 12)
+    nodes, idx = oracle.bvh_build(v, i)
+    rays = synth.primary_rays(synth.camera_uniform(eye=(0, 0, 6), pitch_deg=0), 40, 40)
+    it, rec = oracle.traverse_iter(nodes, v, idx, rays), oracle.traverse_recursive(nodes, v, idx, rays)
+    assert (it >= 0).sum() > 100 and np.array_equal(rec[it >= 0], it[it >= 0])

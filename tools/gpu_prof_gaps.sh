@@ -24,6 +24,25 @@ agg=collections.defaultdict(lambda:[0,0])
 for r in seq:
     n=r['Kernel_Name'].replace('(anonymous namespace)::','').split('(')[0][:30]; agg[n][0]+=1; agg[n][1]+=int(r['End_Timestamp'])-int(r['Start_Timestamp'])
 for n,(c,t) in sorted(agg.items(),key=lambda kv:-kv[1][1])[:16]: print(f"  {n:32s} calls {c:5d} total {t/1e6:7.2f} ms avg {t/c/1e3:8.1f} us")
+# per level of phase A (a level starts at a_seg_begin_kernel): span, busy, and where the busy time goes
+lv=[i for i,r in enumerate(seq) if 'a_seg_begin' in r['Kernel_Name']]
+ends_a=[i for i,r in enumerate(seq) if 'a_level_swap' in r['Kernel_Name']]
+lv_all=[]
+for k,i1 in enumerate(ends_a):
+    i0=(ends_a[k-1]+1) if k else next(i for i,r in enumerate(seq) if 'c_root' in r['Kernel_Name'])+1
+    lv_all.append(i0)
+lv=lv_all
+print("level  span_ms busy_ms  count+scan+ranks+apply  bits  bin+eval  child  big-tier(LDS)  other   (phase A)")
+for k,(i0,i1) in enumerate(zip(lv,ends_a)):
+    part=seq[i0:i1+1]
+    span_l=(int(part[-1]['End_Timestamp'])-int(part[0]['Start_Timestamp']))/1e6
+    d=collections.defaultdict(float)
+    for r in part:
+        n=r['Kernel_Name']; t=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6
+        key='big' if 'blas_mid_kernel' in n else 'round' if any(x in n for x in ('a_count','a_scan_kernel','a_ranks','a_apply')) else 'bits' if 'a_bits' in n else 'bin' if ('a_bin' in n or 'a_eval' in n) else 'child' if 'a_child' in n else 'other'
+        d[key]+=t
+    nxt=int(seq[lv[k+1]]['Start_Timestamp']) if k+1<len(lv) else int(seq[i1+1]['Start_Timestamp'])
+    print(f"{k:5d} {span_l:8.3f} {sum(d.values()):7.3f}  {d['round']:8.3f} {d['bits']:12.3f} {d['bin']:8.3f} {d['child']:7.3f} {d['big']:9.3f} {d['other']:10.3f}   gap to next level {(nxt-int(part[-1]['End_Timestamp']))/1e3:.1f} us")
 big=[(g,seq[i]['Kernel_Name'][:40],seq[i+1]['Kernel_Name'][:40]) for i,g in enumerate(gaps) if g>30000]
 print("gaps > 30 us:",len(big), "sum %.2f ms"%(sum(b[0] for b in big)/1e6))
 for b in sorted(big, reverse=True)[:10]: print("  %.1f us after %s before %s"%(b[0]/1e3,b[1],b[2]))

@@ -1,29 +1,47 @@
 #!/bin/bash
-# Full GPU pass for a round: parity tests, smoke, bench, rocprof kernel stats + PMC passes.
+# Full GPU pass for a round: parity tests, smoke, bench (N = 1 and, with gloo on one device, N = 2), rocprof kernel stats +
+# PMC passes.  Usage (from the repo root, through gpurun): bash tools/gpu_round.sh r02
+# Everything lands in gpurun_out/round/ under the names profiles/ uses; tools/make_profiles_readme.py then writes
+# profiles/README.md from those files (no number in it is typed by hand).
 set -u
+R=${1:-r00}
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/round
 rm -rf $O; mkdir -p $O
-echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 | tee $O/pytest_gpu.log
-echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee $O/smoke.log
-echo "== bench"; timeout 900 python bench.py 2>&1 | grep -v amdgpu.ids | tail -2 | tee $O/bench.json
+echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -q -m gpu --durations=8 2>&1 | tail -14 | tee $O/${R}_pytest_gpu.log
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee $O/${R}_smoke.log
+echo "== bench"; timeout 900 python bench.py 2>&1 | grep -v amdgpu.ids | grep '^{' | tail -1 > $O/${R}_bench_line.json; cut -c1-400 $O/${R}_bench_line.json
+echo "== bench --gpus 2 (two ranks on this one GPU, gloo rendezvous: functional, the timing is not a scaling number)"
+VOIDIN_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 --no-extra 2>&1 | grep '^{' | tail -1 > $O/${R}_bench_line_2ranks_1gpu_gloo.json; cut -c1-300 $O/${R}_bench_line_2ranks_1gpu_gloo.json
 echo "== rocprof kernel stats (bench)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-verify > $O/kt_stdout.log 2>&1
 find $O/kt -name "*kernel_trace.csv" -delete
-head -4 $O/kt/bench_kernel_stats.csv | cut -c1-220
+cp $(find $O/kt -name "bench_kernel_stats.csv" | head -1) $O/${R}_bench_kernel_stats.csv
+head -4 $O/${R}_bench_kernel_stats.csv | cut -c1-200
+echo "== rocprof kernel stats (BVH side)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kb -o bvh -- python3 tools/bench_bvh.py --u 2048 --v 2048 --reps 2 > $O/kb_stdout.log 2>&1
+find $O/kb -name "*kernel_trace.csv" -delete
+cp $(find $O/kb -name "bvh_kernel_stats.csv" | head -1) $O/${R}_bvh_kernel_stats.csv
+grep -v amdgpu.ids $O/kb_stdout.log | tail -12 > $O/${R}_bench_bvh.log
 echo "== rocprof pmc"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o cull -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-extra > $O/pmc_fetch_stdout.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o cull -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-extra > $O/pmc_write_stdout.log 2>&1
-python3 - <<'PY'
-import csv,glob,json
+R=$R python3 - <<'PY'
+import csv,glob,json,os,shutil
+R=os.environ['R']
 out={'note':'mean per launch; rocprofv3 --pmc, one counter per pass; units KB; gfx950 FETCH_SIZE = 1/2 of the bytes read by wide coalesced loads'}
 for d,c in [('pmc_fetch','FETCH_SIZE'),('pmc_write','WRITE_SIZE')]:
-    for f in glob.glob(f'gpurun_out/round/{d}/*counter_collection.csv'):
+    for f in glob.glob(f'gpurun_out/round/{d}/**/*counter_collection.csv',recursive=True):
         rows=list(csv.DictReader(open(f)))
+        keep=[r for r in rows if any(k in r['Kernel_Name'] for k in ('cull_mask_tiled_kernel','expand_mask_u8_kernel','mask_scan_kernel','cull_compact_kernel'))]
+        with open(f'gpurun_out/round/{R}_cull_pmc_{c.lower()}.csv','w',newline='') as g:
+            w=csv.DictWriter(g,fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep[:72])
         for kern in ['cull_mask_tiled_kernel','expand_mask_u8_kernel','mask_scan_kernel','cull_compact_kernel']:
             v=[float(r['Counter_Value']) for r in rows if kern in r['Kernel_Name'] and r['Counter_Name']==c]
             if v:
                 out.setdefault(kern,{})[c+'_KB']=sum(v)/len(v); out[kern][c+'_launches']=len(v)
-json.dump(out,open('gpurun_out/round/cull_pmc.json','w'),indent=1); print(out)
+json.dump(out,open(f'gpurun_out/round/{R}_cull_pmc.json','w'),indent=1); print(out)
 PY
+rm -rf $O/kt $O/kb $O/pmc_fetch $O/pmc_write
+ls -la $O
