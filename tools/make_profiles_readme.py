@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Write profiles/README.md from the files under profiles/ (kernel-stat CSVs, PMC summaries, bench lines): every number in
+the per-round tables is computed here, none is typed by hand (the hand-kept README was one refresh behind).
+    python tools/make_profiles_readme.py"""
+import csv
+import glob
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def stats(path):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        short = re.split(r"[(<]", name)[0]
+        key = short + (re.search(r"<[^>]*>", name).group(0) if "<" in name.split("(")[0] else "")
+        out.setdefault(key, []).append((int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["Percentage"])))
+    return out
+
+
+def k(st, name):
+    v = st.get(name)
+    if not v:
+        return "n/a"
+    c, avg, mn, pct = v[0]
+    return f"avg {avg:.1f} µs over {c} launches (min {mn:.1f})"
+
+
+def round_section(tag):
+    L = [f"## {tag}", ""]
+    bl = os.path.join(P, f"{tag}_bench_line.json")
+    if os.path.exists(bl):
+        d = json.load(open(bl))
+        rf, ex = d["roofline"], d.get("extra", {})
+        L += [f"* `{tag}_bench_line.json` (`python bench.py`): **{d['ms_per_step']} ms/step = {d['value']} {d['unit']}**, "
+              f"`{rf['kernel']}` {rf['kernel_ms']} ms by HIP events -> {rf['achieved']} GB/s = {rf['frac']} of {rf['peak']}; "
+              f"traffic {rf['traffic']} B vs algorithmic {rf['algorithmic_bytes_per_launch']} B; "
+              f"verified bit-exact vs oracle: {d['config']['verified_bit_exact_vs_oracle']}; cpu_baseline {d['cpu_baseline']['value']} "
+              f"{d['cpu_baseline']['unit']} on {d['cpu_baseline']['cores']} threads."]
+        if "bvh_build" in ex and "roofline" in ex["bvh_build"]:
+            b = ex["bvh_build"]
+            L += [f"* BLAS {b['n_tris']} tris: {b['ms']} ms = {b['value']} Mprims/s, bit-exact vs oracle on the timed mesh: {b.get('bit_exact_vs_oracle')}; "
+                  f"phases (ms) {b.get('phases_ms')}; depth {b['roofline']['depth']}, sum of active prims {b['roofline']['sum_active_prims']}; "
+                  f"770 B/prim/level definition: {b['roofline']['emulating_770B_per_prim_level']['achieved']} GB/s "
+                  f"({b['roofline']['emulating_770B_per_prim_level']['frac']}), 44 B: {b['roofline']['binned_44B_per_prim_level']['achieved']} GB/s "
+                  f"({b['roofline']['binned_44B_per_prim_level']['frac']}); CPU oracle {b.get('cpu_baseline', {}).get('value')} Mprims/s (1 core)."]
+        if "tlas" in ex:
+            t, w = ex["tlas"], ex.get("tlas_wide_64k", {})
+            L += [f"* TLAS 32768: build {t['build_ms']} ms (bit-exact vs oracle: {t.get('bit_exact_vs_oracle')}; oracle {t.get('cpu_baseline', {}).get('value')} ms), "
+                  f"refit {t['refit_queued_ms']} ms queued; 65536 wide: build {w.get('build_ms')} ms, refit {w.get('refit_gpu_ms')} ms, "
+                  f"refit after motion bit-exact: {w.get('refit_after_motion_bit_exact_vs_oracle')}."]
+        if "trace" in ex:
+            t = ex["trace"]
+            L += [f"* trace (2000 x 131k-tri stress scene): {t['closest_hit_Mrays_per_s']} Mrays/s closest hit, {t['occlusion_Mrays_per_s']} occlusion; "
+                  f"CPU oracle {t.get('cpu_baseline', {}).get('value')} Mrays/s on {t.get('cpu_baseline', {}).get('cores')} threads; harness scene "
+                  f"{ex.get('trace_harness_scene', {}).get('closest_hit_Mrays_per_s')} Mrays/s."]
+    b2 = os.path.join(P, f"{tag}_bench_line_2ranks_1gpu_gloo.json")
+    if os.path.exists(b2):
+        d = json.load(open(b2))
+        L += [f"* `{tag}_bench_line_2ranks_1gpu_gloo.json` (`VOIDIN_DIST_BACKEND=gloo python bench.py --gpus 2 ...`, two ranks sharing the one GPU: "
+              f"functional evidence of the launcher, NOT a scaling number - gloo moves the masks through the host): n_gpus {d['n_gpus']}, scaling {d['scaling']}, "
+              f"whole list verified vs oracle: {d['config']['verified_bit_exact_vs_oracle']}, CRC {d['config']['draw_list_crc32']}."]
+    ks = os.path.join(P, f"{tag}_bench_kernel_stats.csv")
+    if os.path.exists(ks):
+        st = stats(ks)
+        L += [f"* `{tag}_bench_kernel_stats.csv` (`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline "
+              f"--no-verify`): `cull_mask_tiled_kernel<unsigned char>` {k(st, 'cull_mask_tiled_kernel<unsigned char>')}; `mask_scan_kernel` {k(st, 'mask_scan_kernel')}; "
+              f"`expand_mask_u8_kernel<true, 0>` {k(st, 'expand_mask_u8_kernel<true, 0>')}; `emit_all_u8_kernel` {k(st, 'emit_all_u8_kernel')}; "
+              f"`tlas_build_indexed_kernel<VdTlasNode>` {k(st, 'tlas_build_indexed_kernel<VdTlasNode>')}; `blas_small_kernel` {k(st, 'blas_small_kernel')}."]
+    pm = os.path.join(P, f"{tag}_cull_pmc.json")
+    if os.path.exists(pm):
+        d = json.load(open(pm))
+        c, e = d.get("cull_mask_tiled_kernel", {}), d.get("expand_mask_u8_kernel", {})
+        if c:
+            tr = (2 * c["FETCH_SIZE_KB"] + c["WRITE_SIZE_KB"]) * 1024
+            L += [f"* `{tag}_cull_pmc.json` (+ `_fetch_size.csv`, `_write_size.csv`; separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of "
+                  f"`bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-extra`): `cull_mask_tiled_kernel` FETCH_SIZE {c['FETCH_SIZE_KB']:.0f} KB, "
+                  f"WRITE_SIZE {c['WRITE_SIZE_KB']:.0f} KB per launch -> traffic = 2 x FETCH + WRITE = {tr / 1e9:.4f} GB (gfx950: FETCH_SIZE counts 64 B per 128-B "
+                  f"request, MI355X_MICROARCH.md HBM section); `expand_mask_u8_kernel` WRITE_SIZE {e.get('WRITE_SIZE_KB', 0):.0f} KB."]
+    bv = os.path.join(P, f"{tag}_bvh_kernel_stats.csv")
+    if os.path.exists(bv):
+        st = stats(bv)
+        L += [f"* `{tag}_bvh_kernel_stats.csv` (`rocprofv3 --kernel-trace --stats -- python3 tools/bench_bvh.py --u 2048 --v 2048 --reps 2`; its stdout: "
+              f"`{tag}_bench_bvh.log`): `a_apply_kernel` {k(st, 'a_apply_kernel')}, `a_ranks_kernel` {k(st, 'a_ranks_kernel')}, `a_count_kernel` "
+              f"{k(st, 'a_count_kernel')}, `a_scan_kernel` {k(st, 'a_scan_kernel')}, `a_bin_kernel` {k(st, 'a_bin_kernel')}, `a_child_kernel` {k(st, 'a_child_kernel')}, "
+              f"`blas_mid_kernel` {k(st, 'blas_mid_kernel')}, `blas_small_kernel` {k(st, 'blas_small_kernel')}."]
+    for extra in sorted(glob.glob(os.path.join(P, f"{tag}_*.log"))):
+        base = os.path.basename(extra)
+        if base.endswith("bench_bvh.log") or base.split("_", 1)[1] not in NOTES:
+            continue
+        first = open(extra).readline().strip()
+        L += [f"* `{base}`: {NOTES.get(base.split('_', 1)[1], 'log')} - first line: `{first[:160]}`"]
+    return L + [""]
+
+
+NOTES = {
+    "pytest_gpu.log": "tail of `python -m pytest tests -q -m gpu --durations=8` on the GPU box",
+    "tlas_time.log": "`tools/tlas_time.py`: TLAS build ms at 32768 / 65536 for VD_TLAS_PHASE2 / VD_TLAS_REFRESH variants, bit-exactness vs oracle",
+    "tlas_index_profile.log": "`VD_TLAS_PROFILE=1 tools/tlas_time.py`: in-kernel cycle counts of the indexed TLAS build per query stage (4-wave form)",
+    "blas_levels.log": "`tools/gpu_prof_gaps.sh`: per-level span / busy time of phase A of one 8.4 M-triangle build, launch gaps",
+    "blas_big_tier_experiment.log": "measured and NOT kept: an LDS tier for 2049..8192-prim segments (in-kernel cycles per phase)",
+}
+
+
+def main():
+    head = open(os.path.join(P, "README.md")).read().split("<!-- generated below -->")[0].rstrip()
+    tags = sorted({os.path.basename(f).split("_")[0] for f in glob.glob(os.path.join(P, "r[0-9][0-9]_*"))} )
+    body = [head, "", "<!-- generated below -->", "",
+            "Everything below this line is written by `tools/make_profiles_readme.py` from the files it names.", ""]
+    for t in tags:
+        body += round_section(t)
+    open(os.path.join(P, "README.md"), "w").write("\n".join(body))
+    print("profiles/README.md: rounds", tags)
+
+
+if __name__ == "__main__":
+    main()
