@@ -20,6 +20,14 @@ def test_header_and_bindings_agree():
     assert declared_symbols() == sorted(abi.PROTOTYPES)
 
 
+def test_integration_md_binds_every_export():
+    """INTEGRATION.md section 2 (the Rust `extern "C"` block a maintainer adds) binds every function the header declares."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("<!-- ffi:begin -->"): doc.index("<!-- ffi:end -->")]
+    bound = sorted(set(re.findall(r"pub fn (vd_[a-z_0-9]+)\(", block)))
+    assert bound == declared_symbols()
+
+
 def test_library_exports_every_declared_symbol():
     lib = abi.load()
     for name in declared_symbols():

@@ -40,7 +40,7 @@ for r in range(args.reps + 1):
     print(f"  build {r}: {dt*1e3:.1f} ms  ({n_tri/dt/1e6:.1f} Mprims/s), nodes {n_nodes}, gpu_ms {ctx.last_gpu_ms():.1f}", flush=True)
 best = min(times)
 print(f"BLAS build: {n_tri} prims, best {best*1e3:.1f} ms = {n_tri/best/1e6:.1f} Mprims/s")
-# (parity against the oracle lives in tests/test_gpu_blas.py and tests/perf_verify_bvh.py; this tool only times)
+# (parity against the oracle lives in tests/test_gpu_blas.py and tests/test_gpu_full_size.py; this tool only times)
 
 # TLAS
 meshes = synth.mesh_infos()
