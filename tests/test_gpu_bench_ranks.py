@@ -24,7 +24,7 @@ def _bench(*argv, env=None):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("gather", ["full", "indices"])
+@pytest.mark.parametrize("gather", ["full", "indices", "draws", "shard"])
 def test_two_ranks_one_gpu_equal_single_gpu(gather):
     common = ["--instances", "3000001", "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline"]
     one = _bench("--gpus", "1", *common)
@@ -36,7 +36,9 @@ def test_two_ranks_one_gpu_equal_single_gpu(gather):
     assert set(two["extra"]["gather_modes"]) >= {"full", "draws", "indices", "shard"}
     assert one["config"]["verified_bit_exact_vs_oracle"] is True
     assert two["config"]["verified_bit_exact_vs_oracle"] is True
-    assert one["config"]["draw_list_crc32"] == two["config"]["draw_list_crc32"]
+    if gather != "shard":          # shard: every rank keeps its own list (rank 0's is checked against the oracle inside bench)
+        assert one["config"]["draw_list_crc32"] == two["config"]["draw_list_crc32"]
+    assert two["config"]["parallelism"].startswith("instance-shard x2") and f"gather={gather}" in two["config"]["parallelism"]
 
 
 def test_weak_scaling_mode_two_ranks():

@@ -19,6 +19,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python
 find $O/kt -name "*kernel_trace.csv" -delete
 cp $(find $O/kt -name "bench_kernel_stats.csv" | head -1) $O/${R}_bench_kernel_stats.csv
 head -4 $O/${R}_bench_kernel_stats.csv | cut -c1-200
+echo "== rocprof kernel stats (headline legs only: --no-extra)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kh -o head -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-verify --no-extra > $O/kh_stdout.log 2>&1
+find $O/kh -name "*kernel_trace.csv" -delete
+cp $(find $O/kh -name "head_kernel_stats.csv" | head -1) $O/${R}_bench_noextra_kernel_stats.csv
+head -3 $O/${R}_bench_noextra_kernel_stats.csv | cut -c1-200
 echo "== rocprof kernel stats (BVH side)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kb -o bvh -- python3 tools/bench_bvh.py --u 2048 --v 2048 --reps 2 > $O/kb_stdout.log 2>&1
 find $O/kb -name "*kernel_trace.csv" -delete
@@ -43,5 +48,5 @@ for d,c in [('pmc_fetch','FETCH_SIZE'),('pmc_write','WRITE_SIZE')]:
                 out.setdefault(kern,{})[c+'_KB']=sum(v)/len(v); out[kern][c+'_launches']=len(v)
 json.dump(out,open(f'gpurun_out/round/{R}_cull_pmc.json','w'),indent=1); print(out)
 PY
-rm -rf $O/kt $O/kb $O/pmc_fetch $O/pmc_write
+rm -rf $O/kt $O/kh $O/kb $O/pmc_fetch $O/pmc_write
 ls -la $O

@@ -71,6 +71,12 @@ def round_section(tag):
               f"--no-verify`): `cull_mask_tiled_kernel<unsigned char>` {k(st, 'cull_mask_tiled_kernel<unsigned char>')}; `mask_scan_kernel` {k(st, 'mask_scan_kernel')}; "
               f"`expand_mask_u8_kernel<true, 0>` {k(st, 'expand_mask_u8_kernel<true, 0>')}; `emit_all_u8_kernel` {k(st, 'emit_all_u8_kernel')}; "
               f"`tlas_build_indexed_kernel<VdTlasNode>` {k(st, 'tlas_build_indexed_kernel<VdTlasNode>')}; `blas_small_kernel` {k(st, 'blas_small_kernel')}."]
+    kh = os.path.join(P, f"{tag}_bench_noextra_kernel_stats.csv")
+    if os.path.exists(kh):
+        st = stats(kh)
+        L += [f"* `{tag}_bench_noextra_kernel_stats.csv` (the same with `--no-extra`: only the headline's launches, i.e. without the every-mesh-id-changes leg "
+              f"that runs the same kernel in its worse regime): `cull_mask_tiled_kernel<unsigned char>` {k(st, 'cull_mask_tiled_kernel<unsigned char>')}; "
+              f"`mask_scan_kernel` {k(st, 'mask_scan_kernel')}; `expand_mask_u8_kernel<true, 0>` {k(st, 'expand_mask_u8_kernel<true, 0>')}."]
     pm = os.path.join(P, f"{tag}_cull_pmc.json")
     if os.path.exists(pm):
         d = json.load(open(pm))
