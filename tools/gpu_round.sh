@@ -14,6 +14,8 @@ echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== bench"; timeout 900 python bench.py 2>&1 | grep -v amdgpu.ids | grep '^{' | tail -1 > $O/${R}_bench_line.json; cut -c1-400 $O/${R}_bench_line.json
 echo "== bench --gpus 2 (two ranks on this one GPU, gloo rendezvous: functional, the timing is not a scaling number)"
 VOIDIN_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 --no-extra 2>&1 | grep '^{' | tail -1 > $O/${R}_bench_line_2ranks_1gpu_gloo.json; cut -c1-300 $O/${R}_bench_line_2ranks_1gpu_gloo.json
+echo "== the driver's multi-GPU form: torch.distributed.run starts the ranks (here 2 on one GPU over gloo)"
+VOIDIN_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-extra --gather shard 2>&1 | grep '^{' | tail -1 > $O/${R}_bench_line_torchrun_2ranks_shard.json; cut -c1-300 $O/${R}_bench_line_torchrun_2ranks_shard.json
 echo "== rocprof kernel stats (bench)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-verify > $O/kt_stdout.log 2>&1
 find $O/kt -name "*kernel_trace.csv" -delete
