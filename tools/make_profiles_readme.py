@@ -64,6 +64,12 @@ def round_section(tag):
         L += [f"* `{tag}_bench_line_2ranks_1gpu_gloo.json` (`VOIDIN_DIST_BACKEND=gloo python bench.py --gpus 2 ...`, two ranks sharing the one GPU: "
               f"functional evidence of the launcher, NOT a scaling number - gloo moves the masks through the host): n_gpus {d['n_gpus']}, scaling {d['scaling']}, "
               f"whole list verified vs oracle: {d['config']['verified_bit_exact_vs_oracle']}, CRC {d['config']['draw_list_crc32']}."]
+    b3 = os.path.join(P, f"{tag}_bench_line_torchrun_2ranks_shard.json")
+    if os.path.exists(b3):
+        d = json.load(open(b3))
+        L += [f"* `{tag}_bench_line_torchrun_2ranks_shard.json` (the driver's multi-GPU form, `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 "
+              f"--master-addr 127.0.0.1 ... bench.py --gpus 2 --gather shard`, again two ranks on the one GPU over gloo): n_gpus {d['n_gpus']}, "
+              f"{d['ms_per_step']} ms/step with both ranks' kernels sharing the device, rank 0's shard list verified vs oracle: {d['config']['verified_bit_exact_vs_oracle']}."]
     ks = os.path.join(P, f"{tag}_bench_kernel_stats.csv")
     if os.path.exists(ks):
         st = stats(ks)
