@@ -120,6 +120,26 @@ __device__ __forceinline__ vd_u64 wave_min_u64(vd_u64 v) {
     return v;
 }
 
+// Wave minimum of a 64-bit key without the LDS crossbar: all-reduce inside each 16-lane row (DPP), then row_bcast:15 folds
+// row 0 into 1 and 2 into 3, row_bcast:31 folds rows 0-1 into 2-3, and lane 63 holds the minimum (two readlanes make it
+// uniform).  The ds_bpermute steps of wave_min_u64 cost an LDS round trip each, and the chain pays for every one.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ vd_u64 dpp_u64_rows(vd_u64 v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)v, (int)(unsigned)v, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(v >> 32), (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((vd_u64)hi << 32) | lo;
+}
+__device__ __forceinline__ vd_u64 ix_wave_min(vd_u64 v) {
+    vd_u64 o;
+    o = dpp_u64<0xB1>(v); v = o < v ? o : v;
+    o = dpp_u64<0x4E>(v); v = o < v ? o : v;
+    o = dpp_u64<0x141>(v); v = o < v ? o : v;
+    o = dpp_u64<0x140>(v); v = o < v ? o : v;                    // every lane: minimum of its row
+    o = dpp_u64_rows<0x142, 0xa>(v); v = o < v ? o : v;            // row_bcast:15 into rows 1 and 3
+    o = dpp_u64_rows<0x143, 0xc>(v); v = o < v ? o : v;            // row_bcast:31 into rows 2 and 3
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((vd_u64)hi << 32) | lo;
+}
+
 // tlas.rs:87-105 over the compacted slot arrays; every thread returns the same slot.
 // A scan is bound by VALU issue on the one CU that runs the chain (16 k slots x ~50 instructions / 64 lanes per
 // clock ~ 5 us), not by the 24 B per slot it streams from L2, so the per-slot arithmetic is what counts.
@@ -185,7 +205,7 @@ __device__ __forceinline__ unsigned find_best_match(const float* sb, unsigned ca
     // one barrier per scan: every wave leaves its key in its own word (two-deep by scan parity, so the words of this
     // scan are not rewritten before everybody has read them) and every wave reduces the 16 words itself, in one DPP row
     if (FAST && fbits != 0xffffffffu) best = match_key(__uint_as_float(fbits), fslot);
-    best = wave_min_u64(best);
+    best = ix_wave_min(best);
     vd_u64* words = s_red + (call & 1u) * 16u;
     if (lane == 0) words[tid >> 6] = best;
     __syncthreads();
@@ -681,7 +701,7 @@ __device__ __forceinline__ IxHit ix_query(const IxEntry* entries, const IxLds& L
     IxLane mine{~0ull, 0u, float4{0, 0, 0, 0}, float4{0, 0, 0, 0}};
     if (!(bound == bound)) {                              // no candidate known: the target's own block supplies one
         ix_eval(mine, entries, (e_t / kIxBlock) * kIxBlock + lane, t_slot, tb);
-        const vd_u64 m = wave_min_u64(mine.key);
+        const vd_u64 m = ix_wave_min(mine.key);
         bound = __uint_as_float((unsigned)(m >> 32));     // 0xffffffff reads back as NaN: still none
         if (prof && tid == 0u) prof->own += 1;
     }
@@ -745,7 +765,7 @@ __device__ __forceinline__ IxHit ix_query(const IxEntry* entries, const IxLds& L
     }
     long long t2 = 0;
     if (prof) { t2 = clock64(); }
-    const vd_u64 m = wave_min_u64(mine.key);
+    const vd_u64 m = ix_wave_min(mine.key);
     if (m == ~0ull) {
         if (lane == 0u) sh->res_key[p][wave] = ~0ull;
     } else if (mine.key == m) {                           // slots are unique: exactly one lane
@@ -754,14 +774,23 @@ __device__ __forceinline__ IxHit ix_query(const IxEntry* entries, const IxLds& L
         sh->res_box[p][wave][3] = mine.hi.x; sh->res_box[p][wave][4] = mine.hi.y; sh->res_box[p][wave][5] = mine.hi.z;
     }
     __syncthreads();
-    unsigned w = 0;
-    vd_u64 best = sh->res_key[p][0];
+    // lane w < 4 fetches wave w's whole record in one LDS phase; the winner's fields are then read out of its lane
+    const unsigned rw = lane & 3u;
+    vd_u64 rkey = sh->res_key[p][rw];
+    const unsigned re = sh->res_e[p][rw], rnode = sh->res_node[p][rw];
+    float rbox[6];
 #pragma unroll
-    for (unsigned k = 1; k < 4u; ++k) { const vd_u64 o = sh->res_key[p][k]; if (o < best) { best = o; w = k; } }
+    for (int k = 0; k < 6; ++k) rbox[k] = sh->res_box[p][rw][k];
+    vd_u64 best = rkey, o;
+    o = dpp_u64<0xB1>(best); best = o < best ? o : best;
+    o = dpp_u64<0x4E>(best); best = o < best ? o : best;          // minimum over the quad = over the four waves
+    const unsigned long long who = __ballot(rkey == best);
+    const int w = (int)__builtin_ctzll(who);                       // first wave that holds it (ties carry identical records)
     IxHit h;
-    h.key = best; h.e = sh->res_e[p][w]; h.node = sh->res_node[p][w];
+    h.key = ((vd_u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(best >> 32), 0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)best, 0);
+    h.e = (unsigned)__builtin_amdgcn_readlane((int)re, w); h.node = (unsigned)__builtin_amdgcn_readlane((int)rnode, w);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) h.box[k] = sh->res_box[p][w][k];
+    for (int k = 0; k < 6; ++k) h.box[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox[k]), w));
     if (prof && tid == 0u) {
         const long long t3 = clock64();
         prof->t_bounds += (unsigned long long)(t1 - t0); prof->t_entries += (unsigned long long)(t2 - t1); prof->t_reduce += (unsigned long long)(t3 - t2);
