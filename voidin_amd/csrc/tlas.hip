@@ -713,15 +713,17 @@ __device__ __forceinline__ IxHit ix_query(const IxEntry* entries, const IxLds& L
     const unsigned n1 = L.n_super <= 64u ? ix_supers<1>(L, tb, have, bound, my1, lane)
                       : (L.n_super <= 128u ? ix_supers<2>(L, tb, have, bound, my1, lane) : ix_supers<4>(L, tb, have, bound, my1, lane));
     vd_wave_lds_sync();
-    // slices of the surviving super-slices: item i is dealt to wave i % 4 (neighbouring slices survive together)
+    // slices of the surviving super-slices: item i is dealt to wave i % 4 (neighbouring slices survive together).  Up to 16
+    // surviving super-slices (the usual case) are one round of 64 lanes per wave; more go two rounds at a time.
     const unsigned items1 = n1 * kIxSuper;
     unsigned n2 = 0;
-    for (unsigned base = 0; base < items1; base += 512u) {
-        float lb[2];
-        bool in[2];
-        unsigned sl[2];
+    auto slices = [&](auto rounds, unsigned base) {
+        constexpr int R = decltype(rounds)::value;
+        float lb[R];
+        bool in[R];
+        unsigned sl[R];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) {
             const unsigned item = base + (64u * r + lane) * 4u + wave;
             in[r] = item < items1;
             sl[r] = in[r] ? (unsigned)my1[item / kIxSuper] * kIxSuper + (item % kIxSuper) : 0u;
@@ -730,13 +732,15 @@ __device__ __forceinline__ IxHit ix_query(const IxEntry* entries, const IxLds& L
             lb[r] = ix_lower_bound(tb, L.slice[2u * sc], L.slice[2u * sc + 1u]);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) {
             const bool keep = in[r] && (!have || lb[r] <= bound);
             const unsigned long long mask = __ballot(keep);
             if (keep) my2[n2 + vd_mbcnt(mask)] = (unsigned short)sl[r];
             n2 += (unsigned)__popcll(mask);
         }
-    }
+    };
+    if (items1 <= 256u) { if (items1) slices(std::integral_constant<int, 1>{}, 0u); }
+    else for (unsigned base = 0; base < items1; base += 512u) slices(std::integral_constant<int, 2>{}, base);
     vd_wave_lds_sync();
     long long t1 = 0;
     if (prof) t1 = clock64();
