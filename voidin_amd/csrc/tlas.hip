@@ -6,13 +6,15 @@
 //
 //  * leaf boxes (tlas.rs:34-54): one lane per instance, 8 transformed corners folded with the
 //    object-space mesh box as seed (bug-compatible), total-order min/max;
-//  * build (tlas.rs:56-84): the reference is a sequential chain of ~2.5 N `find_best_match`
-//    scans whose tie-breaking depends on the slot order, so the chain itself cannot be
-//    reordered.  One 1024-lane workgroup runs the chain (16 of them from 12288 instances on, see
-//    "build, several workgroups"); each scan is data-parallel over the
-//    active slots, which are kept as a compacted SoA (six float arrays + node ids) so a scan is
-//    a pure stream of 24 B per slot; the argmin is a 64-bit {area bits, slot} key reduced by
-//    DPP / wave shuffles + per-wave LDS words, which reproduces "strict <, first slot wins";
+//  * build (tlas.rs:56-84): the reference is a sequential chain of ~3 N `find_best_match` calls whose tie-breaking
+//    depends on the slot order, so the chain itself cannot be reordered; what is made cheap is ONE call:
+//      - 4096 <= n <= 65536 ("build, indexed"): a call is an exact nearest-neighbour query through a spatial index
+//        (inner-corner lower bounds over Morton-ordered groups, pruned against a bound the chain supplies); one
+//        256-lane workgroup, cost independent of n;
+//      - otherwise a scan of all active slots, kept as a compacted SoA (six float arrays + node ids) so that a scan is a
+//        pure stream of 24 B per slot, by one 1024-lane workgroup below 4096 instances and by 16 of them above 65536
+//        ("build, several workgroups"); the argmin is a 64-bit {area bits, slot} key reduced by DPP / wave shuffles + per-wave LDS
+//        words, which reproduces "strict <, first slot wins";
 //  * refit: leaves recomputed, interior boxes by a bottom-up walk with per-node handshake counters
 //    (write-through agent-scope stores, no fences; boxes re-read L1/L2-bypassing).
 #include "vd_common.hpp"
