@@ -354,3 +354,23 @@ def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, monkeypatch)
         want, got = oracle.tlas_build(inst, meshes), ctx.tlas_build(inst, meshes)
         assert got["left_right"].tobytes() == want["left_right"].tobytes()
         assert got["min"].view(np.uint32).tobytes() == want["min"].view(np.uint32).tobytes() and got["max"].view(np.uint32).tobytes() == want["max"].view(np.uint32).tobytes()
+
+
+def test_indexed_build_declines_when_every_area_ties(ctx, oracle):
+    """Boxes that defeat the pruning (thousands of identical instances; a nest of boxes that all contain the origin cube):
+    every union area ties, a query through the index would look into most slices, so the indexed build declines on the
+    device and the plain chain queued behind it (16 workgroups at this size) starts over.  Same nodes as the oracle."""
+    import time
+    n = 13000
+    same = np.tile(np.array([[-1, -2, -3, 1, 2, 3]], np.float32), (n, 1))
+    rng = np.random.default_rng(3)
+    r = (1.0 + rng.random((n, 1)) * 50).astype(np.float32)
+    nest = np.concatenate([-r, -r, -r, r, r, r], axis=1).astype(np.float32)          # cubes around the origin: totally ordered by inclusion
+    for boxes in (same, nest):
+        inst, meshes = _boxes_as_scene(boxes)
+        want = oracle.tlas_build(inst, meshes)
+        t = time.perf_counter()
+        got = ctx.tlas_build(inst, meshes)
+        dt = time.perf_counter() - t
+        assert fields_equal(got, want)
+        assert dt < 3.0, f"{dt:.1f} s: the build did not fall back to the plain chain"

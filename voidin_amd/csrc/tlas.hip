@@ -468,7 +468,9 @@ __device__ __forceinline__ void mw_build_chain(Node* __restrict__ nodes, unsigne
 
 template <typename Node>
 __global__ __launch_bounds__(kMwThreads) void tlas_build_mw_kernel(Node* __restrict__ nodes, unsigned n, float* sb,
-                                                                      unsigned* slot_node, unsigned cap, MwShared* sh, unsigned spin_limit) {
+                                                                      unsigned* slot_node, unsigned cap, MwShared* sh, unsigned spin_limit,
+                                                                      const unsigned* __restrict__ only_if) {
+    if (only_if && *only_if == 0u) return;                  // queued behind the indexed build: only when that one declined
     __shared__ vd_u64 s_red[34];   // [2][16] per-wave keys by scan parity, [32 + parity] the exchanged result
     if (threadIdx.x < 34) s_red[threadIdx.x] = ~0ull;
     int nan = 0;
@@ -626,9 +628,10 @@ struct IxShared {
     vd_u64 res_key[2][4];                                // by query parity: a wave may start the next query before the
     unsigned res_e[2][4], res_node[2][4];                // others have read this one's result
     float res_box[2][4][6];
+    unsigned work;                                       // slices looked into since the last check (the build declines when pruning fails)
     vd_u64 red[32];                                      // s_red of the plain chain (phase 2)
 };
-struct IxHit { vd_u64 key; unsigned e, node; float box[6]; };
+struct IxHit { vd_u64 key; unsigned e, node, slices; float box[6]; };   // slices: of the CALLING wave (the only field that differs between waves)
 // list1 / list2: per-wave survivor lists (every wave owns a quarter of each array)
 struct IxLds { IxShared* sh; float4* slice; float4* super; unsigned short* list1; unsigned short* list2; unsigned n_slices, n_super, cap1, cap2; };
 struct IxProf { unsigned long long t_bounds, t_entries, t_reduce, t_merge, t_refresh, queries, own, n1, n2; };
@@ -795,6 +798,7 @@ __device__ __forceinline__ IxHit ix_query(const IxEntry* entries, const IxLds& L
     IxHit h;
     h.key = ((vd_u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(best >> 32), 0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)best, 0);
     h.e = (unsigned)__builtin_amdgcn_readlane((int)re, w); h.node = (unsigned)__builtin_amdgcn_readlane((int)rnode, w);
+    h.slices = n2;
 #pragma unroll
     for (int k = 0; k < 6; ++k) h.box[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox[k]), w));
     if (prof && tid == 0u) {
@@ -843,7 +847,7 @@ static size_t ix_lds_bytes(unsigned n_slices, unsigned n_super) {
 template <typename Node>
 __global__ __launch_bounds__(kIxThreads) void tlas_build_indexed_kernel(Node* __restrict__ nodes, unsigned n, IxEntry* entries, unsigned* slot_ent,
                                                                         unsigned E, float* sb, unsigned* slot_node, unsigned cap,
-                                                                        const IxCtl* ctl, unsigned phase2_cnt, unsigned refresh_every, int profile) {
+                                                                        IxCtl* ctl, unsigned phase2_cnt, unsigned refresh_every, int profile) {
     if (ctl->ok == 0u) return;                            // precondition failed: the plain chain is queued behind
     extern __shared__ __attribute__((aligned(16))) char smem[];
     IxLds L;
@@ -874,8 +878,16 @@ __global__ __launch_bounds__(kIxThreads) void tlas_build_indexed_kernel(Node* __
         box_a[0] = lo.x; box_a[1] = lo.y; box_a[2] = lo.z; box_a[3] = hi.x; box_a[4] = hi.y; box_a[5] = hi.z;
     }
     const float kNone = __uint_as_float(0x7fc00000u);
+    // Pruning needs slack between the areas: when the targets' bounds keep most slices alive (identical or deeply nested
+    // boxes - every union area ties) a query through the index costs more than a plain scan.  The build then declines:
+    // it sets the fallback flag and returns, and the plain chain queued behind it starts over from the leaves (it rewrites
+    // every node this kernel wrote; the slot arrays were not touched).
+    unsigned work = 0;                                    // per wave; the four are added up at a check
+    unsigned next_check = 256u, last_check = 0u;
+    if (tid == 0u) L.sh->work = 0u;
     auto take = [&](const IxHit& h, unsigned t_slot, unsigned e_t, unsigned node_t, const float (&tb)[6], unsigned& o_slot, unsigned& o_e,
                     unsigned& o_node, float (&o_box)[6]) {
+        work += h.slices;
         if (h.key == ~0ull) {                             // nothing: find_best_match returns the target (tlas.rs:89)
             o_slot = t_slot; o_e = e_t; o_node = node_t;
 #pragma unroll
@@ -888,6 +900,18 @@ __global__ __launch_bounds__(kIxThreads) void tlas_build_indexed_kernel(Node* __
     };
     take(ix_query(entries, L, q++, a, box_a, ea, kNone, prof), a, ea, node_a, box_a, b, eb, node_b, box_b);
     while (cnt > phase2_cnt) {
+        if (q >= next_check) {                              // every ~256 queries: more than an eighth of all slices per query?
+            if ((tid & 63u) == 0u) atomicAdd(&L.sh->work, work);
+            __syncthreads();
+            const unsigned total = L.sh->work;
+            __syncthreads();
+            if ((unsigned long long)total > (unsigned long long)(L.n_slices / 8u + 1u) * (q - last_check)) {
+                if (tid == 0u) { ctl->fallback = 1u; ctl->ok = 0u; }
+                return;
+            }
+            if (tid == 0u) L.sh->work = 0u;                 // the next add is 256 queries (and as many barriers) away
+            work = 0; last_check = q; next_check = q + 256u;
+        }
         float bound = kNone;
         if (!a_stale) bound = ix_union_area(box_b, box_a);                        // a is a live candidate of best(b)
         else if (have_prev && e_prev != eb) bound = ix_union_area(box_b, box_prev);
@@ -1118,17 +1142,28 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
                            entries, slot_ent, ctl);
         hipLaunchKernelGGL((tlas_build_indexed_kernel<Node>), dim3(1), dim3(kIxThreads), lds, ctx->stream, d_nodes, n, entries, slot_ent, E, sb,
                            slot_node, (unsigned)cap, ctl, phase2, refresh, getenv("VD_TLAS_PROFILE") ? 1 : 0);
-        // leaf coordinates the fast arithmetic cannot order (NaN, inf, |x| >= 1e18): decided on the device, the plain chain
-        // runs instead (the indexed kernel returned at once and left the slot arrays as the leaves kernel wrote them)
-        hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
-                           (unsigned)cap, (const unsigned*)&ctl->fallback);
+        // Decided on the device: leaf coordinates the fast arithmetic cannot order (NaN, inf, |x| >= 1e18), or boxes that
+        // defeat the pruning (all union areas tie).  The indexed kernel then returned early and left the slot arrays as the
+        // leaves kernel wrote them; the plain chain runs instead - on 16 workgroups where that pays, with ITS redo behind it.
+        if (groups <= 1u) {
+            hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
+                               (unsigned)cap, (const unsigned*)&ctl->fallback);
+        } else {
+            VD_HIP_CHECK(ctx, hipMemsetAsync(sh, 0, sizeof(MwShared), ctx->stream));
+            hipLaunchKernelGGL((tlas_build_mw_kernel<Node>), dim3(groups * 8u), dim3(kMwThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
+                               (unsigned)cap, sh, spin_limit, (const unsigned*)&ctl->fallback);
+            hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
+                               n_mesh, d_nodes, sb, slot_node, (unsigned)cap, 0, (const unsigned*)&sh->fail);
+            hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
+                               (unsigned)cap, (const unsigned*)&sh->fail);
+        }
     } else if (groups <= 1u) {
         hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
                            (unsigned)cap, (const unsigned*)nullptr);
     } else {
         VD_HIP_CHECK(ctx, hipMemsetAsync(sh, 0, sizeof(MwShared), ctx->stream));
         hipLaunchKernelGGL((tlas_build_mw_kernel<Node>), dim3(groups * 8u), dim3(kMwThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
-                           (unsigned)cap, sh, spin_limit);
+                           (unsigned)cap, sh, spin_limit, (const unsigned*)nullptr);
         // If the workgroups did not hear from each other in time (not co-resident: spin limit) they set sh->fail and
         // leave; the two launches below then redo the build on one workgroup, and return at once otherwise - decided
         // on the device, so the call stays asynchronous.  Every node a build writes is written again by the redo.
