@@ -51,7 +51,11 @@ constexpr int kSmallMax = VD_SMALL_MAX;  // largest segment built by one wave ou
 constexpr int kChunks = kSmallMax / 64;
 constexpr int kCand = 21;               // 3 axes x 7 planes (blas.rs:144-145; `bins` hard-coded to 8)
 constexpr int kBig = 0x7fffffff;
-constexpr int kItem = 1024;             // phase A: positions per workgroup item (256 lanes x 4)
+#ifndef VD_ITEM
+#define VD_ITEM 1024
+#endif
+constexpr int kItem = VD_ITEM;          // phase A: positions per workgroup item (256 lanes x kPer)
+constexpr int kPer = kItem / 256;       // positions per lane: position = rel0 + wave * (kItem / 4) + j * 64 + lane
 constexpr int kBinItems = 8;            // a_bin_kernel: consecutive items per workgroup
 #ifndef VD_MID_MAX
 #define VD_MID_MAX 2048
@@ -1178,12 +1182,12 @@ __device__ __forceinline__ Window round_window(const Seg* sg, int r) {
 
 // predicates of the item's positions that lie in the shuffled window (positions below `act` stay out of the ballots)
 __device__ __forceinline__ void item_masks(const Seg* sg, const ItemCtx& ic, const u32x2* __restrict__ pay, int c,
-                                           unsigned act, unsigned long long (&masks)[4], u32x2 (&vals)[4]) {
+                                           unsigned act, unsigned long long (&masks)[kPer], u32x2 (&vals)[kPer]) {
     const unsigned cc = c >= 0 ? (unsigned)c : sg->best;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned x = wave * 256u + j * 64u + lane;
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned x = wave * (unsigned)(kItem / 4) + j * 64u + lane;
         bool p = false;
         if (x < ic.n_here && ic.rel0 + x >= act) {
             vals[j] = pay[sg->start + ic.rel0 + x];
@@ -1201,11 +1205,11 @@ __global__ __launch_bounds__(256) void a_count_kernel(const Seg* segs, const uns
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     const Window win = round_window(sg, c >= 0 ? c : kCand);
     if (ic.rel0 + ic.n_here <= win.act) { if (threadIdx.x == 0) item_cnt[blockIdx.x] = 0u; return; }   // wholly frozen
-    unsigned long long masks[4]; u32x2 vals[4];
+    unsigned long long masks[kPer]; u32x2 vals[kPer];
     item_masks(sg, ic, pay, c, win.act, masks, vals);
     unsigned t = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t += (unsigned)__popcll(masks[j]);
+    for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
     if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = t;
     __syncthreads();
     if (threadIdx.x == 0) item_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
@@ -1260,12 +1264,12 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     const Window win = round_window(sg, c >= 0 ? c : kCand);
     if (ic.rel0 + ic.n_here <= win.act) return;             // wholly frozen
-    unsigned long long masks[4]; u32x2 vals[4];
+    unsigned long long masks[kPer]; u32x2 vals[kPer];
     item_masks(sg, ic, pay, c, win.act, masks, vals);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned t = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t += (unsigned)__popcll(masks[j]);
+    for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
     if (lane == 0u) s_w[wave] = t;
     __syncthreads();
     unsigned run = item_pre[blockIdx.x] - item_pre[sg->item_first];
@@ -1273,8 +1277,8 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
     // positions and table indices are relative to the window [act, n); the tables of the window start at s + act
     const unsigned ttot = sg->ttot_cur, s = sg->start + win.act;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned xr = wave * 256u + j * 64u + lane;
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
         if (xr < ic.n_here && ic.rel0 + xr >= win.act) {
             const unsigned x = ic.rel0 + xr - win.act;
             const bool p = (masks[j] >> lane) & 1ull;
@@ -1300,17 +1304,17 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // the band the previous round froze: straight copy, so that `dst` holds the whole arrangement
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned xr = wave * 256u + j * 64u + lane, xa = ic.rel0 + xr;
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane, xa = ic.rel0 + xr;
         if (xr < ic.n_here && xa >= win.band && xa < win.act) dst[sg->start + xa] = src[sg->start + xa];
     }
     if (ic.rel0 + ic.n_here <= win.act) return;
     // predicates and TL are recomputed from the payload (cheaper than a per-position word through HBM)
-    unsigned long long masks[4]; u32x2 vals[4];
+    unsigned long long masks[kPer]; u32x2 vals[kPer];
     item_masks(sg, ic, src, c, win.act, masks, vals);
     unsigned t = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t += (unsigned)__popcll(masks[j]);
+    for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
     if (lane == 0u) s_w[wave] = t;
     __syncthreads();
     unsigned run = item_pre[blockIdx.x] - item_pre[sg->item_first];
@@ -1318,8 +1322,8 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     // everything below is partition_shuffle on the window [act, n): positions relative to act
     const unsigned n = sg->count - win.act, s = sg->start + win.act, ttot = sg->ttot_cur, ftot = n - ttot;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned xr = wave * 256u + j * 64u + lane;
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
         if (xr < ic.n_here && ic.rel0 + xr >= win.act) {
             const unsigned x = ic.rel0 + xr - win.act;
             const bool p = (masks[j] >> lane) & 1ull;
