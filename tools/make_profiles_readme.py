@@ -114,6 +114,7 @@ NOTES = {
     "tlas_time.log": "`tools/tlas_time.py`: TLAS build ms at 32768 / 65536 for VD_TLAS_PHASE2 / VD_TLAS_REFRESH variants, bit-exactness vs oracle",
     "tlas_index_profile.log": "`VD_TLAS_PROFILE=1 tools/tlas_time.py`: in-kernel cycle counts of the indexed TLAS build per query stage (4-wave form)",
     "blas_levels.log": "`tools/gpu_prof_gaps.sh`: per-level span / busy time of phase A of one 8.4 M-triangle build, launch gaps",
+    "expand_pipe_experiment.log": "measured and NOT kept: persistent register-prefetch form of the 80 M-instance expansion",
     "blas_item_sweep.log": "phase A item size sweep (`-DVD_ITEM`), 8.4 M triangles",
     "blas_big_tier_experiment.log": "measured and NOT kept: an LDS tier for 2049..8192-prim segments (in-kernel cycles per phase)",
 }
