@@ -130,16 +130,28 @@ template <int CTRL, int ROW_MASK> __device__ __forceinline__ vd_u64 dpp_u64_rows
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(v >> 32), (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
     return ((vd_u64)hi << 32) | lo;
 }
+// Minimum of a 32-bit value over the wave, in every lane's scalar copy: six v_min_u32 with a DPP operand (the compiler
+// folds the move into the min: lanes without a source keep the identity), the result read from lane 63.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned dpp_min_u32(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned ix_wave_min_u32(unsigned v) {
+    v = dpp_min_u32<0x111, 0xf>(v);                                // row_shr:1
+    v = dpp_min_u32<0x112, 0xf>(v);                                // row_shr:2
+    v = dpp_min_u32<0x114, 0xf>(v);                                // row_shr:4
+    v = dpp_min_u32<0x118, 0xf>(v);                                // row_shr:8   -> lane 15 of a row: its minimum
+    v = dpp_min_u32<0x142, 0xa>(v);                                // row_bcast:15 into rows 1 and 3
+    v = dpp_min_u32<0x143, 0xc>(v);                                // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Minimum of {area bits, slot} keys: first the area, then the slot among the lanes that hold it - twelve one-instruction
+// steps instead of six five-instruction 64-bit ones (this sits on the chain's critical path, twice per scan).
 __device__ __forceinline__ vd_u64 ix_wave_min(vd_u64 v) {
-    vd_u64 o;
-    o = dpp_u64<0xB1>(v); v = o < v ? o : v;
-    o = dpp_u64<0x4E>(v); v = o < v ? o : v;
-    o = dpp_u64<0x141>(v); v = o < v ? o : v;
-    o = dpp_u64<0x140>(v); v = o < v ? o : v;                    // every lane: minimum of its row
-    o = dpp_u64_rows<0x142, 0xa>(v); v = o < v ? o : v;            // row_bcast:15 into rows 1 and 3
-    o = dpp_u64_rows<0x143, 0xc>(v); v = o < v ? o : v;            // row_bcast:31 into rows 2 and 3
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-    return ((vd_u64)hi << 32) | lo;
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned m_hi = ix_wave_min_u32(hi);
+    const unsigned m_lo = ix_wave_min_u32(hi == m_hi ? lo : 0xffffffffu);
+    return ((vd_u64)m_hi << 32) | m_lo;
 }
 
 // tlas.rs:87-105 over the compacted slot arrays; every thread returns the same slot.
@@ -509,10 +521,11 @@ __global__ __launch_bounds__(kMwThreads) void tlas_build_mw_kernel(Node* __restr
 // otherwise the plain chain above runs.  tests/cpp/tlas_index_model.cpp restates this algorithm on the CPU and
 // tests/test_tlas_index_model.py checks it against the literal oracle, ties, nesting and stale slots included.
 //
-// One 256-lane workgroup (a wave per SIMD) runs the chain; a query is three barriers: super-slice bounds -> slice
-// bounds -> surviving entries -> minimum.  When cnt falls to kIxPhase2 the plain scan takes over (few, large clusters:
-// every group overlaps every target).
-constexpr int kIxThreads = 256;
+// One workgroup runs the chain: four waves (one per SIMD) answer a query - super-slice bounds -> slice bounds ->
+// surviving entries -> minimum, through wave-private lists and ONE barrier - and four more answer, at the same time, the
+// query that follows if this one ends in a merge (ix_query).  When cnt falls to kIxPhase2 the plain scan takes over (few,
+// large clusters: every group overlaps every target).
+constexpr int kIxGroup = 4;              // waves per question; profiles/r02_tlas_group_sweep.txt has 1 / 2 / 4 with and without helpers
 constexpr unsigned kIxSlice = 16u, kIxSuper = 16u, kIxBlock = 64u, kIxDead = 0xffffffffu;
 constexpr unsigned kIxMaxInstances = 65536u;         // slice corners of 65536 entries fill 128 KB of the 160 KB LDS
 constexpr int kSortThreads = 512;
@@ -624,10 +637,10 @@ __global__ __launch_bounds__(kSortThreads) void tlas_index_kernel(const float* _
     }
 }
 
+struct __attribute__((aligned(16))) IxRec { vd_u64 key; unsigned e, node; float box[8]; };   // three 16-byte LDS accesses
 struct IxShared {
-    vd_u64 res_key[2][4];                                // by query parity: a wave may start the next query before the
-    unsigned res_e[2][4], res_node[2][4];                // others have read this one's result
-    float res_box[2][4][6];
+    IxRec res[2][8];                                     // by query parity: a wave may start the next query before the others
+                                                         // have read this one's result; [4..7]: the helper waves' records
     unsigned work;                                       // slices looked into since the last check (the build declines when pruning fails)
     vd_u64 red[32];                                      // s_red of the plain chain (phase 2)
 };
@@ -696,122 +709,157 @@ __device__ __forceinline__ unsigned ix_supers(const IxLds& L, const float (&tb)[
 // ONE workgroup barrier per query: every wave works out the surviving super-slices by itself (their corners sit in LDS:
 // the same few reads in all four waves), then takes a quarter of their slices, then the entries of the slices ITS
 // quarter left over - through wave-private lists, no cross-wave hand-off until the four minima meet.
-__device__ __forceinline__ IxHit ix_query(const IxEntry* entries, const IxLds& L, unsigned q, unsigned t_slot, const float (&tb)[6],
-                                          unsigned e_t, float bound, IxProf* prof) {
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+// Speculation (round 2): when the chain asks c = best(b) it already knows what it will ask next IF c turns out to be a:
+// best(a ∪ b), bounded by the previous chain element.  Waves 4-7 answer THAT question meanwhile, on the state the merge
+// will leave behind: the entries of a and b are left out (a ∪ b is the target, b dies), and the entry that holds the last
+// slot counts as slot b (tlas.rs:75 moves it there) - the only things a merge changes.  The corners of the groups are the
+// same for both (a merged box contains every corner its parts contained), so the answer is the one the query after the
+// merge would give, and the chain takes it without asking.  About a third of all queries follow a merge.
+struct IxSpec { float box[6]; float bound; unsigned ea, eb, last, b; bool valid; };
+struct IxPair { IxHit main, spec; };
+template <int G, bool SPEC>
+__device__ __forceinline__ IxPair ix_query(const IxEntry* entries, const IxLds& L, unsigned q, unsigned t_slot, const float (&tb)[6],
+                                           unsigned e_t, float bound, IxProf* prof, const IxSpec& spec) {
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool helper = SPEC && wave >= (unsigned)G;
+    const unsigned w4 = helper ? wave - (unsigned)G : wave, ri = helper ? 4u + w4 : w4;
     IxShared* sh = L.sh;
     const unsigned p = q & 1u;
     long long t0 = 0;
     if (prof) t0 = clock64();
+    // this wave's question (uniform per wave)
+    float box[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) box[k] = helper ? spec.box[k] : tb[k];
+    float bnd = helper ? spec.bound : bound;
+    const unsigned not_slot = helper ? 0xfffffffeu : t_slot;          // the target, by slot ...
+    const unsigned not_e1 = helper ? spec.ea : 0xffffffffu, not_e2 = helper ? spec.eb : 0xffffffffu;   // ... or by entry
+    const unsigned from_slot = helper ? spec.last : 0xfffffffeu, to_slot = spec.b;
+    const bool active = !helper || spec.valid;
     IxLane mine{~0ull, 0u, float4{0, 0, 0, 0}, float4{0, 0, 0, 0}};
-    if (!(bound == bound)) {                              // no candidate known: the target's own block supplies one
-        ix_eval(mine, entries, (e_t / kIxBlock) * kIxBlock + lane, t_slot, tb);
-        const vd_u64 m = ix_wave_min(mine.key);
-        bound = __uint_as_float((unsigned)(m >> 32));     // 0xffffffff reads back as NaN: still none
-        if (prof && tid == 0u) prof->own += 1;
-    }
-    const bool have = bound == bound;
     unsigned short* my1 = L.list1 + wave * L.cap1;
     unsigned short* my2 = L.list2 + wave * L.cap2;
-    // One wave per SIMD: nothing hides latency but the wave's own independent instructions, so every stage first issues
-    // all its loads and evaluates up to four items per lane side by side, and only then does the (serial) bookkeeping.
-    const unsigned n1 = L.n_super <= 64u ? ix_supers<1>(L, tb, have, bound, my1, lane)
-                      : (L.n_super <= 128u ? ix_supers<2>(L, tb, have, bound, my1, lane) : ix_supers<4>(L, tb, have, bound, my1, lane));
-    vd_wave_lds_sync();
-    // slices of the surviving super-slices: item i is dealt to wave i % 4 (neighbouring slices survive together).  Up to 16
-    // surviving super-slices (the usual case) are one round of 64 lanes per wave; more go two rounds at a time.
-    const unsigned items1 = n1 * kIxSuper;
     unsigned n2 = 0;
-    auto slices = [&](auto rounds, unsigned base) {
-        constexpr int R = decltype(rounds)::value;
-        float lb[R];
-        bool in[R];
-        unsigned sl[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const unsigned item = base + (64u * r + lane) * 4u + wave;
-            in[r] = item < items1;
-            sl[r] = in[r] ? (unsigned)my1[item / kIxSuper] * kIxSuper + (item % kIxSuper) : 0u;
-            in[r] = in[r] && sl[r] < L.n_slices;
-            const unsigned sc = in[r] ? sl[r] : 0u;
-            lb[r] = ix_lower_bound(tb, L.slice[2u * sc], L.slice[2u * sc + 1u]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool keep = in[r] && (!have || lb[r] <= bound);
-            const unsigned long long mask = __ballot(keep);
-            if (keep) my2[n2 + vd_mbcnt(mask)] = (unsigned short)sl[r];
-            n2 += (unsigned)__popcll(mask);
-        }
-    };
-    if (items1 <= 256u) { if (items1) slices(std::integral_constant<int, 1>{}, 0u); }
-    else for (unsigned base = 0; base < items1; base += 512u) slices(std::integral_constant<int, 2>{}, base);
-    vd_wave_lds_sync();
     long long t1 = 0;
-    if (prof) t1 = clock64();
-    const unsigned items2 = n2 * kIxSlice;
-    for (unsigned base = 0; base < items2; base += 128u) {
-        float4 lo[2], hi[2];
-        unsigned e[2];
-        bool in[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const unsigned item = base + 64u * r + lane;
-            in[r] = item < items2;
-            e[r] = in[r] ? (unsigned)my2[item / kIxSlice] * kIxSlice + (item % kIxSlice) : 0u;
-            lo[r] = reinterpret_cast<const float4*>(entries + e[r])[0];
-            hi[r] = reinterpret_cast<const float4*>(entries + e[r])[1];
+    // One wave per SIMD and question: nothing hides latency but the wave's own independent instructions, so every stage
+    // first issues all its loads and evaluates several items per lane side by side, and only then does the bookkeeping.
+    if (active) {
+        if (!(bnd == bnd)) {                                  // no candidate known: the target's own block supplies one (main waves only)
+            ix_eval(mine, entries, (e_t / kIxBlock) * kIxBlock + lane, t_slot, tb);
+            const vd_u64 m = ix_wave_min(mine.key);
+            bnd = __uint_as_float((unsigned)(m >> 32));       // 0xffffffff reads back as NaN: still none
+            if (prof && tid == 0u) prof->own += 1;
         }
+        const bool have = bnd == bnd;
+        const unsigned n1 = L.n_super <= 64u ? ix_supers<1>(L, box, have, bnd, my1, lane)
+                          : (L.n_super <= 128u ? ix_supers<2>(L, box, have, bnd, my1, lane) : ix_supers<4>(L, box, have, bnd, my1, lane));
+        vd_wave_lds_sync();
+        // slices of the surviving super-slices; item i is dealt to wave i % 4 of the group (neighbouring slices survive together)
+        const unsigned items1 = n1 * kIxSuper;
+        auto slices = [&](auto rounds, unsigned base) {
+            constexpr int R = decltype(rounds)::value;
+            float lb[R];
+            bool in[R];
+            unsigned sl[R];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const unsigned slot = __float_as_uint(lo[r].w);
-            const float o[6] = {lo[r].x, lo[r].y, lo[r].z, hi[r].x, hi[r].y, hi[r].z};
-            const float area = ix_union_area(tb, o);
-            const bool ok = in[r] && slot != kIxDead && slot != t_slot && area < 1e30f;
-            const vd_u64 key = ok ? (((vd_u64)__float_as_uint(area) << 32) | slot) : ~0ull;
-            if (key < mine.key) { mine.key = key; mine.e = e[r]; mine.lo = lo[r]; mine.hi = hi[r]; }
-        }
+            for (int r = 0; r < R; ++r) {
+                const unsigned item = base + (64u * r + lane) * (unsigned)G + w4;
+                in[r] = item < items1;
+                sl[r] = in[r] ? (unsigned)my1[item / kIxSuper] * kIxSuper + (item % kIxSuper) : 0u;
+                in[r] = in[r] && sl[r] < L.n_slices;
+                const unsigned sc = in[r] ? sl[r] : 0u;
+                lb[r] = ix_lower_bound(box, L.slice[2u * sc], L.slice[2u * sc + 1u]);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool keep = in[r] && (!have || lb[r] <= bnd);
+                const unsigned long long mask = __ballot(keep);
+                if (keep) my2[n2 + vd_mbcnt(mask)] = (unsigned short)sl[r];
+                n2 += (unsigned)__popcll(mask);
+            }
+        };
+        // up to 16 surviving super-slices (the usual case) are one round of 64 lanes per wave; more go two rounds at a time
+        if (items1 <= 64u * G) { if (items1) slices(std::integral_constant<int, 1>{}, 0u); }
+        else if (G < 4 && items1 <= 256u * G) slices(std::integral_constant<int, 4>{}, 0u);
+        else for (unsigned base = 0; base < items1; base += 128u * G) slices(std::integral_constant<int, 2>{}, base);
+        vd_wave_lds_sync();
+        if (prof) t1 = clock64();
+        const unsigned items2 = n2 * kIxSlice;
+        auto ents = [&](auto rounds, unsigned base) {
+            constexpr int R = decltype(rounds)::value;
+            float4 lo[R], hi[R];
+            unsigned e[R];
+            bool in[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned item = base + 64u * r + lane;
+                in[r] = item < items2;
+                e[r] = in[r] ? (unsigned)my2[item / kIxSlice] * kIxSlice + (item % kIxSlice) : 0u;
+                lo[r] = reinterpret_cast<const float4*>(entries + e[r])[0];
+                hi[r] = reinterpret_cast<const float4*>(entries + e[r])[1];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                unsigned slot = __float_as_uint(lo[r].w);
+                const float o[6] = {lo[r].x, lo[r].y, lo[r].z, hi[r].x, hi[r].y, hi[r].z};
+                const float area = ix_union_area(box, o);
+                const bool ok = in[r] && slot != kIxDead && slot != not_slot && e[r] != not_e1 && e[r] != not_e2 && area < 1e30f;
+                slot = slot == from_slot ? to_slot : slot;
+                const vd_u64 key = ok ? (((vd_u64)__float_as_uint(area) << 32) | slot) : ~0ull;
+                if (key < mine.key) { mine.key = key; mine.e = e[r]; mine.lo = lo[r]; mine.hi = hi[r]; }
+            }
+        };
+        constexpr int kDeep = G == 1 ? 6 : (G == 2 ? 4 : 2);      // loads in flight per lane: fewer waves, deeper rounds
+        if (items2 <= 128u) { if (items2) ents(std::integral_constant<int, 2>{}, 0u); }
+        else for (unsigned base = 0; base < items2; base += 64u * kDeep) ents(std::integral_constant<int, kDeep>{}, base);
     }
     long long t2 = 0;
     if (prof) { t2 = clock64(); }
     const vd_u64 m = ix_wave_min(mine.key);
+    float4* rec = reinterpret_cast<float4*>(&sh->res[p][ri]);
     if (m == ~0ull) {
-        if (lane == 0u) sh->res_key[p][wave] = ~0ull;
+        if (lane == 0u) sh->res[p][ri].key = ~0ull;
     } else if (mine.key == m) {                           // slots are unique: exactly one lane
-        sh->res_key[p][wave] = m; sh->res_e[p][wave] = mine.e; sh->res_node[p][wave] = __float_as_uint(mine.hi.w);
-        sh->res_box[p][wave][0] = mine.lo.x; sh->res_box[p][wave][1] = mine.lo.y; sh->res_box[p][wave][2] = mine.lo.z;
-        sh->res_box[p][wave][3] = mine.hi.x; sh->res_box[p][wave][4] = mine.hi.y; sh->res_box[p][wave][5] = mine.hi.z;
+        rec[0] = float4{__uint_as_float((unsigned)m), __uint_as_float((unsigned)(m >> 32)), __uint_as_float(mine.e), mine.hi.w};
+        rec[1] = float4{mine.lo.x, mine.lo.y, mine.lo.z, mine.hi.x};
+        rec[2] = float4{mine.hi.y, mine.hi.z, 0.0f, 0.0f};
     }
     __syncthreads();
-    // lane w < 4 fetches wave w's whole record in one LDS phase; the winner's fields are then read out of its lane
-    const unsigned rw = lane & 3u;
-    vd_u64 rkey = sh->res_key[p][rw];
-    const unsigned re = sh->res_e[p][rw], rnode = sh->res_node[p][rw];
-    float rbox[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) rbox[k] = sh->res_box[p][rw][k];
+    // lane w < 8 fetches wave w's whole record; quad 0 holds the answer, quad 1 the speculative one
+    const float4* rrec = reinterpret_cast<const float4*>(&sh->res[p][lane & 7u]);
+    const float4 r0 = rrec[0], r1 = rrec[1], r2 = rrec[2];
+    vd_u64 rkey = ((vd_u64)__float_as_uint(r0.y) << 32) | __float_as_uint(r0.x);
+    const unsigned re = __float_as_uint(r0.z), rnode = __float_as_uint(r0.w);
+    const float rbox[6] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
     vd_u64 best = rkey, o;
     o = dpp_u64<0xB1>(best); best = o < best ? o : best;
-    o = dpp_u64<0x4E>(best); best = o < best ? o : best;          // minimum over the quad = over the four waves
+    o = dpp_u64<0x4E>(best); best = o < best ? o : best;          // minimum over each quad = over the four waves of a group
     const unsigned long long who = __ballot(rkey == best);
-    const int w = (int)__builtin_ctzll(who);                       // first wave that holds it (ties carry identical records)
-    IxHit h;
-    h.key = ((vd_u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(best >> 32), 0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)best, 0);
-    h.e = (unsigned)__builtin_amdgcn_readlane((int)re, w); h.node = (unsigned)__builtin_amdgcn_readlane((int)rnode, w);
-    h.slices = n2;
+    auto pick = [&](int first, IxHit& h) {
+        const int w = first + (int)__builtin_ctz((unsigned)(who >> first) & 0xfu);   // first wave that holds it (ties carry identical records)
+        h.key = ((vd_u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(best >> 32), first) << 32) |
+                (unsigned)__builtin_amdgcn_readlane((int)(unsigned)best, first);
+        h.e = (unsigned)__builtin_amdgcn_readlane((int)re, w); h.node = (unsigned)__builtin_amdgcn_readlane((int)rnode, w);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) h.box[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox[k]), w));
-    if (prof && tid == 0u) {
+        for (int k = 0; k < 6; ++k) h.box[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rbox[k]), w));
+    };
+    IxPair r;
+    pick(0, r.main);
+    pick(4, r.spec);
+    r.main.slices = helper ? 0u : n2;                         // of the calling wave: what the decline check adds up
+    r.spec.slices = 0u;
+    if (prof && (tid == 0u || (tid == 64u * G && active))) {   // thread 0: the answering group; first helper lane: the speculation
         const long long t3 = clock64();
         prof->t_bounds += (unsigned long long)(t1 - t0); prof->t_entries += (unsigned long long)(t2 - t1); prof->t_reduce += (unsigned long long)(t3 - t2);
-        prof->queries += 1; prof->n1 += n1; prof->n2 += n2;
+        prof->queries += 1; prof->n2 += n2;
     }
-    return h;
+    return r;
 }
 
 // inner corners of all groups from the live entries (a slice per thread, then a super-slice per thread)
 __device__ __forceinline__ void ix_refresh(const IxEntry* entries, const IxLds& L) {
-    for (unsigned sl = threadIdx.x; sl < L.n_slices; sl += kIxThreads) {
+    for (unsigned sl = threadIdx.x; sl < L.n_slices; sl += blockDim.x) {
         float4 lo{-1e30f, -1e30f, -1e30f, 0.0f}, hi{1e30f, 1e30f, 1e30f, 0.0f};      // empty group: every bound overflows to +inf
         for (unsigned j = 0; j < kIxSlice; ++j) {
             const float4 a = reinterpret_cast<const float4*>(entries + sl * kIxSlice + j)[0];
@@ -824,7 +872,7 @@ __device__ __forceinline__ void ix_refresh(const IxEntry* entries, const IxLds& 
         L.slice[2u * sl] = lo; L.slice[2u * sl + 1u] = hi;
     }
     __syncthreads();
-    for (unsigned sp = threadIdx.x; sp < L.n_super; sp += kIxThreads) {
+    for (unsigned sp = threadIdx.x; sp < L.n_super; sp += blockDim.x) {
         float4 lo{-1e30f, -1e30f, -1e30f, 0.0f}, hi{1e30f, 1e30f, 1e30f, 0.0f};
         for (unsigned j = 0; j < kIxSuper && sp * kIxSuper + j < L.n_slices; ++j) {
             const float4 a = L.slice[2u * (sp * kIxSuper + j)], b = L.slice[2u * (sp * kIxSuper + j) + 1u];
@@ -838,16 +886,18 @@ __device__ __forceinline__ void ix_refresh(const IxEntry* entries, const IxLds& 
 
 // wave-private survivor lists: every wave may keep all super-slices, and of the slices its quarter (+ one round of slack)
 static __host__ __device__ unsigned ix_cap1(unsigned n_super) { return (n_super + 7u) & ~7u; }
-static __host__ __device__ unsigned ix_cap2(unsigned n_slices) { return ((n_slices + 3u) / 4u + 64u + 7u) & ~7u; }
-static size_t ix_lds_bytes(unsigned n_slices, unsigned n_super) {
-    return ((sizeof(IxShared) + 15) & ~(size_t)15) + (size_t)n_slices * 32 + (size_t)n_super * 32 + (size_t)ix_cap1(n_super) * 8 +
-           (size_t)ix_cap2(n_slices) * 8 + 16;
+static __host__ __device__ unsigned ix_cap2(unsigned n_slices, unsigned g) { return ((n_slices + g - 1u) / g + 64u + 7u) & ~7u; }
+static size_t ix_lds_bytes(unsigned n_slices, unsigned n_super, unsigned g, unsigned waves) {
+    return ((sizeof(IxShared) + 15) & ~(size_t)15) + (size_t)n_slices * 32 + (size_t)n_super * 32 + (size_t)ix_cap1(n_super) * 2 * waves +
+           (size_t)ix_cap2(n_slices, g) * 2 * waves + 16;            // lists: 2 bytes x waves
 }
 
-template <typename Node>
-__global__ __launch_bounds__(kIxThreads) void tlas_build_indexed_kernel(Node* __restrict__ nodes, unsigned n, IxEntry* entries, unsigned* slot_ent,
+template <typename Node, int G, bool SPEC>
+__global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_kernel(Node* __restrict__ nodes, unsigned n, IxEntry* entries, unsigned* slot_ent,
                                                                         unsigned E, float* sb, unsigned* slot_node, unsigned cap,
                                                                         IxCtl* ctl, unsigned phase2_cnt, unsigned refresh_every, int profile) {
+    constexpr int kThreads = 64 * G * (SPEC ? 2 : 1), kWaves = kThreads / 64;
+    constexpr bool spec_on = SPEC;
     if (ctl->ok == 0u) return;                            // precondition failed: the plain chain is queued behind
     extern __shared__ __attribute__((aligned(16))) char smem[];
     IxLds L;
@@ -857,11 +907,12 @@ __global__ __launch_bounds__(kIxThreads) void tlas_build_indexed_kernel(Node* __
     L.sh = reinterpret_cast<IxShared*>(p); p += (sizeof(IxShared) + 15) & ~(size_t)15;
     L.slice = reinterpret_cast<float4*>(p); p += (size_t)L.n_slices * 32;
     L.super = reinterpret_cast<float4*>(p); p += (size_t)L.n_super * 32;
-    L.cap1 = ix_cap1(L.n_super); L.cap2 = ix_cap2(L.n_slices);
-    L.list1 = reinterpret_cast<unsigned short*>(p); p += (size_t)L.cap1 * 8;
+    L.cap1 = ix_cap1(L.n_super); L.cap2 = ix_cap2(L.n_slices, G);
+    L.list1 = reinterpret_cast<unsigned short*>(p); p += (size_t)L.cap1 * 2 * kWaves;
     L.list2 = reinterpret_cast<unsigned short*>(p);
     const unsigned tid = threadIdx.x;
     if (tid < 32u) L.sh->red[tid] = ~0ull;
+    if (tid < 16u) L.sh->res[tid >> 3][tid & 7u].key = ~0ull;   // records of waves that do not exist stay empty
     IxProf prof_data{0, 0, 0, 0, 0, 0, 0, 0, 0};
     IxProf* prof = profile ? &prof_data : nullptr;
     ix_refresh(entries, L);                               // ends with a barrier
@@ -898,7 +949,8 @@ __global__ __launch_bounds__(kIxThreads) void tlas_build_indexed_kernel(Node* __
             for (int k = 0; k < 6; ++k) o_box[k] = h.box[k];
         }
     };
-    take(ix_query(entries, L, q++, a, box_a, ea, kNone, prof), a, ea, node_a, box_a, b, eb, node_b, box_b);
+    const IxSpec no_spec{{0, 0, 0, 0, 0, 0}, 0.0f, 0u, 0u, 0u, 0u, false};
+    take(ix_query<G, SPEC>(entries, L, q++, a, box_a, ea, kNone, prof, no_spec).main, a, ea, node_a, box_a, b, eb, node_b, box_b);
     while (cnt > phase2_cnt) {
         if (q >= next_check) {                              // every ~256 queries: more than an eighth of all slices per query?
             if ((tid & 63u) == 0u) atomicAdd(&L.sh->work, work);
@@ -917,11 +969,19 @@ __global__ __launch_bounds__(kIxThreads) void tlas_build_indexed_kernel(Node* __
         else if (have_prev && e_prev != eb) bound = ix_union_area(box_b, box_prev);
         unsigned c, ec, node_c;
         float box_c[6];
-        take(ix_query(entries, L, q++, b, box_b, eb, bound, prof), b, eb, node_b, box_b, c, ec, node_c, box_c);
+        // if c comes back as a, the next question is best(a ∪ b) bounded by the previous chain element: prepare it meanwhile
+        IxSpec spec;
+        spec.valid = spec_on && !a_stale && cnt - 1u != a && have_prev && e_prev != eb && e_prev != ea;
+        spec.ea = ea; spec.eb = eb; spec.last = cnt - 1u; spec.b = b;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { spec.box[k] = vd_min_to(box_a[k], box_b[k]); spec.box[3 + k] = vd_max_to(box_a[3 + k], box_b[3 + k]); }
+        spec.bound = ix_union_area(spec.box, box_prev);
+        const IxPair hit = ix_query<G, SPEC>(entries, L, q++, b, box_b, eb, bound, prof, spec);
+        take(hit.main, b, eb, node_b, box_b, c, ec, node_c, box_c);
         if (a == c) {
             float u[6];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { u[k] = vd_min_to(box_a[k], box_b[k]); u[3 + k] = vd_max_to(box_a[3 + k], box_b[3 + k]); }
+            for (int k = 0; k < 6; ++k) u[k] = spec.box[k];
             const unsigned last = cnt - 1u;
             long long tm = 0;
             if (prof) tm = clock64();
@@ -955,8 +1015,12 @@ __global__ __launch_bounds__(kIxThreads) void tlas_build_indexed_kernel(Node* __
                 since_refresh = 0u;
                 if (prof && tid == 0u) prof->t_refresh += (unsigned long long)(clock64() - tm);
             }
-            const float bnd = have_prev ? ix_union_area(box_a, box_prev) : kNone;
-            take(ix_query(entries, L, q++, a, box_a, ea, bnd, prof), a, ea, node_a, box_a, b, eb, node_b, box_b);
+            if (spec.valid) {                             // answered while best(b) was being worked out
+                take(hit.spec, a, ea, node_a, box_a, b, eb, node_b, box_b);
+            } else {
+                const float bnd = have_prev ? ix_union_area(box_a, box_prev) : kNone;
+                take(ix_query<G, SPEC>(entries, L, q++, a, box_a, ea, bnd, prof, no_spec).main, a, ea, node_a, box_a, b, eb, node_b, box_b);
+            }
         } else {
             have_prev = true; e_prev = ea;
 #pragma unroll
@@ -965,14 +1029,14 @@ __global__ __launch_bounds__(kIxThreads) void tlas_build_indexed_kernel(Node* __
             b = c; eb = ec; node_b = node_c;
         }
     }
-    if (prof && tid == 0u)
+    if (prof && (tid == 0u || (SPEC && tid == 64u * G)))
         printf("tlas indexed build n=%u: %llu queries (%llu with an own-block bound), survivors per query: %.1f super-slices, %.1f slices; "
                "cycles per query: bounds %.0f, entries %.0f, reduce+barrier %.0f; per merge %.0f; refresh total %llu\n",
-               n, prof->queries, prof->own, (double)prof->n1 / prof->queries, 4.0 * prof->n2 / prof->queries, (double)prof->t_bounds / prof->queries,
+               n, prof->queries, prof->own, (double)prof->n1 / prof->queries, (double)G * prof->n2 / prof->queries, (double)prof->t_bounds / prof->queries,
                (double)prof->t_entries / prof->queries, (double)prof->t_reduce / prof->queries, (double)prof->t_merge / (n - cnt), prof->t_refresh);
     // ---- hand over to the plain scan: slot arrays from the live entries (+ the stale slot a the chain may still name) ----
     __syncthreads();
-    for (unsigned e = tid; e < E; e += kIxThreads) {
+    for (unsigned e = tid; e < E; e += kThreads) {
         const float4 lo = reinterpret_cast<const float4*>(entries + e)[0], hi = reinterpret_cast<const float4*>(entries + e)[1];
         const unsigned slot = __float_as_uint(lo.w);
         if (slot != kIxDead) {
@@ -988,7 +1052,7 @@ __global__ __launch_bounds__(kIxThreads) void tlas_build_indexed_kernel(Node* __
         slot_node[a] = node_a;
     }
     __syncthreads();
-    tlas_build_chain<Node, true, kIxThreads>(nodes, sb, slot_node, cap, L.sh->red, ChainState{cnt, used, a, b, true});
+    tlas_build_chain<Node, true, kThreads>(nodes, sb, slot_node, cap, L.sh->red, ChainState{cnt, used, a, b, true});
 }
 
 // ---- refit -------------------------------------------------------------------------------
@@ -1131,17 +1195,30 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
         for (int k = 0; k < 4; ++k) keys[k] = reinterpret_cast<unsigned*>(base + off_sort + k * sort_stride);
         IxCtl* ctl = reinterpret_cast<IxCtl*>(base + off_ctl);
         const unsigned n_slices = E / kIxSlice, n_super = (n_slices + kIxSuper - 1u) / kIxSuper;
-        const size_t lds = ix_lds_bytes(n_slices, n_super);
-        constexpr int which = std::is_same<Node, VdTlasNode>::value ? 0 : 1;
-        if (!ctx->tlas_ix_lds_opt_in[which]) {            // per context (= per device): up to 160 KB of dynamic LDS
-            VD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tlas_build_indexed_kernel<Node>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)ix_lds_bytes(kIxMaxInstances / kIxSlice, kIxMaxInstances / kIxSlice / kIxSuper)));
-            ctx->tlas_ix_lds_opt_in[which] = true;
-        }
+        const bool spec = getenv("VD_TLAS_SPEC") ? atoi(getenv("VD_TLAS_SPEC")) != 0 : true;
         hipLaunchKernelGGL(tlas_index_kernel, dim3(1), dim3(kSortThreads), 0, ctx->stream, sb, (unsigned)cap, n, E, keys[0], keys[1], keys[2], keys[3],
                            entries, slot_ent, ctl);
-        hipLaunchKernelGGL((tlas_build_indexed_kernel<Node>), dim3(1), dim3(kIxThreads), lds, ctx->stream, d_nodes, n, entries, slot_ent, E, sb,
-                           slot_node, (unsigned)cap, ctl, phase2, refresh, getenv("VD_TLAS_PROFILE") ? 1 : 0);
+        auto launch = [&](auto gc, auto sc) -> int {
+            constexpr int G = decltype(gc)::value;
+            constexpr bool S = decltype(sc)::value;
+            constexpr unsigned waves = G * (S ? 2 : 1);
+            const size_t lds = ix_lds_bytes(n_slices, n_super, G, waves);
+            constexpr int which = (std::is_same<Node, VdTlasNode>::value ? 0 : 1) + (S ? 2 : 0);
+            if (!ctx->tlas_ix_lds_opt_in[which]) {        // per context (= per device): up to 160 KB of dynamic LDS
+                constexpr unsigned max_slices = kIxMaxInstances / kIxSlice;
+                VD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tlas_build_indexed_kernel<Node, G, S>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)ix_lds_bytes(max_slices, max_slices / kIxSuper, G, waves)));
+                ctx->tlas_ix_lds_opt_in[which] = true;
+            }
+            hipLaunchKernelGGL((tlas_build_indexed_kernel<Node, G, S>), dim3(1), dim3(64 * waves), lds, ctx->stream, d_nodes, n, entries, slot_ent, E, sb,
+                               slot_node, (unsigned)cap, ctl, phase2, refresh, getenv("VD_TLAS_PROFILE") ? 1 : 0);
+            return 0;
+        };
+        using std::integral_constant;
+        // VD_TLAS_SPEC=0: without the helper waves (A/B)
+        const int lrc = spec ? launch(integral_constant<int, kIxGroup>{}, std::true_type{}) : launch(integral_constant<int, kIxGroup>{}, std::false_type{});
+        if (lrc) return lrc;
         // Decided on the device: leaf coordinates the fast arithmetic cannot order (NaN, inf, |x| >= 1e18), or boxes that
         // defeat the pruning (all union areas tie).  The indexed kernel then returned early and left the slot arrays as the
         // leaves kernel wrote them; the plain chain runs instead - on 16 workgroups where that pays, with ITS redo behind it.
