@@ -340,6 +340,15 @@ def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, monkeypatch)
     x = np.cumsum(1.0 + 0.01 * np.arange(n))[::-1].astype(np.float32)          # the closest pair is always the last two slots
     stale = np.zeros((n, 6), np.float32); stale[:, 0], stale[:, 3] = x, x + np.float32(0.25); stale[:, 4:] = 0.25
     cases.append(stale)
+    # zeros of both signs on the box faces: the unions must pick -0 as the minimum and +0 as the maximum like the oracle's
+    # total order (the indexed build uses single v_min_f32 / v_max_f32 instructions, which order the zeros the same way)
+    zed = cloud(600, 13, 30.0, 20.0)
+    sign = np.where(rng.random((600, 6)) < 0.5, np.float32(-0.0), np.float32(0.0)).astype(np.float32)
+    snap = rng.random((600, 6)) < 0.4
+    snap[:, :3] &= zed[:, :3] <= 0                                                # keeps mn <= 0 <= mx where a face is moved onto zero
+    snap[:, 3:] &= zed[:, 3:] >= 0
+    zed[snap] = sign[snap]
+    cases.append(zed)
     for k, boxes in enumerate(cases):
         inst, meshes = _boxes_as_scene(boxes)
         want = oracle.tlas_build(inst, meshes)

@@ -681,7 +681,7 @@ __device__ __forceinline__ void ix_eval(IxLane& L, const IxEntry* entries, unsig
 
 // survivors among the super-slices into a wave-private list; R rounds of 64 evaluated side by side
 template <int R>
-__device__ __forceinline__ unsigned ix_supers(const IxLds& L, const float (&tb)[6], bool have, float bound, unsigned short* my1, unsigned lane) {
+__device__ __forceinline__ unsigned ix_supers(const IxLds& L, const float (&tb)[6], float bound, unsigned short* my1, unsigned lane) {
     unsigned n1 = 0;
     for (unsigned base = 0; base < L.n_super; base += 64u * R) {
         float lb[R];
@@ -695,7 +695,7 @@ __device__ __forceinline__ unsigned ix_supers(const IxLds& L, const float (&tb)[
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const bool keep = in[r] && (!have || lb[r] <= bound);
+            const bool keep = in[r] && !(lb[r] > bound);      // no bound = NaN: nothing is greater, everything is kept
             const unsigned long long mask = __ballot(keep);
             if (keep) my1[n1 + vd_mbcnt(mask)] = (unsigned short)(base + 64u * r + lane);
             n1 += (unsigned)__popcll(mask);
@@ -751,9 +751,8 @@ __device__ __forceinline__ IxPair ix_query(const IxEntry* entries, const IxLds& 
             bnd = __uint_as_float((unsigned)(m >> 32));       // 0xffffffff reads back as NaN: still none
             if (prof && tid == 0u) prof->own += 1;
         }
-        const bool have = bnd == bnd;
-        const unsigned n1 = L.n_super <= 64u ? ix_supers<1>(L, box, have, bnd, my1, lane)
-                          : (L.n_super <= 128u ? ix_supers<2>(L, box, have, bnd, my1, lane) : ix_supers<4>(L, box, have, bnd, my1, lane));
+        const unsigned n1 = L.n_super <= 64u ? ix_supers<1>(L, box, bnd, my1, lane)
+                          : (L.n_super <= 128u ? ix_supers<2>(L, box, bnd, my1, lane) : ix_supers<4>(L, box, bnd, my1, lane));
         vd_wave_lds_sync();
         // slices of the surviving super-slices; item i is dealt to wave i % 4 of the group (neighbouring slices survive together)
         const unsigned items1 = n1 * kIxSuper;
@@ -766,14 +765,14 @@ __device__ __forceinline__ IxPair ix_query(const IxEntry* entries, const IxLds& 
             for (int r = 0; r < R; ++r) {
                 const unsigned item = base + (64u * r + lane) * (unsigned)G + w4;
                 in[r] = item < items1;
-                sl[r] = in[r] ? (unsigned)my1[item / kIxSuper] * kIxSuper + (item % kIxSuper) : 0u;
+                sl[r] = (unsigned)my1[(in[r] ? item : 0u) / kIxSuper] * kIxSuper + (item % kIxSuper);   // read unconditionally: no branch, the rounds' reads go out together
                 in[r] = in[r] && sl[r] < L.n_slices;
                 const unsigned sc = in[r] ? sl[r] : 0u;
                 lb[r] = ix_lower_bound(box, L.slice[2u * sc], L.slice[2u * sc + 1u]);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const bool keep = in[r] && (!have || lb[r] <= bnd);
+                const bool keep = in[r] && !(lb[r] > bnd);
                 const unsigned long long mask = __ballot(keep);
                 if (keep) my2[n2 + vd_mbcnt(mask)] = (unsigned short)sl[r];
                 n2 += (unsigned)__popcll(mask);
@@ -795,7 +794,8 @@ __device__ __forceinline__ IxPair ix_query(const IxEntry* entries, const IxLds& 
             for (int r = 0; r < R; ++r) {
                 const unsigned item = base + 64u * r + lane;
                 in[r] = item < items2;
-                e[r] = in[r] ? (unsigned)my2[item / kIxSlice] * kIxSlice + (item % kIxSlice) : 0u;
+                e[r] = (unsigned)my2[(in[r] ? item : 0u) / kIxSlice] * kIxSlice + (item % kIxSlice);
+                e[r] = in[r] ? e[r] : 0u;
                 lo[r] = reinterpret_cast<const float4*>(entries + e[r])[0];
                 hi[r] = reinterpret_cast<const float4*>(entries + e[r])[1];
             }
@@ -974,11 +974,13 @@ __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_ke
         spec.valid = spec_on && !a_stale && cnt - 1u != a && have_prev && e_prev != eb && e_prev != ea;
         spec.ea = ea; spec.eb = eb; spec.last = cnt - 1u; spec.b = b;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { spec.box[k] = vd_min_to(box_a[k], box_b[k]); spec.box[3 + k] = vd_max_to(box_a[3 + k], box_b[3 + k]); }
+        for (int k = 0; k < 3; ++k) { spec.box[k] = ix_min(box_a[k], box_b[k]); spec.box[3 + k] = ix_max(box_a[3 + k], box_b[3 + k]); }
         spec.bound = ix_union_area(spec.box, box_prev);
         const IxPair hit = ix_query<G, SPEC>(entries, L, q++, b, box_b, eb, bound, prof, spec);
         take(hit.main, b, eb, node_b, box_b, c, ec, node_c, box_c);
         if (a == c) {
+            // v_min_f32 / v_max_f32 order -0 below +0 (the ISA's LT_NEG_ZERO compare), so without NaNs (the precondition)
+            // the single instruction IS the total-order minimum the nodes are defined with: spec.box is the merged box
             float u[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) u[k] = spec.box[k];
