@@ -24,6 +24,8 @@ def stats(path):
 
 def k(st, name):
     v = st.get(name)
+    if not v:                                  # template arguments changed between rounds: first kernel with that prefix
+        v = next((x for key, x in sorted(st.items()) if key.startswith(name)), None)
     if not v:
         return "n/a"
     c, avg, mn, pct = v[0]
@@ -76,7 +78,7 @@ def round_section(tag):
         L += [f"* `{tag}_bench_kernel_stats.csv` (`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline "
               f"--no-verify`): `cull_mask_tiled_kernel<unsigned char>` {k(st, 'cull_mask_tiled_kernel<unsigned char>')}; `mask_scan_kernel` {k(st, 'mask_scan_kernel')}; "
               f"`expand_mask_u8_kernel<true, 0>` {k(st, 'expand_mask_u8_kernel<true, 0>')}; `emit_all_u8_kernel` {k(st, 'emit_all_u8_kernel')}; "
-              f"`tlas_build_indexed_kernel<VdTlasNode>` {k(st, 'tlas_build_indexed_kernel<VdTlasNode>')}; `blas_small_kernel` {k(st, 'blas_small_kernel')}."]
+              f"`tlas_build_indexed_kernel<VdTlasNode…>` {k(st, 'tlas_build_indexed_kernel<VdTlasNode')}; `blas_small_kernel` {k(st, 'blas_small_kernel')}."]
     kh = os.path.join(P, f"{tag}_bench_noextra_kernel_stats.csv")
     if os.path.exists(kh):
         st = stats(kh)
