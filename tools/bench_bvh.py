@@ -17,6 +17,7 @@ ap.add_argument("--u", type=int, default=2048)
 ap.add_argument("--v", type=int, default=2048)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--tlas", type=int, default=32768)
+ap.add_argument("--blas-only", action="store_true", help="stop after the BLAS builds (tools/gpu_pmc_bvh.sh)")
 args = ap.parse_args()
 
 ctx = Context(0)
@@ -41,6 +42,8 @@ for r in range(args.reps + 1):
 best = min(times)
 print(f"BLAS build: {n_tri} prims, best {best*1e3:.1f} ms = {n_tri/best/1e6:.1f} Mprims/s")
 # (parity against the oracle lives in tests/test_gpu_blas.py and tests/test_gpu_full_size.py; this tool only times)
+if args.blas_only:
+    sys.exit(0)
 
 # TLAS
 meshes = synth.mesh_infos()
