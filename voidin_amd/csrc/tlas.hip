@@ -10,7 +10,8 @@
 //    depends on the slot order, so the chain itself cannot be reordered; what is made cheap is ONE call:
 //      - 4096 <= n <= 65536 ("build, indexed"): a call is an exact nearest-neighbour query through a spatial index
 //        (inner-corner lower bounds over Morton-ordered groups, pruned against a bound the chain supplies); one
-//        256-lane workgroup, cost independent of n;
+//        512-lane workgroup - four waves answer the call, four answer the call a merge would make next - cost
+//        independent of n;
 //      - otherwise a scan of all active slots, kept as a compacted SoA (six float arrays + node ids) so that a scan is a
 //        pure stream of 24 B per slot, by one 1024-lane workgroup below 4096 instances and by 16 of them above 65536
 //        ("build, several workgroups"); the argmin is a 64-bit {area bits, slot} key reduced by DPP / wave shuffles + per-wave LDS
