@@ -73,7 +73,7 @@ struct Scene {
 // the same as the closest-hit traversal's: until something is accepted nothing is pruned by distance, so both walks
 // visit the same nodes up to that point (the reference's shadow pass uses only `.hit`: raytraced_shadows.wgsl:97-102).
 constexpr unsigned kRefillBelow = 56;   // draw new rays when fewer than this many lanes are busy
-constexpr unsigned kWavesPerCu = 32;    // persistent grid   // draw new rays when fewer than this many lanes are busy
+constexpr unsigned kWavesPerCu = 28;    // persistent grid = what is resident (7 waves per SIMD at 72 VGPRs): no wave starts late
 template <bool ANY>
 __global__ __launch_bounds__(64, 7) void trace_kernel(Scene s, const VdRay* __restrict__ rays, unsigned n_rays,
                                                               VdHit* __restrict__ out, unsigned* __restrict__ out_any,
