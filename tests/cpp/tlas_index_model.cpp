@@ -11,6 +11,11 @@
 //     answer for as long as X and Y are both alive and unchanged: every cluster that exists later is a cluster that
 //     existed then, or a union of such clusters not containing X or Y, whose union area with X is >= the smallest of
 //     theirs (monotone again) > area(X u Y).  The slot index plays no part, so slot relabelling cannot change it.
+//  5. SPECULATION (claim 4 is further down, at the chain).  While c = best(b) is being answered, the answer of the query
+//     that follows IF c == a - best(a u b), bounded by the chain element before a - can be computed on the state BEFORE
+//     the merge: leave out the entries of a and b, count the entry that holds the last slot as slot b, same group
+//     corners.  That is all a merge changes (tlas.rs:72-75), so the chain may take that answer without asking
+//     (params[6]; the model also asks in the normal way and returns -2 if the two ever differ).
 //  3. SLOTS.  The reference works on slot indices (tlas.rs:56-84): idx[a] = merged, idx[b] = idx[cnt-1].  When a is
 //     the last slot, the merged cluster lands in slot b and the chain goes on with the stale index a (>= cnt): the
 //     next find_best_match(a) sees the merged cluster itself as a candidate in slot b.  Modelled as in the kernel:
@@ -82,11 +87,14 @@ struct Model {
     // chain knows one most of the time: see tlas_index_model below), NaN when there is none - then the target's own
     // block of entries is scanned first and supplies the bound.  A group is skipped when its lower bound EXCEEDS the
     // bound; the bound is not tightened while the groups are visited (the kernel visits them in parallel).
-    Hit query(uint32_t t_slot, const Box& tb, uint32_t e_t, float bound) {
+    // skip1 / skip2 / from_slot -> to_slot: the speculative form (claim 5); DEAD = not used
+    Hit query(uint32_t t_slot, const Box& tb, uint32_t e_t, float bound, uint32_t skip1 = DEAD, uint32_t skip2 = DEAD,
+              uint32_t from_slot = 0xfffffffeu, uint32_t to_slot = 0) {
         uint64_t best = ~0ull; uint32_t best_e = 0; bool tie = false;
         auto eval = [&](uint32_t e) {
-            const uint32_t s = ent_slot[e];
-            if (s == DEAD || s == t_slot) return;
+            uint32_t s = ent_slot[e];
+            if (s == DEAD || s == t_slot || e == skip1 || e == skip2) return;
+            if (s == from_slot) s = to_slot;
             const float a = union_area(tb, ent_box[e]);
             ++st_cand;
             if (!(a < 1e30f)) return;
@@ -125,13 +133,15 @@ struct Model {
 extern "C" {
 
 // leaf_boxes: n x {mn[3], mx[3]}; out_box: (2n+1) x 6 floats; out_left/out_right/out_inst: 2n+1 each.
-// params: {slice, block, super_slices, phase2_threshold, use_cache, refresh_every (merges; 0 = never)}; stats (may be null): 8 x u64.
+// params: {slice, block, super_slices, phase2_threshold, use_cache, refresh_every (merges; 0 = never), use_spec}; stats (may be null): 9 x u64.
 // Returns 0, or -1 when the precondition (finite, |x| < 1e18, mn <= mx) fails (the kernel then runs the plain chain).
 int tlas_index_model(const float* leaf_boxes, uint32_t n, const uint32_t* params, float* out_box, uint32_t* out_left,
                      uint32_t* out_right, uint32_t* out_inst, uint64_t* stats) {
     Model M;
     M.n = n; M.slice = params[0]; M.block = params[1]; M.super_slices = params[2]; M.phase2 = params[3];
     const bool use_cache = params[4] != 0;
+    const bool use_spec = params[6] != 0 && !use_cache;
+    uint64_t st_spec_used = 0;
     std::vector<Box> leaf(n);
     Box scene = empty_box();
     for (uint32_t i = 0; i < n; ++i) {
@@ -261,6 +271,14 @@ int tlas_index_model(const float* leaf_boxes, uint32_t n, const uint32_t* params
             } else { a = b; b = c; }
             continue;
         }
+        // claim 5: the query a merge of (a, b) would ask next, answered on the state before the merge
+        bool spec_valid = false; Model::Hit spec_hit{~0ull, 0, false};
+        if (use_spec && M.ent_slot[ea] == a && cnt - 1 != a && have_prev && e_prev != eb && e_prev != ea) {
+            Box u;
+            for (int k = 0; k < 3; ++k) { u.mn[k] = min_to(box_a.mn[k], box_b.mn[k]); u.mx[k] = max_to(box_a.mx[k], box_b.mx[k]); }
+            spec_hit = M.query(0xfffffffeu, u, ea, union_area(u, box_prev), ea, eb, cnt - 1, b);
+            spec_valid = true;
+        }
         {
             float bound = NAN;
             if (M.ent_slot[ea] == a) bound = union_area(box_b, box_a);        // a is a live candidate of best(b)
@@ -287,7 +305,15 @@ int tlas_index_model(const float* leaf_boxes, uint32_t n, const uint32_t* params
             box_a = u;
             if (refresh_every && ++since_refresh >= refresh_every) { refresh(); since_refresh = 0; }
             if (cnt == 0) break;                   // (never in phase 1 when phase2 >= 1: kept for phase2 == 0)
-            b = best(a, ea, box_a, have_prev ? union_area(box_a, box_prev) : NAN, eb); box_b = M.ent_box[eb];
+            if (spec_valid) {
+                const Model::Hit real = M.query(a, box_a, ea, have_prev ? union_area(box_a, box_prev) : NAN);
+                if (real.key != spec_hit.key || (real.key != ~0ull && real.e != spec_hit.e)) return -2;
+                if (spec_hit.key == ~0ull) { b = a; eb = ea; } else { b = (uint32_t)spec_hit.key; eb = spec_hit.e; }
+                ++st_spec_used;
+            } else {
+                b = best(a, ea, box_a, have_prev ? union_area(box_a, box_prev) : NAN, eb);
+            }
+            box_b = M.ent_box[eb];
         } else {
             have_prev = true; box_prev = box_a; e_prev = ea;
             a = b; ea = eb; box_a = box_b;
@@ -301,7 +327,7 @@ int tlas_index_model(const float* leaf_boxes, uint32_t n, const uint32_t* params
     std::memcpy(out_box, node_box.data(), total * sizeof(Box));
     if (stats) {
         stats[0] = M.st_full; stats[1] = M.st_cached; stats[2] = M.st_cand; stats[3] = M.st_slices; stats[4] = M.st_phase2;
-        stats[5] = M.st_nonstrict; stats[6] = M.st_lb; stats[7] = M.st_ownblock;
+        stats[5] = M.st_nonstrict; stats[6] = M.st_lb; stats[7] = M.st_ownblock; stats[8] = st_spec_used;
     }
     return 0;
 }

@@ -309,7 +309,8 @@ def _boxes_as_scene(boxes):
     return inst, meshes
 
 
-def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, monkeypatch):
+@pytest.mark.parametrize("helpers", ["1", "0"])
+def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, monkeypatch, helpers):
     """The indexed build (tlas.hip, "build, indexed": pruned queries, two at a time - the one the chain needs and the one a
     merge would need) forced onto small inputs made of what can break it: identical and nested boxes (every union area
     ties: the slot index decides), lattices, zero extents, chains that keep ending on the last slot (the stale index of
@@ -317,6 +318,7 @@ def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, monkeypatch)
     monkeypatch.setenv("VD_TLAS_INDEX_MIN", "65")
     monkeypatch.setenv("VD_TLAS_PHASE2", "64")
     monkeypatch.setenv("VD_TLAS_REFRESH", "37")
+    monkeypatch.setenv("VD_TLAS_SPEC", helpers)                                 # with / without the four helper waves
 
     def cloud(n, seed, extent=60.0, size=4.0):
         u = synth.uniform01(seed, 0, 6 * n).reshape(n, 6).astype(np.float32)
