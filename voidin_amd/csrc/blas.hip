@@ -662,24 +662,55 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
 #pragma unroll
                   for (int q = 0; q < 6; ++q) bk[q] = bb.k[q]; }
             }
-            vd_u64 key = ~0ull;
-            for (int c = 0; c < kCand; ++c) {
-                const unsigned ue = W.g_ue[grp][c], tu = W.g_tt[grp][c];
-                const bool inl = valid && ((pb >> c) & 1u) && el != ue, inr = valid && !inl;
-                int k12[12];
+            // One LANE per (node, candidate) pair - 21 x count pairs, up to three passes of 64 - walks the node's elements,
+            // fetching each element's box keys and predicate word from the lane that holds it (ds_bpermute: the LDS crossbar,
+            // not the VALU this kernel is bound by), and the cost is worked out once per pair.  (Candidate by candidate with
+            // twelve group reductions each, every lane repeating the cost arithmetic, this evaluation was a third of phase B.)
+            unsigned* g_hi = reinterpret_cast<unsigned*>(&W.bin_min[0][0][0]);     // per group: smallest cost key, then the first
+            unsigned* g_lo = g_hi + 8;                                             // candidate that has it (the bins are idle here)
+            if (lane < 16u) g_hi[lane] = 0xffffffffu;
+            vd_wave_lds_sync();
+            const unsigned word = el | (pb << 10);
+            const unsigned n_pairs = count * (unsigned)kCand;
+            unsigned hi3[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, lo3[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, g3[3] = {0u, 0u, 0u};
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    k12[q] = inl ? bk[q] : kBig; k12[3 + q] = inl ? bk[3 + q] : -kBig - 1;
-                    k12[6 + q] = inr ? bk[q] : kBig; k12[9 + q] = inr ? bk[3 + q] : -kBig - 1;
+            for (int pass = 0; pass < 3; ++pass) {
+                if ((unsigned)pass * 64u >= n_pairs) break;                          // wave-uniform
+                const unsigned pidx = (unsigned)pass * 64u + lane;
+                const bool pv = pidx < n_pairs;
+                const unsigned g = pv ? pidx / (unsigned)kCand : 0u, c = pv ? pidx - g * (unsigned)kCand : 0u;
+                const unsigned src0 = g << (3u + cls);
+                const unsigned n_g = (unsigned)__builtin_amdgcn_ds_bpermute((int)(src0 << 2), (int)n);
+                const unsigned ue = W.g_ue[g][c], tu = W.g_tt[g][c];
+                int lk[6] = {kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1}, rk[6] = {kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1};
+                for (unsigned i = 0; i < gw; ++i) {                                  // every lane takes part in the moves
+                    const int from = (int)((src0 + i) << 2);
+                    const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)word);
+                    int k[6];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) k[q] = __builtin_amdgcn_ds_bpermute(from, bk[q]);
+                    const bool vi = i < n_g;
+                    const bool inl = vi && ((w >> (10u + c)) & 1u) && (w & 1023u) != ue, inr = vi && !inl;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        lk[q] = min(lk[q], inl ? k[q] : kBig); lk[3 + q] = max(lk[3 + q], inl ? k[3 + q] : -kBig - 1);
+                        rk[q] = min(rk[q], inr ? k[q] : kBig); rk[3 + q] = max(rk[3 + q], inr ? k[3 + q] : -kBig - 1);
+                    }
                 }
-#pragma unroll
-                for (int i2 = 0; i2 < 12; ++i2) k12[i2] = (i2 % 6) < 3 ? group_min_i(k12[i2], gw) : group_max_i(k12[i2], gw);
                 const unsigned n1 = (tu & 127u) - (tu >> 7);
-                const float a1 = vd_area(box_hi(k12[3]) - box_lo(k12[0]), box_hi(k12[4]) - box_lo(k12[1]), box_hi(k12[5]) - box_lo(k12[2]));
-                const float a2 = vd_area(box_hi(k12[9]) - box_lo(k12[6]), box_hi(k12[10]) - box_lo(k12[7]), box_hi(k12[11]) - box_lo(k12[8]));
-                const vd_u64 kc = cost_key(a1 * (float)n1 + a2 * (float)(n - n1), (unsigned)c);
-                key = kc < key ? kc : key;
+                const float a1 = vd_area(box_hi(lk[3]) - box_lo(lk[0]), box_hi(lk[4]) - box_lo(lk[1]), box_hi(lk[5]) - box_lo(lk[2]));
+                const float a2 = vd_area(box_hi(rk[3]) - box_lo(rk[0]), box_hi(rk[4]) - box_lo(rk[1]), box_hi(rk[5]) - box_lo(rk[2]));
+                const vd_u64 kc = pv ? cost_key(a1 * (float)n1 + a2 * (float)(n_g - n1), c) : ~0ull;
+                hi3[pass] = (unsigned)(kc >> 32); lo3[pass] = (unsigned)kc; g3[pass] = g;
+                if (pv) atomicMin(&g_hi[g], hi3[pass]);
             }
+            vd_wave_lds_sync();
+#pragma unroll
+            for (int pass = 0; pass < 3; ++pass)
+                if ((unsigned)pass * 64u + lane < n_pairs && hi3[pass] == g_hi[g3[pass]]) atomicMin(&g_lo[g3[pass]], lo3[pass]);
+            vd_wave_lds_sync();
+            const vd_u64 key = have ? (((vd_u64)g_hi[grp] << 32) | g_lo[grp]) : ~0ull;
+            vd_wave_lds_sync();
             const bool rejected = have && key == ~0ull;
             const int best = rejected || !have ? 0 : (int)(unsigned)key;
             const unsigned tb = W.g_tt[grp][best];
