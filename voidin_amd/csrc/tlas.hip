@@ -812,7 +812,10 @@ __device__ __forceinline__ IxPair ix_query(const IxEntry* entries, const IxLds& 
             }
         };
         constexpr int kDeep = G == 1 ? 6 : (G == 2 ? 4 : 2);      // loads in flight per lane: fewer waves, deeper rounds
+        // one pass whenever the wave's share fits four loads per lane: a second pass is a second L2 round trip, and the
+        // helper waves (looser bound: 8.4 slices per wave on average against 7.2) needed one in most of their queries
         if (items2 <= 128u) { if (items2) ents(std::integral_constant<int, 2>{}, 0u); }
+        else if (items2 <= 256u) ents(std::integral_constant<int, 4>{}, 0u);
         else for (unsigned base = 0; base < items2; base += 64u * kDeep) ents(std::integral_constant<int, kDeep>{}, base);
     }
     long long t2 = 0;
