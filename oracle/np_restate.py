@@ -67,6 +67,42 @@ def compact(draws):
     return draws[keep].copy(), int(keep.sum())
 
 
+
+# ------------------------------------------------------------------ Rust f32::min / max ----
+def _key(x):
+    i = np.asarray(x, dtype=F).view(np.int32)
+    return i ^ ((i >> 31) & np.int32(0x7FFFFFFF))
+
+
+def rmin(a, b):
+    """Rust f32::min, component-wise (glam 0.24 scalar Vec3::min): a NaN operand is ignored;
+    -0 < +0 (spec decision)."""
+    a, b = np.broadcast_arrays(np.asarray(a, dtype=F), np.asarray(b, dtype=F))
+    return np.where(np.isnan(a), b, np.where(np.isnan(b), a, np.where(_key(b) < _key(a), b, a))).astype(F)
+
+
+def rmax(a, b):
+    a, b = np.broadcast_arrays(np.asarray(a, dtype=F), np.asarray(b, dtype=F))
+    return np.where(np.isnan(a), b, np.where(np.isnan(b), a, np.where(_key(b) > _key(a), b, a))).astype(F)
+
+
+def _unkey(k):
+    k = np.asarray(k, dtype=np.int32)
+    return (k ^ ((k >> 31) & np.int32(0x7FFFFFFF))).view(F)
+
+
+def _fold_min(arr, seed):
+    """fold of rmin over axis 0 from `seed` (the reference folds from +1e30: blas.rs:185-186);
+    order-independent: the minimum of the non-NaN keys."""
+    k = np.where(np.isnan(arr), np.int32(0x7FFFFFFF), _key(arr)).min(axis=0)
+    return np.where(k < _key(seed), _unkey(k), seed).astype(F)
+
+
+def _fold_max(arr, seed):
+    k = np.where(np.isnan(arr), np.int32(-0x80000000), _key(arr)).max(axis=0)
+    return np.where(k > _key(seed), _unkey(k), seed).astype(F)
+
+
 # ------------------------------------------------------------------ BLAS ------------------
 def _area(mn, mx):
     d = (mx - mn).astype(F)
@@ -80,8 +116,8 @@ class _Blas:
         t = self.v[self.idx]                                      # [T][3][3]
         with np.errstate(over="ignore"):
             self.cent = (((t[:, 0] + t[:, 1]) + t[:, 2]) / F(3.0)).astype(F)
-        self.tmin = t.min(axis=1)
-        self.tmax = t.max(axis=1)
+        self.tmin = rmin(rmin(t[:, 0], t[:, 1]), t[:, 2])      # NaN vertices drop out (f32::min ignores a NaN)
+        self.tmax = rmax(rmax(t[:, 0], t[:, 1]), t[:, 2])
         self.ids = list(range(len(self.idx)))
         self.nodes = np.zeros(2 * len(self.idx), dtype=abi.BVH_NODE)
         self.cent_cols = [self.cent[:, a].tolist() for a in range(3)]
@@ -90,12 +126,8 @@ class _Blas:
         if amount == 0:
             return np.full(3, MAX_DIST, F), np.full(3, -MAX_DIST, F)
         sel = np.asarray(self.ids[first:first + amount], dtype=np.int64)
-        if centroids:
-            c = self.cent[sel]
-            mn, mx = c.min(axis=0), c.max(axis=0)
-        else:
-            mn, mx = self.tmin[sel].min(axis=0), self.tmax[sel].max(axis=0)
-        return np.minimum(mn, MAX_DIST).astype(F), np.maximum(mx, -MAX_DIST).astype(F)
+        lo, hi = (self.cent[sel], self.cent[sel]) if centroids else (self.tmin[sel], self.tmax[sel])
+        return _fold_min(lo, np.full(3, MAX_DIST, F)), _fold_max(hi, np.full(3, -MAX_DIST, F))
 
     def shuffle(self, axis, pos, start, count):
         ids, key = self.ids, self.cent_cols[axis]
@@ -174,7 +206,7 @@ def tlas_leaf_bounds(inst, meshes):
         ix, iy, iz = int((i & 1) == 0), int((i & 2) == 0), int((i & 4) == 0)
         px, py, pz = b[:, ix, 0], b[:, iy, 1], b[:, iz, 2]
         p = np.stack([((T[:, 0, r] * px + T[:, 1, r] * py) + T[:, 2, r] * pz) + T[:, 3, r] for r in range(3)], axis=1)
-        mn, mx = np.minimum(mn, p), np.maximum(mx, p)
+        mn, mx = rmin(mn, p), rmax(mx, p)
     return mn.astype(F), mx.astype(F)
 
 
@@ -197,10 +229,10 @@ def tlas_build(inst, meshes):
         if cnt == 0:
             return t
         sel = ni[:cnt]
-        a = _areas(np.minimum(bmin[ni[t]], bmin[sel]), np.maximum(bmax[ni[t]], bmax[sel]))
+        a = _areas(rmin(bmin[ni[t]], bmin[sel]), rmax(bmax[ni[t]], bmax[sel]))
         if t < cnt:
             a[t] = np.inf
-        k = int(np.argmin(a))
+        k = int(np.argmin(np.where(np.isnan(a), np.inf, a)))     # a NaN area never passes `<` (tlas.rs:99)
         return k if a[k] < F(1e30) else t
 
     cnt, used, a = n, n + 1, 0
@@ -209,7 +241,7 @@ def tlas_build(inst, meshes):
         c = best(cnt, b)
         if a == c:
             ia, ib = ni[a], ni[b]
-            bmin[used], bmax[used] = np.minimum(bmin[ia], bmin[ib]), np.maximum(bmax[ia], bmax[ib])
+            bmin[used], bmax[used] = rmin(bmin[ia], bmin[ib]), rmax(bmax[ia], bmax[ib])
             left[used], right[used], iidx[used] = ia, ib, 0xFFFFFFFF
             ni[a] = used
             used += 1

@@ -12,8 +12,8 @@
  *
  * glam 0.24.1 (Cargo.lock:844) is not on disk; the two glam-dependent choices are spec
  * decisions from its published source: Vec3::lerp(rhs,s) = self + (rhs - self)*s and
- * Vec3 / f32 = component-wise true division.  min/max use the total order of
- * vd_oracle_math.h (Rust leaves min(-0,+0) unspecified).
+ * Vec3 / f32 = component-wise true division.  min/max are Rust's f32::min/max (a NaN operand
+ * is ignored; -0 < +0 as the tie rule Rust leaves open): vd_oracle_math.h.
  */
 #include "vd_oracle.h"
 #include "vd_oracle_math.h"

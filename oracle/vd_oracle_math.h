@@ -30,15 +30,26 @@ static inline float v3_length(v3 a) { return sqrtf(v3_dot(a, a)); }
 static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-/* Total-order key: signed-int comparable, -0 < +0.  Rust's f32::min/max leave the sign of
- * min(-0,+0) unspecified; the oracle and the HIP kernels both use this
- * total order so that bounds are order-independent and bit-reproducible. */
+/* Rust's f32::min / f32::max (glam 0.24 scalar Vec3::min/max call them component-wise:
+ * crates/bvh/src/blas.rs:190-198, tlas.rs:43,69-70,96-97): "if one of the arguments is NaN, then
+ * the other argument is returned" - a NaN operand is IGNORED, never propagated (both NaN -> NaN).
+ * Rust leaves the sign of min(-0,+0) unspecified; spec decision: -0 < +0, so
+ * that bounds are order-independent and bit-reproducible (total-order key on the non-NaN values;
+ * gfx950's v_min_f32 / v_max_f32 have exactly these semantics). */
 static inline int32_t f32_key(float f) {
     int32_t i = (int32_t)f32_bits(f);
     return i ^ ((i >> 31) & 0x7fffffff);
 }
-static inline float f32_min_to(float a, float b) { return f32_key(b) < f32_key(a) ? b : a; }
-static inline float f32_max_to(float a, float b) { return f32_key(b) > f32_key(a) ? b : a; }
+static inline float f32_min_to(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    return f32_key(b) < f32_key(a) ? b : a;
+}
+static inline float f32_max_to(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    return f32_key(b) > f32_key(a) ? b : a;
+}
 static inline v3 v3_min_to(v3 a, v3 b) {
     return v3_make(f32_min_to(a.x, b.x), f32_min_to(a.y, b.y), f32_min_to(a.z, b.z));
 }

@@ -84,6 +84,54 @@ def blas_cases():
         print("blas", name, "tris", len(i) // 3, "nodes", len(n_np))
 
 
+def nan_soup(n_tri=200):
+    """A soup with NaN vertices: Rust's f32::min/max (glam scalar Vec3::min/max, blas.rs:190-198) IGNORE a NaN operand,
+    so the reference builds a tree - the NaN vertex drops out of every box, its triangle's centroid fails every `<`
+    (blas.rs:173) and goes right.  One vertex has a single NaN coordinate, one triangle is NaN in all three vertices."""
+    v, i = synth.triangle_soup(n_tri, seed=synth.SEED_BASE + 77)
+    v = v.copy()
+    v[5, 1] = np.nan                       # one coordinate of one vertex
+    v[3 * 40: 3 * 40 + 3, 0] = np.nan      # triangle 40: x of all three vertices -> its x box stays at the +-1e30 seeds
+    v[3 * 90 + 1] = np.nan                 # a whole vertex
+    return v, i
+
+
+def nan_tlas_instances(n=60):
+    """Transforms that poison leaf corners: a NaN entry, and inf / -inf columns whose products cancel to a NaN the
+    arithmetic GENERATES (inf - inf: 0xFFC00000 on x86, 0x7FC00000 on gfx950 - the sign must not matter).  The fold of
+    tlas.rs:39-44 starts from the mesh box and f32::min/max ignore the NaN corners."""
+    inst = synth.instances(n, n_mesh=3, seed=synth.SEED_BASE + 31, extent=30.0, scale_range=(0.5, 3.0))
+    inst["transform"][7, 12] = np.nan                      # translation x
+    inst["transform"][19, 5] = np.nan                      # a rotation / scale entry
+    inst["transform"][23, 0] = np.inf; inst["transform"][23, 4] = -np.inf    # X.x = inf, Y.x = -inf: inf*px + (-inf)*py
+    inst["transform"][41, 13] = -np.inf                    # translation y = -inf: an infinite (not NaN) leaf box
+    inst["transform"][52, 2] = np.inf; inst["transform"][52, 10] = np.inf; inst["transform"][52, 6] = -np.inf
+    return inst
+
+
+def nan_cases():
+    v, i = nan_soup()
+    n_np, i_np = npr.bvh_build(v, i)
+    n_c, i_c = ref.bvh_build(v, i)
+    assert same_bits(n_np, n_c) and np.array_equal(i_np, i_c)
+    assert not np.isnan(n_np["min"]).any() and not np.isnan(n_np["max"]).any()
+    np.savez_compressed(os.path.join(OUT, "blas_soup_nan.npz"), vertices=v, indices=i, nodes=n_np, indices_out=i_np)
+    print("blas soup_nan tris", len(i) // 3, "nodes", len(n_np))
+    infos, V, I, B = pool([synth.uv_sphere(1.0, 2), synth.knot_mesh(32, 8), synth.triangle_soup(64)])
+    inst = nan_tlas_instances()
+    with np.errstate(invalid="ignore", over="ignore"):
+        t_np = npr.tlas_nodes(inst, infos)
+    t_c = ref.tlas_build(inst, infos)
+    assert same_bits(t_np, t_c)
+    assert not np.isnan(t_np["min"]).any() and not np.isnan(t_np["max"]).any()
+    np.savez_compressed(os.path.join(OUT, "tlas_nan_60.npz"), instances=inst, meshes=infos, nodes=t_np)
+    print("tlas nan_60")
+
+
+def same_bits(a, b):
+    return all(np.ascontiguousarray(a[f]).view(np.uint8).tobytes() == np.ascontiguousarray(b[f]).view(np.uint8).tobytes() for f in a.dtype.names)
+
+
 def pool(mesh_list):
     V, I, B = [], [], []
     infos = np.zeros(len(mesh_list), dtype=abi.MESH_INFO)
@@ -168,6 +216,7 @@ if __name__ == "__main__":
     blas_cases()
     builtin_pool_case()
     tlas_trace_cases()
+    nan_cases()
     harness_case()
     occlusion_case()
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

@@ -10,7 +10,8 @@ from voidin_amd.runtime import BvhBuilder, VoidinError
 pytestmark = pytest.mark.gpu
 
 BLAS = ["blas_plane.npz", "blas_sphere_1_1.npz", "blas_soup64.npz", "blas_knot_2k.npz", "blas_sphere_1_10.npz",
-        "blas_plane_rot.npz", "blas_cube_obj.npz"]   # reference-held inputs: mesh/mod.rs:269-272, assets/cube/cube.obj
+        "blas_plane_rot.npz", "blas_cube_obj.npz",   # reference-held inputs: mesh/mod.rs:269-272, assets/cube/cube.obj
+        "blas_soup_nan.npz"]                         # NaN vertices build (f32::min/max ignore a NaN: blas.rs:190-198)
 
 
 def diff_report(got, want):
@@ -74,11 +75,22 @@ def test_chain_like_trees_vs_oracle(ctx, oracle, n_tri, ratio):
 
 @pytest.mark.parametrize("n_tri", [40, 700, 5000])
 def test_extreme_vertex_values_agree_with_oracle(ctx, oracle, n_tri):
-    """NaN / inf vertices make every split candidate of some node NaN: the reference would crash (blas.rs:137-140), the
-    oracle and the library both answer VD_ERR_DEGENERATE; a coordinate beyond the 1e30 bound seeds (blas.rs:185-186)
-    and heavily duplicated vertices still build - the same tree, bit for bit."""
+    """A NaN vertex does NOT stop the reference: Rust's f32::min/max (glam scalar Vec3::min/max, blas.rs:190-198) ignore
+    a NaN operand, the NaN centroid fails every `<` (blas.rs:173) and goes right - the tree builds, and must be the
+    oracle's tree, bit for bit, with no NaN in any box.  An infinite vertex makes every candidate cost of its node
+    inf or NaN (`cost < optimal_cost` never holds, blas.rs:156): the reference crashes there (blas.rs:137-140,114-116),
+    the oracle and the library both answer VD_ERR_DEGENERATE.  A coordinate beyond the 1e30 bound seeds
+    (blas.rs:185-186) and heavily duplicated vertices still build - the same tree."""
     v, i = synth.triangle_soup(n_tri, seed=77)
-    for val in (np.nan, np.inf, -np.inf):
+    nan1 = v.copy(); nan1[5, 1] = np.nan
+    nan3 = v.copy(); nan3[5, 1] = np.nan; nan3[30:33, 2] = np.nan; nan3[61] = np.nan      # one coordinate, a whole triangle's z, a whole vertex
+    for vv in (nan1, nan3):
+        want_nodes, want_idx = oracle.bvh_build(vv, i)
+        nodes, idx = ctx.bvh_build(vv, i)
+        assert fields_equal(nodes, want_nodes), diff_report(nodes, want_nodes)
+        assert np.array_equal(idx, want_idx)
+        assert not np.isnan(nodes["min"]).any() and not np.isnan(nodes["max"]).any()
+    for val in (np.inf, -np.inf):
         v2 = v.copy(); v2[5, 1] = val
         with pytest.raises(oracle.OracleError):
             oracle.bvh_build(v2, i)
@@ -92,6 +104,27 @@ def test_extreme_vertex_values_agree_with_oracle(ctx, oracle, n_tri):
         nodes, idx = ctx.bvh_build(vv, i)
         assert fields_equal(nodes, want_nodes), diff_report(nodes, want_nodes)
         assert np.array_equal(idx, want_idx)
+
+
+def test_generated_nan_centroids_agree_with_oracle(ctx, oracle):
+    """NaNs the arithmetic GENERATES differ between the checker and the device (inf - inf is 0xFFC00000 on x86 and
+    0x7FC00000 on gfx950): vertices at +inf and -inf in one triangle make its centroid inf + -inf = NaN on both sides,
+    with different sign bits.  Nothing may depend on the sign: the centroid drops out of `cb`, the predicate is false
+    either way.  (Such a triangle's box is infinite, so its node is degenerate for the reference - both sides must
+    say so; a finite-box variant - 3e38 + 3e38 overflowing to inf in the centroid sum, then inf - inf never arises -
+    builds.)"""
+    v, i = synth.triangle_soup(300, seed=78)
+    g = v.copy(); g[3, 0] = np.inf; g[4, 0] = -np.inf
+    with pytest.raises(oracle.OracleError):
+        oracle.bvh_build(g, i)
+    with pytest.raises(VoidinError) as e:
+        ctx.bvh_build(g, i)
+    assert e.value.code == abi.VD_ERR_DEGENERATE
+    h = v.copy(); h[9:12, 2] = 3e38                       # (3e38 + 3e38) overflows: centroid z = inf, box z finite
+    want_nodes, want_idx = oracle.bvh_build(h, i)
+    nodes, idx = ctx.bvh_build(h, i)
+    assert fields_equal(nodes, want_nodes), diff_report(nodes, want_nodes)
+    assert np.array_equal(idx, want_idx)
 
 
 def test_builder_api_permutes_callers_indices(ctx):

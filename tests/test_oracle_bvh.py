@@ -9,7 +9,8 @@ from voidin_amd import abi, synth
 
 BLAS = ["blas_plane.npz", "blas_sphere_1_1.npz", "blas_sphere_1_10.npz", "blas_soup64.npz", "blas_knot_2k.npz",
         "blas_plane_rot.npz",    # the X-rotated built-in plane, crates/pools/src/mesh/mod.rs:269-272
-        "blas_cube_obj.npz"]     # the reference's own asset assets/cube/cube.obj through ObjModel::load
+        "blas_cube_obj.npz",     # the reference's own asset assets/cube/cube.obj through ObjModel::load
+        "blas_soup_nan.npz"]     # NaN vertices: f32::min/max ignore them (blas.rs:190-198), the reference builds a tree
 
 
 @pytest.mark.parametrize("name", BLAS)
@@ -19,7 +20,7 @@ def test_blas_c_oracle_matches_golden(oracle, name):
     assert fields_equal(nodes, g["nodes"]) and np.array_equal(idx, g["indices_out"])
 
 
-@pytest.mark.parametrize("name", ["blas_sphere_1_1.npz", "blas_soup64.npz"])
+@pytest.mark.parametrize("name", ["blas_sphere_1_1.npz", "blas_soup64.npz", "blas_soup_nan.npz"])
 def test_blas_numpy_matches_golden(name):
     g = golden(name)
     nodes, idx = npr.bvh_build(g["vertices"], g["indices"])
@@ -30,7 +31,9 @@ def check_tree(nodes, verts, idx):
     """B1/B2/B6 invariants: node 1 unused, DFS pre-order pair allocation, leaves <= 3 tris
     covering [0,T) exactly once in order, bounds = vertex bounds of the subtree."""
     tri = verts[idx.reshape(-1, 3)]
-    tmin, tmax = tri.min(axis=1), tri.max(axis=1)
+    with np.errstate(invalid="ignore"):
+        tmin, tmax = np.fmin.reduce(tri, axis=1), np.fmax.reduce(tri, axis=1)      # f32::min/max ignore a NaN vertex
+    seed = np.float32(1e30)                                                       # blas.rs:185-186
     assert not nodes[1:2].view(np.uint8).any()
     pool, covered = [2], [0]
 
@@ -48,8 +51,8 @@ def check_tree(nodes, verts, idx):
         b = rec(l + 1)
         assert a[1] == b[0]
         for c, (lo, hi) in ((l, a), (l + 1, b)):
-            assert np.array_equal(nodes[c]["min"], tmin[lo:hi].min(axis=0))
-            assert np.array_equal(nodes[c]["max"], tmax[lo:hi].max(axis=0))
+            assert np.array_equal(nodes[c]["min"], np.fmin(seed, np.fmin.reduce(tmin[lo:hi], axis=0)))
+            assert np.array_equal(nodes[c]["max"], np.fmax(-seed, np.fmax.reduce(tmax[lo:hi], axis=0)))
         return a[0], b[1]
 
     import sys
@@ -101,9 +104,34 @@ def test_tlas_c_oracle_matches_golden(oracle, n):
     assert np.array_equal(wide["min"], nodes["min"]) and np.array_equal(wide["max"], nodes["max"])
 
 
-def test_tlas_numpy_matches_golden():
-    g = golden("tlas_40.npz")
-    assert fields_equal(npr.tlas_nodes(g["instances"], g["meshes"]), g["nodes"])
+@pytest.mark.parametrize("name", ["tlas_40.npz", "tlas_nan_60.npz"])
+def test_tlas_numpy_matches_golden(name):
+    g = golden(name)
+    with np.errstate(invalid="ignore", over="ignore"):
+        assert fields_equal(npr.tlas_nodes(g["instances"], g["meshes"]), g["nodes"])
+
+
+def test_min_max_are_rusts(oracle):
+    """Rust's f32::min / f32::max - what glam 0.24's scalar Vec3::min/max call (blas.rs:190-198, tlas.rs:43,69-70,96-97) -
+    return the OTHER operand when one is a NaN, so a NaN never enters a box: a mesh with NaN vertices builds (the NaN
+    centroid fails every `<` and goes right), a NaN / inf - inf transform leaves the seeded mesh box plus the finite
+    corners.  Both restatements agree on the fixtures (make_golden.py asserts it); here: the C oracle reproduces them
+    and no box of either holds a NaN."""
+    g = golden("blas_soup_nan.npz")
+    assert np.isnan(g["vertices"]).sum() >= 5
+    nodes, idx = oracle.bvh_build(g["vertices"], g["indices"])
+    assert fields_equal(nodes, g["nodes"]) and np.array_equal(idx, g["indices_out"])
+    assert not np.isnan(nodes["min"]).any() and not np.isnan(nodes["max"]).any()
+    # the triangle whose x is NaN in all three vertices keeps the +-1e30 seeds in x wherever it sits alone
+    t = golden("tlas_nan_60.npz")
+    tn = oracle.tlas_build(t["instances"], t["meshes"])
+    assert fields_equal(tn, t["nodes"])
+    assert not np.isnan(tn["min"]).any() and not np.isnan(tn["max"]).any()
+    m = t["meshes"][t["instances"]["mesh"][7]]
+    # instance 7 (NaN translation x): every corner's x is NaN -> the leaf's x range is the object-space seed (tlas.rs:39)
+    assert tn["min"][8][0] == m["min"][0] and tn["max"][8][0] == m["max"][0]
+    assert np.isinf(tn["min"]).any()          # the infinite (not NaN) boxes are kept as they are
+    assert oracle.tlas_refit(t["instances"], t["meshes"], tn).tobytes() == tn.tobytes()
 
 
 def test_tlas_leaf_seeded_with_object_space_box():

@@ -158,12 +158,15 @@ __global__ __launch_bounds__(256) void blas_precompute_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             ce[k] = ((a[k] + b[k]) + c[k]) / 3.0f;          // blas.rs:80
-            bx.mn[k] = vd_min_to(vd_min_to(a[k], b[k]), c[k]);
-            bx.mx[k] = vd_max_to(vd_max_to(a[k], b[k]), c[k]);
+            // the fold of blas.rs:184-204 starts from +-MAX_DIST and f32::min / max ignore a NaN vertex: a stored box
+            // is the seeded fold over its own three vertices - never NaN - and min(1e30, .) is idempotent, so node
+            // boxes reduced from these (box_lo / box_hi) equal the reference's fold over all vertices of the node
+            bx.mn[k] = vd_min_to(vd_min_to(vd_min_to(1e30f, a[k]), b[k]), c[k]);
+            bx.mx[k] = vd_max_to(vd_max_to(vd_max_to(-1e30f, a[k]), b[k]), c[k]);
             k12[k] = min(k12[k], vd_key(bx.mn[k]));
             k12[3 + k] = max(k12[3 + k], vd_key(bx.mx[k]));
-            k12[6 + k] = min(k12[6 + k], vd_key(ce[k]));
-            k12[9 + k] = max(k12[9 + k], vd_key(ce[k]));
+            k12[6 + k] = min(k12[6 + k], vd_key_lo(ce[k]));     // a NaN centroid (NaN vertex) drops out of `cb`
+            k12[9 + k] = max(k12[9 + k], vd_key_hi(ce[k]));
         }
         bx.pad0 = bx.pad1 = 0.0f;
         const u32x2 p = {t, 0u};
@@ -610,7 +613,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 const float ce3[3] = {cx, cy, cz};
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    kmn[k] = group_min_i(valid ? vd_key(ce3[k]) : kBig, gw); kmx[k] = group_max_i(valid ? vd_key(ce3[k]) : -kBig - 1, gw);
+                    kmn[k] = group_min_i(valid ? vd_key_lo(ce3[k]) : kBig, gw); kmx[k] = group_max_i(valid ? vd_key_hi(ce3[k]) : -kBig - 1, gw);
                     cbmin[k] = box_lo(kmn[k]); cbmax[k] = box_hi(kmx[k]);
                 }
             }
@@ -795,7 +798,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             for (unsigned x = lane; x < n; x += 64u) {
                 const unsigned e = L.perm[cur][s + x];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { const int key = vd_key(L.cent[k][e]); kmn[k] = min(kmn[k], key); kmx[k] = max(kmx[k], key); }
+                for (int k = 0; k < 3; ++k) { const float cv = L.cent[k][e]; kmn[k] = min(kmn[k], vd_key_lo(cv)); kmx[k] = max(kmx[k], vd_key_hi(cv)); }
             }
             float cbmin[3], cbmax[3];
 #pragma unroll
@@ -1481,8 +1484,8 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
         for (int q = 0; q < 3; ++q) {
             k24[o + q] = min(k24[o + q], vd_key(bx.mn[q]));
             k24[o + 3 + q] = max(k24[o + 3 + q], vd_key(bx.mx[q]));
-            k24[12 + o + q] = min(k24[12 + o + q], vd_key(ce[q]));
-            k24[12 + o + 3 + q] = max(k24[12 + o + 3 + q], vd_key(ce[q]));
+            k24[12 + o + q] = min(k24[12 + o + q], vd_key_lo(ce[q]));
+            k24[12 + o + 3 + q] = max(k24[12 + o + 3 + q], vd_key_hi(ce[q]));
         }
     }
 #pragma unroll
@@ -1726,8 +1729,8 @@ __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot*
                 for (int q = 0; q < 3; ++q) {
                     k24[o + q] = min(k24[o + q], vd_key(bx.mn[q]));
                     k24[o + 3 + q] = max(k24[o + 3 + q], vd_key(bx.mx[q]));
-                    k24[12 + o + q] = min(k24[12 + o + q], vd_key(ce[q]));
-                    k24[12 + o + 3 + q] = max(k24[12 + o + 3 + q], vd_key(ce[q]));
+                    k24[12 + o + q] = min(k24[12 + o + q], vd_key_lo(ce[q]));
+                    k24[12 + o + 3 + q] = max(k24[12 + o + 3 + q], vd_key_hi(ce[q]));
                 }
             }
 #pragma unroll

@@ -98,8 +98,11 @@ static inline void vd_time_end(VdCtx* ctx) {
 #ifdef __HIPCC__
 // ---- device helpers ------------------------------------------------------------------
 
-// Total-order float key (-0 < +0): bounds reductions are order-independent and bit-exact
-// against the oracle (Rust leaves min(-0,+0) unspecified: SURVEY.md §8a B5).
+// Order-preserving float key (-0 < +0) and Rust's f32::min / f32::max on top of it (glam 0.24 scalar
+// Vec3::min/max, crates/bvh/src/blas.rs:190-198, tlas.rs:43,69-70,96-97): a NaN operand is IGNORED - the other
+// operand is returned - and -0 < +0 is the tie rule Rust leaves open, which makes bounds
+// reductions order-independent and bit-exact against the oracle.  Key reductions (integer atomic min / max) skip
+// NaNs through vd_key_lo / vd_key_hi: a NaN maps to the neutral element of the reduction.
 __device__ __forceinline__ int vd_key(float f) {
     int i = __float_as_int(f);
     return i ^ ((i >> 31) & 0x7fffffff);
@@ -107,8 +110,10 @@ __device__ __forceinline__ int vd_key(float f) {
 __device__ __forceinline__ float vd_unkey(int k) {
     return __int_as_float(k ^ ((k >> 31) & 0x7fffffff));
 }
-__device__ __forceinline__ float vd_min_to(float a, float b) { return vd_key(b) < vd_key(a) ? b : a; }
-__device__ __forceinline__ float vd_max_to(float a, float b) { return vd_key(b) > vd_key(a) ? b : a; }
+__device__ __forceinline__ int vd_key_lo(float f) { return f != f ? 0x7fffffff : vd_key(f); }        // operand of a min
+__device__ __forceinline__ int vd_key_hi(float f) { return f != f ? (int)0x80000000 : vd_key(f); }   // operand of a max
+__device__ __forceinline__ float vd_min_to(float a, float b) { return a != a ? b : (b != b ? a : (vd_key(b) < vd_key(a) ? b : a)); }
+__device__ __forceinline__ float vd_max_to(float a, float b) { return a != a ? b : (b != b ? a : (vd_key(b) > vd_key(a) ? b : a)); }
 
 // crates/bvh/src/intersection.rs:16-19
 __device__ __forceinline__ float vd_area(float dx, float dy, float dz) {
