@@ -48,6 +48,11 @@ def parse_args(argv=None):
                     help="N > 1: strong = --instances in total (BASELINE configs[3]); weak = --instances per GPU")
     ap.add_argument("--gather", choices=["full", "draws", "indices", "shard"], default="full",
                     help="N > 1: what every GPU holds after a step (see the module docstring)")
+    ap.add_argument("--exchange", choices=["rccl", "torch"], default=None,
+                    help="N > 1: rccl (default) = the exchange behind the C ABI (vd_dist_*: RCCL on the ctx stream, bound by the "
+                         "library); torch = torch.distributed collectives between the two kernels (default when "
+                         "VOIDIN_DIST_BACKEND is set; gloo runs several ranks on one GPU)")
+    ap.add_argument("--timeout", type=float, default=0.0, help="launcher: kill the ranks and fail after this many seconds (0 = none)")
     ap.add_argument("--dist", choices=["baseline", "small"], default="baseline",
                     help="baseline = BASELINE.md §3 (S in [0.25,4]); small = S in [0.02,0.6] (more culled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -71,7 +76,8 @@ def _free_port():
     return p
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, timeout=0.0):
+    import signal
     port = _free_port()
     procs = []
     for r in range(n):
@@ -80,20 +86,48 @@ def launch_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this pool
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+
+    def stop_all(grace=5.0):
+        """terminate() exactly the children started above, kill() what is still there after the grace period"""
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + grace
+        while time.time() < t_end and any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+
+    def on_signal(signum, _frame):      # the launcher itself is being stopped (e.g. `timeout 600 python bench.py --gpus 2`)
+        print(f"bench.py: launcher got signal {signum}; stopping the ranks", file=sys.stderr, flush=True)
+        stop_all()
+        sys.exit(128 + signum)
+
+    old_handlers = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    deadline = time.time() + timeout if timeout and timeout > 0 else None
     rc = 0
     alive = set(range(n))
-    while alive:
-        for r in sorted(alive):
-            c = procs[r].poll()
-            if c is None:
-                continue
-            alive.discard(r)
-            if c != 0 and rc == 0:
-                rc = c
-                print(f"bench.py: rank {r} exited with {c}; stopping the other ranks", file=sys.stderr, flush=True)
-                for q in alive:
-                    procs[q].terminate()        # exactly the children started above
-        time.sleep(0.05)
+    try:
+        while alive:
+            for r in sorted(alive):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                alive.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c
+                    print(f"bench.py: rank {r} exited with {c}; stopping the other ranks", file=sys.stderr, flush=True)
+                    stop_all()
+            if deadline and alive and time.time() > deadline:
+                print(f"bench.py: ranks {sorted(alive)} still running after {timeout:.0f} s; stopping them", file=sys.stderr, flush=True)
+                stop_all()
+                rc = rc or 124
+                break
+            time.sleep(0.05)
+    finally:
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     return rc
 
 
@@ -119,6 +153,9 @@ def launch_check():
         dist.destroy_process_group()
     else:
         n_gpus, ranks = 1, [0]
+    hold = float(os.environ.get("VOIDIN_LAUNCH_CHECK_HOLD_S", "0"))     # tests of the launcher's signal / deadline handling
+    if hold > 0:
+        time.sleep(hold)
     if rank == 0:
         print(json.dumps({"launch_check": True, "n_gpus": n_gpus, "ranks": ranks, "backend": backend if world > 1 else None}), flush=True)
 
@@ -147,6 +184,23 @@ def tree_shape(nodes):
             "sum_active_prims": int(sum(per_level)), "levels_with_work": int(sum(1 for a in per_level if a))}
 
 
+def scaling_ceiling(n_total, world, vis, weak):
+    """DESIGN.md 6's model of one step at N GPUs, from the one-GPU kernel rates measured in round 2 (pass 1 reads at
+    6.5 TB/s, launch floor 8 us; the expansion writes at 5.5 TB/s after a 6 us scan) and an ASSUMED 25 us for the
+    latency-bound all-gather of the bitmasks (unmeasured until an 8-GPU run exists).  `full`: every GPU expands the
+    whole list, so that leg does not shrink with N; `shard`: no exchange."""
+    shard = (n_total + world - 1) // world
+    cull = max(8e-3, shard * 145.125 / 6.5e12 * 1e3)
+    expand_all = 6e-3 + n_total * (1.125 + 20.0 * vis) / 5.5e12 * 1e3
+    expand_own = 6e-3 + shard * (1.125 + 20.0 * vis) / 5.5e12 * 1e3
+    full = cull + (25e-3 if world > 1 else 0.0) + expand_all
+    own = cull + expand_own
+    return {"full_ms_per_step": round(full, 4), "shard_ms_per_step": round(own, 4),
+            "full_M_inst_per_s": round(n_total / full / 1e3, 1), "shard_M_inst_per_s": round(n_total / own / 1e3, 1),
+            "model": "max(8us, shard*145.1B/6.5TB/s) + [25us all-gather, assumed] + 6us + list bytes/5.5TB/s (DESIGN.md 6); "
+                     "full = every GPU writes the whole list, shard = its own part only"}
+
+
 def latest_pmc():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cull_pmc.json")))
     return files[-1] if files else None
@@ -167,14 +221,21 @@ def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world_env > 1
+    exchange = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # one rank per GPU over RCCL ("nccl" on ROCm).  VOIDIN_DIST_BACKEND=gloo lets the same code path be
-        # exercised with several ranks on ONE GPU (tests / debugging): ranks then share the devices round-robin.
-        backend = os.environ.get("VOIDIN_DIST_BACKEND", "nccl")
+        # One rank per GPU; the data path is RCCL over xGMI either way:
+        #   --exchange rccl (default): the exchange lives behind the C ABI (vd_dist_*, csrc/dist.hip): cull_mask ->
+        #       ncclAllGather ON THE CTX STREAM -> expand_mask in one call; torch.distributed is only the control plane
+        #       (the 128-byte communicator id, the barrier and the max over ranks of the timed region) and runs on gloo;
+        #   --exchange torch: torch.distributed collectives between the two kernels, backend VOIDIN_DIST_BACKEND (nccl =
+        #       RCCL; gloo lets several ranks share ONE GPU - functional check only, RCCL refuses two ranks per device).
+        env_backend = os.environ.get("VOIDIN_DIST_BACKEND")
+        exchange = args.exchange or ("torch" if env_backend else "rccl")
+        backend = env_backend or ("gloo" if exchange == "rccl" else "nccl")
         n_dev = torch.cuda.device_count()
-        if backend == "nccl" and n_dev < world_env:
+        if (backend == "nccl" or exchange == "rccl") and n_dev < world_env:
             raise SystemExit(f"bench.py: {world_env} ranks over RCCL need {world_env} GPUs, {n_dev} visible "
                              "(VOIDIN_DIST_BACKEND=gloo runs the ranks on fewer devices: functional check only)")
         dev_index = local_rank % max(n_dev, 1)
@@ -224,7 +285,27 @@ def run_rank(args):
     del d_all_idx
 
     # N > 1: the sharded scene.  d_all = the whole scene's list (full / draws / indices), on every rank.
-    sv = vdist.ShardedVisibility(ctx, n_total, d_m, n_mesh, d_i) if distributed else None
+    sv, rccl_info = None, None
+    if distributed and exchange == "rccl":
+        try:
+            sv = vdist.RcclVisibility(ctx, n_total, d_m, n_mesh, d_i)
+            ok = 1
+        except Exception as e:      # VD_ERR_COMM: RCCL not loadable / communicator refused -> every rank falls back together
+            ok, why = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if rank == 0:
+                print(f"bench.py: C-ABI RCCL exchange unavailable ({why if not ok else 'another rank failed'}); "
+                      f"falling back to torch.distributed over {backend}", file=sys.stderr, flush=True)
+            if sv is not None:
+                sv.close()
+            sv, exchange = None, "torch (fallback)"
+        else:
+            rccl_info = {"version": int(sv.info.rccl_version), "library": sv.info.rccl_library.decode()}
+    if distributed and sv is None:
+        sv = vdist.ShardedVisibility(ctx, n_total, d_m, n_mesh, d_i)
+    via_c = distributed and exchange == "rccl"
     d_all = ctx.empty(n_total * 20) if distributed else None
     d_cnt_all = torch.zeros(4, dtype=torch.int32, device=dev) if distributed else None
     step_no = [0]
@@ -242,20 +323,23 @@ def run_rank(args):
             elif mode == "draws":
                 sv.step_draws(cam, d_all, d_cnt_all)
             elif mode == "indices":
+                if via_c:
+                    raise SystemExit("bench.py: --gather indices has no C-ABI form; use --exchange torch")
                 sv.step_indices(cam, d_all, d_cnt_all)
             else:
                 sv.step_shard(cam, d_out, d_cnt)
         return f
 
     def barrier():
+        torch.cuda.synchronize()          # this rank's GPU work is done (every stream of the device) ...
         if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.barrier()                # ... and so is every other rank's
+            torch.cuda.synchronize()
 
     def max_over_ranks(x):
         if not distributed:
             return x
-        tw = torch.tensor([x], dtype=torch.float64, device=dev)
+        tw = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         return float(tw.item())
 
@@ -279,15 +363,20 @@ def run_rank(args):
         # bitmask, the RCCL all-gather of the masks alone, and the expansion of ALL shards to the full draw list
         leg = lambda fn: round(timed(fn, args.steps, 1), 4)
         sv.d_inst = d_i
+        if via_c:
+            legs = (lambda: sv.cull_to_mask(cam), sv.allgather_masks, lambda: sv.expand_all(d_all, d_cnt_all))
+        else:
+            legs = (lambda: ctx.cull_mask_dev(cam, d_m, n_mesh, d_i, n, sv.d_mask),
+                    lambda: dist.all_gather_into_tensor(sv.d_mask_all, sv.d_mask),
+                    lambda: ctx.expand_mask_dev(sv.d_mask_all, n_total, sv.S, sv.d_mesh_ids, d_m, n_mesh, d_all, d_cnt_all, id_bytes=sv.id_bytes))
         breakdown = {
-            "cull_to_mask_ms": leg(lambda: ctx.cull_mask_dev(cam, d_m, n_mesh, d_i, n, sv.d_mask)),
-            "mask_allgather_ms": leg(lambda: dist.all_gather_into_tensor(sv.d_mask_all, sv.d_mask)),
-            "expand_all_shards_ms": leg(lambda: ctx.expand_mask_dev(sv.d_mask_all, n_total, sv.S, sv.d_mesh_ids, d_m, n_mesh, d_all, d_cnt_all,
-                                                                    id_bytes=sv.id_bytes)),
+            "cull_to_mask_ms": leg(legs[0]),
+            "mask_allgather_ms": leg(legs[1]),
+            "expand_all_shards_ms": leg(legs[2]),
             "mask_bytes_per_rank": int(sv.wps * 8),
             "note": "gather=full: every GPU materialises the whole list, so the expansion leg does not shrink with N (DESIGN.md 6)"}
         gather_modes = {}
-        for m_ in ("full", "draws", "indices", "shard"):
+        for m_ in (("full", "draws", "shard") if via_c else ("full", "draws", "indices", "shard")):
             t_ = ms_per_step if m_ == mode else timed(step_fn(m_), args.steps, 2)
             gather_modes[m_] = {"ms_per_step": round(t_, 4), "M_inst_per_s": round(n_total / t_ / 1e3, 1)}
         gather_modes["note"] = ("full/draws/indices: every GPU ends with the whole ordered list (wire: 1 bit per instance / 20 B per survivor / "
@@ -299,13 +388,15 @@ def run_rank(args):
             inst_w = synth.instances(n_w, seed=synth.SEED_BASE + 3, offset=rank * n_w, with_inverse=False, **kw)
             d_iw = ctx.upload(inst_w)
             del inst_w
-            sv_w = vdist.ShardedVisibility(ctx, n_w * world, d_m, n_mesh, d_iw)
+            sv_w = (vdist.RcclVisibility if via_c else vdist.ShardedVisibility)(ctx, n_w * world, d_m, n_mesh, d_iw)
             d_all_w, d_cnt_w = ctx.empty(n_w * world * 20), torch.zeros(4, dtype=torch.int32, device=dev)
             t_full = timed(lambda: sv_w.step(cam, d_all_w, d_cnt_w), args.steps, 2)
             t_shard = timed(lambda: sv_w.step_shard(cam, d_all_w, d_cnt_w), args.steps, 2)
             weak_line = {"instances_per_gpu": n_w, "instances_total": n_w * world,
                          "full": {"ms_per_step": round(t_full, 4), "M_inst_per_s": round(n_w * world / t_full / 1e3, 1)},
                          "shard": {"ms_per_step": round(t_shard, 4), "M_inst_per_s": round(n_w * world / t_shard / 1e3, 1)}}
+            if via_c:
+                sv_w.close()
             del sv_w, d_all_w, d_iw
         # leave d_all / d_cnt_all as a step of the headline mode on d_i leaves them
         step_no[0] = 0
@@ -427,7 +518,9 @@ def run_rank(args):
                          "draws": "every GPU ends the step with the whole list (literal all-gather of the 20-byte commands)",
                          "indices": "every GPU ends the step with the whole list (survivor indices exchanged, commands rebuilt locally)",
                          "shard": "every GPU keeps the ordered compacted list of its own shard (no exchange)"}[mode])
-            par = (f"instance-shard x{world}, one process per GPU, backend {backend}; gather={mode}" +
+            par = (f"instance-shard x{world}, one process per GPU; exchange: " +
+                   (f"C ABI vd_dist_* over RCCL {rccl_info['version']} on the ctx stream (control plane: torch.distributed/{backend})" if via_c
+                    else f"torch.distributed/{backend} ({exchange})") + f"; gather={mode}" +
                    {"full": ": visibility-bitmask all-gather (RCCL) + local expansion to the full draw list",
                     "draws": ": counts all-gather + exact-size direct all-gather of the commands (RCCL send/recv)",
                     "indices": ": counts all-gather + exact-size direct all-gather of u32 survivor indices + local rebuild",
@@ -452,7 +545,9 @@ def run_rank(args):
                        "input_gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
+                         "traffic": traffic, "traffic_source": (os.path.join("profiles", os.path.basename(pmc_path)) +
+                                                                " (separate rocprofv3 --pmc passes of this command, committed; not re-measured by this run)") if traffic else None,
+                         "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "second_kernel": None if not split else {
                              "kernel": "mask_scan_kernel + expand_mask_u8_kernel", "kernel_ms": round(expand_ms, 4),
@@ -464,9 +559,14 @@ def run_rank(args):
             "cpu_baseline": cpu,
             "extra": extra,
         }
+        line["scaling_ceiling"] = scaling_ceiling(n_total, world, vis if not distributed else count / max(n, 1), weak)
+        if rccl_info:
+            line["config"]["rccl"] = rccl_info
         if breakdown:
             line["step_breakdown"] = breakdown
         print(json.dumps(line), flush=True)
+    if via_c:
+        sv.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -790,7 +890,7 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.timeout))
     if args.launch_check:
         launch_check()
         return

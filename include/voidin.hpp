@@ -101,6 +101,18 @@ struct Bvh {
             if (t[i] >= 0.0f) out[i] = Dist{DistKind::Hit, t[i]};
         return out;
     }
+    // `Bvh::traverse(&self, &[Vec4], &[UVec4], Ray, node_idx, t) -> Dist` (blas.rs:211-245), the recursive walk, from node 0,
+    // for a batch of rays; Hit(t0) when the root box is entered and nothing is hit (the reference's quirk)
+    std::vector<Dist> traverse(const Gpu& gpu, const Vec3* vertices, size_t n_vertices, const UVec3* indices, size_t n_triangles,
+                               const std::vector<VdRay>& rays, float t0 = 1e30f) const {
+        std::vector<float> t(rays.size());
+        gpu.check(vd_traverse(gpu.ctx(), nodes.data(), (uint32_t)nodes.size(), &vertices->x, (uint32_t)n_vertices, &indices->x,
+                              (uint32_t)n_triangles, rays.data(), (uint32_t)rays.size(), t0, t.data()));
+        std::vector<Dist> out(rays.size());
+        for (size_t i = 0; i < t.size(); ++i)
+            if (t[i] >= 0.0f) out[i] = Dist{DistKind::Hit, t[i]};
+        return out;
+    }
 };
 
 // One ray per pixel from camera.clip_to_world, as the CPU harness makes them (src/bin/bvh_cpu.rs:71-83)

@@ -10,7 +10,9 @@
  *   - every function returns VD_OK (0) or a negative VdStatus; nothing aborts or throws
  *     across the boundary (the reference panics — crates/bvh/src/blas.rs:114-116 — we do not);
  *   - `*_dev` variants take DEVICE pointers (hipMalloc'd on the ctx's device) and enqueue
- *     on the ctx's stream without synchronising; the plain variants take HOST pointers,
+ *     on the ctx's stream without synchronising (exceptions, stated at their declarations:
+ *     vd_bvh_build_dev, vd_dist_step_draws_dev and the traversal entry points that report a
+ *     stack overflow read a word back and block); the plain variants take HOST pointers,
  *     stage through ctx-owned device buffers and return after the result is in host memory;
  *   - the caller owns every in/out buffer; device scratch belongs to the VdCtx;
  *   - a VdCtx is thread-compatible, not thread-safe (the reference's `World` is
@@ -157,7 +159,9 @@ typedef enum VdStatus {
     VD_ERR_NO_DEVICE = -5,       /* no gfx950 device / extension built for another arch  */
     VD_ERR_STACK_OVERFLOW = -6,  /* traversal stack exceeded (reference has no check:
                                     shaders/utils/stack.wgsl:1-20)                       */
-    VD_ERR_OOM = -7
+    VD_ERR_OOM = -7,
+    VD_ERR_COMM = -8             /* RCCL: library not found, communicator or collective failed;
+                                    text in vd_last_error                                  */
 } VdStatus;
 
 typedef struct VdCtx VdCtx;
@@ -176,6 +180,29 @@ int         vd_ctx_reset_stream(VdCtx* ctx);
 int         vd_ctx_synchronize(VdCtx* ctx);
 const char* vd_last_error(const VdCtx* ctx);
 const char* vd_version(void);
+
+/* Per-context options.  The library reads NO environment variable for these (the one it reads
+ * at all is VD_RCCL_LIB, the path of the RCCL shared object: "Multi-GPU exchange" below); defaults
+ * are the measured optima.  They exist for A/B measurements (tools/) and so that the
+ * tests can force paths that otherwise depend on timing or size (the single-workgroup redo of the
+ * TLAS chain, the indexed build on small inputs).  value < 0 restores the default.            */
+typedef enum VdOption {
+    VD_OPT_CULL_SPLIT_MIN = 1,    /* vd_cull_*: inputs of at least this many instances run the split form
+                                     (pass 1 -> scan -> pass 2); default 2 Mi                            */
+    VD_OPT_CULL_VARIANT = 2,      /* cull kernel variant (A/B; a small SIGNED id taken as is); default 0  */
+    VD_OPT_TLAS_INDEX = 10,       /* 0: never use the indexed TLAS build; default 1                       */
+    VD_OPT_TLAS_INDEX_MIN = 11,   /* smallest n the indexed build takes; default 4096                     */
+    VD_OPT_TLAS_PHASE2 = 12,      /* clusters left at which the indexed build hands over to plain scans;
+                                     default 2048                                                        */
+    VD_OPT_TLAS_REFRESH = 13,     /* merges between two re-tightenings of the index corners; default 1024 */
+    VD_OPT_TLAS_GROUPS = 14,      /* workgroups of the plain chain (1 = single workgroup); default by n   */
+    VD_OPT_TLAS_SPIN_LIMIT = 15,  /* polls before the several-workgroup chain gives up and the build is
+                                     redone on one workgroup (0 forces the redo: tests)                   */
+    VD_OPT_TLAS_SPEC = 16,        /* 0: indexed build without the speculative helper waves; default 1     */
+    VD_OPT_TLAS_PROFILE = 17,     /* 1: the indexed build prints its in-kernel cycle counters             */
+    VD_OPT_COUNT_ = 32
+} VdOption;
+int         vd_ctx_set_option(VdCtx* ctx, int option /* VdOption */, int64_t value);
 
 /* HIP -> wgpu hand-off.  The renderer owns `draw_cmd_buffer`
  * (ResizableBuffer<DrawIndexedIndirect>, crates/components/src/buffer.rs:42-47, created in
@@ -281,7 +308,16 @@ int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t
  *   out_nodes      capacity node_cap (>= 2*n_tri as the reference allocates, blas.rs:52)
  *   out_n_nodes    number of nodes used (`nodes.truncate(pool)`, blas.rs:93); node 1 is
  *                  the reference's never-used all-zero slot
- * VD_ERR_DEGENERATE where the reference would crash.                 */
+ * VD_ERR_DEGENERATE where the reference would crash.
+ *
+ * vd_bvh_build_dev takes device pointers but - unlike the per-frame `*_dev` entry points - it
+ * BLOCKS: it returns when the build is complete on the ctx stream, out_n_nodes is a HOST pointer,
+ * and errors (degenerate input, bad index) are reported by its return value.  The builder is a
+ * load-time call in the reference (MeshPool::add, mesh/mod.rs:320-345, before the first frame), the
+ * level loop reads one 32-byte control word per level back to size the next level's launches, and
+ * the DFS pre-order numbering of the top tree (blas.rs:110-112) is a host pass that overlaps the
+ * device's phase B; it cannot be captured into a HIP graph.  Builds of different meshes overlap by
+ * using one VdCtx (= one stream) per concurrent build.                                       */
 int vd_bvh_build(VdCtx* ctx, const float* verts_xyz, uint32_t n_vert,
                  uint32_t* indices_inout, uint32_t n_tri,
                  VdBvhNode* out_nodes, uint32_t node_cap, uint32_t* out_n_nodes);
@@ -371,12 +407,83 @@ int vd_primary_rays_dev(VdCtx* ctx, const VdCameraUniform* camera /* host */, ui
 int vd_traverse_iter_dev(VdCtx* ctx, const VdBvhNode* d_nodes, uint32_t n_nodes,
                          const float* d_verts_xyz, const uint32_t* d_indices,
                          const VdRay* d_rays, uint32_t n_rays, float* d_out_dist);
+/* vd_traverse_dev: `Bvh::traverse` (crates/bvh/src/blas.rs:211-245), the reference's RECURSIVE
+ * walk (its one call, `self.bvh.traverse(.., ray, 0, 1e30)`, is commented out at
+ * src/bin/bvh_cpu.rs:86), for every ray against one mesh, started at node 0 with `t = t0`: same
+ * slab and triangle tests as traverse_iter, children visited left then right without ordering,
+ * the running t handed from call to call.  d_out_dist[i] = the returned Hit(t) - which is t0
+ * itself when the ray enters the root box and hits nothing (the reference's quirk, kept) - or
+ * -1 for Dist::Miss (root box missed).  The recursion is run with an explicit stack of pending
+ * right children: 128 entries, VD_ERR_STACK_OVERFLOW beyond.  (The reference passes Vec4 / UVec4
+ * arrays there and uses xyz; here the Vec3 / UVec3 arrays of traverse_iter.)                 */
+int vd_traverse_dev(VdCtx* ctx, const VdBvhNode* d_nodes, uint32_t n_nodes,
+                    const float* d_verts_xyz, const uint32_t* d_indices,
+                    const VdRay* d_rays, uint32_t n_rays, float t0, float* d_out_dist);
 /* host-pointer forms (staged through the context, synchronous)                            */
 int vd_primary_rays(VdCtx* ctx, const VdCameraUniform* camera, uint32_t width, uint32_t height,
                     VdRay* rays);
 int vd_traverse_iter(VdCtx* ctx, const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz,
                      uint32_t n_vert, const uint32_t* indices /* 3 * n_tri, as vd_bvh_build left them */,
                      uint32_t n_tri, const VdRay* rays, uint32_t n_rays, float* out_dist);
+int vd_traverse(VdCtx* ctx, const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz,
+                uint32_t n_vert, const uint32_t* indices, uint32_t n_tri, const VdRay* rays,
+                uint32_t n_rays, float t0, float* out_dist);
+
+/* ------------------------------------------------------------------------------------ */
+/* Multi-GPU exchange over RCCL  (NEW; SURVEY.md §8e, BASELINE.json configs[3])          */
+/* ------------------------------------------------------------------------------------ */
+/* The reference is single-GPU (one wgpu::Device, crates/app/src/app.rs:108-118); this is the
+ * north-star extension: instances shard by contiguous ranges - rank r of `world` owns
+ * [r*S, min(N, (r+1)*S)), S = ceil(N / world) - and every rank ends a step with the ordered
+ * compacted draw list of the WHOLE scene, bit-identical to vd_cull_compact on one GPU.  One
+ * process (or thread) per GPU, one VdDist per VdCtx; the collectives are enqueued on the
+ * context's stream between the two kernels, so a step is three enqueues on one stream.
+ *
+ *   vd_dist_unique_id       rank 0 makes the 128-byte communicator id (ncclGetUniqueId) and hands it to
+ *                           the other ranks by whatever channel the host has (the Rust host: its own
+ *                           IPC; the tests: a gloo broadcast).
+ *   vd_dist_create          ncclCommInitRank on ctx's device; collective over all ranks.  world = 1 is a
+ *                           valid communicator (a one-GPU functional check of the whole path).
+ *   vd_dist_set_scene_dev   per scene: sizes the shard, builds this rank's rows of the replicated
+ *                           instance -> mesh table (min(instance.mesh, n_mesh - 1); 1, 2 or 4 bytes by
+ *                           table size) and all-gathers the table.  n_local must be this rank's shard
+ *                           size.  Mesh assignment is static in the reference's scenes (only transforms
+ *                           animate: shaders/compute_update.wgsl:10-28); call again when it changes.
+ *   vd_dist_step_full_dev   vd_cull_mask_dev(own shard) -> ncclAllGather(1 bit per instance) ->
+ *                           vd_expand_mask_dev(all shards): d_out[0..*d_out_count) = the whole scene's
+ *                           list (d_out holds n_total commands).  No host round trip, no allocation.
+ *   vd_dist_step_draws_dev  the literal exchange of the 20-byte commands: compact the own shard, all-gather
+ *                           the counts (read back on the host: the sizes are data dependent), exact-size
+ *                           grouped ncclSend / ncclRecv straight into every peer's final buffer.
+ *   vd_dist_allgather_dev   plain byte all-gather on the ctx stream (d_recv holds world * bytes_per_rank).
+ * RCCL is bound at run time: the copy already loaded in the process if there is one, else
+ * $VD_RCCL_LIB, else librccl.so.1 / /opt/rocm/lib; failure is VD_ERR_COMM, never an abort.            */
+#define VD_DIST_ID_BYTES 128
+typedef struct VdDist VdDist;
+typedef struct VdDistInfo {
+    int32_t  rank, world;
+    uint32_t n_total, shard_size, first_instance, n_local;
+    uint32_t mask_words_per_shard, id_bytes;
+    uint64_t* d_mask;        /* this rank's mask (mask_words_per_shard words)                  */
+    uint64_t* d_mask_all;    /* all shards' masks after a full step                            */
+    void*     d_mesh_ids;    /* replicated instance -> mesh table (shard_size * world rows)    */
+    int32_t  rccl_version;   /* ncclGetVersion, e.g. 22606                                     */
+    int32_t  _pad;
+    char     rccl_library[128];
+} VdDistInfo;
+int vd_dist_unique_id(void* out_id /* VD_DIST_ID_BYTES */);
+int vd_dist_create(VdCtx* ctx, const void* unique_id /* VD_DIST_ID_BYTES */, int rank, int world, VdDist** out);
+int vd_dist_destroy(VdDist* dist);
+int vd_dist_info(const VdDist* dist, VdDistInfo* out);
+int vd_dist_set_scene_dev(VdDist* dist, const VdInstance* d_shard_instances, uint32_t n_local, uint32_t n_total,
+                          uint32_t n_mesh);
+int vd_dist_step_full_dev(VdDist* dist, const VdCameraUniform* camera /* host */, const VdMeshInfo* d_meshes,
+                          uint32_t n_mesh, const VdInstance* d_shard_instances, VdDrawIndexedIndirect* d_out,
+                          uint32_t* d_out_count);
+int vd_dist_step_draws_dev(VdDist* dist, const VdCameraUniform* camera /* host */, const VdMeshInfo* d_meshes,
+                           uint32_t n_mesh, const VdInstance* d_shard_instances, VdDrawIndexedIndirect* d_out,
+                           uint32_t* d_out_count);
+int vd_dist_allgather_dev(VdDist* dist, const void* d_send, void* d_recv, uint64_t bytes_per_rank);
 
 /* ------------------------------------------------------------------------------------ */
 /* Occlusion culling  (SURVEY.md §8a C4 / §8f N4 — EXTENSION, no reference counterpart)     */

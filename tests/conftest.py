@@ -59,3 +59,16 @@ def ctx():
     c = Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture
+def ctx_options(ctx):
+    """Per-context options (vd_ctx_set_option) for one test: set(name, value); everything is back to default afterwards."""
+    touched = []
+
+    def set_(name, value):
+        ctx.set_option(name, value)
+        touched.append(name)
+    yield set_
+    for name in touched:
+        ctx.set_option(name, None)

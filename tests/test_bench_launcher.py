@@ -53,6 +53,40 @@ def test_failing_rank_fails_the_launch():
     assert p.returncode != 0
 
 
+def _rank_pids(launcher_pid):
+    out = subprocess.run(["ps", "-o", "pid=", "--ppid", str(launcher_pid)], capture_output=True, text=True).stdout.split()
+    return [int(x) for x in out]
+
+
+def test_a_stopped_launcher_takes_its_ranks_with_it():
+    """SIGTERM to the launcher (what `timeout 600 python bench.py --gpus 2` sends) must not orphan the ranks,
+    and --timeout bounds a launch whose ranks never finish."""
+    import signal
+    import time
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e["VOIDIN_DIST_BACKEND"] = "gloo"
+    e["VOIDIN_LAUNCH_CHECK_HOLD_S"] = "60"            # the ranks rendezvous and then sit there
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"]
+    p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    kids = []
+    for _ in range(100):
+        kids = _rank_pids(p.pid)
+        if len(kids) == 2:
+            break
+        time.sleep(0.1)
+    assert len(kids) == 2
+    time.sleep(1.0)
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    time.sleep(0.2)
+    for k in kids:
+        assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z", f"rank process {k} survived its launcher"
+    t0 = time.time()
+    q = subprocess.run(cmd + ["--timeout", "6"], env=e, capture_output=True, text=True, timeout=120)
+    assert q.returncode == 124 and time.time() - t0 < 60 and "still running" in q.stderr
+
+
 def test_tree_shape_counts_every_partitioned_primitive(oracle):
     import bench
     from voidin_amd import synth

@@ -122,3 +122,19 @@ def test_external_buffer_import_round_trip():
     if "SKIP" in out.stdout:
         pytest.skip(out.stdout.strip())
     assert "external_buffer_test OK" in out.stdout
+
+
+def test_dist_world1_test_compiles():
+    _build_cpp("dist_world1_test")
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_from_a_cpp_host_with_one_rank():
+    """SURVEY.md §8e behind the C ABI: vd_dist_create (world = 1) -> vd_dist_step_full_dev / vd_dist_step_draws_dev from a
+    plain C++ process (RCCL bound by the library itself) == vd_cull_compact_dev, byte for byte."""
+    exe = _build_cpp("dist_world1_test")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run(["timeout", "240", exe], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "dist_world1_test OK" in out.stdout and out.stdout.count("identical to vd_cull_compact_dev") == 4, out.stdout

@@ -59,14 +59,17 @@ def test_tlas_refit_climb_repeats(ctx):
             assert torch.equal(d_t, built), f"refit n={n}: run {it} differs from the build"
 
 
-def test_several_workgroup_tlas_chain_repeats(ctx, monkeypatch):
-    """The 16-workgroup chain (sizes above what the indexed build takes, or VD_TLAS_INDEX=0): tagged-word exchange."""
-    monkeypatch.setenv("VD_TLAS_INDEX", "0")
-    meshes = synth.mesh_infos()
-    inst = synth.instances(16461, seed=synth.SEED_BASE + 14, extent=700.0)
-    first = ctx.tlas_build(inst, meshes).tobytes()
-    for it in range(6):
-        assert ctx.tlas_build(inst, meshes).tobytes() == first, f"run {it} differs"
+def test_several_workgroup_tlas_chain_repeats(ctx):
+    """The 16-workgroup chain (sizes above what the indexed build takes, or VD_OPT_TLAS_INDEX = 0): tagged-word exchange."""
+    ctx.set_option("tlas.index", 0)
+    try:
+        meshes = synth.mesh_infos()
+        inst = synth.instances(16461, seed=synth.SEED_BASE + 14, extent=700.0)
+        first = ctx.tlas_build(inst, meshes).tobytes()
+        for it in range(6):
+            assert ctx.tlas_build(inst, meshes).tobytes() == first, f"run {it} differs"
+    finally:
+        ctx.set_option("tlas.index", None)
 
 
 def test_indexed_tlas_build_repeats(ctx):

@@ -50,12 +50,11 @@ def test_tlas_build_on_several_workgroups_vs_oracle(ctx, oracle):
     got_b, want_b = ctx.tlas_build(bad, meshes), oracle.tlas_build(bad, meshes)
     assert fields_equal(got_b, want_b)
     # workgroups that do not hear from each other in time give up and the build is redone on one workgroup
-    import os
-    os.environ["VD_TLAS_SPIN_LIMIT"] = "0"
+    ctx.set_option("tlas.spin_limit", 0)
     try:
         assert fields_equal(ctx.tlas_build(inst, meshes), want)
     finally:
-        del os.environ["VD_TLAS_SPIN_LIMIT"]
+        ctx.set_option("tlas.spin_limit", None)
     big = synth.instances(32768, seed=synth.SEED_BASE + 6, extent=300.0)
     first = ctx.tlas_build(big, meshes).tobytes()
     for _ in range(3):
@@ -132,6 +131,45 @@ def test_cpu_harness_rays_and_traverse_iter(ctx, oracle):
     got = d_out.cpu().numpy()
     assert got.view(np.uint32).tobytes() == want.view(np.uint32).tobytes()
     assert (got[: 6 * k] >= 0).sum() > k
+
+
+def test_recursive_traverse_vs_oracle(ctx, oracle):
+    """SURVEY 8a R3: `Bvh::traverse` (crates/bvh/src/blas.rs:211-245), the reference's recursive walk - left then right,
+    no near / far ordering, Hit(t0) when the root box is entered and nothing is hit, Miss only when the root box is
+    missed - on the device with an explicit stack, bit for bit against the oracle's literal recursion: the harness soup,
+    a knot mesh (deep tree), axis-aligned / degenerate rays, a finite t0, and the host-pointer form."""
+    import ctypes as C
+    import torch
+    g = golden("harness_soup64.npz")
+    cases = [(g["nodes"], g["vertices"].astype(np.float32), g["indices"].astype(np.uint32), g["rays"])]
+    v, i = synth.knot_mesh(96, 24)
+    nodes, idx = oracle.bvh_build(v, i)
+    cases.append((nodes, v, idx, synth.primary_rays(synth.camera_uniform(eye=(0, 0, 6), pitch_deg=0), 64, 64)))
+    for nodes, v, idx, rays in cases:
+        odd = rays[:64].copy()
+        odd["dir"][:16] = (0, 0, -1); odd["dir"][16:32] = (1, 0, 0); odd["dir"][32] = (0, 0, 0); odd["dir"][33] = (np.nan, 1, 0)
+        odd["eye"][34] = (np.inf, 0, 0)
+        rays = np.concatenate([rays, odd])
+        d_n, d_v, d_i, d_r = ctx.upload(nodes), ctx.upload(v), ctx.upload(idx), ctx.upload(rays)
+        for t0 in (1e30, 14.0):
+            want = oracle.traverse_recursive(nodes, v, idx, rays, t0=t0)
+            d_out = torch.zeros(len(rays), dtype=torch.float32, device="cuda")
+            ctx.traverse_dev(d_n, len(nodes), d_v, d_i, d_r, len(rays), d_out, t0=t0)
+            got = d_out.cpu().numpy()
+            assert got.view(np.uint32).tobytes() == want.view(np.uint32).tobytes()
+        hits = (want >= 0) & (want < np.float32(14.0))
+        assert hits.sum() > 20 and (want == np.float32(14.0)).sum() > 0 and (want < 0).sum() > 0   # real hits, Hit(t0) quirk, Miss
+        # where traverse_iter hits, the recursive walk returns the same distance
+        it = oracle.traverse_iter(nodes, v, idx, rays)
+        full = oracle.traverse_recursive(nodes, v, idx, rays)
+        assert np.array_equal(full[it >= 0], it[it >= 0])
+    # host-pointer form + argument checks
+    nodes, v, idx, rays = cases[0]
+    out = np.zeros(len(rays), dtype=np.float32)
+    rc = ctx.lib.vd_traverse(ctx.h, nodes.ctypes.data, len(nodes), v.ctypes.data, len(v), idx.ctypes.data, len(idx) // 3,
+                             np.ascontiguousarray(rays).ctypes.data, len(rays), C.c_float(1e30), out.ctypes.data)
+    assert rc == 0 and out.tobytes() == oracle.traverse_recursive(nodes, v, idx, rays).tobytes()
+    assert ctx.lib.vd_traverse_dev(ctx.h, None, 0, None, None, None, 4, C.c_float(1e30), None) == abi.VD_ERR_INVALID_ARG
 
 
 def test_tlas_build_with_nan_and_inf_boxes(ctx, oracle):
@@ -321,15 +359,15 @@ def _boxes_as_scene(boxes):
 
 
 @pytest.mark.parametrize("helpers", ["1", "0"])
-def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, monkeypatch, helpers):
+def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, ctx_options, helpers):
     """The indexed build (tlas.hip, "build, indexed": pruned queries, two at a time - the one the chain needs and the one a
     merge would need) forced onto small inputs made of what can break it: identical and nested boxes (every union area
     ties: the slot index decides), lattices, zero extents, chains that keep ending on the last slot (the stale index of
     tlas.rs:72-75), and ordinary clouds; and inputs it must hand to the plain chain (NaN, inf, huge)."""
-    monkeypatch.setenv("VD_TLAS_INDEX_MIN", "65")
-    monkeypatch.setenv("VD_TLAS_PHASE2", "64")
-    monkeypatch.setenv("VD_TLAS_REFRESH", "37")
-    monkeypatch.setenv("VD_TLAS_SPEC", helpers)                                 # with / without the four helper waves
+    ctx_options("tlas.index_min", 65)
+    ctx_options("tlas.phase2", 64)
+    ctx_options("tlas.refresh", 37)
+    ctx_options("tlas.spec", int(helpers))                                      # with / without the four helper waves
 
     def cloud(n, seed, extent=60.0, size=4.0):
         u = synth.uniform01(seed, 0, 6 * n).reshape(n, 6).astype(np.float32)

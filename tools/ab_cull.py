@@ -28,8 +28,6 @@ args = ap.parse_args()
 
 ctx = Context(0)
 lib = ctx.lib
-lib.vd_debug_set_cull_variant.restype = C.c_int
-lib.vd_debug_set_cull_variant.argtypes = [C.c_void_p, C.c_int]
 cam, meshes = synth.camera_uniform(), synth.mesh_infos()
 kw = dict(scale_range=(0.25, 4.0)) if args.dist == "baseline" else dict(scale_range=(0.02, 0.6), extent=600.0)
 inst = synth.instances(args.n, seed=synth.SEED_BASE + 3, with_inverse=False, **kw)
@@ -42,7 +40,7 @@ ref_bytes = None
 times = {v: [] for v in variants}
 for rnd in range(args.rounds):
     for v in variants:
-        lib.vd_debug_set_cull_variant(ctx.h, v)
+        lib.vd_ctx_set_option(ctx.h, 2, v)      # VD_OPT_CULL_VARIANT: signed ids, taken as is
         for _ in range(2):
             ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt)
         torch.cuda.synchronize()

@@ -1,3 +1,4 @@
+# needs the tuning build: make -C voidin_amd/csrc tuning && VOIDIN_HIP_LIB=voidin_amd/csrc/libvoidin_hip_tuning.so python tools/blas_hist.py
 import ctypes as C, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from voidin_amd import synth

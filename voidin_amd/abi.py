@@ -55,10 +55,20 @@ VD_ERR_TLAS_OVERFLOW = -4
 VD_ERR_NO_DEVICE = -5
 VD_ERR_STACK_OVERFLOW = -6
 VD_ERR_OOM = -7
+VD_ERR_COMM = -8
+VD_DIST_ID_BYTES = 128
+# VdOption (include/voidin_abi.h); the environment names are read by the PYTHON harness only (Context.apply_env_options),
+# never by the library
+OPTIONS = {"cull.split_min": 1, "cull.variant": 2, "tlas.index": 10, "tlas.index_min": 11, "tlas.phase2": 12, "tlas.refresh": 13,
+           "tlas.groups": 14, "tlas.spin_limit": 15, "tlas.spec": 16, "tlas.profile": 17}
+OPTION_ENV = {"VD_SPLIT_MIN": "cull.split_min", "VD_CULL_VARIANT": "cull.variant", "VD_TLAS_INDEX": "tlas.index",
+              "VD_TLAS_INDEX_MIN": "tlas.index_min", "VD_TLAS_PHASE2": "tlas.phase2", "VD_TLAS_REFRESH": "tlas.refresh",
+              "VD_TLAS_GROUPS": "tlas.groups", "VD_TLAS_SPIN_LIMIT": "tlas.spin_limit", "VD_TLAS_SPEC": "tlas.spec",
+              "VD_TLAS_PROFILE": "tlas.profile"}
 
 STATUS_NAMES = {0: "VD_OK", -1: "VD_ERR_INVALID_ARG", -2: "VD_ERR_HIP", -3: "VD_ERR_DEGENERATE",
                 -4: "VD_ERR_TLAS_OVERFLOW", -5: "VD_ERR_NO_DEVICE", -6: "VD_ERR_STACK_OVERFLOW",
-                -7: "VD_ERR_OOM"}
+                -7: "VD_ERR_OOM", -8: "VD_ERR_COMM"}
 
 
 class TraceScene(C.Structure):
@@ -76,6 +86,14 @@ class HizLayout(C.Structure):
     """VdHizLayout (include/voidin_abi.h, occlusion extension): sizes and texel offsets of the depth pyramid."""
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("n_levels", C.c_uint32), ("total_texels", C.c_uint32),
                 ("level_offset", C.c_uint32 * 17), ("level_width", C.c_uint32 * 17), ("level_height", C.c_uint32 * 17)]
+
+
+class DistInfo(C.Structure):
+    """VdDistInfo (include/voidin_abi.h, multi-GPU exchange)."""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("n_total", C.c_uint32), ("shard_size", C.c_uint32),
+                ("first_instance", C.c_uint32), ("n_local", C.c_uint32), ("mask_words_per_shard", C.c_uint32), ("id_bytes", C.c_uint32),
+                ("d_mask", C.c_void_p), ("d_mask_all", C.c_void_p), ("d_mesh_ids", C.c_void_p), ("rccl_version", C.c_int32),
+                ("_pad", C.c_int32), ("rccl_library", C.c_char * 128)]
 
 
 class BvhBuildStats(C.Structure):
@@ -96,6 +114,7 @@ PROTOTYPES = {
     "vd_ctx_set_stream": (_I, [_P, _P]),
     "vd_ctx_reset_stream": (_I, [_P]),
     "vd_ctx_synchronize": (_I, [_P]),
+    "vd_ctx_set_option": (_I, [_P, _I, C.c_int64]),
     "vd_last_error": (C.c_char_p, [_P]),
     "vd_version": (C.c_char_p, []),
     "vd_cull_emit": (_I, [_P, _P, _P, _U, _P, _U, _P]),
@@ -126,6 +145,8 @@ PROTOTYPES = {
     "vd_shadow_rays_dev": (_I, [_P, _P, _P, _U, C.POINTER(C.c_float), _P]),
     "vd_primary_rays_dev": (_I, [_P, _P, _U, _U, _P]),
     "vd_traverse_iter_dev": (_I, [_P, _P, _U, _P, _P, _P, _U, _P]),
+    "vd_traverse_dev": (_I, [_P, _P, _U, _P, _P, _P, _U, C.c_float, _P]),
+    "vd_traverse": (_I, [_P, _P, _U, _P, _U, _P, _U, _P, _U, C.c_float, _P]),
     "vd_primary_rays": (_I, [_P, _P, _U, _U, _P]),
     "vd_traverse_iter": (_I, [_P, _P, _U, _P, _U, _P, _U, _P, _U, _P]),
     "vd_hiz_layout": (_I, [_U, _U, _P]),
@@ -136,6 +157,14 @@ PROTOTYPES = {
     "vd_last_gpu_ms": (C.c_float, [_P]),
     "vd_last_gpu_ms_stage": (C.c_float, [_P, _I]),
     "vd_bvh_last_build_stats": (_I, [_P, C.POINTER(BvhBuildStats)]),
+    "vd_dist_unique_id": (_I, [_P]),
+    "vd_dist_create": (_I, [_P, _P, _I, _I, C.POINTER(_P)]),
+    "vd_dist_destroy": (_I, [_P]),
+    "vd_dist_info": (_I, [_P, C.POINTER(DistInfo)]),
+    "vd_dist_set_scene_dev": (_I, [_P, _P, _U, _U, _U]),
+    "vd_dist_step_full_dev": (_I, [_P, _P, _P, _U, _P, _P, _P]),
+    "vd_dist_step_draws_dev": (_I, [_P, _P, _P, _U, _P, _P, _P]),
+    "vd_dist_allgather_dev": (_I, [_P, _P, _P, C.c_uint64]),
 }
 
 _lib = None

@@ -2086,7 +2086,9 @@ int vd_bvh_last_build_stats(const VdCtx* ctx, VdBvhBuildStats* out) {
     return VD_OK;
 }
 
-// Tuning hook: per-subtree {cycles, prims} pairs of the last phase B run.
+#ifdef VD_TUNING
+// Tuning hook (make tuning -> libvoidin_hip_tuning.so; not in the product library): per-subtree {cycles, prims} pairs
+// of the last phase B run.
 int vd_debug_blas_cycles(VdCtx* ctx, uint32_t* out, uint32_t cap) {
     VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx || !ctx->dbg_ptr) return 0;
@@ -2094,6 +2096,7 @@ int vd_debug_blas_cycles(VdCtx* ctx, uint32_t* out, uint32_t cap) {
     if (hipMemcpy(out, ctx->dbg_ptr, 4 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return (int)n;
 }
+#endif
 
 int vd_bvh_build_dev(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32_t* d_idx, uint32_t n_tri, VdBvhNode* d_out,
                      uint32_t node_cap, uint32_t* out_n_nodes) {

@@ -84,8 +84,7 @@ int vd_ctx_create(int device, VdCtx** out_ctx) {
         return VD_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    if (const char* v = getenv("VD_CULL_VARIANT")) ctx->cull_variant = atoi(v);
-    if (const char* v = getenv("VD_SPLIT_MIN")) ctx->split_min = (unsigned)atoi(v);
+    for (int o = 0; o < VD_OPT_COUNT_; ++o) ctx->opt[o] = -1;
     *out_ctx = ctx;
     return VD_OK;
 }
@@ -177,9 +176,12 @@ int vd_release_external_buffer(VdCtx* ctx, VdExternalBuffer* handle) {
     return VD_OK;
 }
 
-int vd_debug_set_cull_variant(VdCtx* ctx, int variant) {
+int vd_ctx_set_option(VdCtx* ctx, int option, int64_t value) {
     if (!ctx) return VD_ERR_INVALID_ARG;
-    ctx->cull_variant = variant;
+    if (option <= 0 || option >= VD_OPT_COUNT_) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_ctx_set_option: unknown option");
+    ctx->opt[option] = value < 0 ? -1 : (long long)value;
+    if (option == VD_OPT_CULL_SPLIT_MIN) ctx->split_min = value < 0 ? (2u << 20) : (unsigned)value;
+    if (option == VD_OPT_CULL_VARIANT) ctx->cull_variant = (int)value;     // variants are small signed ids, 0 = default
     return VD_OK;
 }
 

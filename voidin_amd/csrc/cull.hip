@@ -520,9 +520,16 @@ __global__ __launch_bounds__(kScanBlock) void mask_scan_kernel(const vd_u64* __r
     // read at agent scope (other XCDs wrote the counts)
     const unsigned per = (n_chunks + kScanBlock - 1) / kScanBlock;
     const unsigned begin = min(threadIdx.x * per, n_chunks), end = min(begin + per, n_chunks);
+    // Bounded like every other cross-workgroup wait of the library: if the header and the entries ever disagree (a
+    // launch on this context faulted mid-kernel, a stray write hit the state) the count becomes the sentinel 0xffffffff
+    // - which the expansion pass and every consumer of *out_count treat as "no list" (it exceeds any instance count) -
+    // instead of a stream that never finishes.
+    bool stuck = false;
     auto entry = [&](unsigned c) -> unsigned {
         vd_u64 e = __hip_atomic_load(&chunk_entry[c], VD_RLX_AGENT);
+        unsigned spins = 0;
         while ((e >> 32) != (vd_u64)ep) {                    // still in flight: its writer has arrived, the store lands shortly
+            if (++spins > (1u << 22)) { stuck = true; return 0u; }
             __builtin_amdgcn_s_sleep(1);
             e = __hip_atomic_load(&chunk_entry[c], VD_RLX_AGENT);
         }
@@ -530,6 +537,7 @@ __global__ __launch_bounds__(kScanBlock) void mask_scan_kernel(const vd_u64* __r
     };
     unsigned sum = 0;
     for (unsigned c = begin; c < end; ++c) sum += entry(c);
+    const bool any_stuck = __syncthreads_or(stuck ? 1 : 0) != 0;
     unsigned incl = sum;                                   // inclusive scan of the per-thread sums
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -541,12 +549,13 @@ __global__ __launch_bounds__(kScanBlock) void mask_scan_kernel(const vd_u64* __r
     unsigned run = incl - sum;
     for (unsigned w = 0; w < wave; ++w) run += s_wave_sum[w];
     for (unsigned c = begin; c < end; ++c) {
+        if (any_stuck) { chunk_entry[c] = tag | 0xffffffffu; continue; }   // pass 2b leaves such a chunk alone
         const unsigned v = entry(c);
         chunk_entry[c] = tag | run;                        // read by pass 2b, a later launch on this stream
         run += v;
     }
     if (threadIdx.x == kScanBlock - 1u) {
-        *out_count = run;
+        *out_count = any_stuck ? 0xffffffffu : run;
         __hip_atomic_store(&state->done, 0u, VD_RLX_AGENT);        // re-armed for the next launch on this stream
         __hip_atomic_store(&state->epoch, ep + 1u, VD_RLX_AGENT);  // every workgroup of this launch has read it (all arrived)
     }
@@ -574,6 +583,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_kernel(const vd_u64* __res
     const unsigned cw0 = chunk * kChunkWords;
     const unsigned w0 = __builtin_amdgcn_readfirstlane(cw0 + wave * kExpandWords);   // wave-uniform: scalar index math
     unsigned base = (unsigned)chunk_entry[chunk];
+    if (base == 0xffffffffu) return;                       // the scan gave up (mask_scan_kernel): no list
     // survivors of the chunk's earlier waves: lane l looks at words cw0 + l and cw0 + 64 + l
     unsigned before = 0;
     if (lane < wave * kExpandWords && cw0 + lane < n_words) before = (unsigned)__popcll(mask[cw0 + lane]);
@@ -690,6 +700,7 @@ __global__ __launch_bounds__(kBlock) void expand_mask_u8_kernel(const vd_u64* __
     const unsigned cw0 = chunk * kChunkWords;
     const unsigned w0 = cw0 + wave * kExpandWords;
     unsigned base = (unsigned)chunk_entry[chunk];
+    if (base == 0xffffffffu) return;                       // the scan gave up (mask_scan_kernel): no list
     // survivors of the chunk's earlier waves: lane l looks at words cw0 + l and cw0 + 64 + l
     unsigned before = 0;
     if (lane < wave * kExpandWords && cw0 + lane < n_words) before = (unsigned)__popcll(mask[cw0 + lane]);
@@ -914,6 +925,7 @@ __global__ __launch_bounds__(kBlock) void mask_to_indices_kernel(const vd_u64* _
     const unsigned cw0 = blockIdx.x * kChunkWords;
     const unsigned w0 = cw0 + wave * kExpandWords;
     unsigned base = (unsigned)chunk_entry[blockIdx.x];
+    if (base == 0xffffffffu) return;                       // the scan gave up (mask_scan_kernel): no list
     unsigned before = 0;
     if (lane < wave * kExpandWords && cw0 + lane < n_words) before = (unsigned)__popcll(mask[cw0 + lane]);
     if (lane + 64u < wave * kExpandWords && cw0 + 64u + lane < n_words) before += (unsigned)__popcll(mask[cw0 + 64u + lane]);

@@ -1156,8 +1156,17 @@ __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigne
 template <typename Node>
 int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                     Node* d_nodes) {
-    // scratch: 6 float slot arrays + slot node ids (capacity n), the several-workgroup exchange words, and for the indexed
-    // build the entries, the slot -> entry map, two key / value pairs of the sort and the control words
+    // The indexed build (one workgroup, exact pruning) from a few thousand instances up to what its corner table fits in
+    // LDS; above that the scans are spread over several workgroups.  Per-context options (vd_ctx_set_option):
+    // VD_OPT_TLAS_INDEX = 0 switches it off (A/B), VD_OPT_TLAS_INDEX_MIN / _PHASE2 / _REFRESH tune it.
+    const int env_index = (int)ctx->option(VD_OPT_TLAS_INDEX, 1);
+    const unsigned ix_min = (unsigned)ctx->option(VD_OPT_TLAS_INDEX_MIN, 4096);
+    unsigned phase2 = (unsigned)ctx->option(VD_OPT_TLAS_PHASE2, 2048);
+    const unsigned refresh = (unsigned)ctx->option(VD_OPT_TLAS_REFRESH, 1024);
+    if (phase2 < 64u) phase2 = 64u;
+    const bool indexed = env_index != 0 && n >= ix_min && n > phase2 && n <= kIxMaxInstances;
+    // scratch: 6 float slot arrays + slot node ids (capacity n), the several-workgroup exchange words, and - only when the
+    // indexed build runs - the entries, the slot -> entry map, two key / value pairs of the sort and the control words
     const size_t cap = ((size_t)n + 7) & ~(size_t)3;   // multiple of 4 (+ slack): slot arrays are read 16 B at a time
     const size_t off_sh = (cap * 7 * 4 + 255) & ~(size_t)255;
     const unsigned E = (n + kIxBlock - 1u) / kIxBlock * kIxBlock;
@@ -1166,26 +1175,17 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     const size_t off_sort = off_map + (((size_t)n * 4 + 255) & ~(size_t)255);
     const size_t sort_stride = ((size_t)n * 4 + 255) & ~(size_t)255;
     const size_t off_ctl = off_sort + 4 * sort_stride;
-    const size_t need = off_ctl + 256;
+    const size_t need = indexed ? off_ctl + 256 : off_ent;
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
     if (rc) return rc;
     char* base = reinterpret_cast<char*>(ctx->scratch);
     float* sb = reinterpret_cast<float*>(base);
     unsigned* slot_node = reinterpret_cast<unsigned*>(sb + 6 * cap);
     MwShared* sh = reinterpret_cast<MwShared*>(base + off_sh);
-    // The indexed build (one workgroup, exact pruning) from a few thousand instances up to what its corner table fits in
-    // LDS; above that the scans are spread over several workgroups.  VD_TLAS_INDEX=0 switches it off (A/B),
-    // VD_TLAS_INDEX_MIN / VD_TLAS_PHASE2 / VD_TLAS_REFRESH tune it.
-    const int env_index = getenv("VD_TLAS_INDEX") ? atoi(getenv("VD_TLAS_INDEX")) : 1;
-    const unsigned ix_min = getenv("VD_TLAS_INDEX_MIN") ? (unsigned)atoi(getenv("VD_TLAS_INDEX_MIN")) : 4096u;
-    unsigned phase2 = getenv("VD_TLAS_PHASE2") ? (unsigned)atoi(getenv("VD_TLAS_PHASE2")) : 2048u;
-    const unsigned refresh = getenv("VD_TLAS_REFRESH") ? (unsigned)atoi(getenv("VD_TLAS_REFRESH")) : 1024u;
-    if (phase2 < 64u) phase2 = 64u;
-    const bool indexed = env_index != 0 && n >= ix_min && n > phase2 && n <= kIxMaxInstances;
     // several workgroups from a few thousand instances on (below, the exchange costs more than the shorter scans save);
-    // the slot field of the exchanged key holds 20 bits.  VD_TLAS_GROUPS = 1 forces the single-workgroup kernel.
-    const int env_groups = getenv("VD_TLAS_GROUPS") ? atoi(getenv("VD_TLAS_GROUPS")) : 0;
-    const unsigned spin_limit = getenv("VD_TLAS_SPIN_LIMIT") ? (unsigned)atoi(getenv("VD_TLAS_SPIN_LIMIT")) : kSpinLimit;   // tests: 0 forces the fallback
+    // the slot field of the exchanged key holds 20 bits.  VD_OPT_TLAS_GROUPS = 1 forces the single-workgroup kernel.
+    const int env_groups = (int)ctx->option(VD_OPT_TLAS_GROUPS, 0);
+    const unsigned spin_limit = (unsigned)ctx->option(VD_OPT_TLAS_SPIN_LIMIT, kSpinLimit);   // tests: 0 forces the fallback
     unsigned groups = env_groups > 0 ? (unsigned)env_groups : (n >= 12288u ? 16u : 1u);
     if (groups > kMwMaxGroups) groups = kMwMaxGroups;
     if (groups > (unsigned)ctx->num_cus) groups = (unsigned)ctx->num_cus;
@@ -1201,7 +1201,7 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
         for (int k = 0; k < 4; ++k) keys[k] = reinterpret_cast<unsigned*>(base + off_sort + k * sort_stride);
         IxCtl* ctl = reinterpret_cast<IxCtl*>(base + off_ctl);
         const unsigned n_slices = E / kIxSlice, n_super = (n_slices + kIxSuper - 1u) / kIxSuper;
-        const bool spec = getenv("VD_TLAS_SPEC") ? atoi(getenv("VD_TLAS_SPEC")) != 0 : true;
+        const bool spec = ctx->option(VD_OPT_TLAS_SPEC, 1) != 0;
         hipLaunchKernelGGL(tlas_index_kernel, dim3(1), dim3(kSortThreads), 0, ctx->stream, sb, (unsigned)cap, n, E, keys[0], keys[1], keys[2], keys[3],
                            entries, slot_ent, ctl);
         auto launch = [&](auto gc, auto sc) -> int {
@@ -1218,7 +1218,7 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
                 ctx->tlas_ix_lds_opt_in[which] = true;
             }
             hipLaunchKernelGGL((tlas_build_indexed_kernel<Node, G, S>), dim3(1), dim3(64 * waves), lds, ctx->stream, d_nodes, n, entries, slot_ent, E, sb,
-                               slot_node, (unsigned)cap, ctl, phase2, refresh, getenv("VD_TLAS_PROFILE") ? 1 : 0);
+                               slot_node, (unsigned)cap, ctl, phase2, refresh, ctx->option(VD_OPT_TLAS_PROFILE, 0) ? 1 : 0);
             return 0;
         };
         using std::integral_constant;

@@ -319,6 +319,53 @@ __global__ __launch_bounds__(64) void traverse_iter_kernel(const VdBvhNode* __re
     if (ovf) atomicOr(overflow, 1u);
 }
 
+// `Bvh::traverse` (crates/bvh/src/blas.rs:211-245), the RECURSIVE walk of the reference (its only call
+// site is commented out at src/bin/bvh_cpu.rs:86).  traverse(node, t): Miss when the node's box is missed under t
+// (same slab test as traverse_iter, intersection.rs:47-55); a leaf folds its triangles into t (`t = t.min(dist)`); an
+// interior node calls left THEN right - no near / far ordering - each with the t found so far; every entered node
+// returns Hit(t).  The returned t is only ever the running minimum handed on, so the recursion equals a pre-order walk
+// with one running t and a stack of pending right children; one lane per ray runs that.  Quirk kept: a ray that enters
+// the root box and hits nothing returns Hit(t0) - the t it was GIVEN - and Miss (-1) only when the root box is missed.
+__global__ __launch_bounds__(64) void traverse_rec_kernel(const VdBvhNode* __restrict__ nodes, const float* __restrict__ verts,
+                                                          const unsigned* __restrict__ indices, const VdRay* __restrict__ rays,
+                                                          unsigned n_rays, float t0, float* __restrict__ out_dist,
+                                                          unsigned* __restrict__ overflow) {
+    const unsigned r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= n_rays) return;
+    const float4 e4 = reinterpret_cast<const float4*>(rays + r)[0], d4 = reinterpret_cast<const float4*>(rays + r)[1];
+    const float ox = e4.x, oy = e4.y, oz = e4.z, dx = d4.x, dy = d4.y, dz = d4.z;
+    unsigned stack[kIterStack];
+    int head = 0;
+    float t = t0;
+    bool ovf = false, entered_root = false;
+    unsigned cur = 0u;
+    bool have = true;
+    while (have) {
+        const VdBvhNode node = nodes[cur];
+        have = false;
+        const DistRs box = intersect_aabb_rs(ox, oy, oz, dx, dy, dz, node.min, node.max, t);   // blas.rs:220-222
+        if (box.hit) {
+            if (cur == 0u) entered_root = true;
+            if (node.count > 0u) {                                                             // blas.rs:223-235
+                for (unsigned i = 0; i < node.count; ++i) {
+                    const unsigned* idx = indices + 3u * (size_t)(node.left_first + i);
+                    const float d = ray_intersect_rs(ox, oy, oz, dx, dy, dz, verts + 3u * (size_t)idx[0], verts + 3u * (size_t)idx[1],
+                                                     verts + 3u * (size_t)idx[2]);
+                    if (d >= 0.0f) t = fminf(t, d);
+                }
+            } else {                                                                           // blas.rs:236-243: left, then right
+                if (head + 1 > kIterStack) { ovf = true; break; }
+                stack[head++] = node.left_first + 1u;
+                cur = node.left_first; have = true;
+                continue;
+            }
+        }
+        if (head > 0) { cur = stack[--head]; have = true; }
+    }
+    out_dist[r] = entered_root ? t : -1.0f;                                                    // blas.rs:244 / :221
+    if (ovf) atomicOr(overflow, 1u);
+}
+
 int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out, uint32_t* d_any = nullptr) {
     // idle waves keep drawing from the ray counter after the last ray: leave it room below 2^32
     if (n_rays > 0xf0000000u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: more than 0xf0000000 rays in one call");
@@ -416,6 +463,28 @@ int vd_traverse_iter_dev(VdCtx* ctx, const VdBvhNode* d_nodes, uint32_t n_nodes,
     return VD_OK;
 }
 
+int vd_traverse_dev(VdCtx* ctx, const VdBvhNode* d_nodes, uint32_t n_nodes, const float* d_verts_xyz, const uint32_t* d_indices,
+                    const VdRay* d_rays, uint32_t n_rays, float t0, float* d_out_dist) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!d_nodes || n_nodes == 0 || !d_verts_xyz || !d_indices) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse: incomplete mesh");
+    if (n_rays == 0) return VD_OK;
+    if (!d_rays || !d_out_dist) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse: null rays/out");
+    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256);
+    if (rc) return rc;
+    unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);
+    vd_time_begin(ctx);
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(traverse_rec_kernel, dim3((n_rays + 63u) / 64u), dim3(64), 0, ctx->stream, d_nodes, d_verts_xyz, d_indices, d_rays,
+                       n_rays, t0, d_out_dist, d_flag);
+    vd_time_end(ctx);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->host_pinned[0]) VD_FAIL(ctx, VD_ERR_STACK_OVERFLOW, "vd_traverse: traversal stack (128 pending right children per ray) exceeded");
+    return VD_OK;
+}
+
 int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t n_rays, VdHit* out) {
     VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     if (!ctx) return VD_ERR_INVALID_ARG;
@@ -465,13 +534,12 @@ int vd_primary_rays(VdCtx* ctx, const VdCameraUniform* camera, uint32_t width, u
     return VD_OK;
 }
 
-int vd_traverse_iter(VdCtx* ctx, const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz, uint32_t n_vert,
-                     const uint32_t* indices, uint32_t n_tri, const VdRay* rays, uint32_t n_rays, float* out_dist) {
-    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
+static int traverse_host(VdCtx* ctx, bool recursive, float t0, const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz, uint32_t n_vert,
+                         const uint32_t* indices, uint32_t n_tri, const VdRay* rays, uint32_t n_rays, float* out_dist) {
     if (!ctx) return VD_ERR_INVALID_ARG;
-    if (!nodes || n_nodes == 0 || !verts_xyz || !indices) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse_iter: incomplete mesh");
+    if (!nodes || n_nodes == 0 || !verts_xyz || !indices) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse[_iter]: incomplete mesh");
     if (n_rays == 0) return VD_OK;
-    if (!rays || !out_dist) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse_iter: null rays/out");
+    if (!rays || !out_dist) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_traverse[_iter]: null rays/out");
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const size_t sz[5] = {(size_t)n_nodes * sizeof(VdBvhNode), (size_t)n_vert * 12, (size_t)n_tri * 12, (size_t)n_rays * sizeof(VdRay),
                           (size_t)n_rays * 4};
@@ -484,12 +552,27 @@ int vd_traverse_iter(VdCtx* ctx, const VdBvhNode* nodes, uint32_t n_nodes, const
     for (int k = 0; k < 4; ++k)
         if (sz[k]) VD_HIP_CHECK(ctx, hipMemcpyAsync(base + off[k], src[k], sz[k], hipMemcpyHostToDevice, ctx->stream));
     float* d_out = reinterpret_cast<float*>(base + off[4]);
-    rc = vd_traverse_iter_dev(ctx, reinterpret_cast<const VdBvhNode*>(base + off[0]), n_nodes, reinterpret_cast<const float*>(base + off[1]),
-                              reinterpret_cast<const uint32_t*>(base + off[2]), reinterpret_cast<const VdRay*>(base + off[3]), n_rays, d_out);
+    const VdBvhNode* dn = reinterpret_cast<const VdBvhNode*>(base + off[0]);
+    const float* dv = reinterpret_cast<const float*>(base + off[1]);
+    const uint32_t* di = reinterpret_cast<const uint32_t*>(base + off[2]);
+    const VdRay* dr = reinterpret_cast<const VdRay*>(base + off[3]);
+    rc = recursive ? vd_traverse_dev(ctx, dn, n_nodes, dv, di, dr, n_rays, t0, d_out) : vd_traverse_iter_dev(ctx, dn, n_nodes, dv, di, dr, n_rays, d_out);
     if (rc) return rc;
     VD_HIP_CHECK(ctx, hipMemcpyAsync(out_dist, d_out, sz[4], hipMemcpyDeviceToHost, ctx->stream));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return VD_OK;
+}
+
+int vd_traverse_iter(VdCtx* ctx, const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz, uint32_t n_vert,
+                     const uint32_t* indices, uint32_t n_tri, const VdRay* rays, uint32_t n_rays, float* out_dist) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
+    return traverse_host(ctx, false, 0.0f, nodes, n_nodes, verts_xyz, n_vert, indices, n_tri, rays, n_rays, out_dist);
+}
+
+int vd_traverse(VdCtx* ctx, const VdBvhNode* nodes, uint32_t n_nodes, const float* verts_xyz, uint32_t n_vert,
+                const uint32_t* indices, uint32_t n_tri, const VdRay* rays, uint32_t n_rays, float t0, float* out_dist) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
+    return traverse_host(ctx, true, t0, nodes, n_nodes, verts_xyz, n_vert, indices, n_tri, rays, n_rays, out_dist);
 }
 
 }  // extern "C"

@@ -22,10 +22,12 @@ struct VdCtx {
     bool timing_enabled = false;        // event pairs around kernels cost a few us of GPU idle each: opt-in
     char err[512] = {0};
     int num_cus = 256;
-    int cull_variant = 0;               // kernel variant for A/B tuning (env VD_CULL_VARIANT)
-    unsigned split_min = 2u << 20;      // inputs of at least this many instances run the split form of the cull (env
-                                        // VD_SPLIT_MIN): below, the fused single launch is faster (tools/ab_split_min.py:
+    int cull_variant = 0;               // kernel variant for A/B tuning (VD_OPT_CULL_VARIANT)
+    unsigned split_min = 2u << 20;      // inputs of at least this many instances run the split form of the cull
+                                        // (VD_OPT_CULL_SPLIT_MIN): below, the fused single launch is faster (tools/ab_split_min.py:
                                         // 1 Mi 39 vs 47 us, 2 Mi 65 vs 65, 3 Mi 97 vs 93, 10 M 312 vs 256)
+    long long opt[VD_OPT_COUNT_];       // vd_ctx_set_option: -1 = default (set in vd_ctx_create)
+    long long option(int o, long long dflt) const { return opt[o] < 0 ? dflt : opt[o]; }
 
     // grow-only device scratch arenas
     void* scratch = nullptr;     size_t scratch_bytes = 0;     // general purpose

@@ -15,7 +15,13 @@ xGMI (≈153 GB/s per link) is ~40x slower than HBM, so the exchange is sized fo
     all-gather: every rank sends its list straight into every peer's final buffer, one xGMI link
     per peer) — kept for consumers that do not hold the instance->mesh table.
 
-Backend "nccl" is RCCL on ROCm; the same code runs on gloo for the CPU tests.
+Two hosts of the same exchange:
+
+  * RcclVisibility — the product path: the exchange lives in the C ABI (vd_dist_*, voidin_amd/csrc/dist.hip):
+    cull_mask -> ncclAllGather -> expand_mask enqueued on the context's stream by ONE call, RCCL bound by the
+    library itself.  torch.distributed (any backend, gloo is enough) only carries the 128-byte communicator id.
+  * ShardedVisibility — the same steps with torch.distributed collectives between the two kernels; runs on gloo,
+    so it is what the CPU / shared-GPU tests exercise (RCCL refuses two ranks on one device).
 """
 from __future__ import annotations
 
@@ -140,6 +146,98 @@ class ShardedVisibility:
             total = int(self.d_cnt[0].item())
             d_out[: total * DRAW_BYTES].copy_(self.d_local[: total * DRAW_BYTES])
         d_count[:1].fill_(total)
+
+
+class RcclVisibility:
+    """The sharded visibility step behind the C ABI: `vd_dist_step_full_dev` / `vd_dist_step_draws_dev`
+    (include/voidin_abi.h, "Multi-GPU exchange over RCCL").  Same interface as ShardedVisibility.
+
+    The communicator id is made by rank 0 (vd_dist_unique_id) and broadcast through `group` (a torch.distributed
+    group of any backend) - or passed in as `unique_id` by a host that has its own channel.  world = 1 works without
+    any process group: a one-rank RCCL communicator, the functional check of the path on one GPU."""
+
+    def __init__(self, ctx, n_total: int, d_meshes, n_mesh: int, d_inst_shard, group=None, unique_id: bytes | None = None,
+                 rank: int | None = None, world: int | None = None):
+        import ctypes as C
+
+        from . import abi
+        self.ctx, self.lib = ctx, ctx.lib
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world, self.rank = world, rank
+        self.n_total, self.n_mesh, self.d_meshes = n_total, n_mesh, d_meshes
+        self.S = shard_size(n_total, world)
+        self.lo, self.hi = shard_range(n_total, rank, world)
+        self.n_local = self.hi - self.lo
+        self.d_inst = d_inst_shard
+        if unique_id is None:
+            buf = (C.c_ubyte * abi.VD_DIST_ID_BYTES)()
+            if rank == 0:
+                ctx._chk(self.lib.vd_dist_unique_id(C.addressof(buf)))
+            if world > 1:
+                t = torch.tensor(list(bytes(buf)), dtype=torch.uint8)
+                backend = dist.get_backend(group)
+                t = t.cuda() if backend == "nccl" else t
+                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group else 0, group=group)
+                unique_id = bytes(t.cpu().tolist())
+            else:
+                unique_id = bytes(buf)
+        assert len(unique_id) == abi.VD_DIST_ID_BYTES
+        h = C.c_void_p()
+        idb = C.create_string_buffer(unique_id, abi.VD_DIST_ID_BYTES)
+        ctx._chk(self.lib.vd_dist_create(ctx.h, C.addressof(idb), rank, world, C.byref(h)))
+        self.h = h
+        ctx._chk(self.lib.vd_dist_set_scene_dev(self.h, abi.ptr(d_inst_shard), self.n_local, n_total, n_mesh))
+        self.info = abi.DistInfo()
+        ctx._chk(self.lib.vd_dist_info(self.h, C.byref(self.info)))
+        self.wps, self.id_bytes = self.info.mask_words_per_shard, self.info.id_bytes
+        self._abi, self._C = abi, C
+
+    def _cam(self, camera):
+        import numpy as np
+        return np.ascontiguousarray(camera, dtype=self._abi.CAMERA).reshape(1)
+
+    def step(self, camera, d_out, d_count):
+        """Full list on every rank; wire = 1 bit per instance.  One call, three enqueues on the ctx stream."""
+        cam = self._cam(camera)
+        self.ctx._chk(self.lib.vd_dist_step_full_dev(self.h, cam.ctypes.data, self._abi.ptr(self.d_meshes), self.n_mesh,
+                                                     self._abi.ptr(self.d_inst), self._abi.ptr(d_out), self._abi.ptr(d_count)))
+
+    def step_draws(self, camera, d_out, d_count):
+        """Full list on every rank; wire = the 20-byte commands (counts read back on the host)."""
+        cam = self._cam(camera)
+        self.ctx._chk(self.lib.vd_dist_step_draws_dev(self.h, cam.ctypes.data, self._abi.ptr(self.d_meshes), self.n_mesh,
+                                                      self._abi.ptr(self.d_inst), self._abi.ptr(d_out), self._abi.ptr(d_count)))
+
+    def step_shard(self, camera, d_out_local, d_count_local):
+        self.ctx.cull_compact_dev(camera, self.d_meshes, self.n_mesh, self.d_inst, self.n_local, d_out_local, d_count_local,
+                                  False, self.lo)
+
+    def allgather(self, d_send, d_recv, bytes_per_rank: int):
+        self.ctx._chk(self.lib.vd_dist_allgather_dev(self.h, self._abi.ptr(d_send), self._abi.ptr(d_recv), bytes_per_rank))
+
+    def cull_to_mask(self, camera):
+        """The first leg alone (bench breakdown): own shard -> the VdDist's mask buffer."""
+        self.ctx.cull_mask_dev(camera, self.d_meshes, self.n_mesh, self.d_inst, self.n_local, self.info.d_mask)
+
+    def allgather_masks(self):
+        self.allgather(self.info.d_mask, self.info.d_mask_all, self.wps * 8)
+
+    def expand_all(self, d_out, d_count):
+        self.ctx.expand_mask_dev(self.info.d_mask_all, self.n_total, self.S, self.info.d_mesh_ids, self.d_meshes, self.n_mesh,
+                                 d_out, d_count, id_bytes=self.id_bytes)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vd_dist_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def allgather_counts(local_count: torch.Tensor, group=None) -> torch.Tensor:

@@ -50,6 +50,20 @@ class Context:
             import torch
             self.torch_device = torch.device("cuda", device)
             self.set_stream(torch.cuda.current_stream(self.torch_device).cuda_stream)
+        self.apply_env_options()
+
+    def set_option(self, name: str, value: int | None):
+        """vd_ctx_set_option (include/voidin_abi.h VdOption) by name, e.g. "tlas.spin_limit"; None = default."""
+        dflt = 0 if name == "cull.variant" else -1            # the variant is a signed id taken as is (0 = default)
+        self._chk(self.lib.vd_ctx_set_option(self.h, abi.OPTIONS[name], dflt if value is None else int(value)))
+
+    def apply_env_options(self):
+        """A/B scripts under tools/ select variants with VD_* environment variables; the LIBRARY reads none of them -
+        this harness forwards them as per-context options when a Context is made."""
+        import os
+        for env, name in abi.OPTION_ENV.items():
+            if os.environ.get(env) not in (None, ""):
+                self.set_option(name, int(os.environ[env]))
 
     # -- plumbing -------------------------------------------------------------------------
     def _chk(self, rc: int):
@@ -256,6 +270,12 @@ class Context:
         """Bvh::traverse_iter (crates/bvh/src/blas.rs:247-295) for a batch of rays against one mesh; -1 = Miss."""
         self._chk(self.lib.vd_traverse_iter_dev(self.h, abi.ptr(d_nodes), n_nodes, abi.ptr(d_verts), abi.ptr(d_indices),
                                                 abi.ptr(d_rays), n_rays, abi.ptr(d_out_dist)))
+
+    def traverse_dev(self, d_nodes, n_nodes, d_verts, d_indices, d_rays, n_rays, d_out_dist, t0=1e30):
+        """Bvh::traverse (crates/bvh/src/blas.rs:211-245), the recursive walk, started as bvh_cpu.rs:86 would
+        (`traverse(.., ray, 0, 1e30)`); Hit(t0) when the root box is entered and nothing is hit, -1 = Miss."""
+        self._chk(self.lib.vd_traverse_dev(self.h, abi.ptr(d_nodes), n_nodes, abi.ptr(d_verts), abi.ptr(d_indices),
+                                           abi.ptr(d_rays), n_rays, C.c_float(t0), abi.ptr(d_out_dist)))
 
     # -- occlusion extension (no reference counterpart; include/voidin_abi.h "Occlusion culling") ----------
     def hiz_layout(self, width, height) -> "abi.HizLayout":
