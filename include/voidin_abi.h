@@ -200,6 +200,11 @@ typedef enum VdOption {
                                      redone on one workgroup (0 forces the redo: tests)                   */
     VD_OPT_TLAS_SPEC = 16,        /* 0: indexed build without the speculative helper waves; default 1     */
     VD_OPT_TLAS_PROFILE = 17,     /* 1: the indexed build prints its in-kernel cycle counters             */
+    VD_OPT_TRACE_LEGACY = 20,     /* 1: vd_trace* hands single rays to idle lanes from one global counter (the round-2
+                                     supply) instead of sorted chunks per workgroup; default 0                  */
+    VD_OPT_TRACE_SORT = 21,       /* 0: no binning pre-pass (rays are handed out in input order); default 1      */
+    VD_OPT_TRACE_SORT_MIN = 22,   /* fewest rays a call bins; default 65536                                      */
+    VD_OPT_TRACE_CHUNK = 23,      /* rays per chunk a workgroup works off (multiple of 64); default by ray count */
     VD_OPT_COUNT_ = 32
 } VdOption;
 int         vd_ctx_set_option(VdCtx* ctx, int option /* VdOption */, int64_t value);
@@ -378,6 +383,21 @@ int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t 
              VdHit* out);
 int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene /* struct on host, pointers on device */,
                  const VdRay* d_rays, uint32_t n_rays, VdHit* d_out);
+
+/* Per-scene preparation for many trace calls over static geometry (the reference binds the six
+ * buffers once per scene: app.rs:255-287): the leaf triangles are written out de-indexed, 36 bytes
+ * per triangle in index-buffer (= leaf) order, so that a BLAS leaf is ONE contiguous fetch instead
+ * of indices[] -> vertices[] (bvh.wgsl:30-33, 49-53).  Same vertices, same arithmetic: results are
+ * bit-identical to vd_trace_dev / vd_trace_any_dev.  The accel holds a copy of the scene struct
+ * (the pointers, not the data): rebuild it when vertices / indices / meshes change; instances
+ * and TLAS nodes may change freely (they are read through the scene's pointers).  vd_trace_prepare_dev
+ * blocks (it validates the index ranges); release with vd_trace_release.                      */
+typedef struct VdTraceAccel VdTraceAccel;
+int vd_trace_prepare_dev(VdCtx* ctx, const VdTraceScene* d_scene, VdTraceAccel** out);
+int vd_trace_release(VdCtx* ctx, VdTraceAccel* accel);
+int vd_trace_prepared_dev(VdCtx* ctx, const VdTraceAccel* accel, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out);
+int vd_trace_any_prepared_dev(VdCtx* ctx, const VdTraceAccel* accel, const VdRay* d_rays, uint32_t n_rays,
+                              uint32_t* d_out_hit);
 
 /* Occlusion query: d_out_hit[i] = traverse_tlas(ray i).hit, which is all the
  * reference's shadow pass reads (src/bin/raytraced_shadows.wgsl:97-102).  Same walk as vd_trace

@@ -312,6 +312,68 @@ def test_trace_seeded_scene_vs_oracle(ctx, oracle):
     assert 0 < occ_want["hit"].sum() < len(pts)
 
 
+@pytest.mark.parametrize("side", [96, 320])
+def test_trace_supply_binning_and_prepared_triangles_are_order_only(ctx, oracle, ctx_options, side):
+    """Round 3: rays are binned (sorted by origin cell and direction), handed to workgroups in chunks of the sorted
+    order, and leaf triangles may come de-indexed from vd_trace_prepare_dev.  All of that changes the ORDER in which rays
+    are walked and where a triangle's vertices are fetched from - never a result: every variant must reproduce the
+    oracle's hit flags / distances exactly as the round-2 single-ray supply does, byte for byte, on a multi-mesh scene
+    (vertex_offset / base_index / bvh_index all non-zero) with degenerate rays mixed in."""
+    import torch
+    meshes_src = [synth.uv_sphere(1.0, 4), synth.knot_mesh(96, 24), synth.triangle_soup(64)]
+    V, I, B = [], [], []
+    infos = np.zeros(len(meshes_src), dtype=abi.MESH_INFO)
+    vo = bo = no = 0
+    for k, (v, i) in enumerate(meshes_src):
+        nodes, idx = oracle.bvh_build(v, i)
+        infos[k]["min"], infos[k]["max"] = synth.mesh_bounds(v)
+        infos[k]["index_count"], infos[k]["base_index"] = len(idx), bo
+        infos[k]["vertex_offset"], infos[k]["bvh_index"] = vo, no
+        V.append(v); I.append(idx); B.append(nodes)
+        vo += len(v); bo += len(idx); no += len(nodes)
+    V, I, B = np.concatenate(V), np.concatenate(I), np.concatenate(B)
+    inst = synth.instances(300, n_mesh=3, seed=synth.SEED_BASE + 18, extent=50.0, scale_range=(0.5, 3.0))
+    tl = ctx.tlas_build(inst, infos)
+    rays = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 40), pitch_deg=0), side, side)
+    rays = np.concatenate([rays, rays[::7]])                    # duplicates: equal keys in the sort
+    rays["dir"][5] = (0, 0, 0); rays["dir"][6] = (np.nan, 1, 0); rays["eye"][7] = (np.inf, 0, 0); rays["dir"][8] = (0, 0, -1)
+    rays["eye"][9] = (1e30, -1e30, 0)
+    scene = (tl, inst, infos, B, V, I)
+    want, _ = oracle.trace(scene, rays, threads=8)
+    ds = ctx.device_scene(scene)
+    acc = ctx.trace_prepare(ds)
+    d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
+    d_any = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
+    first = None
+    variants = [dict(legacy=1), dict(sort=0), dict(sort_min=1), dict(sort_min=1, chunk=64), dict(sort_min=1, chunk=4096),
+                dict(sort=0, chunk=128)]
+    for opts in variants:
+        for k in ("legacy", "sort", "sort_min", "chunk"):
+            ctx_options("trace." + k, opts.get(k))
+        for prep in (False, True):
+            d_hits.zero_(); d_any.fill_(9)
+            if prep:
+                ctx.trace_prepared_dev(acc, d_rays, len(rays), d_hits); ctx.trace_any_prepared_dev(acc, d_rays, len(rays), d_any)
+            else:
+                ctx.trace_dev(ds, d_rays, len(rays), d_hits); ctx.trace_any_dev(ds, d_rays, len(rays), d_any)
+            torch.cuda.synchronize()
+            got = d_hits.cpu().numpy().view(abi.HIT)[: len(rays)]
+            if first is None:
+                first = got.tobytes()
+                assert np.array_equal(got["hit"], want["hit"]) and want["hit"].sum() > 300
+                hit = want["hit"] == 1
+                assert got["dist"][hit].tobytes() == want["dist"][hit].tobytes()          # bit-equal in fact (tolerance: 1e-5)
+            assert got.tobytes() == first, (opts, prep)
+            assert np.array_equal(d_any.cpu().numpy().astype(np.uint32), want["hit"]), (opts, prep)
+    acc.close()
+    # argument checks of the prepared form
+    assert ctx.lib.vd_trace_prepared_dev(ctx.h, None, abi.ptr(d_rays), 4, abi.ptr(d_hits)) == abi.VD_ERR_INVALID_ARG
+    bad = ctx.device_scene((tl, inst, infos, B, V, I[: len(I) - 30]))         # the last mesh's index range runs past the buffer
+    with pytest.raises(VoidinError) as e:
+        ctx.trace_prepare(bad)
+    assert e.value.code == abi.VD_ERR_INVALID_ARG
+
+
 def test_trace_axis_aligned_and_degenerate_rays(ctx, oracle):
     """The WGSL walk multiplies by inv_dir = 1 / dir: rays with zero direction components give inf and 0 * inf = NaN
     in the slab test, which must flow through min / max as in the restated shader (WGSL min / max = IEEE minNum /

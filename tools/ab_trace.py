@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""A/B of the traversal on the bench scenes: supply (round-2 single-ray counter / chunks per workgroup), ray binning,
+chunk size, de-indexed leaf triangles.  Every variant's output is compared byte for byte with the first one's.
+    python tools/ab_trace.py [--rays 1024] [--harness]"""
+import argparse, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from voidin_amd import abi, synth
+from voidin_amd.runtime import Context
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rays", type=int, default=1024)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--harness", action="store_true", help="the bvh_gpu.rs-shaped scene instead of the stress scene")
+args = ap.parse_args()
+ctx = Context(0)
+if args.harness:
+    import bench
+    sys.exit("use bench.py for the harness scene")
+tv, ti = synth.knot_mesh(512, 128)
+nodes_b, idx_b = ctx.bvh_build(tv, ti)
+infos = np.zeros(1, dtype=abi.MESH_INFO)
+infos[0]["min"], infos[0]["max"] = synth.mesh_bounds(tv)
+infos[0]["index_count"] = len(idx_b)
+inst_t = synth.instances(2000, n_mesh=1, seed=synth.SEED_BASE + 8, extent=120.0, scale_range=(0.5, 2.0))
+tl = ctx.tlas_build(inst_t, infos)
+rays = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 90), pitch_deg=0), args.rays, args.rays)
+ds = ctx.device_scene((tl, inst_t, infos, nodes_b, tv, idx_b))
+acc = ctx.trace_prepare(ds)
+d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
+d_any = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
+variants = [("legacy", dict(legacy=1), False), ("legacy+prep", dict(legacy=1), True),
+            ("chunk nosort", dict(sort=0), False), ("chunk sort", dict(), False), ("chunk sort prep", dict(), True),
+            ("chunk64 sort prep", dict(chunk=64), True), ("chunk256 sort prep", dict(chunk=256), True),
+            ("chunk1024 sort prep", dict(chunk=1024), True), ("chunk4096 sort prep", dict(chunk=4096), True)]
+ref_bytes = ref_any = None
+ctx.set_timing(True)
+for name, opts, prep in variants:
+    for k in ("legacy", "sort", "chunk"):
+        ctx.set_option("trace." + k, opts.get(k))
+    t_cl, t_any = [], []
+    for _ in range(args.reps):
+        if prep:
+            ctx.trace_prepared_dev(acc, d_rays, len(rays), d_hits); t_cl.append(ctx.last_gpu_ms())
+            ctx.trace_any_prepared_dev(acc, d_rays, len(rays), d_any); t_any.append(ctx.last_gpu_ms())
+        else:
+            ctx.trace_dev(ds, d_rays, len(rays), d_hits); t_cl.append(ctx.last_gpu_ms())
+            ctx.trace_any_dev(ds, d_rays, len(rays), d_any); t_any.append(ctx.last_gpu_ms())
+    b, a = d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes()
+    if ref_bytes is None:
+        ref_bytes, ref_any = b, a
+    print(f"{name:22s} closest {len(rays) / min(t_cl) / 1e3:7.1f} Mrays/s ({min(t_cl):7.2f} ms)  occlusion {len(rays) / min(t_any) / 1e3:7.1f} Mrays/s"
+          f"  same bytes: {b == ref_bytes} {a == ref_any}", flush=True)

@@ -1140,7 +1140,12 @@ __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigne
         }
         const uint2 u = up[k];                            // {parent, sibling}
         const unsigned p = u.x, s = u.y;
-        if (s == k) { k = p; continue; }                  // node 2n merges the true root with itself: same box
+        // No parent: the reference's chain DROPS a cluster whose unions all have an area >= 1e30 or NaN (an infinite
+        // leaf box): find_best_match answers the target itself (tlas.rs:88-104), the cluster is merged with itself into
+        // a node nothing refers to, and its slot is given to the last cluster (tlas.rs:62-79).  Such a node is the top
+        // of an orphaned chain; its box has just been written, as the ascending recompute of SURVEY 8a T3 would.
+        if (p == 0xffffffffu) return;
+        if (s == k) { k = p; continue; }                  // a cluster merged with itself (node 2n: the true root): same box
         if (s <= n) { box = box_union(box, load_box_plain(nodes, s)); k = p; continue; }
         const unsigned v = __hip_atomic_fetch_add(&arrivals[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v != 3u) {
@@ -1270,6 +1275,7 @@ int tlas_refit_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     uint2* parent = reinterpret_cast<uint2*>(ctx->scratch);                    // {parent, sibling} per node
     unsigned* arrivals = reinterpret_cast<unsigned*>(parent + total);
     vd_time_begin(ctx);
+    VD_HIP_CHECK(ctx, hipMemsetAsync(parent, 0xff, total * sizeof(uint2), ctx->stream));      // "no parent" until the prep pass links a node
     hipLaunchKernelGGL((tlas_refit_prep_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes, n_mesh,
                        d_nodes, parent, arrivals);
     hipLaunchKernelGGL((tlas_refit_up_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_nodes, n, parent, arrivals);

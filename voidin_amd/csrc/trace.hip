@@ -10,6 +10,11 @@
 // triangles do not occur (BvhBuilder stops at <= 3: blas.rs:108) and are not representable in a stack entry.
 #include "vd_common.hpp"
 
+#include <new>
+
+// vd_trace_prepare_dev: per-scene data derived once from the six trace buffers
+struct VdTraceAccel { VdTraceScene scene; float* tris = nullptr; };
+
 namespace {
 
 constexpr int kStack = 64;
@@ -60,7 +65,16 @@ __device__ __forceinline__ bool intersect_trig(const Ray& r, const float* v0, co
 struct Scene {
     const VdTlasNode* tlas; const VdInstance* inst; const VdMeshInfo* meshes; const VdBvhNode* bvh;
     const float* verts; const unsigned* indices; unsigned n_meshes;
+    const float* tris;          // vd_trace_prepare_dev: 9 floats per triangle in index-buffer order (nullptr: not prepared)
 };
+
+// Where a wave's rays come from.  `order` (nullptr = identity) lists the ray ids in the order they are handed out - the
+// binning pre-pass sorts them by origin cell and direction, so that rays which walk the same nodes are neighbours.  They
+// are handed out in CHUNKS of consecutive positions: a workgroup (several waves = one CU's L1) works one chunk off
+// before it takes the next, so that at any time the lanes of a wave AND the waves of a CU sit in a small window of the
+// sorted order, whatever their rays cost.  (One global counter handing single rays to whoever is idle - the round-2 scheme
+// - spreads every wave over the ~450 k rays that are in flight chip-wide.)
+struct RaySource { const unsigned* order; unsigned n_rays, chunk, n_chunks; unsigned* next_chunk; };
 
 // A fixed grid of waves; a lane whose ray is finished draws the next ray from a counter, so a wave stays full while
 // rays of very different cost (a few node visits to tens of thousands) pass through it, and there is no tail of
@@ -74,11 +88,21 @@ struct Scene {
 // visit the same nodes up to that point (the reference's shadow pass uses only `.hit`: raytraced_shadows.wgsl:97-102).
 constexpr unsigned kRefillBelow = 56;   // draw new rays when fewer than this many lanes are busy
 constexpr unsigned kWavesPerCu = 28;    // persistent grid = what is resident (7 waves per SIMD at 72 VGPRs): no wave starts late
-template <bool ANY>
-__global__ __launch_bounds__(64, 7) void trace_kernel(Scene s, const VdRay* __restrict__ rays, unsigned n_rays,
-                                                              VdHit* __restrict__ out, unsigned* __restrict__ out_any,
-                                                              unsigned* __restrict__ overflow, unsigned* next_ray) {
-    const unsigned lane = threadIdx.x;
+constexpr int kWgWaves = 7;             // waves per workgroup of the chunked form: 4 workgroups per CU
+// PREP: leaf triangles come de-indexed from Scene::tris (one contiguous fetch instead of indices[] -> verts[]).
+// WG_WAVES == 1: the round-2 supply (single rays from one global counter, `src.next_chunk` is that counter).
+template <bool ANY, bool PREP, int WG_WAVES>
+__global__ __launch_bounds__(64 * WG_WAVES, 7)   // second argument (HIP): waves per SIMD = 28 per CU
+void trace_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
+                  unsigned* __restrict__ overflow) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned n_rays = src.n_rays;
+    __shared__ vd_u64 s_word;              // chunked supply: {next, end} positions of the workgroup's current chunk
+    unsigned p_next = 0, p_end = 0;        // a chunk this wave could not publish (another wave's was installed first)
+    if (WG_WAVES > 1) {
+        if (threadIdx.x == 0) s_word = 0ull;
+        __syncthreads();
+    }
     unsigned stack[2 * kStack];            // BLAS entries sit above the TLAS entries of the same ray
     Ray world, ray;                        // `ray` is the active one (object space inside an instance)
     VdHit res;
@@ -106,12 +130,41 @@ __global__ __launch_bounds__(64, 7) void trace_kernel(Scene s, const VdRay* __re
         if (!exhausted && (unsigned)__popcll(busy_mask) < kRefillBelow) {
             const unsigned long long idle = ~busy_mask;
             const unsigned want = (unsigned)__popcll(idle);
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(next_ray, want);
-            base = __shfl(base, 0);
+            unsigned base = 0, got = 0, done = 0;
+            if (WG_WAVES == 1) {
+                if (lane == 0) base = atomicAdd(src.next_chunk, want);
+                base = __shfl(base, 0);
+                got = base < n_rays ? min(want, n_rays - base) : 0u;
+                done = base + want >= n_rays ? 1u : 0u;
+            } else {
+                if (lane == 0) {
+                    if (p_next < p_end) { got = min(want, p_end - p_next); base = p_next; p_next += got; }
+                    else for (;;) {
+                        const vd_u64 old = __hip_atomic_load(&s_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const unsigned nx = (unsigned)old, en = (unsigned)(old >> 32);
+                        if (nx < en) {                                  // the workgroup's chunk still has rays
+                            const unsigned take = min(want, en - nx);
+                            vd_u64 expect = old;
+                            if (__hip_atomic_compare_exchange_strong(&s_word, &expect, ((vd_u64)en << 32) | (nx + take), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) { base = nx; got = take; break; }
+                            continue;
+                        }
+                        const unsigned c = atomicAdd(src.next_chunk, 1u);
+                        if (c >= src.n_chunks) { done = 1u; break; }
+                        const unsigned b = c * src.chunk, e = min(b + src.chunk, n_rays);
+                        base = b; got = min(want, e - b);
+                        vd_u64 expect = old;                            // the rest is for the whole workgroup - unless another wave installed a chunk meanwhile
+                        if (!__hip_atomic_compare_exchange_strong(&s_word, &expect, ((vd_u64)e << 32) | (b + got), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_WORKGROUP)) { p_next = b + got; p_end = e; }
+                        break;
+                    }
+                }
+                base = __shfl(base, 0); got = __shfl(got, 0); done = __shfl(done, 0);
+            }
             if (!busy) {
-                const unsigned id = base + vd_mbcnt(idle);
-                if (id < n_rays) {
+                const unsigned k = vd_mbcnt(idle);
+                if (k < got) {
+                    const unsigned id = src.order ? src.order[base + k] : base + k;
                     const float4 a = reinterpret_cast<const float4*>(rays + id)[0], b = reinterpret_cast<const float4*>(rays + id)[1];
                     world.ex = a.x; world.ey = a.y; world.ez = a.z; world.dx = b.x; world.dy = b.y; world.dz = b.z;
                     world.ix = 1.0f / world.dx; world.iy = 1.0f / world.dy; world.iz = 1.0f / world.dz;   // ray_new: inv_dir = 1. / dir
@@ -122,7 +175,7 @@ __global__ __launch_bounds__(64, 7) void trace_kernel(Scene s, const VdRay* __re
                     ray_id = id; busy = true; ray_done = false; in_blas = false; head = 0; blas_base = 0;
                 }
             }
-            if (base + want >= n_rays) exhausted = true;     // wave-uniform
+            if (done) exhausted = true;     // wave-uniform
         }
         if (!__ballot(busy)) break;
         // ---- interior steps (bvh.wgsl:56-74 and 104-121) ----
@@ -180,13 +233,19 @@ __global__ __launch_bounds__(64, 7) void trace_kernel(Scene s, const VdRay* __re
             // ---- BLAS leaf (bvh.wgsl:48-55) ----
             for (unsigned k = 0; k < cn.y; ++k) {
                 const unsigned idx = cn.x + k;
-                const unsigned i0 = vertex_offset + s.indices[base_index + 3u * idx + 0u];
-                const unsigned i1 = vertex_offset + s.indices[base_index + 3u * idx + 1u];
-                const unsigned i2 = vertex_offset + s.indices[base_index + 3u * idx + 2u];
-                const float* v0 = s.verts + 3u * (size_t)i0;
-                const float* v1 = s.verts + 3u * (size_t)i1;
-                const float* v2 = s.verts + 3u * (size_t)i2;
-                const float a0[3] = {v0[0], v0[1], v0[2]}, a1[3] = {v1[0], v1[1], v1[2]}, a2[3] = {v2[0], v2[1], v2[2]};
+                float a0[3], a1[3], a2[3];
+                if (PREP) {          // the same three vertices fetch_vertex (bvh.wgsl:30-33) returns, stored side by side
+                    const float* T = s.tris + 9u * ((size_t)(base_index / 3u) + idx);
+                    a0[0] = T[0]; a0[1] = T[1]; a0[2] = T[2]; a1[0] = T[3]; a1[1] = T[4]; a1[2] = T[5]; a2[0] = T[6]; a2[1] = T[7]; a2[2] = T[8];
+                } else {
+                    const unsigned i0 = vertex_offset + s.indices[base_index + 3u * idx + 0u];
+                    const unsigned i1 = vertex_offset + s.indices[base_index + 3u * idx + 1u];
+                    const unsigned i2 = vertex_offset + s.indices[base_index + 3u * idx + 2u];
+                    const float* v0 = s.verts + 3u * (size_t)i0;
+                    const float* v1 = s.verts + 3u * (size_t)i1;
+                    const float* v2 = s.verts + 3u * (size_t)i2;
+                    a0[0] = v0[0]; a0[1] = v0[1]; a0[2] = v0[2]; a1[0] = v1[0]; a1[1] = v1[1]; a1[2] = v1[2]; a2[0] = v2[0]; a2[1] = v2[1]; a2[2] = v2[2];
+                }
                 float hit = res.dist;
                 if (intersect_trig(ray, a0, a1, a2, hit)) {
                     res.dist = hit; res.hit = 1u; res.instance = instance_idx; res.triangle = idx;
@@ -366,18 +425,188 @@ __global__ __launch_bounds__(64) void traverse_rec_kernel(const VdBvhNode* __res
     if (ovf) atomicOr(overflow, 1u);
 }
 
-int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out, uint32_t* d_any = nullptr) {
+// ---- ray binning (order only: results are per ray, so any permutation gives the same output) ----------------------------
+// key = origin cell (4 bits per axis over a box three times the scene's, Morton) in the high 12 bits, direction cell
+// (octahedral map of the normalised direction, 10 + 10 bits, Morton) in the low 20: rays that start close together and
+// point the same way - the pixels of a screen tile, the shadow rays of a surface patch - become neighbours.
+__device__ __forceinline__ unsigned spread3(unsigned v) {    // 4 bits -> every third bit
+    v &= 0xfu; v = (v | (v << 4)) & 0xc3u; v = (v | (v << 2)) & 0x249u; return v;
+}
+__device__ __forceinline__ unsigned spread2(unsigned v) {    // 10 bits -> every other bit
+    v &= 0x3ffu; v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v;
+}
+__global__ __launch_bounds__(256) void ray_keys_kernel(const VdRay* __restrict__ rays, unsigned n, const VdTlasNode* __restrict__ tlas,
+                                                       unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = reinterpret_cast<const float4*>(rays + i)[0], b = reinterpret_cast<const float4*>(rays + i)[1];
+    const VdTlasNode root = tlas[0];
+    float q[3];
+    const float o[3] = {a.x, a.y, a.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float lo = root.min[k], hi = root.max[k], w = hi - lo;
+        const float t = (o[k] - (lo - w)) / (3.0f * w);                  // [lo - w, hi + w] -> [0, 1]
+        q[k] = t > 0.0f ? (t < 1.0f ? t : 1.0f) : 0.0f;                  // NaN -> 0
+    }
+    const unsigned oc = spread3((unsigned)(q[0] * 15.99f)) | (spread3((unsigned)(q[1] * 15.99f)) << 1) | (spread3((unsigned)(q[2] * 15.99f)) << 2);
+    const float l1 = (fabsf(b.x) + fabsf(b.y)) + fabsf(b.z);
+    float u = b.x / l1, v = b.y / l1;
+    if (b.z < 0.0f) { const float uu = (1.0f - fabsf(v)) * (u >= 0.0f ? 1.0f : -1.0f), vv = (1.0f - fabsf(u)) * (v >= 0.0f ? 1.0f : -1.0f); u = uu; v = vv; }
+    u = u * 0.5f + 0.5f; v = v * 0.5f + 0.5f;
+    u = u > 0.0f ? (u < 1.0f ? u : 1.0f) : 0.0f; v = v > 0.0f ? (v < 1.0f ? v : 1.0f) : 0.0f;
+    const unsigned dc = spread2((unsigned)(u * 1023.99f)) | (spread2((unsigned)(v * 1023.99f)) << 1);
+    keys[i] = (oc << 20) | dc;
+    vals[i] = i;
+}
+
+// Stable LSD radix sort of (key, value) pairs, 8 bits per pass.  A UNIT is one wave's 1024 consecutive pairs; units are
+// independent: pass 1 counts a unit's digits, a single-workgroup scan turns the [digit][unit] table into start offsets,
+// pass 2 re-reads the unit in order - 16 groups of 64 - and ranks every pair among the equal digits before it (8 ballots
+// give the lanes with the same digit; the unit's running offsets sit in LDS).
+constexpr unsigned kSortUnit = 1024;
+constexpr int kSortWaves = 4;
+__global__ __launch_bounds__(64 * kSortWaves) void rs_count_kernel(const unsigned* __restrict__ keys, unsigned n, unsigned shift, unsigned n_units,
+                                                                   unsigned* __restrict__ table) {
+    __shared__ unsigned s_h[kSortWaves][256];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, unit = blockIdx.x * kSortWaves + wave;
+    for (unsigned d = lane; d < 256u; d += 64u) s_h[wave][d] = 0u;
+    vd_wave_lds_sync();
+    if (unit < n_units) {
+        const unsigned b0 = unit * kSortUnit;
+        for (unsigned g = 0; g < kSortUnit; g += 64u) {
+            const unsigned i = b0 + g + lane;
+            if (i < n) atomicAdd(&s_h[wave][(keys[i] >> shift) & 255u], 1u);
+        }
+        vd_wave_lds_sync();
+        for (unsigned d = lane; d < 256u; d += 64u) table[(size_t)d * n_units + unit] = s_h[wave][d];
+    }
+}
+// exclusive scan of `m` counters in place (single workgroup; thread t owns a contiguous range)
+__global__ __launch_bounds__(1024) void rs_scan_kernel(unsigned* __restrict__ table, unsigned m) {
+    __shared__ unsigned s_wave[16];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned per = (m + 1023u) / 1024u;
+    const unsigned lo = min(m, tid * per), hi = min(m, lo + per);
+    unsigned sum = 0;
+    for (unsigned i = lo; i < hi; ++i) sum += table[i];
+    unsigned incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_up(incl, off); if (lane >= (unsigned)off) incl += t; }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (unsigned w = 0; w < wave; ++w) run += s_wave[w];
+    for (unsigned i = lo; i < hi; ++i) { const unsigned c = table[i]; table[i] = run; run += c; }
+}
+__global__ __launch_bounds__(64 * kSortWaves) void rs_scatter_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, unsigned n,
+                                                                     unsigned shift, unsigned n_units, const unsigned* __restrict__ table,
+                                                                     unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out) {
+    __shared__ unsigned s_off[kSortWaves][256];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, unit = blockIdx.x * kSortWaves + wave;
+    if (unit >= n_units) return;
+    for (unsigned d = lane; d < 256u; d += 64u) s_off[wave][d] = table[(size_t)d * n_units + unit];
+    vd_wave_lds_sync();
+    const unsigned b0 = unit * kSortUnit;
+    for (unsigned g = 0; g < kSortUnit; g += 64u) {
+        const unsigned i = b0 + g + lane;
+        const bool valid = i < n;
+        const unsigned key = valid ? keys[i] : 0u, val = valid ? vals[i] : 0u;
+        const unsigned d = (key >> shift) & 255u;
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long bm = __ballot((d >> bit) & 1u);
+            same &= ((d >> bit) & 1u) ? bm : ~bm;
+        }
+        const unsigned rank = vd_mbcnt(same), cnt = (unsigned)__popcll(same);
+        unsigned dst = 0;
+        if (valid) dst = s_off[wave][d] + rank;
+        vd_wave_lds_sync();
+        if (valid && rank == 0u) s_off[wave][d] += cnt;      // the first lane of each digit advances the unit's offset
+        vd_wave_lds_sync();
+        if (valid) { keys_out[dst] = key; vals_out[dst] = val; }
+    }
+}
+
+// De-indexed leaf triangles: tris[9 * (base_index / 3 + t)] = the three vertices fetch_vertex (bvh.wgsl:30-33) returns for
+// triangle t of the mesh, i.e. vertices[vertex_offset + indices[base_index + 3 t + c]].
+__global__ __launch_bounds__(256) void prepare_tris_kernel(const VdMeshInfo* __restrict__ meshes, const float* __restrict__ verts,
+                                                           const unsigned* __restrict__ indices, unsigned n_indices, unsigned n_vertices,
+                                                           float* __restrict__ tris, unsigned* __restrict__ err) {
+    const VdMeshInfo m = meshes[blockIdx.y];
+    const unsigned n_tri = m.index_count / 3u;
+    if (m.base_index % 3u != 0u || (size_t)m.base_index + m.index_count > n_indices) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err, 4u); return; }
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < n_tri; t += gridDim.x * 256u) {
+        float* T = tris + 9u * ((size_t)(m.base_index / 3u) + t);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned vi = (unsigned)m.vertex_offset + indices[m.base_index + 3u * t + c];
+            if (vi >= n_vertices) { atomicOr(err, 4u); T[3 * c] = T[3 * c + 1] = T[3 * c + 2] = 0.0f; continue; }
+            T[3 * c] = verts[3u * (size_t)vi]; T[3 * c + 1] = verts[3u * (size_t)vi + 1u]; T[3 * c + 2] = verts[3u * (size_t)vi + 2u];
+        }
+    }
+}
+
+// order = the ray ids sorted by ray key (scratch of the context, past the first 256 bytes); nullptr when not worth it
+int sort_rays(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n, const unsigned** out_order) {
+    const unsigned n_units = (n + kSortUnit - 1u) / kSortUnit;
+    const size_t arr = ((size_t)n * 4 + 255) & ~(size_t)255, tab = ((size_t)256 * n_units * 4 + 255) & ~(size_t)255;
+    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256 + 4 * arr + tab);
+    if (rc) return rc;
+    char* base = reinterpret_cast<char*>(ctx->scratch) + 256;
+    unsigned* k[2] = {reinterpret_cast<unsigned*>(base), reinterpret_cast<unsigned*>(base + arr)};
+    unsigned* v[2] = {reinterpret_cast<unsigned*>(base + 2 * arr), reinterpret_cast<unsigned*>(base + 3 * arr)};
+    unsigned* table = reinterpret_cast<unsigned*>(base + 4 * arr);
+    hipLaunchKernelGGL(ray_keys_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, d_rays, n, sc->tlas_nodes, k[0], v[0]);
+    const unsigned blocks = (n_units + kSortWaves - 1u) / kSortWaves;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int a = pass & 1, b = a ^ 1;
+        hipLaunchKernelGGL(rs_count_kernel, dim3(blocks), dim3(64 * kSortWaves), 0, ctx->stream, k[a], n, 8u * pass, n_units, table);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, table, 256u * n_units);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(blocks), dim3(64 * kSortWaves), 0, ctx->stream, k[a], v[a], n, 8u * pass, n_units, table, k[b], v[b]);
+    }
+    *out_order = v[0];            // four passes: back in buffer 0
+    return VD_OK;
+}
+
+int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out,
+                 uint32_t* d_any = nullptr) {
     // idle waves keep drawing from the ray counter after the last ray: leave it room below 2^32
     if (n_rays > 0xf0000000u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: more than 0xf0000000 rays in one call");
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256);
     if (rc) return rc;
-    unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);
-    Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes};
+    Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, d_tris};
+    const bool legacy = ctx->option(VD_OPT_TRACE_LEGACY, 0) != 0;
+    // binning pays when there are enough rays to fill the chip several times over (the sort is ~13 launches)
+    const bool sorted = !legacy && ctx->option(VD_OPT_TRACE_SORT, 1) != 0 && n_rays >= (unsigned)ctx->option(VD_OPT_TRACE_SORT_MIN, 65536);
     vd_time_begin(ctx);
+    const unsigned* order = nullptr;
+    if (sorted) { rc = sort_rays(ctx, sc, d_rays, n_rays, &order); if (rc) return rc; }
+    unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);      // after sort_rays: the scratch may have grown
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 16, ctx->stream));
-    const unsigned waves = (unsigned)ctx->num_cus * kWavesPerCu;
-    if (d_any) hipLaunchKernelGGL(trace_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, s, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1);
-    else hipLaunchKernelGGL(trace_kernel<false>, dim3(waves), dim3(64), 0, ctx->stream, s, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1);
+    if (legacy) {
+        const RaySource src{nullptr, n_rays, 1u, n_rays, d_flag + 1};
+        const unsigned waves = (unsigned)ctx->num_cus * kWavesPerCu;
+#define VD_TRACE_L(A, P) hipLaunchKernelGGL((trace_kernel<A, P, 1>), dim3(waves), dim3(64), 0, ctx->stream, s, d_rays, src, d_out, d_any, d_flag)
+        if (d_any) { if (d_tris) VD_TRACE_L(true, true); else VD_TRACE_L(true, false); }
+        else { if (d_tris) VD_TRACE_L(false, true); else VD_TRACE_L(false, false); }
+#undef VD_TRACE_L
+    } else {
+        // chunk: a few generations of rays per workgroup, so that the chip-wide tail stays short
+        const unsigned groups = (unsigned)ctx->num_cus * (kWavesPerCu / kWgWaves);
+        unsigned chunk = (unsigned)ctx->option(VD_OPT_TRACE_CHUNK, 0);
+        if (chunk == 0u) {
+            chunk = n_rays / (groups * 4u);
+            chunk = chunk > 2048u ? 2048u : (chunk < 64u ? 64u : chunk);
+            chunk &= ~63u;
+        }
+        const RaySource src{order, n_rays, chunk, (n_rays + chunk - 1u) / chunk, d_flag + 1};
+#define VD_TRACE_C(A, P) hipLaunchKernelGGL((trace_kernel<A, P, kWgWaves>), dim3(groups), dim3(64 * kWgWaves), 0, ctx->stream, s, d_rays, src, d_out, d_any, d_flag)
+        if (d_any) { if (d_tris) VD_TRACE_C(true, true); else VD_TRACE_C(true, false); }
+        else { if (d_tris) VD_TRACE_C(false, true); else VD_TRACE_C(false, false); }
+#undef VD_TRACE_C
+    }
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -402,7 +631,7 @@ int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_rays, u
     if (!scene_ok(d_scene)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: incomplete scene");
     if (n_rays == 0) return VD_OK;
     if (!d_rays || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: null rays/out");
-    return launch_trace(ctx, d_scene, d_rays, n_rays, d_out);
+    return launch_trace(ctx, d_scene, nullptr, d_rays, n_rays, d_out);
 }
 
 int vd_trace_any_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_rays, uint32_t n_rays, uint32_t* d_out_hit) {
@@ -411,7 +640,62 @@ int vd_trace_any_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_ray
     if (!scene_ok(d_scene)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_any: incomplete scene");
     if (n_rays == 0) return VD_OK;
     if (!d_rays || !d_out_hit) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_any: null rays/out");
-    return launch_trace(ctx, d_scene, d_rays, n_rays, nullptr, d_out_hit);
+    return launch_trace(ctx, d_scene, nullptr, d_rays, n_rays, nullptr, d_out_hit);
+}
+
+int vd_trace_prepare_dev(VdCtx* ctx, const VdTraceScene* d_scene, VdTraceAccel** out) {
+    VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
+    if (!ctx || !out) return VD_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!scene_ok(d_scene) || d_scene->n_indices == 0u || d_scene->n_vertices == 0u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_prepare: incomplete scene");
+    VdTraceAccel* a = new (std::nothrow) VdTraceAccel();
+    if (!a) return VD_ERR_OOM;
+    a->scene = *d_scene;
+    const size_t n_tri = d_scene->n_indices / 3u;
+    if (hipMalloc(reinterpret_cast<void**>(&a->tris), 36 * n_tri + 64) != hipSuccess) { delete a; VD_FAIL(ctx, VD_ERR_OOM, "vd_trace_prepare: triangle array"); }
+    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256);
+    if (rc) { (void)hipFree(a->tris); delete a; return rc; }
+    unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);
+    (void)hipMemsetAsync(d_flag, 0, 4, ctx->stream);
+    (void)hipMemsetAsync(a->tris, 0, 36 * n_tri + 64, ctx->stream);      // index ranges no mesh covers
+    hipLaunchKernelGGL(prepare_tris_kernel, dim3(256, d_scene->n_meshes), dim3(256), 0, ctx->stream, d_scene->meshes, d_scene->vertices, d_scene->indices,
+                       d_scene->n_indices, d_scene->n_vertices, a->tris, d_flag);
+    hipError_t e = hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess || ctx->host_pinned[0]) {
+        (void)hipFree(a->tris); delete a;
+        if (e != hipSuccess) VD_FAIL(ctx, VD_ERR_HIP, hipGetErrorString(e));
+        VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_prepare: a mesh's index range or a vertex index lies outside the scene's buffers");
+    }
+    *out = a;
+    return VD_OK;
+}
+
+int vd_trace_release(VdCtx* ctx, VdTraceAccel* accel) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx || !accel) return VD_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (accel->tris) (void)hipFree(accel->tris);
+    delete accel;
+    return VD_OK;
+}
+
+int vd_trace_prepared_dev(VdCtx* ctx, const VdTraceAccel* accel, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!accel) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_prepared: null accel");
+    if (n_rays == 0) return VD_OK;
+    if (!d_rays || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_prepared: null rays/out");
+    return launch_trace(ctx, &accel->scene, accel->tris, d_rays, n_rays, d_out);
+}
+
+int vd_trace_any_prepared_dev(VdCtx* ctx, const VdTraceAccel* accel, const VdRay* d_rays, uint32_t n_rays, uint32_t* d_out_hit) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!accel) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_any_prepared: null accel");
+    if (n_rays == 0) return VD_OK;
+    if (!d_rays || !d_out_hit) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_any_prepared: null rays/out");
+    return launch_trace(ctx, &accel->scene, accel->tris, d_rays, n_rays, nullptr, d_out_hit);
 }
 
 int vd_shadow_rays_dev(VdCtx* ctx, const float* d_positions, const float* d_normals, uint32_t n_points, const float* light_position,
@@ -513,7 +797,7 @@ int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t 
     d.vertices = reinterpret_cast<const float*>(base + off[4]);
     d.indices = reinterpret_cast<const uint32_t*>(base + off[5]);
     VdHit* d_out = reinterpret_cast<VdHit*>(base + off[7]);
-    rc = launch_trace(ctx, &d, reinterpret_cast<const VdRay*>(base + off[6]), n_rays, d_out);
+    rc = launch_trace(ctx, &d, nullptr, reinterpret_cast<const VdRay*>(base + off[6]), n_rays, d_out);
     if (rc) return rc;
     VD_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, sz[7], hipMemcpyDeviceToHost, ctx->stream));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -257,6 +257,35 @@ class Context:
         """Occlusion query: d_out_hit[i] (u32) = 1 iff ray i hits anything (raytraced_shadows.wgsl:97-102)."""
         self._chk(self.lib.vd_trace_any_dev(self.h, C.byref(scene.struct), abi.ptr(d_rays), n_rays, abi.ptr(d_out_hit)))
 
+    class TraceAccel:
+        """vd_trace_prepare_dev: per-scene de-indexed leaf triangles (include/voidin_abi.h); keeps the DeviceScene alive."""
+
+        def __init__(self, ctx: "Context", scene: "Context.DeviceScene"):
+            self.ctx, self.scene = ctx, scene
+            h = C.c_void_p()
+            ctx._chk(ctx.lib.vd_trace_prepare_dev(ctx.h, C.byref(scene.struct), C.byref(h)))
+            self.h = h
+
+        def close(self):
+            if getattr(self, "h", None):
+                self.ctx.lib.vd_trace_release(self.ctx.h, self.h)
+                self.h = None
+
+        def __del__(self):
+            try:
+                self.close()
+            except Exception:
+                pass
+
+    def trace_prepare(self, scene: "Context.DeviceScene") -> "Context.TraceAccel":
+        return Context.TraceAccel(self, scene)
+
+    def trace_prepared_dev(self, accel: "Context.TraceAccel", d_rays, n_rays, d_out):
+        self._chk(self.lib.vd_trace_prepared_dev(self.h, accel.h, abi.ptr(d_rays), n_rays, abi.ptr(d_out)))
+
+    def trace_any_prepared_dev(self, accel: "Context.TraceAccel", d_rays, n_rays, d_out_hit):
+        self._chk(self.lib.vd_trace_any_prepared_dev(self.h, accel.h, abi.ptr(d_rays), n_rays, abi.ptr(d_out_hit)))
+
     def shadow_rays_dev(self, d_positions, d_normals, n_points, light_position, d_rays):
         lp = (C.c_float * 3)(*[float(x) for x in light_position])
         self._chk(self.lib.vd_shadow_rays_dev(self.h, abi.ptr(d_positions), abi.ptr(d_normals), n_points, lp, abi.ptr(d_rays)))
