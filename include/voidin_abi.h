@@ -200,8 +200,6 @@ typedef enum VdOption {
                                      redone on one workgroup (0 forces the redo: tests)                   */
     VD_OPT_TLAS_SPEC = 16,        /* 0: indexed build without the speculative helper waves; default 1     */
     VD_OPT_TLAS_PROFILE = 17,     /* 1: the indexed build prints its in-kernel cycle counters             */
-    VD_OPT_TRACE_LEGACY = 20,     /* 1: vd_trace* hands single rays to idle lanes from one global counter (the round-2
-                                     supply) instead of sorted chunks per workgroup; default 0                  */
     VD_OPT_TRACE_SORT = 21,       /* 0: no binning pre-pass (rays are handed out in input order); default 1      */
     VD_OPT_TRACE_SORT_MIN = 22,   /* fewest rays a call bins; default 65536                                      */
     VD_OPT_TRACE_CHUNK = 23,      /* rays per chunk a workgroup works off (multiple of 64); default by ray count */

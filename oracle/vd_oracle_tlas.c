@@ -173,7 +173,19 @@ int vd_ref_tlas_refit(const VdInstance* instances, uint32_t n, const VdMeshInfo*
         v3_store(nodes[k].min, v3_min_to(v3_load(nodes[l].min), v3_load(nodes[r].min)));
         v3_store(nodes[k].max, v3_max_to(v3_load(nodes[l].max), v3_load(nodes[r].max)));
     }
-    nodes[0] = nodes[2u * (size_t)n];
+    /* node 0 is a COPY of the node the chain ended on (tlas.rs:84) - node 2n in every ordinary build, but any node when
+     * the chain ended on a stale slot (a cluster whose unions all reach 1e30 is dropped: tlas.rs:62-79, 88-104; the root
+     * can then be a single leaf): its box follows from its OWN payload, which a refit never touches */
+    {
+        uint32_t l = nodes[0].left_right & 0xffffu, r = nodes[0].left_right >> 16;
+        if (nodes[0].left_right == 0u) {
+            aabb b = leaf_bounds(&instances[nodes[0].instance_idx], meshes, n_mesh);
+            v3_store(nodes[0].min, b.mn); v3_store(nodes[0].max, b.mx);
+        } else {
+            v3 mn = v3_min_to(v3_load(nodes[l].min), v3_load(nodes[r].min)), mx = v3_max_to(v3_load(nodes[l].max), v3_load(nodes[r].max));
+            v3_store(nodes[0].min, mn); v3_store(nodes[0].max, mx);
+        }
+    }
     return VD_OK;
 }
 
@@ -190,6 +202,15 @@ int vd_ref_tlas_refit_wide(const VdInstance* instances, uint32_t n, const VdMesh
         v3_store(nodes[k].min, v3_min_to(v3_load(nodes[l].min), v3_load(nodes[r].min)));
         v3_store(nodes[k].max, v3_max_to(v3_load(nodes[l].max), v3_load(nodes[r].max)));
     }
-    nodes[0] = nodes[2u * (size_t)n];
+    {   /* node 0 from its own payload: see vd_ref_tlas_refit */
+        uint32_t l = nodes[0].left, r = nodes[0].right;
+        if (l == 0u && r == 0u) {
+            aabb b = leaf_bounds(&instances[nodes[0].instance_idx], meshes, n_mesh);
+            v3_store(nodes[0].min, b.mn); v3_store(nodes[0].max, b.mx);
+        } else {
+            v3 mn = v3_min_to(v3_load(nodes[l].min), v3_load(nodes[r].min)), mx = v3_max_to(v3_load(nodes[l].max), v3_load(nodes[r].max));
+            v3_store(nodes[0].min, mn); v3_store(nodes[0].max, mx);
+        }
+    }
     return VD_OK;
 }

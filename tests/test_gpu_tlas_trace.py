@@ -317,7 +317,7 @@ def test_trace_supply_binning_and_prepared_triangles_are_order_only(ctx, oracle,
     """Round 3: rays are binned (sorted by origin cell and direction), handed to workgroups in chunks of the sorted
     order, and leaf triangles may come de-indexed from vd_trace_prepare_dev.  All of that changes the ORDER in which rays
     are walked and where a triangle's vertices are fetched from - never a result: every variant must reproduce the
-    oracle's hit flags / distances exactly as the round-2 single-ray supply does, byte for byte, on a multi-mesh scene
+    oracle's hit flags / distances, and all variants the same bytes, on a multi-mesh scene
     (vertex_offset / base_index / bvh_index all non-zero) with degenerate rays mixed in."""
     import torch
     meshes_src = [synth.uv_sphere(1.0, 4), synth.knot_mesh(96, 24), synth.triangle_soup(64)]
@@ -345,10 +345,10 @@ def test_trace_supply_binning_and_prepared_triangles_are_order_only(ctx, oracle,
     d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
     d_any = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
     first = None
-    variants = [dict(legacy=1), dict(sort=0), dict(sort_min=1), dict(sort_min=1, chunk=64), dict(sort_min=1, chunk=4096),
-                dict(sort=0, chunk=128)]
+    variants = [dict(sort=0, chunk=64), dict(sort=0), dict(sort_min=1), dict(sort_min=1, chunk=64), dict(sort_min=1, chunk=4096),
+                dict(sort_min=1, chunk=100)]
     for opts in variants:
-        for k in ("legacy", "sort", "sort_min", "chunk"):
+        for k in ("sort", "sort_min", "chunk"):
             ctx_options("trace." + k, opts.get(k))
         for prep in (False, True):
             d_hits.zero_(); d_any.fill_(9)

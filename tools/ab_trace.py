@@ -29,14 +29,14 @@ ds = ctx.device_scene((tl, inst_t, infos, nodes_b, tv, idx_b))
 acc = ctx.trace_prepare(ds)
 d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
 d_any = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
-variants = [("legacy", dict(legacy=1), False), ("legacy+prep", dict(legacy=1), True),
+variants = [("chunk64 nosort (~r2 supply)", dict(sort=0, chunk=64), False), ("chunk64 nosort prep", dict(sort=0, chunk=64), True),
             ("chunk nosort", dict(sort=0), False), ("chunk sort", dict(), False), ("chunk sort prep", dict(), True),
             ("chunk64 sort prep", dict(chunk=64), True), ("chunk256 sort prep", dict(chunk=256), True),
             ("chunk1024 sort prep", dict(chunk=1024), True), ("chunk4096 sort prep", dict(chunk=4096), True)]
 ref_bytes = ref_any = None
 ctx.set_timing(True)
 for name, opts, prep in variants:
-    for k in ("legacy", "sort", "chunk"):
+    for k in ("sort", "chunk"):
         ctx.set_option("trace." + k, opts.get(k))
     t_cl, t_any = [], []
     for _ in range(args.reps):
@@ -49,5 +49,5 @@ for name, opts, prep in variants:
     b, a = d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes()
     if ref_bytes is None:
         ref_bytes, ref_any = b, a
-    print(f"{name:22s} closest {len(rays) / min(t_cl) / 1e3:7.1f} Mrays/s ({min(t_cl):7.2f} ms)  occlusion {len(rays) / min(t_any) / 1e3:7.1f} Mrays/s"
+    print(f"{name:28s} closest {len(rays) / min(t_cl) / 1e3:7.1f} Mrays/s ({min(t_cl):7.2f} ms)  occlusion {len(rays) / min(t_any) / 1e3:7.1f} Mrays/s"
           f"  same bytes: {b == ref_bytes} {a == ref_any}", flush=True)

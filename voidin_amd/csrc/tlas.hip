@@ -1133,11 +1133,6 @@ __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigne
             __hip_atomic_store(&nodes[k].min[q], box.mn[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&nodes[k].max[q], box.mx[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (k == 2u * n) {                                // tlas.rs:84: nodes[0] is a copy of the last node
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { nodes[0].min[q] = box.mn[q]; nodes[0].max[q] = box.mx[q]; }
-            return;
-        }
         const uint2 u = up[k];                            // {parent, sibling}
         const unsigned p = u.x, s = u.y;
         // No parent: the reference's chain DROPS a cluster whose unions all have an area >= 1e30 or NaN (an infinite
@@ -1156,6 +1151,22 @@ __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigne
         box = box_union(box, load_box_agent(nodes, s));
         k = p;
     }
+}
+
+// Launch 3 (one lane): node 0.  tlas.rs:84 makes it a COPY of the node the chain ends on - node 2n in every ordinary
+// build, but any node when the chain ended on a stale slot (a cluster with an infinite box is dropped, and the root can
+// even be a single leaf) - so a refit recomputes its box from its OWN payload, like any other node: the leaf box of its
+// instance, or the union of its children's refitted boxes.  Its payload is never touched.
+template <typename Node>
+__global__ void tlas_refit_root_kernel(const VdInstance* __restrict__ inst, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
+                                       Node* __restrict__ nodes) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned l, r;
+    node_get_children(nodes[0], l, r);
+    const Box b = (l == 0u && r == 0u) ? leaf_box(inst, meshes, n_mesh, nodes[0].instance_idx)
+                                       : box_union(load_box_plain(nodes, l), load_box_plain(nodes, r));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { nodes[0].min[c] = b.mn[c]; nodes[0].max[c] = b.mx[c]; }
 }
 
 template <typename Node>
@@ -1279,6 +1290,7 @@ int tlas_refit_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     hipLaunchKernelGGL((tlas_refit_prep_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes, n_mesh,
                        d_nodes, parent, arrivals);
     hipLaunchKernelGGL((tlas_refit_up_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_nodes, n, parent, arrivals);
+    hipLaunchKernelGGL((tlas_refit_root_kernel<Node>), dim3(1), dim3(64), 0, ctx->stream, d_inst, d_meshes, n_mesh, d_nodes);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;

@@ -90,7 +90,6 @@ constexpr unsigned kRefillBelow = 56;   // draw new rays when fewer than this ma
 constexpr unsigned kWavesPerCu = 28;    // persistent grid = what is resident (7 waves per SIMD at 72 VGPRs): no wave starts late
 constexpr int kWgWaves = 7;             // waves per workgroup of the chunked form: 4 workgroups per CU
 // PREP: leaf triangles come de-indexed from Scene::tris (one contiguous fetch instead of indices[] -> verts[]).
-// WG_WAVES == 1: the round-2 supply (single rays from one global counter, `src.next_chunk` is that counter).
 template <bool ANY, bool PREP, int WG_WAVES>
 __global__ __launch_bounds__(64 * WG_WAVES, 7)   // second argument (HIP): waves per SIMD = 28 per CU
 void trace_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
@@ -99,10 +98,8 @@ void trace_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit*
     const unsigned n_rays = src.n_rays;
     __shared__ vd_u64 s_word;              // chunked supply: {next, end} positions of the workgroup's current chunk
     unsigned p_next = 0, p_end = 0;        // a chunk this wave could not publish (another wave's was installed first)
-    if (WG_WAVES > 1) {
-        if (threadIdx.x == 0) s_word = 0ull;
-        __syncthreads();
-    }
+    if (threadIdx.x == 0) s_word = 0ull;
+    __syncthreads();
     unsigned stack[2 * kStack];            // BLAS entries sit above the TLAS entries of the same ray
     Ray world, ray;                        // `ray` is the active one (object space inside an instance)
     VdHit res;
@@ -131,12 +128,7 @@ void trace_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit*
             const unsigned long long idle = ~busy_mask;
             const unsigned want = (unsigned)__popcll(idle);
             unsigned base = 0, got = 0, done = 0;
-            if (WG_WAVES == 1) {
-                if (lane == 0) base = atomicAdd(src.next_chunk, want);
-                base = __shfl(base, 0);
-                got = base < n_rays ? min(want, n_rays - base) : 0u;
-                done = base + want >= n_rays ? 1u : 0u;
-            } else {
+            {
                 if (lane == 0) {
                     if (p_next < p_end) { got = min(want, p_end - p_next); base = p_next; p_next += got; }
                     else for (;;) {
@@ -577,30 +569,22 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256);
     if (rc) return rc;
     Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, d_tris};
-    const bool legacy = ctx->option(VD_OPT_TRACE_LEGACY, 0) != 0;
     // binning pays when there are enough rays to fill the chip several times over (the sort is ~13 launches)
-    const bool sorted = !legacy && ctx->option(VD_OPT_TRACE_SORT, 1) != 0 && n_rays >= (unsigned)ctx->option(VD_OPT_TRACE_SORT_MIN, 65536);
+    const bool sorted = ctx->option(VD_OPT_TRACE_SORT, 1) != 0 && n_rays >= (unsigned)ctx->option(VD_OPT_TRACE_SORT_MIN, 65536);
     vd_time_begin(ctx);
     const unsigned* order = nullptr;
     if (sorted) { rc = sort_rays(ctx, sc, d_rays, n_rays, &order); if (rc) return rc; }
     unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);      // after sort_rays: the scratch may have grown
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 16, ctx->stream));
-    if (legacy) {
-        const RaySource src{nullptr, n_rays, 1u, n_rays, d_flag + 1};
-        const unsigned waves = (unsigned)ctx->num_cus * kWavesPerCu;
-#define VD_TRACE_L(A, P) hipLaunchKernelGGL((trace_kernel<A, P, 1>), dim3(waves), dim3(64), 0, ctx->stream, s, d_rays, src, d_out, d_any, d_flag)
-        if (d_any) { if (d_tris) VD_TRACE_L(true, true); else VD_TRACE_L(true, false); }
-        else { if (d_tris) VD_TRACE_L(false, true); else VD_TRACE_L(false, false); }
-#undef VD_TRACE_L
-    } else {
+    {
         // chunk: a few generations of rays per workgroup, so that the chip-wide tail stays short
         const unsigned groups = (unsigned)ctx->num_cus * (kWavesPerCu / kWgWaves);
         unsigned chunk = (unsigned)ctx->option(VD_OPT_TRACE_CHUNK, 0);
         if (chunk == 0u) {
             chunk = n_rays / (groups * 4u);
             chunk = chunk > 2048u ? 2048u : (chunk < 64u ? 64u : chunk);
-            chunk &= ~63u;
         }
+        chunk = (chunk + 63u) & ~63u;
         const RaySource src{order, n_rays, chunk, (n_rays + chunk - 1u) / chunk, d_flag + 1};
 #define VD_TRACE_C(A, P) hipLaunchKernelGGL((trace_kernel<A, P, kWgWaves>), dim3(groups), dim3(64 * kWgWaves), 0, ctx->stream, s, d_rays, src, d_out, d_any, d_flag)
         if (d_any) { if (d_tris) VD_TRACE_C(true, true); else VD_TRACE_C(true, false); }
