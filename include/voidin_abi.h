@@ -200,9 +200,12 @@ typedef enum VdOption {
                                      redone on one workgroup (0 forces the redo: tests)                   */
     VD_OPT_TLAS_SPEC = 16,        /* 0: indexed build without the speculative helper waves; default 1     */
     VD_OPT_TLAS_PROFILE = 17,     /* 1: the indexed build prints its in-kernel cycle counters             */
-    VD_OPT_TRACE_SORT = 21,       /* 0: no binning pre-pass (rays are handed out in input order); default 1      */
-    VD_OPT_TRACE_SORT_MIN = 22,   /* fewest rays a call bins; default 65536                                      */
-    VD_OPT_TRACE_CHUNK = 23,      /* rays per chunk a workgroup works off (multiple of 64); default by ray count */
+    VD_OPT_TRACE_SORT = 21,       /* 1: vd_trace* bin the rays first (sorted by origin cell + direction) and hand them
+                                     out in that order; results are per ray, so only the order changes.  Default 0:
+                                     measured slower on this part                                */
+    VD_OPT_TRACE_SORT_MIN = 22,   /* fewest rays a call bins when VD_OPT_TRACE_SORT is on; default 65536          */
+    VD_OPT_TRACE_CHUNK = 23,      /* 1 (default): idle lanes draw single rays from one counter; >= 64: consecutive
+                                     rays per workgroup in chunks of this size (measured slower: imbalance)      */
     VD_OPT_COUNT_ = 32
 } VdOption;
 int         vd_ctx_set_option(VdCtx* ctx, int option /* VdOption */, int64_t value);

@@ -29,10 +29,12 @@ ds = ctx.device_scene((tl, inst_t, infos, nodes_b, tv, idx_b))
 acc = ctx.trace_prepare(ds)
 d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
 d_any = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
-variants = [("chunk64 nosort (~r2 supply)", dict(sort=0, chunk=64), False), ("chunk64 nosort prep", dict(sort=0, chunk=64), True),
+variants = [("single rays nosort (r2 supply)", dict(sort=0, chunk=1), False), ("single rays nosort prep", dict(sort=0, chunk=1), True),
+            ("single rays sort prep", dict(chunk=1), True),
+            ("chunk64 nosort", dict(sort=0, chunk=64), False), ("chunk64 nosort prep", dict(sort=0, chunk=64), True),
             ("chunk nosort", dict(sort=0), False), ("chunk sort", dict(), False), ("chunk sort prep", dict(), True),
             ("chunk64 sort prep", dict(chunk=64), True), ("chunk256 sort prep", dict(chunk=256), True),
-            ("chunk1024 sort prep", dict(chunk=1024), True), ("chunk4096 sort prep", dict(chunk=4096), True)]
+            ("chunk128 sort prep", dict(chunk=128), True)]
 ref_bytes = ref_any = None
 ctx.set_timing(True)
 for name, opts, prep in variants:
@@ -49,5 +51,5 @@ for name, opts, prep in variants:
     b, a = d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes()
     if ref_bytes is None:
         ref_bytes, ref_any = b, a
-    print(f"{name:28s} closest {len(rays) / min(t_cl) / 1e3:7.1f} Mrays/s ({min(t_cl):7.2f} ms)  occlusion {len(rays) / min(t_any) / 1e3:7.1f} Mrays/s"
+    print(f"{name:32s} closest {len(rays) / min(t_cl) / 1e3:7.1f} Mrays/s ({min(t_cl):7.2f} ms)  occlusion {len(rays) / min(t_any) / 1e3:7.1f} Mrays/s"
           f"  same bytes: {b == ref_bytes} {a == ref_any}", flush=True)

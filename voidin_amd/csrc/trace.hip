@@ -68,12 +68,12 @@ struct Scene {
     const float* tris;          // vd_trace_prepare_dev: 9 floats per triangle in index-buffer order (nullptr: not prepared)
 };
 
-// Where a wave's rays come from.  `order` (nullptr = identity) lists the ray ids in the order they are handed out - the
-// binning pre-pass sorts them by origin cell and direction, so that rays which walk the same nodes are neighbours.  They
-// are handed out in CHUNKS of consecutive positions: a workgroup (several waves = one CU's L1) works one chunk off
-// before it takes the next, so that at any time the lanes of a wave AND the waves of a CU sit in a small window of the
-// sorted order, whatever their rays cost.  (One global counter handing single rays to whoever is idle - the round-2 scheme
-// - spreads every wave over the ~450 k rays that are in flight chip-wide.)
+// Where a wave's rays come from.  `order` (nullptr = identity) lists the ray ids in the order they are handed out (the
+// optional binning pre-pass sorts them by origin cell and direction).  chunk == 1 (default): idle lanes draw single
+// rays from one global counter.  chunk >= 64: rays are handed out in CHUNKS of consecutive positions, a workgroup (several
+// waves = one CU's L1) working one chunk off before it takes the next, so that the lanes of a wave and the waves of a CU
+// sit in a small window of the order.  Both were built to test whether locality pays on this part; it does not
+// (launch_trace), and the defaults are the round-2 supply.
 struct RaySource { const unsigned* order; unsigned n_rays, chunk, n_chunks; unsigned* next_chunk; };
 
 // A fixed grid of waves; a lane whose ray is finished draws the next ray from a counter, so a wave stays full while
@@ -130,7 +130,11 @@ void trace_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit*
             unsigned base = 0, got = 0, done = 0;
             {
                 if (lane == 0) {
-                    if (p_next < p_end) { got = min(want, p_end - p_next); base = p_next; p_next += got; }
+                    if (src.chunk == 1u) {                              // single rays from one global counter: the finest balance
+                        base = atomicAdd(src.next_chunk, want);
+                        got = base < n_rays ? min(want, n_rays - base) : 0u;
+                        done = base + want >= n_rays ? 1u : 0u;
+                    } else if (p_next < p_end) { got = min(want, p_end - p_next); base = p_next; p_next += got; }
                     else for (;;) {
                         const vd_u64 old = __hip_atomic_load(&s_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         const unsigned nx = (unsigned)old, en = (unsigned)(old >> 32);
@@ -569,22 +573,23 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256);
     if (rc) return rc;
     Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, d_tris};
-    // binning pays when there are enough rays to fill the chip several times over (the sort is ~13 launches)
-    const bool sorted = ctx->option(VD_OPT_TRACE_SORT, 1) != 0 && n_rays >= (unsigned)ctx->option(VD_OPT_TRACE_SORT_MIN, 65536);
+    // Binning is OFF by default: measured on the stress scene (tools/ab_trace.py, profiles/r03_ab_trace.log) rays handed
+    // out in sorted order are SLOWER (32.0 against 35.7 Mrays/s): the walk is bound by the slowest of a wave's 64 fetches,
+    // not by the L1 hit rate, and sorting puts the expensive rays of the dense screen centre side by side in time.
+    const bool sorted = ctx->option(VD_OPT_TRACE_SORT, 0) != 0 && n_rays >= (unsigned)ctx->option(VD_OPT_TRACE_SORT_MIN, 65536);
     vd_time_begin(ctx);
     const unsigned* order = nullptr;
     if (sorted) { rc = sort_rays(ctx, sc, d_rays, n_rays, &order); if (rc) return rc; }
     unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);      // after sort_rays: the scratch may have grown
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 16, ctx->stream));
     {
-        // chunk: a few generations of rays per workgroup, so that the chip-wide tail stays short
+        // Default: single rays from one global counter (chunk = 1) - the finest balance.  Chunks of consecutive rays per
+        // workgroup (a CU-local window of the ray order) lose more to imbalance than they gain in locality: 64 rays per
+        // chunk 32.6, 256 rays 16.9 Mrays/s against 35.2 (same log).
         const unsigned groups = (unsigned)ctx->num_cus * (kWavesPerCu / kWgWaves);
-        unsigned chunk = (unsigned)ctx->option(VD_OPT_TRACE_CHUNK, 0);
-        if (chunk == 0u) {
-            chunk = n_rays / (groups * 4u);
-            chunk = chunk > 2048u ? 2048u : (chunk < 64u ? 64u : chunk);
-        }
-        chunk = (chunk + 63u) & ~63u;
+        unsigned chunk = (unsigned)ctx->option(VD_OPT_TRACE_CHUNK, 1);
+        if (chunk == 0u) chunk = 1u;
+        if (chunk != 1u) chunk = (chunk + 63u) & ~63u;     // 1: single rays from the global counter (no chunks)
         const RaySource src{order, n_rays, chunk, (n_rays + chunk - 1u) / chunk, d_flag + 1};
 #define VD_TRACE_C(A, P) hipLaunchKernelGGL((trace_kernel<A, P, kWgWaves>), dim3(groups), dim3(64 * kWgWaves), 0, ctx->stream, s, d_rays, src, d_out, d_any, d_flag)
         if (d_any) { if (d_tris) VD_TRACE_C(true, true); else VD_TRACE_C(true, false); }
