@@ -200,6 +200,8 @@ typedef enum VdOption {
                                      redone on one workgroup (0 forces the redo: tests)                   */
     VD_OPT_TLAS_SPEC = 16,        /* 0: indexed build without the speculative helper waves; default 1     */
     VD_OPT_TLAS_PROFILE = 17,     /* 1: the indexed build prints its in-kernel cycle counters             */
+    VD_OPT_BLAS_WIDE_PAYLOAD = 30,/* 1: vd_bvh_build moves the 8-byte payload (what meshes above 2^25 triangles use) at
+                                     any size (tests); default 0                                                  */
     VD_OPT_TRACE_SORT = 21,       /* 1: vd_trace* bin the rays first (sorted by origin cell + direction) and hand them
                                      out in that order; results are per ray, so only the order changes.  Default 0:
                                      measured slower on this part                                */

@@ -42,6 +42,17 @@ def test_soup_sizes_vs_oracle(ctx, oracle, n_tri):
     assert np.array_equal(idx, want_idx)
 
 
+def test_wide_payload_path_vs_oracle(ctx, oracle, ctx_options):
+    """Meshes above 2^25 triangles move an 8-byte {pos0, 21 predicate bits} payload through the rounds of phase A instead of
+    the 4-byte {pos0, 7 bits of the current axis} one; VD_OPT_BLAS_WIDE_PAYLOAD forces that path at testable sizes."""
+    ctx_options("blas.wide_payload", 1)
+    for v, i in (synth.knot_mesh(256, 64), synth.triangle_soup(3000, seed=5), synth.triangle_soup(9000, seed=6)):
+        want_nodes, want_idx = oracle.bvh_build(v, i)
+        nodes, idx = ctx.bvh_build(v, i)
+        assert fields_equal(nodes, want_nodes), diff_report(nodes, want_nodes)
+        assert np.array_equal(idx, want_idx)
+
+
 @pytest.mark.parametrize("shape", [(128, 32), (512, 64), (1024, 256)])
 def test_knot_meshes_vs_oracle(ctx, oracle, shape):
     # up to 524k triangles: several phase-A levels over many segments

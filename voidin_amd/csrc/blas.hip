@@ -136,7 +136,7 @@ __device__ __forceinline__ float cand_pos(const float* cbmin, const float* cbmax
 // 393 k of them at 8.4 M triangles - most of this kernel's 0.9 ms.
 constexpr int kPreTris = 8;
 __global__ __launch_bounds__(256) void blas_precompute_kernel(const float* __restrict__ verts, const unsigned* __restrict__ idx,
-                                                              unsigned n_tri, unsigned n_vert, u32x2* __restrict__ slim,
+                                                              unsigned n_tri, unsigned n_vert,
                                                               f32x4* __restrict__ cent, TriBox* __restrict__ boxes,
                                                               int* __restrict__ root_keys /*[12]: box, centroid box*/,
                                                               unsigned* __restrict__ err) {
@@ -169,9 +169,7 @@ __global__ __launch_bounds__(256) void blas_precompute_kernel(const float* __res
             k12[9 + k] = max(k12[9 + k], vd_key_hi(ce[k]));
         }
         bx.pad0 = bx.pad1 = 0.0f;
-        const u32x2 p = {t, 0u};
-        const f32x4 c4 = {ce[0], ce[1], ce[2], 0.0f};
-        slim[t] = p;
+        const f32x4 c4 = {ce[0], ce[1], ce[2], __uint_as_float(t)};   // .w: the triangle's id travels with its centroid
         cent[t] = c4;
         boxes[t] = bx;
     }
@@ -187,6 +185,34 @@ __global__ __launch_bounds__(256) void blas_precompute_kernel(const float* __res
         else atomicMax(&root_keys[threadIdx.x], s_k[threadIdx.x]);
     }
 }
+
+// Per-triangle data lives in two array sets that phase A ping-pongs: a level reads set `cur` by the position an element
+// had when the level started (`pos0`) and its last pass writes set `next` in the order the level left - so the gathers of
+// a level stay inside the segment's own window (cache-local once segments are a few MB) and the first pass of the next
+// level streams.  cent[].w carries the original triangle id.  A segment that leaves phase A keeps the set its last level
+// wrote: `parity` in its root record (bit 0; bit 1: positions were permuted again by the mid tier, see ids32).
+struct ArrSet { f32x4* cent; TriBox* boxes; };
+// What the 22 shuffles of a level move: the element's pos0 and the predicate bits the current rounds test.
+//   Pay4 (n <= 2^25 triangles): 4 bytes = pos0 | the 7 bits of ONE axis << 25; re-derived from bits21[pos0] when the
+//        rounds change axis (rounds 7, 14 and the final one) - 28 instead of 44 bytes per triangle and round through HBM;
+//   Pay8: 8 bytes = {pos0, all 21 bits} for larger meshes.
+struct Pay4 {
+    typedef unsigned T;
+    static constexpr bool kRefresh = true;
+    static __device__ __forceinline__ T make(unsigned pos, unsigned bits21, unsigned axis) { return pos | (((bits21 >> (7u * axis)) & 0x7fu) << 25); }
+    static __device__ __forceinline__ unsigned pos(T v) { return v & 0x1ffffffu; }
+    static __device__ __forceinline__ unsigned word(T v) { return v; }
+    static __device__ __forceinline__ unsigned shift(unsigned c) { return 25u + c % 7u; }
+};
+struct Pay8 {
+    typedef u32x2 T;
+    static constexpr bool kRefresh = false;
+    static __device__ __forceinline__ T make(unsigned pos, unsigned bits21, unsigned) { T v = {pos, bits21}; return v; }
+    static __device__ __forceinline__ unsigned pos(T v) { return v.x; }
+    static __device__ __forceinline__ unsigned word(T v) { return v.y; }
+    static __device__ __forceinline__ unsigned shift(unsigned c) { return c; }
+};
+constexpr unsigned kPay4Max = 1u << 25;
 
 // Cost of one candidate from binned statistics + the held-out `u` elements (blas.rs:149-155).
 // bins: [8][3] keys of the candidate's axis (non-u elements only); u list: payload + box.
@@ -495,7 +521,7 @@ __device__ __forceinline__ void block_shuffle_helpers(WaveLds& L, WaveQueues& Q,
 #endif
 __global__ __launch_bounds__(64 * kSubWaves, VD_SMALL_OCC)
 void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
-                       const u32x2* __restrict__ slim, const f32x4* __restrict__ cent, const TriBox* __restrict__ boxes,
+                       const unsigned* __restrict__ ids32, ArrSet set0, ArrSet set1,
                        TmpNode* __restrict__ subnodes, unsigned short* __restrict__ submap,
                        unsigned* __restrict__ sub_interior, unsigned* __restrict__ final_ids, unsigned* __restrict__ err,
                        unsigned* __restrict__ dbg_cycles) {
@@ -510,11 +536,15 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     if (root_i >= *n_roots_p) return;
     const SmallRoot root = roots[root_i];
     const unsigned base = root.start, N = root.count;
+    // per-triangle data: position order in the set the segment's last phase-A level wrote (pad & 1), through ids32 when
+    // the mid tier permuted the positions again (pad & 2)
+    const f32x4* __restrict__ cent = (root.pad & 1u) ? set1.cent : set0.cent;
+    const TriBox* __restrict__ boxes = (root.pad & 1u) ? set1.boxes : set0.boxes;
     TmpNode* nodes = subnodes + 2u * (size_t)base;   // disjoint region per root: < 2*N nodes, creation order
     unsigned short* nmap = submap + 2u * (size_t)base;
 
     for (unsigned x = tid; x < N; x += 64u * kSubWaves) {
-        const unsigned id = slim[base + x].x;
+        const unsigned id = (root.pad & 2u) ? ids32[base + x] : base + x;
 #if VD_BOX_IN_LDS
         const TriBox bx = boxes[id];
 #endif
@@ -1074,7 +1104,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
         nmap[j] = (unsigned short)(2u * (rl - 1u) + (j & 1u));
         if (IK[j] != 0xffffffffu) { nodes[j].left_first = 2u * R[j]; nodes[j].count = 0u; }   // interior: its own pair in DFS numbering
     }
-    for (unsigned x = tid; x < N; x += 64u * kSubWaves) final_ids[base + x] = L.gid[L.perm[0][x]];
+    for (unsigned x = tid; x < N; x += 64u * kSubWaves) final_ids[base + x] = __float_as_uint(cent[L.gid[L.perm[0][x]]].w);   // the triangle's own id
     if (tid == 0) {
         sub_interior[root_i] = n_interior;
 #ifdef VD_PROF_SEL
@@ -1167,17 +1197,20 @@ __device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_s
 }
 
 // The 21 split planes of a segment are fixed before its first trial (blas.rs:142-146), so every predicate of the
-// level is evaluated once: bit c of slim[x].y = centroid[axis(c)] < pos[c].  The 22 shuffles then move 8 bytes.
+// level is evaluated once: bit c of bits21[x] = centroid[axis(c)] < pos[c].  At the start of a level an element's pos0 IS
+// its position, so this pass streams: centroid in, bits and the first payload (axis 0) out.
+template <typename P>
 __global__ __launch_bounds__(256) void a_bits_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                     u32x2* __restrict__ slim, const f32x4* __restrict__ cent) {
+                                                     typename P::T* __restrict__ pay, const f32x4* __restrict__ cent,
+                                                     unsigned* __restrict__ bits21) {
     __shared__ float s_pos[kCand + 3];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     if (threadIdx.x < (unsigned)kCand) s_pos[threadIdx.x] = sg->pos[threadIdx.x];
     __syncthreads();
     for (unsigned x = threadIdx.x; x < ic.n_here; x += 256u) {
-        u32x2 v = slim[sg->start + ic.rel0 + x];
-        const f32x4 c = cent[v.x];
+        const unsigned a = sg->start + ic.rel0 + x;
+        const f32x4 c = cent[a];
         unsigned bits = 0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -1185,8 +1218,8 @@ __global__ __launch_bounds__(256) void a_bits_kernel(const Seg* segs, const unsi
             bits |= (c.y < s_pos[7 + k] ? 1u : 0u) << (7 + k);
             bits |= (c.z < s_pos[14 + k] ? 1u : 0u) << (14 + k);
         }
-        v.y = bits;
-        slim[sg->start + ic.rel0 + x] = v;
+        bits21[a] = bits;
+        pay[a] = P::make(a, bits, 0u);
     }
 }
 
@@ -1215,9 +1248,11 @@ __device__ __forceinline__ Window round_window(const Seg* sg, int r) {
 }
 
 // predicates of the item's positions that lie in the shuffled window (positions below `act` stay out of the ballots)
-__device__ __forceinline__ void item_masks(const Seg* sg, const ItemCtx& ic, const u32x2* __restrict__ pay, int c,
-                                           unsigned act, unsigned long long (&masks)[kPer], u32x2 (&vals)[kPer]) {
+template <typename P>
+__device__ __forceinline__ void item_masks(const Seg* sg, const ItemCtx& ic, const typename P::T* __restrict__ pay, int c,
+                                           unsigned act, unsigned long long (&masks)[kPer], typename P::T (&vals)[kPer]) {
     const unsigned cc = c >= 0 ? (unsigned)c : sg->best;
+    const unsigned sh = P::shift(cc);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
@@ -1225,22 +1260,34 @@ __device__ __forceinline__ void item_masks(const Seg* sg, const ItemCtx& ic, con
         bool p = false;
         if (x < ic.n_here && ic.rel0 + x >= act) {
             vals[j] = pay[sg->start + ic.rel0 + x];
-            p = (vals[j].y >> cc) & 1u;
+            p = (P::word(vals[j]) >> sh) & 1u;
         }
         masks[j] = __ballot(p);
     }
 }
 
-// round step 1: true count of every item
+// round step 1: true count of every item.  `refresh` (rounds 7, 14 and the final one, whose window is the whole
+// segment): the payload's predicate bits are replaced IN PLACE by those of the axis the coming rounds test.
+template <typename P>
 __global__ __launch_bounds__(256) void a_count_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                      const u32x2* __restrict__ pay, int c, unsigned* item_cnt) {
+                                                      typename P::T* __restrict__ pay, int c, unsigned* item_cnt,
+                                                      const unsigned* __restrict__ bits21, int refresh) {
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     const Window win = round_window(sg, c >= 0 ? c : kCand);
     if (ic.rel0 + ic.n_here <= win.act) { if (threadIdx.x == 0) item_cnt[blockIdx.x] = 0u; return; }   // wholly frozen
-    unsigned long long masks[kPer]; u32x2 vals[kPer];
-    item_masks(sg, ic, pay, c, win.act, masks, vals);
+    if (P::kRefresh && refresh) {
+        const unsigned axis = (c >= 0 ? (unsigned)c : sg->best) / 7u;
+        for (unsigned x = threadIdx.x; x < ic.n_here; x += 256u) {
+            const unsigned a = sg->start + ic.rel0 + x;
+            const unsigned pos = P::pos(pay[a]);
+            pay[a] = P::make(pos, bits21[pos], axis);
+        }
+        __syncthreads();       // item_masks re-reads them in another lane order (same workgroup: its own stores are visible)
+    }
+    unsigned long long masks[kPer]; typename P::T vals[kPer];
+    item_masks<P>(sg, ic, pay, c, win.act, masks, vals);
     unsigned t = 0;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
@@ -1290,16 +1337,17 @@ __global__ __launch_bounds__(1024) void a_scan_kernel(Seg* segs, const LevelCtl*
 }
 
 // round step 3: TL per position + rank -> position tables
+template <typename P>
 __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                      const u32x2* __restrict__ pay, int c, const unsigned* item_pre,
+                                                      const typename P::T* __restrict__ pay, int c, const unsigned* item_pre,
                                                       unsigned* __restrict__ falsepos, unsigned* __restrict__ truepos) {
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     const Window win = round_window(sg, c >= 0 ? c : kCand);
     if (ic.rel0 + ic.n_here <= win.act) return;             // wholly frozen
-    unsigned long long masks[kPer]; u32x2 vals[kPer];
-    item_masks(sg, ic, pay, c, win.act, masks, vals);
+    unsigned long long masks[kPer]; typename P::T vals[kPer];
+    item_masks<P>(sg, ic, pay, c, win.act, masks, vals);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned t = 0;
 #pragma unroll
@@ -1325,10 +1373,12 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
 }
 
 // round step 4: destinations, scatter, `u`
+template <typename P>
 __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                      const u32x2* __restrict__ src, u32x2* __restrict__ dst, int c,
+                                                      const typename P::T* __restrict__ src, typename P::T* __restrict__ dst, int c,
                                                       const unsigned* item_pre, const unsigned* __restrict__ falsepos,
-                                                      const unsigned* __restrict__ truepos, unsigned char* __restrict__ is_u_flag) {
+                                                      const unsigned* __restrict__ truepos, unsigned char* __restrict__ is_u_flag,
+                                                      const unsigned* __restrict__ bits21) {
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
@@ -1344,8 +1394,8 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     }
     if (ic.rel0 + ic.n_here <= win.act) return;
     // predicates and TL are recomputed from the payload (cheaper than a per-position word through HBM)
-    unsigned long long masks[kPer]; u32x2 vals[kPer];
-    item_masks(sg, ic, src, c, win.act, masks, vals);
+    unsigned long long masks[kPer]; typename P::T vals[kPer];
+    item_masks<P>(sg, ic, src, c, win.act, masks, vals);
     unsigned t = 0;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
@@ -1376,9 +1426,11 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
             if (is_u && c >= 0) {
                 Seg& w = segs[ic.seg];
                 // counts as the reference sees them: examined trues of the WHOLE segment = frozen prefix + this window's
-                w.u_pay[c] = vals[j]; w.u_p[c] = p ? 1u : 0u; w.ttot[c] = win.act + ttot;
+                const unsigned upos = P::pos(vals[j]);
+                const u32x2 urec = {upos, bits21[upos]};               // the record keeps all 21 bits: the cost evaluation needs them
+                w.u_pay[c] = urec; w.u_p[c] = p ? 1u : 0u; w.ttot[c] = win.act + ttot;
                 w.act[(r + 1) % 3] = win.act + ttot - (p ? 1u : 0u);   // this trial's pivot: where the next round starts
-                is_u_flag[vals[j].x] = 1;
+                is_u_flag[upos] = 1;
             }
         }
         run += (unsigned)__popcll(masks[j]);
@@ -1386,9 +1438,10 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
 }
 
 // binning over the non-u elements (one pass per level)
+template <typename P>
 __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                    const u32x2* __restrict__ pay, const TriBox* __restrict__ boxes,
-                                                    const unsigned char* __restrict__ is_u_flag) {
+                                                    const typename P::T* __restrict__ pay, const TriBox* __restrict__ boxes,
+                                                    const unsigned char* __restrict__ is_u_flag, const unsigned* __restrict__ bits21) {
     // four private copies of the 144 bins (by quarter wave): neighbouring elements fall into the same few bins, and
     // same-address LDS atomics serialise.  A workgroup covers kBinItems consecutive items and flushes to the segment
     // record only when the segment changes: the flush is 144 same-address global atomics per workgroup (~5 ns each,
@@ -1421,12 +1474,13 @@ __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* i
         const unsigned rel0 = (item - sg->item_first) * kItem;
         const unsigned n_here = min((unsigned)kItem, sg->count - rel0);
         for (unsigned xr = threadIdx.x; xr < n_here; xr += 256u) {
-            const u32x2 v = pay[sg->start + rel0 + xr];
-            if (is_u_flag[v.x]) continue;
-            const TriBox bx = boxes[v.x];
+            const unsigned pos = P::pos(pay[sg->start + rel0 + xr]);
+            if (is_u_flag[pos]) continue;
+            const TriBox bx = boxes[pos];
+            const unsigned b21 = bits21[pos];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const int b = 7 - __popc((v.y >> (7 * a)) & 0x7fu);   // bin = number of planes the centroid is not below
+                const int b = 7 - __popc((b21 >> (7 * a)) & 0x7fu);   // bin = number of planes the centroid is not below
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     atomicMin(&s_min[copy][a][b][q], vd_key(bx.mn[q]));
@@ -1458,10 +1512,13 @@ __global__ __launch_bounds__(64) void a_eval_kernel(Seg* segs, LevelCtl* ctl, co
     }
 }
 
-// children boxes from the final arrangement (blas.rs:115-123)
+// children boxes from the final arrangement (blas.rs:115-123); the same pass writes the per-triangle data out in the
+// order the level left (set `next`), which is what the next level - or the tier that takes the segment over - reads
+template <typename P>
 __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                      const u32x2* __restrict__ pay, const TriBox* __restrict__ boxes,
-                                                      const f32x4* __restrict__ cent) {
+                                                      const typename P::T* __restrict__ pay, const TriBox* __restrict__ boxes,
+                                                      const f32x4* __restrict__ cent, TriBox* __restrict__ boxes_next,
+                                                      f32x4* __restrict__ cent_next) {
     __shared__ int s_k[24];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
@@ -1475,9 +1532,11 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
     const unsigned Lst = sg->Lst;
     for (unsigned xr = threadIdx.x; xr < ic.n_here; xr += 256u) {
         const unsigned x = ic.rel0 + xr;
-        const unsigned id = pay[sg->start + x].x;
+        const unsigned id = P::pos(pay[sg->start + x]);
         const TriBox bx = boxes[id];
         const f32x4 c = cent[id];
+        boxes_next[sg->start + x] = bx;
+        cent_next[sg->start + x] = c;
         const float ce[3] = {c.x, c.y, c.z};
         const int o = x < Lst ? 0 : 6;
 #pragma unroll
@@ -1504,7 +1563,8 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
 
 // one thread per segment: emit the two children, classify them, clear u flags
 __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, TopNode* top, SmallRoot* small,
-                                  unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap, MidRoot* mid, unsigned mid_cap) {
+                                  unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap, MidRoot* mid, unsigned mid_cap,
+                                  unsigned parity /* the set this level's a_child wrote */) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ctl->n_seg) return;
     const Seg& sg = segs[i];
@@ -1518,13 +1578,13 @@ __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, Top
         for (int q = 0; q < 3; ++q) { t.mn[q] = box_lo(sg.child_k[side * 6 + q]); t.mx[q] = box_hi(sg.child_k[side * 6 + 3 + q]); }
         t.start = side == 0 ? sg.start : sg.start + sg.Lst;
         t.count = side == 0 ? sg.Lst : sg.count - sg.Lst;
-        t.left = 0; t.small = 0; t.pad = 0;
+        t.left = 0; t.small = 0; t.pad = parity;
         if (t.count <= 3u) {
             t.kind = 0u;
         } else if (t.count <= (unsigned)kSmallMax) {
             t.kind = 2u;
             const unsigned si = atomicAdd(&ctl->n_small, 1u);
-            if (si < small_cap) small[si] = SmallRoot{t.start, t.count, pair + side, 0u};
+            if (si < small_cap) small[si] = SmallRoot{t.start, t.count, pair + side, parity};
             else atomicOr(&ctl->err, 4u);
             t.small = si;
         } else if (t.count <= (unsigned)kMidMax) {
@@ -1532,7 +1592,7 @@ __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, Top
             const unsigned mi = atomicAdd(&ctl->n_mid, 1u);
             if (mi < mid_cap) {
                 MidRoot& m = mid[mi];
-                m.start = t.start; m.count = t.count; m.node = pair + side; m.pad = 0;
+                m.start = t.start; m.count = t.count; m.node = pair + side; m.pad = parity;
                 for (int q = 0; q < 6; ++q) m.cbk[q] = sg.child_k[12 + side * 6 + q];
             } else atomicOr(&ctl->err, 4u);
         } else {
@@ -1632,15 +1692,17 @@ __device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, 
 }
 
 __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
-                                                               u32x2* __restrict__ slim, const f32x4* __restrict__ cent,
-                                                               const TriBox* __restrict__ boxes, LevelCtl* ctl, TopNode* top,
+                                                               unsigned* __restrict__ ids32, ArrSet set0, ArrSet set1, LevelCtl* ctl, TopNode* top,
                                                                SmallRoot* small, unsigned top_cap, unsigned small_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MidLds& L = *reinterpret_cast<MidLds*>(smem);
     if (blockIdx.x >= *n_roots_p) return;
     const MidRoot root = roots[blockIdx.x];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (unsigned x = tid; x < root.count; x += kMidThreads) L.pay[x] = slim[root.start + x];
+    // the segment's data sits, in position order, in the set its last phase-A level wrote (root.pad & 1)
+    const f32x4* __restrict__ cent = (root.pad & 1u) ? set1.cent : set0.cent;
+    const TriBox* __restrict__ boxes = (root.pad & 1u) ? set1.boxes : set0.boxes;
+    for (unsigned x = tid; x < root.count; x += kMidThreads) { const u32x2 v = {root.start + x, 0u}; L.pay[x] = v; }
     if (tid == 0) {
         L.n_stack = 1;
         L.stack[0].s0 = 0; L.stack[0].n = root.count; L.stack[0].node = root.node;
@@ -1754,13 +1816,13 @@ __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot*
                     const unsigned ls = side == 0 ? s0 : s0 + Lst;
                     t.start = root.start + ls;
                     t.count = side == 0 ? Lst : n - Lst;
-                    t.left = 0; t.small = 0; t.pad = 0;
+                    t.left = 0; t.small = 0; t.pad = (root.pad & 1u) | 2u;       // | 2: positions -> pos0 through ids32
                     if (t.count <= 3u) {
                         t.kind = 0u;
                     } else if (t.count <= (unsigned)kSmallMax) {
                         t.kind = 2u;
                         const unsigned si = atomicAdd(&ctl->n_small, 1u);
-                        if (si < small_cap) small[si] = SmallRoot{t.start, t.count, pair + side, 0u};
+                        if (si < small_cap) small[si] = SmallRoot{t.start, t.count, pair + side, (root.pad & 1u) | 2u};
                         else atomicOr(&ctl->err, 4u);
                         t.small = si;
                     } else {
@@ -1775,7 +1837,7 @@ __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot*
         }
         __syncthreads();
     }
-    for (unsigned x = tid; x < root.count; x += kMidThreads) slim[root.start + x] = L.pay[x];
+    for (unsigned x = tid; x < root.count; x += kMidThreads) ids32[root.start + x] = L.pay[x].x;
 }
 
 // =============================================================================================
@@ -1812,12 +1874,16 @@ __global__ __launch_bounds__(256) void c_sub_kernel(const SmallRoot* roots, cons
     }
 }
 
-__global__ void c_ids_big_leaves_kernel(const TopNode* top, unsigned n_top, const u32x2* pay, unsigned* final_ids) {
+__global__ void c_ids_big_leaves_kernel(const TopNode* top, unsigned n_top, const unsigned* ids32, ArrSet set0, ArrSet set1, unsigned* final_ids) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_top || i == 1u) return;
     const TopNode t = top[i];
     if (t.kind != 0u) return;
-    for (unsigned k = 0; k < t.count; ++k) final_ids[t.start + k] = pay[t.start + k].x;
+    const f32x4* cent = (t.pad & 1u) ? set1.cent : set0.cent;
+    for (unsigned k = 0; k < t.count; ++k) {
+        const unsigned pos0 = (t.pad & 2u) ? ids32[t.start + k] : t.start + k;
+        final_ids[t.start + k] = __float_as_uint(cent[pos0].w);
+    }
 }
 
 __global__ void c_permute_kernel(const unsigned* __restrict__ final_ids, const unsigned* __restrict__ idx_in,
@@ -1876,10 +1942,15 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     // ---- scratch layout ----
     Arena probe{nullptr, 0};
     auto layout = [&](Arena& a, bool) {
-        struct P { u32x2 *pay0, *pay1; f32x4* cent; TriBox* boxes; unsigned *falsepos, *truepos, *final_ids, *stack, *idx_copy;
+        struct P { u32x2 *pay0, *pay1; f32x4 *cent, *cent1; TriBox *boxes, *boxes1; unsigned *bits21, *ids32;
+                   unsigned *falsepos, *truepos, *final_ids, *stack, *idx_copy;
                    unsigned char* is_u; Seg *seg0, *seg1; MidRoot* mid; unsigned *item_seg, *item_cnt, *item_pre; TopNode* top; SmallRoot* small;
                    unsigned* sub_interior; TmpNode* subnodes; unsigned short* submap; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair; } p;
-        p.pay0 = a.take<u32x2>(T); p.pay1 = a.take<u32x2>(T); p.cent = a.take<f32x4>(T); p.boxes = a.take<TriBox>(T);
+        // payload ping-pong: 4 bytes per triangle up to 2^25 triangles, 8 beyond (allocated for the width in use)
+        const size_t pay_words = T <= kPay4Max ? (T + 1) / 2 : T;
+        p.pay0 = a.take<u32x2>(pay_words); p.pay1 = a.take<u32x2>(pay_words);
+        p.cent = a.take<f32x4>(T); p.boxes = a.take<TriBox>(T); p.cent1 = a.take<f32x4>(T); p.boxes1 = a.take<TriBox>(T);
+        p.bits21 = a.take<unsigned>(T); p.ids32 = a.take<unsigned>(T);
         p.falsepos = a.take<unsigned>(T); p.truepos = a.take<unsigned>(T);
         p.final_ids = a.take<unsigned>(T); p.stack = a.take<unsigned>(T); p.idx_copy = a.take<unsigned>(3 * T);
         p.is_u = a.take<unsigned char>(T);
@@ -1914,8 +1985,9 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         VD_HIP_CHECK(ctx, hipMemcpyAsync(P.idx_copy, d_idx, 3 * T * 4, hipMemcpyDeviceToDevice, st));
     }
     const unsigned tri_blocks = (unsigned)((T + 255) / 256);
-    hipLaunchKernelGGL(blas_precompute_kernel, dim3((unsigned)((T + 256 * kPreTris - 1) / (256 * kPreTris))), dim3(256), 0, st, d_verts, P.idx_copy, n_tri, n_vert, P.pay0,
+    hipLaunchKernelGGL(blas_precompute_kernel, dim3((unsigned)((T + 256 * kPreTris - 1) / (256 * kPreTris))), dim3(256), 0, st, d_verts, P.idx_copy, n_tri, n_vert,
                        P.cent, P.boxes, P.root_keys, &P.ctl->err);
+    const ArrSet sets[2] = {ArrSet{P.cent, P.boxes}, ArrSet{P.cent1, P.boxes1}};
     hipLaunchKernelGGL(c_root_kernel, dim3(1), dim3(64), 0, st, P.top, P.root_keys, n_tri, P.small, P.ctl, P.seg0, P.mid);
 
     // ---- phase A: level loop ----
@@ -1928,35 +2000,46 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     int levels = 0;
     stats.kernel_launches = 2;
     lap(stats.ms_precompute);
-    while (n_seg > 0) {
-        const unsigned seg_blocks = (n_seg + 63) / 64;
+    const bool wide_pay = T > kPay4Max || ctx->option(VD_OPT_BLAS_WIDE_PAYLOAD, 0) != 0;
+    // one level of phase A; PayT = Pay4 / Pay8 (see there)
+    auto run_level = [&](auto pay_tag, unsigned n_seg_now, Seg* seg_cur, Seg* seg_next, int level) {
+        using PayT = decltype(pay_tag);
+        typedef typename PayT::T PT;
+        const ArrSet cur = sets[level & 1], nxt = sets[(level + 1) & 1];
+        const unsigned seg_blocks = (n_seg_now + 63) / 64;
         // upper bound of items this level: sum ceil(count/kItem) <= T/kItem + n_seg
-        const unsigned items_ub = (unsigned)(T / kItem) + n_seg + 1;
+        const unsigned items_ub = (unsigned)(T / kItem) + n_seg_now + 1;
         hipLaunchKernelGGL(a_seg_begin_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, P.ctl);
         hipLaunchKernelGGL(a_items_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl);
-        hipLaunchKernelGGL(a_items_fill_kernel, dim3(n_seg), dim3(64), 0, st, seg_cur, P.ctl, P.item_seg);
+        hipLaunchKernelGGL(a_items_fill_kernel, dim3(n_seg_now), dim3(64), 0, st, seg_cur, P.ctl, P.item_seg);
         hipLaunchKernelGGL(a_planes_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, P.ctl);
-        hipLaunchKernelGGL(a_bits_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, P.pay0, P.cent);
-        u32x2* src = P.pay0; u32x2* dst = P.pay1;
+        PT* src = reinterpret_cast<PT*>(P.pay0); PT* dst = reinterpret_cast<PT*>(P.pay1);
+        hipLaunchKernelGGL((a_bits_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.cent, P.bits21);
         for (int c = 0; c <= kCand; ++c) {
             const int cc = c < kCand ? c : -1;       // -1: final re-shuffle with each segment's best plane
             if (c == kCand) {
-                hipLaunchKernelGGL(a_bin_kernel, dim3((items_ub + kBinItems - 1) / kBinItems), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, P.boxes, P.is_u);
-                hipLaunchKernelGGL(a_eval_kernel, dim3(n_seg), dim3(64), 0, st, seg_cur, P.ctl, P.boxes);
+                hipLaunchKernelGGL((a_bin_kernel<PayT>), dim3((items_ub + kBinItems - 1) / kBinItems), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.boxes,
+                                   P.is_u, P.bits21);
+                hipLaunchKernelGGL(a_eval_kernel, dim3(n_seg_now), dim3(64), 0, st, seg_cur, P.ctl, cur.boxes);
             }
-            hipLaunchKernelGGL(a_count_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_cnt);
+            const int refresh = (c == 7 || c == 14 || c == kCand) ? 1 : 0;   // the rounds that start on another axis
+            hipLaunchKernelGGL((a_count_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_cnt, P.bits21, refresh);
             hipLaunchKernelGGL(a_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl, P.item_cnt, P.item_pre);
-            hipLaunchKernelGGL(a_ranks_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre,
+            hipLaunchKernelGGL((a_ranks_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre,
                                P.falsepos, P.truepos);
-            hipLaunchKernelGGL(a_apply_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, P.item_pre,
-                               P.falsepos, P.truepos, P.is_u);
-            u32x2* t = src; src = dst; dst = t;
+            hipLaunchKernelGGL((a_apply_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, P.item_pre,
+                               P.falsepos, P.truepos, P.is_u, P.bits21);
+            PT* t = src; src = dst; dst = t;
         }
         // 22 swaps: the arrangement is back in pay0
-        hipLaunchKernelGGL(a_child_kernel, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, P.pay0, P.boxes, P.cent);
+        hipLaunchKernelGGL((a_child_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, reinterpret_cast<const PT*>(P.pay0), cur.boxes,
+                           cur.cent, nxt.boxes, nxt.cent);
         hipLaunchKernelGGL(a_finalize_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, seg_next, P.ctl, P.top, P.small, P.is_u,
-                           top_cap, small_cap, P.mid, mid_cap);
+                           top_cap, small_cap, P.mid, mid_cap, (unsigned)((level + 1) & 1));
         hipLaunchKernelGGL(a_level_swap_kernel, dim3(1), dim3(64), 0, st, P.ctl);
+    };
+    while (n_seg > 0) {
+        if (wide_pay) run_level(Pay8{}, n_seg, seg_cur, seg_next, levels); else run_level(Pay4{}, n_seg, seg_cur, seg_next, levels);
         VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
         VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
         if (h_ctl.err & ERR_DEGENERATE)
@@ -1976,7 +2059,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
             VD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(blas_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds)));
             ctx->mid_lds_opt_in = true;
         }
-        hipLaunchKernelGGL(blas_mid_kernel, dim3(h_ctl.n_mid), dim3(kMidThreads), sizeof(MidLds), st, P.mid, &P.ctl->n_mid, P.pay0, P.cent, P.boxes,
+        hipLaunchKernelGGL(blas_mid_kernel, dim3(h_ctl.n_mid), dim3(kMidThreads), sizeof(MidLds), st, P.mid, &P.ctl->n_mid, P.ids32, sets[0], sets[1],
                            P.ctl, P.top, P.small, top_cap, small_cap);
         VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
         VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -1990,8 +2073,8 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     const unsigned n_small = h_ctl.n_small, n_top = h_ctl.n_top;
     stats.n_top_nodes = n_top; stats.n_small_roots = n_small; stats.n_mid_roots = h_ctl.n_mid;
     if (n_small) {
-        hipLaunchKernelGGL(blas_small_kernel, dim3(n_small), dim3(64 * kSubWaves), sizeof(WaveLds) + sizeof(WaveQueues), st, P.small, &P.ctl->n_small, P.pay0,
-                           P.cent, P.boxes, P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err, P.stack);
+        hipLaunchKernelGGL(blas_small_kernel, dim3(n_small), dim3(64 * kSubWaves), sizeof(WaveLds) + sizeof(WaveQueues), st, P.small, &P.ctl->n_small, P.ids32,
+                           sets[0], sets[1], P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err, P.stack);
         ctx->dbg_ptr = P.stack; ctx->dbg_count = 2 * n_small;
     }
     // ---- phase C: DFS numbering of the top tree on the host ----
@@ -2057,7 +2140,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_out, 0, sizeof(VdBvhNode) * 2, st));   // node 1 stays all-zero (blas.rs:52,90)
     hipLaunchKernelGGL(c_top_kernel, dim3((n_top + 63) / 64), dim3(64), 0, st, P.top, P.tout, n_top, d_out);
     if (n_small) hipLaunchKernelGGL(c_sub_kernel, dim3(n_small), dim3(256), 0, st, P.small, P.sub_interior, P.root_pair, n_small, P.subnodes, P.submap, d_out);
-    hipLaunchKernelGGL(c_ids_big_leaves_kernel, dim3((n_top + 63) / 64), dim3(64), 0, st, P.top, n_top, P.pay0, P.final_ids);
+    hipLaunchKernelGGL(c_ids_big_leaves_kernel, dim3((n_top + 63) / 64), dim3(64), 0, st, P.top, n_top, P.ids32, sets[0], sets[1], P.final_ids);
     hipLaunchKernelGGL(c_permute_kernel, dim3(tri_blocks), dim3(256), 0, st, P.final_ids, P.idx_copy, d_idx, n_tri);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
