@@ -72,7 +72,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct TriBox { float mn[3]; float pad0; float mx[3]; float pad1; };   // 32 B, by triangle id
 struct TmpNode { float mn[3]; unsigned left_first; float mx[3]; unsigned count; };   // == VdBvhNode layout
 
-enum : unsigned { ERR_DEGENERATE = 1u, ERR_BAD_INDEX = 2u, ERR_INTERNAL = 4u };
+enum : unsigned { ERR_DEGENERATE = 1u, ERR_BAD_INDEX = 2u, ERR_INTERNAL = 4u, ERR_LOOKBACK = 8u };
 constexpr unsigned kInteriorMark = 0x80000000u;   // phase B: TmpNode.count of a split node until the renumber (n stays in the low bits)
 
 __device__ __forceinline__ float pay_c(const u32x4& v, int axis) {
@@ -1188,7 +1188,7 @@ __global__ void a_items_fill_kernel(const Seg* segs, const LevelCtl* ctl, unsign
 // item is (wave, j, lane): position = rel0 + wave*256 + j*64 + lane.
 struct ItemCtx { unsigned seg, rel0, n_here; };
 __device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl, ItemCtx& ic, Seg const*& sg) {
-    if (blockIdx.x >= ctl->n_items) return false;
+    if (blockIdx.x >= ctl->n_items || (ctl->err & ERR_LOOKBACK)) return false;   // ERR_LOOKBACK: the build is being redone (a_rank1_kernel)
     ic.seg = item_seg[blockIdx.x];
     sg = segs + ic.seg;
     ic.rel0 = (blockIdx.x - sg->item_first) * kItem;
@@ -1372,14 +1372,126 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
     }
 }
 
+// Rounds in ONE pass (default): steps 1-3 as a single kernel.  An item counts its trues, gets the number of trues before
+// it in its segment from a SEGMENTED decoupled look-back over the items (one 8-byte {epoch, status, value} granule per
+// item, the data is its own flag: vd_common.hpp), and writes its share of the rank -> position tables - which therefore
+// index the trues from the LEFT (`ttot` is not known yet; a_apply turns the index round).  Three launches and two grid-wide
+// drains per round become one: the rounds are bound by the ~5 us a dependent launch costs, not by bytes.
+// Items are looked back in blockIdx order WITHOUT tickets (a ticket is a same-address atomic: 5 ns x 8 k items): the
+// dispatcher starts workgroups in index order, so an item's predecessors are running or done.  The programming model does
+// not promise that, so every wait is bounded: on expiry ERR_LOOKBACK is raised, every later kernel of the build returns at
+// once, and the host redoes the build with the three-kernel rounds (and keeps them for this context).
+__device__ __forceinline__ bool lb_wait(const vd_u64* g, unsigned ep, const unsigned* err, vd_u64& out) {
+    vd_u64 s = __hip_atomic_load(g, VD_RLX_AGENT);
+    unsigned spins = 0;
+    while ((unsigned)(s >> 34) != ep || ((unsigned)(s >> 32) & 3u) == 0u) {
+        if ((++spins & 1023u) == 0u && (spins > (1u << 21) || __hip_atomic_load(err, VD_RLX_AGENT) != 0u)) return false;
+        __builtin_amdgcn_s_sleep(2);
+        s = __hip_atomic_load(g, VD_RLX_AGENT);
+    }
+    out = s;
+    return true;
+}
+// ONE full wave: publishes item t's count and returns the exclusive prefix within its segment in every lane
+__device__ __forceinline__ unsigned seg_lookback(vd_u64* tile_state, unsigned epoch, unsigned t, unsigned total, bool first, unsigned* err) {
+    const unsigned lane = vd_lane();
+    const unsigned ep = epoch & 0x3fffffffu;
+    if (first) {
+        if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_INCLUSIVE, total), VD_RLX_AGENT);
+        return 0u;
+    }
+    if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_AGGREGATE, total), VD_RLX_AGENT);
+    unsigned exclusive = 0u;
+    int look = (int)t - 1;
+    bool ok = true;
+    for (;;) {
+        const int idx = look - (int)lane;
+        vd_u64 s = vd_tile_pack(ep, VD_TILE_INCLUSIVE, 0u);   // virtual items before 0 (never reached: a segment's first item is INCLUSIVE)
+        if (idx >= 0) ok = lb_wait(&tile_state[idx], ep, err, s);
+        if (__ballot(!ok)) { if (lane == 0) atomicOr(err, ERR_LOOKBACK); return 0u; }
+        const unsigned status = (unsigned)(s >> 32) & 3u;
+        const unsigned value = (unsigned)s;
+        const unsigned long long incl = __ballot(status == VD_TILE_INCLUSIVE);
+        const unsigned firsti = incl ? (unsigned)__builtin_ctzll(incl) : 63u;   // closest predecessors first
+        unsigned v = lane <= firsti ? value : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        exclusive += v;
+        if (incl) break;
+        look -= 64;
+    }
+    if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_INCLUSIVE, exclusive + total), VD_RLX_AGENT);
+    return exclusive;
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void a_rank1_kernel(Seg* segs, const unsigned* item_seg, LevelCtl* ctl, typename P::T* __restrict__ pay, int c,
+                                                      unsigned* __restrict__ item_pre, unsigned* __restrict__ falsepos,
+                                                      unsigned* __restrict__ trueleft, const unsigned* __restrict__ bits21, int refresh,
+                                                      vd_u64* tile_state, unsigned epoch) {
+    __shared__ unsigned s_w[4], s_excl;
+    if (__hip_atomic_load(&ctl->err, VD_RLX_AGENT) & ERR_LOOKBACK) return;
+    ItemCtx ic; const Seg* sg;
+    if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
+    const Window win = round_window(sg, c >= 0 ? c : kCand);
+    const bool frozen = ic.rel0 + ic.n_here <= win.act;      // nothing to shuffle here, but later items look back through it
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (P::kRefresh && refresh && !frozen) {
+        const unsigned axis = (c >= 0 ? (unsigned)c : sg->best) / 7u;
+        for (unsigned x = threadIdx.x; x < ic.n_here; x += 256u) {
+            const unsigned a = sg->start + ic.rel0 + x;
+            const unsigned pos = P::pos(pay[a]);
+            pay[a] = P::make(pos, bits21[pos], axis);
+        }
+        __syncthreads();
+    }
+    unsigned long long masks[kPer]; typename P::T vals[kPer];
+    unsigned t = 0;
+    if (!frozen) {
+        item_masks<P>(sg, ic, pay, c, win.act, masks, vals);
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
+    }
+    if (lane == 0u) s_w[wave] = t;
+    __syncthreads();
+    const unsigned total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (wave == 0u) {
+        const unsigned ex = seg_lookback(tile_state, epoch, blockIdx.x, total, blockIdx.x == sg->item_first, &ctl->err);
+        if (lane == 0u) {
+            s_excl = ex;
+            item_pre[blockIdx.x] = ex;                                   // relative to the segment's first item
+            if (blockIdx.x == sg->item_first + sg->n_items - 1u) segs[ic.seg].ttot_cur = ex + total;
+        }
+    }
+    __syncthreads();
+    if (frozen) return;
+    unsigned run = s_excl;
+    for (unsigned w = 0; w < wave; ++w) run += s_w[w];
+    // positions and table indices are relative to the window [act, n); the tables of the window start at s + act
+    const unsigned s = sg->start + win.act;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
+        if (xr < ic.n_here && ic.rel0 + xr >= win.act) {
+            const unsigned x = ic.rel0 + xr - win.act;
+            const bool p = (masks[j] >> lane) & 1ull;
+            const unsigned tl = run + vd_mbcnt(masks[j]);
+            if (p) trueleft[s + tl] = x;                  // the (tl+1)-th true from the LEFT
+            else falsepos[s + (x - tl)] = x;              // index F: (F+1)-th false from the left
+        }
+        run += (unsigned)__popcll(masks[j]);
+    }
+}
+
 // round step 4: destinations, scatter, `u`
 template <typename P>
 __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                       const typename P::T* __restrict__ src, typename P::T* __restrict__ dst, int c,
                                                       const unsigned* item_pre, const unsigned* __restrict__ falsepos,
                                                       const unsigned* __restrict__ truepos, unsigned char* __restrict__ is_u_flag,
-                                                      const unsigned* __restrict__ bits21) {
+                                                      const unsigned* __restrict__ bits21, int single /* tables of a_rank1_kernel */) {
     __shared__ unsigned s_w[4];
+    if (single && (__hip_atomic_load(&ctl->err, VD_RLX_AGENT) & ERR_LOOKBACK)) return;
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     const int r = c >= 0 ? c : kCand;
@@ -1401,7 +1513,7 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
     if (lane == 0u) s_w[wave] = t;
     __syncthreads();
-    unsigned run = item_pre[blockIdx.x] - item_pre[sg->item_first];
+    unsigned run = single ? item_pre[blockIdx.x] : item_pre[blockIdx.x] - item_pre[sg->item_first];
     for (unsigned w = 0; w < wave; ++w) run += s_w[w];
     // everything below is partition_shuffle on the window [act, n): positions relative to act
     const unsigned n = sg->count - win.act, s = sg->start + win.act, ttot = sg->ttot_cur, ftot = n - ttot;
@@ -1413,7 +1525,8 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
             const bool p = (masks[j] >> lane) & 1ull;
             const unsigned tl = run + vd_mbcnt(masks[j]);
             const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
-            const long long tF = F == 0u ? (long long)n : (F <= ttot ? (long long)truepos[s + F - 1u] : -1ll);
+            // the F-th true from the right: table index F - 1 from the right = ttot - F from the left
+            const long long tF = F == 0u ? (long long)n : (F <= ttot ? (long long)truepos[s + (single ? ttot - F : F - 1u)] : -1ll);
             const bool left = (long long)x < tF;
             const unsigned fj = (T + 1u <= ftot) ? falsepos[s + T] : n;
             const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
@@ -1442,22 +1555,27 @@ template <typename P>
 __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                     const typename P::T* __restrict__ pay, const TriBox* __restrict__ boxes,
                                                     const unsigned char* __restrict__ is_u_flag, const unsigned* __restrict__ bits21) {
-    // four private copies of the 144 bins (by quarter wave): neighbouring elements fall into the same few bins, and
-    // same-address LDS atomics serialise.  A workgroup covers kBinItems consecutive items and flushes to the segment
-    // record only when the segment changes: the flush is 144 same-address global atomics per workgroup (~5 ns each,
-    // serialised per address), which at the top levels - one segment, 8 k items - used to be the floor of the kernel.
-    __shared__ int s_min[4][3][8][3], s_max[4][3][8][3];
+    // One private copy of the 144 bin keys PER LANE ([entry][lane]: lanes sit in different banks), shared by the four
+    // waves: neighbouring elements fall into the same few bins, and same-address LDS atomics serialise - with four copies
+    // by quarter wave the 18 atomics of an element were most of this kernel (228 us per level at every level, whatever
+    // the gathers cost).  A workgroup covers kBinItems consecutive items and flushes to the segment record only when the
+    // segment changes: the flush is 144 same-address global atomics per workgroup (~5 ns each, serialised per address),
+    // which at the top levels - one segment, 8 k items - used to be the floor of the kernel.
+    __shared__ int s_bins[144][64];                    // entry = (axis * 8 + bin) * 6 + q; q < 3: min keys, q >= 3: max keys
+    if (ctl->err & ERR_LOOKBACK) return;
     const unsigned n_items = ctl->n_items;
-    const unsigned copy = (threadIdx.x >> 4) & 3u;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned cur_seg = kNone;
-    auto reset = [&]() { for (unsigned i = threadIdx.x; i < 288u; i += 256u) { (&s_min[0][0][0][0])[i] = kBig; (&s_max[0][0][0][0])[i] = -kBig - 1; } };
+    auto reset = [&]() { for (unsigned i = threadIdx.x; i < 144u * 64u; i += 256u) (&s_bins[0][0])[i] = ((i >> 6) % 6u) < 3u ? kBig : -kBig - 1; };
     auto flush = [&](unsigned seg) {
-        for (unsigned i = threadIdx.x; i < 72u; i += 256u) {
-            int lo = kBig, hi = -kBig - 1;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { lo = min(lo, (&s_min[k][0][0][0])[i]); hi = max(hi, (&s_max[k][0][0][0])[i]); }
-            if (lo != kBig) atomicMin(&(&segs[seg].bin_min[0][0][0])[i], lo);
-            if (hi != -kBig - 1) atomicMax(&(&segs[seg].bin_max[0][0][0])[i], hi);
+        for (unsigned e = wave; e < 144u; e += 4u) {   // a wave reduces the 64 copies of an entry on the VALU
+            const bool is_min = (e % 6u) < 3u;
+            const int v = is_min ? wave_min_i(s_bins[e][lane]) : wave_max_i(s_bins[e][lane]);
+            if (lane == 0u) {
+                const unsigned ab = e / 6u, q = e % 6u;      // Seg::bin_min / bin_max are [axis][bin][3]
+                if (is_min) { if (v != kBig) atomicMin(&(&segs[seg].bin_min[0][0][0])[ab * 3u + q], v); }
+                else if (v != -kBig - 1) atomicMax(&(&segs[seg].bin_max[0][0][0])[ab * 3u + (q - 3u)], v);
+            }
         }
     };
     reset();
@@ -1481,10 +1599,11 @@ __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* i
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const int b = 7 - __popc((b21 >> (7 * a)) & 0x7fu);   // bin = number of planes the centroid is not below
+                int* row = &s_bins[(a * 8 + b) * 6][lane];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    atomicMin(&s_min[copy][a][b][q], vd_key(bx.mn[q]));
-                    atomicMax(&s_max[copy][a][b][q], vd_key(bx.mx[q]));
+                    atomicMin(row + 64 * q, vd_key(bx.mn[q]));
+                    atomicMax(row + 64 * (3 + q), vd_key(bx.mx[q]));
                 }
             }
         }
@@ -1495,7 +1614,7 @@ __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* i
 
 // one wave per segment: 21 costs -> best plane, stale pivot
 __global__ __launch_bounds__(64) void a_eval_kernel(Seg* segs, LevelCtl* ctl, const TriBox* __restrict__ boxes) {
-    if (blockIdx.x >= ctl->n_seg) return;
+    if (blockIdx.x >= ctl->n_seg || (ctl->err & ERR_LOOKBACK)) return;
     Seg& sg = segs[blockIdx.x];
     const unsigned lane = threadIdx.x;
     vd_u64 key = ~0ull;
@@ -1566,7 +1685,7 @@ __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, Top
                                   unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap, MidRoot* mid, unsigned mid_cap,
                                   unsigned parity /* the set this level's a_child wrote */) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ctl->n_seg) return;
+    if (i >= ctl->n_seg || (ctl->err & ERR_LOOKBACK)) return;
     const Seg& sg = segs[i];
     for (int c = 0; c < kCand; ++c) is_u_flag[sg.u_pay[c].x] = 0;
     const unsigned pair = atomicAdd(&ctl->n_top, 2u);
@@ -1939,18 +2058,19 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     const unsigned item_cap = (unsigned)(T / kItem + seg_cap + 2);
     const unsigned small_cap = (unsigned)(T / 4 + 2);
     const unsigned top_cap = (unsigned)(2 * (size_t)small_cap + 4 * (size_t)seg_cap + 64);
+    const bool wide_pay = T > kPay4Max || ctx->option(VD_OPT_BLAS_WIDE_PAYLOAD, 0) != 0;
     // ---- scratch layout ----
     Arena probe{nullptr, 0};
     auto layout = [&](Arena& a, bool) {
-        struct P { u32x2 *pay0, *pay1; f32x4 *cent, *cent1; TriBox *boxes, *boxes1; unsigned *bits21, *ids32;
+        struct P { u32x2 *pay0, *pay1; f32x4 *cent, *cent1; TriBox *boxes, *boxes1; unsigned *bits21, *ids32; vd_u64* tiles;
                    unsigned *falsepos, *truepos, *final_ids, *stack, *idx_copy;
                    unsigned char* is_u; Seg *seg0, *seg1; MidRoot* mid; unsigned *item_seg, *item_cnt, *item_pre; TopNode* top; SmallRoot* small;
                    unsigned* sub_interior; TmpNode* subnodes; unsigned short* submap; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair; } p;
         // payload ping-pong: 4 bytes per triangle up to 2^25 triangles, 8 beyond (allocated for the width in use)
-        const size_t pay_words = T <= kPay4Max ? (T + 1) / 2 : T;
+        const size_t pay_words = wide_pay ? T : (T + 1) / 2;
         p.pay0 = a.take<u32x2>(pay_words); p.pay1 = a.take<u32x2>(pay_words);
         p.cent = a.take<f32x4>(T); p.boxes = a.take<TriBox>(T); p.cent1 = a.take<f32x4>(T); p.boxes1 = a.take<TriBox>(T);
-        p.bits21 = a.take<unsigned>(T); p.ids32 = a.take<unsigned>(T);
+        p.bits21 = a.take<unsigned>(T); p.ids32 = a.take<unsigned>(T); p.tiles = a.take<vd_u64>(item_cap + 1);
         p.falsepos = a.take<unsigned>(T); p.truepos = a.take<unsigned>(T);
         p.final_ids = a.take<unsigned>(T); p.stack = a.take<unsigned>(T); p.idx_copy = a.take<unsigned>(3 * T);
         p.is_u = a.take<unsigned char>(T);
@@ -1982,6 +2102,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         VD_HIP_CHECK(ctx, hipMemcpyAsync(P.root_keys, h_keys, sizeof(h_keys), hipMemcpyHostToDevice, st));
         VD_HIP_CHECK(ctx, hipMemsetAsync(P.ctl, 0, sizeof(LevelCtl), st));
         VD_HIP_CHECK(ctx, hipMemsetAsync(P.is_u, 0, T, st));
+        VD_HIP_CHECK(ctx, hipMemsetAsync(P.tiles, 0, sizeof(vd_u64) * ((size_t)item_cap + 1), st));   // epoch 0 = never written
         VD_HIP_CHECK(ctx, hipMemcpyAsync(P.idx_copy, d_idx, 3 * T * 4, hipMemcpyDeviceToDevice, st));
     }
     const unsigned tri_blocks = (unsigned)((T + 255) / 256);
@@ -2000,7 +2121,9 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     int levels = 0;
     stats.kernel_launches = 2;
     lap(stats.ms_precompute);
-    const bool wide_pay = T > kPay4Max || ctx->option(VD_OPT_BLAS_WIDE_PAYLOAD, 0) != 0;
+    // rounds as one pass (a_rank1_kernel) unless this context has seen its look-back time out, or the option says otherwise
+    const bool single_pass = !ctx->blas_three_kernel_rounds && ctx->option(VD_OPT_BLAS_SINGLE_PASS, 1) != 0;
+    unsigned tile_epoch = 0;
     // one level of phase A; PayT = Pay4 / Pay8 (see there)
     auto run_level = [&](auto pay_tag, unsigned n_seg_now, Seg* seg_cur, Seg* seg_next, int level) {
         using PayT = decltype(pay_tag);
@@ -2023,12 +2146,17 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
                 hipLaunchKernelGGL(a_eval_kernel, dim3(n_seg_now), dim3(64), 0, st, seg_cur, P.ctl, cur.boxes);
             }
             const int refresh = (c == 7 || c == 14 || c == kCand) ? 1 : 0;   // the rounds that start on another axis
-            hipLaunchKernelGGL((a_count_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_cnt, P.bits21, refresh);
-            hipLaunchKernelGGL(a_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl, P.item_cnt, P.item_pre);
-            hipLaunchKernelGGL((a_ranks_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre,
-                               P.falsepos, P.truepos);
+            if (single_pass) {
+                hipLaunchKernelGGL((a_rank1_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre, P.falsepos,
+                                   P.truepos, P.bits21, refresh, P.tiles, ++tile_epoch);
+            } else {
+                hipLaunchKernelGGL((a_count_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_cnt, P.bits21, refresh);
+                hipLaunchKernelGGL(a_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl, P.item_cnt, P.item_pre);
+                hipLaunchKernelGGL((a_ranks_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre,
+                                   P.falsepos, P.truepos);
+            }
             hipLaunchKernelGGL((a_apply_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, P.item_pre,
-                               P.falsepos, P.truepos, P.is_u, P.bits21);
+                               P.falsepos, P.truepos, P.is_u, P.bits21, single_pass ? 1 : 0);
             PT* t = src; src = dst; dst = t;
         }
         // 22 swaps: the arrangement is back in pay0
@@ -2042,12 +2170,18 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         if (wide_pay) run_level(Pay8{}, n_seg, seg_cur, seg_next, levels); else run_level(Pay4{}, n_seg, seg_cur, seg_next, levels);
         VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
         VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        if (h_ctl.err & ERR_LOOKBACK) {
+            // an item waited too long for its predecessors (workgroups not started in index order?): nothing of this build is
+            // kept - d_idx is untouched until the final permute - and it is redone with the three-kernel rounds
+            ctx->blas_three_kernel_rounds = true;
+            return bvh_build_dev_impl(ctx, d_verts, n_vert, d_idx, n_tri, d_out, node_cap, out_n_nodes);
+        }
         if (h_ctl.err & ERR_DEGENERATE)
             VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
         if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
         n_seg = h_ctl.n_seg;
         Seg* t = seg_cur; seg_cur = seg_next; seg_next = t;
-        stats.kernel_launches += 9 + 4 * (kCand + 1);
+        stats.kernel_launches += 9 + (single_pass ? 2 : 4) * (kCand + 1);
         if (++levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
     }
     stats.levels_phase_a = (uint32_t)levels;
