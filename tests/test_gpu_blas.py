@@ -42,10 +42,10 @@ def test_soup_sizes_vs_oracle(ctx, oracle, n_tri):
     assert np.array_equal(idx, want_idx)
 
 
-def test_three_kernel_rounds_vs_oracle(ctx, oracle, ctx_options):
-    """The shuffle rounds of phase A run as one pass (count + segmented look-back + rank tables); the count / scan / ranks
-    form is what a context falls back to if that look-back ever times out - kept bit-exact here."""
-    ctx_options("blas.single_pass", 0)
+def test_four_kernel_rounds_vs_oracle(ctx, oracle, ctx_options):
+    """The 22 shuffle rounds of a phase-A level run inside one persistent kernel with grid barriers; the count / scan /
+    ranks / apply kernels are what a context falls back to if a barrier ever times out - kept bit-exact here."""
+    ctx_options("blas.persistent_rounds", 0)
     for v, i in (synth.knot_mesh(256, 64), synth.triangle_soup(5000, seed=15), synth.knot_mesh(512, 128)):
         want_nodes, want_idx = oracle.bvh_build(v, i)
         nodes, idx = ctx.bvh_build(v, i)

@@ -72,7 +72,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct TriBox { float mn[3]; float pad0; float mx[3]; float pad1; };   // 32 B, by triangle id
 struct TmpNode { float mn[3]; unsigned left_first; float mx[3]; unsigned count; };   // == VdBvhNode layout
 
-enum : unsigned { ERR_DEGENERATE = 1u, ERR_BAD_INDEX = 2u, ERR_INTERNAL = 4u, ERR_LOOKBACK = 8u };
+enum : unsigned { ERR_DEGENERATE = 1u, ERR_BAD_INDEX = 2u, ERR_INTERNAL = 4u, ERR_GRIDSYNC = 8u };
 constexpr unsigned kInteriorMark = 0x80000000u;   // phase B: TmpNode.count of a split node until the renumber (n stays in the low bits)
 
 __device__ __forceinline__ float pay_c(const u32x4& v, int axis) {
@@ -1188,7 +1188,7 @@ __global__ void a_items_fill_kernel(const Seg* segs, const LevelCtl* ctl, unsign
 // item is (wave, j, lane): position = rel0 + wave*256 + j*64 + lane.
 struct ItemCtx { unsigned seg, rel0, n_here; };
 __device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl, ItemCtx& ic, Seg const*& sg) {
-    if (blockIdx.x >= ctl->n_items || (ctl->err & ERR_LOOKBACK)) return false;   // ERR_LOOKBACK: the build is being redone (a_rank1_kernel)
+    if (blockIdx.x >= ctl->n_items || (ctl->err & ERR_GRIDSYNC)) return false;   // ERR_GRIDSYNC: the build is being redone (a_rounds_kernel)
     ic.seg = item_seg[blockIdx.x];
     sg = segs + ic.seg;
     ic.rel0 = (blockIdx.x - sg->item_first) * kItem;
@@ -1372,126 +1372,14 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
     }
 }
 
-// Rounds in ONE pass (default): steps 1-3 as a single kernel.  An item counts its trues, gets the number of trues before
-// it in its segment from a SEGMENTED decoupled look-back over the items (one 8-byte {epoch, status, value} granule per
-// item, the data is its own flag: vd_common.hpp), and writes its share of the rank -> position tables - which therefore
-// index the trues from the LEFT (`ttot` is not known yet; a_apply turns the index round).  Three launches and two grid-wide
-// drains per round become one: the rounds are bound by the ~5 us a dependent launch costs, not by bytes.
-// Items are looked back in blockIdx order WITHOUT tickets (a ticket is a same-address atomic: 5 ns x 8 k items): the
-// dispatcher starts workgroups in index order, so an item's predecessors are running or done.  The programming model does
-// not promise that, so every wait is bounded: on expiry ERR_LOOKBACK is raised, every later kernel of the build returns at
-// once, and the host redoes the build with the three-kernel rounds (and keeps them for this context).
-__device__ __forceinline__ bool lb_wait(const vd_u64* g, unsigned ep, const unsigned* err, vd_u64& out) {
-    vd_u64 s = __hip_atomic_load(g, VD_RLX_AGENT);
-    unsigned spins = 0;
-    while ((unsigned)(s >> 34) != ep || ((unsigned)(s >> 32) & 3u) == 0u) {
-        if ((++spins & 1023u) == 0u && (spins > (1u << 21) || __hip_atomic_load(err, VD_RLX_AGENT) != 0u)) return false;
-        __builtin_amdgcn_s_sleep(2);
-        s = __hip_atomic_load(g, VD_RLX_AGENT);
-    }
-    out = s;
-    return true;
-}
-// ONE full wave: publishes item t's count and returns the exclusive prefix within its segment in every lane
-__device__ __forceinline__ unsigned seg_lookback(vd_u64* tile_state, unsigned epoch, unsigned t, unsigned total, bool first, unsigned* err) {
-    const unsigned lane = vd_lane();
-    const unsigned ep = epoch & 0x3fffffffu;
-    if (first) {
-        if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_INCLUSIVE, total), VD_RLX_AGENT);
-        return 0u;
-    }
-    if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_AGGREGATE, total), VD_RLX_AGENT);
-    unsigned exclusive = 0u;
-    int look = (int)t - 1;
-    bool ok = true;
-    for (;;) {
-        const int idx = look - (int)lane;
-        vd_u64 s = vd_tile_pack(ep, VD_TILE_INCLUSIVE, 0u);   // virtual items before 0 (never reached: a segment's first item is INCLUSIVE)
-        if (idx >= 0) ok = lb_wait(&tile_state[idx], ep, err, s);
-        if (__ballot(!ok)) { if (lane == 0) atomicOr(err, ERR_LOOKBACK); return 0u; }
-        const unsigned status = (unsigned)(s >> 32) & 3u;
-        const unsigned value = (unsigned)s;
-        const unsigned long long incl = __ballot(status == VD_TILE_INCLUSIVE);
-        const unsigned firsti = incl ? (unsigned)__builtin_ctzll(incl) : 63u;   // closest predecessors first
-        unsigned v = lane <= firsti ? value : 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        exclusive += v;
-        if (incl) break;
-        look -= 64;
-    }
-    if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_INCLUSIVE, exclusive + total), VD_RLX_AGENT);
-    return exclusive;
-}
-
-template <typename P>
-__global__ __launch_bounds__(256) void a_rank1_kernel(Seg* segs, const unsigned* item_seg, LevelCtl* ctl, typename P::T* __restrict__ pay, int c,
-                                                      unsigned* __restrict__ item_pre, unsigned* __restrict__ falsepos,
-                                                      unsigned* __restrict__ trueleft, const unsigned* __restrict__ bits21, int refresh,
-                                                      vd_u64* tile_state, unsigned epoch) {
-    __shared__ unsigned s_w[4], s_excl;
-    if (__hip_atomic_load(&ctl->err, VD_RLX_AGENT) & ERR_LOOKBACK) return;
-    ItemCtx ic; const Seg* sg;
-    if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
-    const Window win = round_window(sg, c >= 0 ? c : kCand);
-    const bool frozen = ic.rel0 + ic.n_here <= win.act;      // nothing to shuffle here, but later items look back through it
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (P::kRefresh && refresh && !frozen) {
-        const unsigned axis = (c >= 0 ? (unsigned)c : sg->best) / 7u;
-        for (unsigned x = threadIdx.x; x < ic.n_here; x += 256u) {
-            const unsigned a = sg->start + ic.rel0 + x;
-            const unsigned pos = P::pos(pay[a]);
-            pay[a] = P::make(pos, bits21[pos], axis);
-        }
-        __syncthreads();
-    }
-    unsigned long long masks[kPer]; typename P::T vals[kPer];
-    unsigned t = 0;
-    if (!frozen) {
-        item_masks<P>(sg, ic, pay, c, win.act, masks, vals);
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
-    }
-    if (lane == 0u) s_w[wave] = t;
-    __syncthreads();
-    const unsigned total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    if (wave == 0u) {
-        const unsigned ex = seg_lookback(tile_state, epoch, blockIdx.x, total, blockIdx.x == sg->item_first, &ctl->err);
-        if (lane == 0u) {
-            s_excl = ex;
-            item_pre[blockIdx.x] = ex;                                   // relative to the segment's first item
-            if (blockIdx.x == sg->item_first + sg->n_items - 1u) segs[ic.seg].ttot_cur = ex + total;
-        }
-    }
-    __syncthreads();
-    if (frozen) return;
-    unsigned run = s_excl;
-    for (unsigned w = 0; w < wave; ++w) run += s_w[w];
-    // positions and table indices are relative to the window [act, n); the tables of the window start at s + act
-    const unsigned s = sg->start + win.act;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
-        if (xr < ic.n_here && ic.rel0 + xr >= win.act) {
-            const unsigned x = ic.rel0 + xr - win.act;
-            const bool p = (masks[j] >> lane) & 1ull;
-            const unsigned tl = run + vd_mbcnt(masks[j]);
-            if (p) trueleft[s + tl] = x;                  // the (tl+1)-th true from the LEFT
-            else falsepos[s + (x - tl)] = x;              // index F: (F+1)-th false from the left
-        }
-        run += (unsigned)__popcll(masks[j]);
-    }
-}
-
 // round step 4: destinations, scatter, `u`
 template <typename P>
 __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                       const typename P::T* __restrict__ src, typename P::T* __restrict__ dst, int c,
                                                       const unsigned* item_pre, const unsigned* __restrict__ falsepos,
                                                       const unsigned* __restrict__ truepos, unsigned char* __restrict__ is_u_flag,
-                                                      const unsigned* __restrict__ bits21, int single /* tables of a_rank1_kernel */) {
+                                                      const unsigned* __restrict__ bits21) {
     __shared__ unsigned s_w[4];
-    if (single && (__hip_atomic_load(&ctl->err, VD_RLX_AGENT) & ERR_LOOKBACK)) return;
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     const int r = c >= 0 ? c : kCand;
@@ -1513,7 +1401,7 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
     if (lane == 0u) s_w[wave] = t;
     __syncthreads();
-    unsigned run = single ? item_pre[blockIdx.x] : item_pre[blockIdx.x] - item_pre[sg->item_first];
+    unsigned run = item_pre[blockIdx.x] - item_pre[sg->item_first];
     for (unsigned w = 0; w < wave; ++w) run += s_w[w];
     // everything below is partition_shuffle on the window [act, n): positions relative to act
     const unsigned n = sg->count - win.act, s = sg->start + win.act, ttot = sg->ttot_cur, ftot = n - ttot;
@@ -1525,8 +1413,7 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
             const bool p = (masks[j] >> lane) & 1ull;
             const unsigned tl = run + vd_mbcnt(masks[j]);
             const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
-            // the F-th true from the right: table index F - 1 from the right = ttot - F from the left
-            const long long tF = F == 0u ? (long long)n : (F <= ttot ? (long long)truepos[s + (single ? ttot - F : F - 1u)] : -1ll);
+            const long long tF = F == 0u ? (long long)n : (F <= ttot ? (long long)truepos[s + F - 1u] : -1ll);
             const bool left = (long long)x < tF;
             const unsigned fj = (T + 1u <= ftot) ? falsepos[s + T] : n;
             const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
@@ -1550,6 +1437,248 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     }
 }
 
+// =============================================================================================
+// The rounds of a level as ONE persistent kernel.
+// A round is four dependent passes over the level's items (count -> scan -> ranks -> apply); as four kernels a round costs
+// ~49 us of which ~22 us are the four dependent launches (a kernel that does nothing takes 5-6 us here) - the rounds are
+// bound by launches, not by bytes (a 4-byte payload instead of 8 bought 1 ms of 25).  Here a grid of co-resident
+// workgroups, each owning every G-th item, runs rounds [r_begin, r_end) with three grid barriers per round; the workgroup
+// that arrives last at the first barrier of a round does the scan of the item counts before it releases the others.
+// Everything one workgroup writes and another reads (payload, rank tables, counts, the per-segment round state) moves
+// as agent-scope relaxed accesses - write-through stores, L1/L2-bypassing loads: the XCDs' L2s are not coherent with each
+// other inside a kernel, and a release fence per barrier would write back a whole L2 - ordered by `s_waitcnt vmcnt(0)`
+// before the arrival atomic (the protocol of the TLAS chain and the refit climb; tests/test_isa_protocols.py).
+// Co-residency is what the launch asks for (occupancy x CUs workgroups), not something the programming model promises:
+// every wait is bounded, on expiry ERR_GRIDSYNC is raised, every later kernel of the build returns at once, and the host
+// redoes the build with the four-kernel rounds (and keeps them for this context).
+// =============================================================================================
+template <typename T> __device__ __forceinline__ T ag_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void ag_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned pay_ld(const unsigned* p) { return ag_ld(p); }
+__device__ __forceinline__ void pay_st(unsigned* p, unsigned v) { ag_st(p, v); }
+__device__ __forceinline__ u32x2 pay_ld(const u32x2* p) {
+    const vd_u64 w = ag_ld(reinterpret_cast<const vd_u64*>(p));
+    u32x2 v = {(unsigned)w, (unsigned)(w >> 32)};
+    return v;
+}
+__device__ __forceinline__ void pay_st(u32x2* p, u32x2 v) { ag_st(reinterpret_cast<vd_u64*>(p), ((vd_u64)v.y << 32) | v.x); }
+
+struct GridBar { unsigned arrive[64][16]; unsigned top, gen, pad[14]; };   // one 64-byte line per group of 64 workgroups
+constexpr unsigned kGridSpinLimit = 1u << 21;
+
+// Barrier over the n_wg workgroups of the grid; `elected` runs - by all threads of the LAST workgroup to arrive - before
+// anyone is released.  Returns false when the wait expired (ERR_GRIDSYNC is set).
+template <typename F>
+__device__ __forceinline__ bool grid_sync(GridBar* bar, unsigned n_wg, unsigned& gen, unsigned* err, F&& elected) {
+    __shared__ unsigned s_role;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's write-through stores have reached memory
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned role = 0;
+        const unsigned g = blockIdx.x >> 6, gsize = min(64u, n_wg - (g << 6)), n_groups = (n_wg + 63u) >> 6;
+        if (__hip_atomic_fetch_add(&bar->arrive[g][0], 1u, VD_RLX_AGENT) == gsize - 1u) {
+            ag_st(&bar->arrive[g][0], 0u);                 // nobody of this group arrives again before `gen` moves
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (__hip_atomic_fetch_add(&bar->top, 1u, VD_RLX_AGENT) == n_groups - 1u) { ag_st(&bar->top, 0u); role = 1u; }
+        }
+        s_role = role;
+    }
+    __syncthreads();
+    if (s_role == 1u) {
+        elected();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) ag_st(&bar->gen, gen + 1u);
+    } else if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (ag_ld(&bar->gen) != gen + 1u) {
+            if (++spins > kGridSpinLimit || ((spins & 255u) == 0u && (ag_ld(err) & ERR_GRIDSYNC))) { atomicOr(err, ERR_GRIDSYNC); s_role = 2u; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    gen += 1u;
+    return s_role != 2u;
+}
+
+template <typename P>
+__global__ __launch_bounds__(256, 2) void a_rounds_kernel(Seg* segs, const unsigned* __restrict__ item_seg, LevelCtl* ctl, typename P::T* pay_a,
+                                                          typename P::T* pay_b, int r_begin, int r_end, unsigned* item_cnt, unsigned* item_pre,
+                                                          unsigned* falsepos, unsigned* truepos, unsigned char* is_u_flag,
+                                                          const unsigned* __restrict__ bits21, GridBar* bar, unsigned gen0) {
+    typedef typename P::T PT;
+    __shared__ unsigned s_w[4], s_wave[4];
+    const unsigned n_items = ctl->n_items, n_seg = ctl->n_seg, n_wg = gridDim.x;
+    if (ctl->err & ERR_GRIDSYNC) return;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    unsigned gen = gen0;
+    auto window = [&](const Seg* sg, int r) {
+        Window w;
+        if (r % 7 == 0) { w.band = w.act = 0u; }
+        else { w.act = ag_ld(&sg->act[r % 3]); w.band = (r % 7 == 1) ? 0u : ag_ld(&sg->act[(r + 2) % 3]); }
+        return w;
+    };
+    // predicates of an item's positions inside the window, from `pay` (agent-scope loads)
+    auto masks_of = [&](const Seg* sg, unsigned rel0, unsigned n_here, const PT* pay, unsigned sh, unsigned act, unsigned long long (&masks)[kPer],
+                        PT (&vals)[kPer]) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned x = wave * (unsigned)(kItem / 4) + j * 64u + lane;
+            bool p = false;
+            if (x < n_here && rel0 + x >= act) {
+                vals[j] = pay_ld(pay + sg->start + rel0 + x);
+                p = (P::word(vals[j]) >> sh) & 1u;
+            }
+            masks[j] = __ballot(p);
+        }
+    };
+    for (int r = r_begin; r < r_end; ++r) {
+        const int c = r < kCand ? r : -1;
+        PT* src = (r & 1) ? pay_b : pay_a;
+        PT* dst = (r & 1) ? pay_a : pay_b;
+        const bool refresh = P::kRefresh && (r == 7 || r == 14 || r == kCand);
+        // ---- 1: true count of every item ----
+        for (unsigned item = blockIdx.x; item < n_items; item += n_wg) {
+            const unsigned seg = item_seg[item];
+            const Seg* sg = segs + seg;
+            const unsigned rel0 = (item - sg->item_first) * kItem, n_here = min((unsigned)kItem, sg->count - rel0);
+            const Window win = window(sg, r);
+            const unsigned cc = c >= 0 ? (unsigned)c : sg->best;
+            unsigned t = 0;
+            if (rel0 + n_here > win.act) {
+                if (refresh) {
+                    for (unsigned x = tid; x < n_here; x += 256u) {
+                        const unsigned a = sg->start + rel0 + x;
+                        const unsigned pos = P::pos(pay_ld(src + a));
+                        pay_st(src + a, P::make(pos, bits21[pos], cc / 7u));
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+                unsigned long long masks[kPer]; PT vals[kPer];
+                masks_of(sg, rel0, n_here, src, P::shift(cc), win.act, masks, vals);
+#pragma unroll
+                for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
+            }
+            if (lane == 0u) s_w[wave] = t;
+            __syncthreads();
+            if (tid == 0u) ag_st(&item_cnt[item], s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+            __syncthreads();
+        }
+        // ---- 2: exclusive scan of the counts + every segment's total, by the last workgroup to arrive ----
+        if (!grid_sync(bar, n_wg, gen, &ctl->err, [&]() {
+                const unsigned per = ((n_items + 255u) / 256u + 3u) & ~3u;
+                const unsigned lo = min(n_items, tid * per), hi = min(n_items, lo + per);
+                unsigned sum = 0;
+                for (unsigned i = lo; i < hi; ++i) sum += ag_ld(&item_cnt[i]);
+                unsigned incl = sum;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const unsigned t2 = __shfl_up(incl, off); if (lane >= (unsigned)off) incl += t2; }
+                if (lane == 63u) s_wave[wave] = incl;
+                __syncthreads();
+                unsigned run = incl - sum, total = 0;
+                for (unsigned w = 0; w < 4u; ++w) { if (w < wave) run += s_wave[w]; total += s_wave[w]; }
+                for (unsigned i = lo; i < hi; ++i) { const unsigned cnt = ag_ld(&item_cnt[i]); ag_st(&item_pre[i], run); run += cnt; }
+                if (tid == 0u) ag_st(&item_pre[n_items], total);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                for (unsigned i = tid; i < n_seg; i += 256u) {
+                    Seg& sg = segs[i];
+                    ag_st(&sg.ttot_cur, ag_ld(&item_pre[sg.item_first + sg.n_items]) - ag_ld(&item_pre[sg.item_first]));
+                }
+            })) return;
+        // ---- 3: rank -> position tables ----
+        for (unsigned item = blockIdx.x; item < n_items; item += n_wg) {
+            const unsigned seg = item_seg[item];
+            const Seg* sg = segs + seg;
+            const unsigned rel0 = (item - sg->item_first) * kItem, n_here = min((unsigned)kItem, sg->count - rel0);
+            const Window win = window(sg, r);
+            if (rel0 + n_here <= win.act) continue;          // wholly frozen (block-uniform)
+            const unsigned cc = c >= 0 ? (unsigned)c : sg->best;
+            unsigned long long masks[kPer]; PT vals[kPer];
+            masks_of(sg, rel0, n_here, src, P::shift(cc), win.act, masks, vals);
+            unsigned t = 0;
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
+            if (lane == 0u) s_w[wave] = t;
+            __syncthreads();
+            unsigned run = ag_ld(&item_pre[item]) - ag_ld(&item_pre[sg->item_first]);
+            for (unsigned w = 0; w < wave; ++w) run += s_w[w];
+            const unsigned ttot = ag_ld(&sg->ttot_cur), s = sg->start + win.act;
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
+                if (xr < n_here && rel0 + xr >= win.act) {
+                    const unsigned x = rel0 + xr - win.act;
+                    const bool p = (masks[j] >> lane) & 1ull;
+                    const unsigned tl = run + vd_mbcnt(masks[j]);
+                    if (p) ag_st(&truepos[s + (ttot - tl - 1u)], x);     // index T: (T+1)-th true from the right
+                    else ag_st(&falsepos[s + (x - tl)], x);              // index F: (F+1)-th false from the left
+                }
+                run += (unsigned)__popcll(masks[j]);
+            }
+            __syncthreads();
+        }
+        if (!grid_sync(bar, n_wg, gen, &ctl->err, []() {})) return;
+        // ---- 4: destinations, scatter, `u` ----
+        for (unsigned item = blockIdx.x; item < n_items; item += n_wg) {
+            const unsigned seg = item_seg[item];
+            const Seg* sg = segs + seg;
+            const unsigned rel0 = (item - sg->item_first) * kItem, n_here = min((unsigned)kItem, sg->count - rel0);
+            const Window win = window(sg, r);
+            if (rel0 + n_here <= win.band) continue;         // frozen before the previous round: both buffers agree
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {                 // the band the previous round froze: straight copy
+                const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane, xa = rel0 + xr;
+                if (xr < n_here && xa >= win.band && xa < win.act) pay_st(dst + sg->start + xa, pay_ld(src + sg->start + xa));
+            }
+            if (rel0 + n_here <= win.act) continue;
+            const unsigned cc = c >= 0 ? (unsigned)c : sg->best;
+            unsigned long long masks[kPer]; PT vals[kPer];
+            masks_of(sg, rel0, n_here, src, P::shift(cc), win.act, masks, vals);
+            unsigned t = 0;
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
+            if (lane == 0u) s_w[wave] = t;
+            __syncthreads();
+            unsigned run = ag_ld(&item_pre[item]) - ag_ld(&item_pre[sg->item_first]);
+            for (unsigned w = 0; w < wave; ++w) run += s_w[w];
+            const unsigned n = sg->count - win.act, s = sg->start + win.act, ttot = ag_ld(&sg->ttot_cur), ftot = n - ttot;
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
+                if (xr < n_here && rel0 + xr >= win.act) {
+                    const unsigned x = rel0 + xr - win.act;
+                    const bool p = (masks[j] >> lane) & 1ull;
+                    const unsigned tl = run + vd_mbcnt(masks[j]);
+                    const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
+                    const long long tF = F == 0u ? (long long)n : (F <= ttot ? (long long)ag_ld(&truepos[s + F - 1u]) : -1ll);
+                    const bool left = (long long)x < tF;
+                    const unsigned fj = (T + 1u <= ftot) ? ag_ld(&falsepos[s + T]) : n;
+                    const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
+                    const bool is_u = fetch == n - 1u;
+                    unsigned dest;
+                    if (is_u) dest = ttot - (p ? 1u : 0u);
+                    else if (left) dest = p ? x : (unsigned)tF - 1u;
+                    else dest = p ? fj : x - 1u;
+                    pay_st(dst + s + dest, vals[j]);
+                    if (is_u && c >= 0) {
+                        Seg& w = segs[seg];
+                        const unsigned upos = P::pos(vals[j]);
+                        ag_st(reinterpret_cast<vd_u64*>(&w.u_pay[c]), ((vd_u64)bits21[upos] << 32) | upos);
+                        ag_st(&w.u_p[c], p ? 1u : 0u); ag_st(&w.ttot[c], win.act + ttot);
+                        ag_st(&w.act[(r + 1) % 3], win.act + ttot - (p ? 1u : 0u));   // this trial's pivot: where the next round starts
+                        ag_st(&is_u_flag[upos], (unsigned char)1);
+                    }
+                }
+                run += (unsigned)__popcll(masks[j]);
+            }
+            __syncthreads();
+        }
+        if (r + 1 < r_end && !grid_sync(bar, n_wg, gen, &ctl->err, []() {})) return;
+    }
+}
+
 // binning over the non-u elements (one pass per level)
 template <typename P>
 __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
@@ -1562,7 +1691,7 @@ __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* i
     // segment changes: the flush is 144 same-address global atomics per workgroup (~5 ns each, serialised per address),
     // which at the top levels - one segment, 8 k items - used to be the floor of the kernel.
     __shared__ int s_bins[144][64];                    // entry = (axis * 8 + bin) * 6 + q; q < 3: min keys, q >= 3: max keys
-    if (ctl->err & ERR_LOOKBACK) return;
+    if (ctl->err & ERR_GRIDSYNC) return;
     const unsigned n_items = ctl->n_items;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned cur_seg = kNone;
@@ -1614,7 +1743,7 @@ __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* i
 
 // one wave per segment: 21 costs -> best plane, stale pivot
 __global__ __launch_bounds__(64) void a_eval_kernel(Seg* segs, LevelCtl* ctl, const TriBox* __restrict__ boxes) {
-    if (blockIdx.x >= ctl->n_seg || (ctl->err & ERR_LOOKBACK)) return;
+    if (blockIdx.x >= ctl->n_seg || (ctl->err & ERR_GRIDSYNC)) return;
     Seg& sg = segs[blockIdx.x];
     const unsigned lane = threadIdx.x;
     vd_u64 key = ~0ull;
@@ -1685,7 +1814,7 @@ __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, Top
                                   unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap, MidRoot* mid, unsigned mid_cap,
                                   unsigned parity /* the set this level's a_child wrote */) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ctl->n_seg || (ctl->err & ERR_LOOKBACK)) return;
+    if (i >= ctl->n_seg || (ctl->err & ERR_GRIDSYNC)) return;
     const Seg& sg = segs[i];
     for (int c = 0; c < kCand; ++c) is_u_flag[sg.u_pay[c].x] = 0;
     const unsigned pair = atomicAdd(&ctl->n_top, 2u);
@@ -2062,7 +2191,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     // ---- scratch layout ----
     Arena probe{nullptr, 0};
     auto layout = [&](Arena& a, bool) {
-        struct P { u32x2 *pay0, *pay1; f32x4 *cent, *cent1; TriBox *boxes, *boxes1; unsigned *bits21, *ids32; vd_u64* tiles;
+        struct P { u32x2 *pay0, *pay1; f32x4 *cent, *cent1; TriBox *boxes, *boxes1; unsigned *bits21, *ids32; GridBar* bar;
                    unsigned *falsepos, *truepos, *final_ids, *stack, *idx_copy;
                    unsigned char* is_u; Seg *seg0, *seg1; MidRoot* mid; unsigned *item_seg, *item_cnt, *item_pre; TopNode* top; SmallRoot* small;
                    unsigned* sub_interior; TmpNode* subnodes; unsigned short* submap; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair; } p;
@@ -2070,7 +2199,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         const size_t pay_words = wide_pay ? T : (T + 1) / 2;
         p.pay0 = a.take<u32x2>(pay_words); p.pay1 = a.take<u32x2>(pay_words);
         p.cent = a.take<f32x4>(T); p.boxes = a.take<TriBox>(T); p.cent1 = a.take<f32x4>(T); p.boxes1 = a.take<TriBox>(T);
-        p.bits21 = a.take<unsigned>(T); p.ids32 = a.take<unsigned>(T); p.tiles = a.take<vd_u64>(item_cap + 1);
+        p.bits21 = a.take<unsigned>(T); p.ids32 = a.take<unsigned>(T); p.bar = a.take<GridBar>(1);
         p.falsepos = a.take<unsigned>(T); p.truepos = a.take<unsigned>(T);
         p.final_ids = a.take<unsigned>(T); p.stack = a.take<unsigned>(T); p.idx_copy = a.take<unsigned>(3 * T);
         p.is_u = a.take<unsigned char>(T);
@@ -2102,7 +2231,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         VD_HIP_CHECK(ctx, hipMemcpyAsync(P.root_keys, h_keys, sizeof(h_keys), hipMemcpyHostToDevice, st));
         VD_HIP_CHECK(ctx, hipMemsetAsync(P.ctl, 0, sizeof(LevelCtl), st));
         VD_HIP_CHECK(ctx, hipMemsetAsync(P.is_u, 0, T, st));
-        VD_HIP_CHECK(ctx, hipMemsetAsync(P.tiles, 0, sizeof(vd_u64) * ((size_t)item_cap + 1), st));   // epoch 0 = never written
+        VD_HIP_CHECK(ctx, hipMemsetAsync(P.bar, 0, sizeof(GridBar), st));
         VD_HIP_CHECK(ctx, hipMemcpyAsync(P.idx_copy, d_idx, 3 * T * 4, hipMemcpyDeviceToDevice, st));
     }
     const unsigned tri_blocks = (unsigned)((T + 255) / 256);
@@ -2121,9 +2250,17 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     int levels = 0;
     stats.kernel_launches = 2;
     lap(stats.ms_precompute);
-    // rounds as one pass (a_rank1_kernel) unless this context has seen its look-back time out, or the option says otherwise
-    const bool single_pass = !ctx->blas_three_kernel_rounds && ctx->option(VD_OPT_BLAS_SINGLE_PASS, 1) != 0;
-    unsigned tile_epoch = 0;
+    // the rounds of a level as one persistent kernel (a_rounds_kernel) unless this context has seen its grid barrier time
+    // out, or the option says otherwise; co-resident workgroups = what the occupancy query promises on this device
+    bool persistent = !ctx->blas_four_kernel_rounds && ctx->option(VD_OPT_BLAS_PERSISTENT_ROUNDS, 1) != 0;
+    unsigned rounds_wgs = 0, bar_gen = 0;
+    if (persistent) {
+        int occ = 0;
+        const void* fn = wide_pay ? reinterpret_cast<const void*>(a_rounds_kernel<Pay8>) : reinterpret_cast<const void*>(a_rounds_kernel<Pay4>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, 0) != hipSuccess || occ < 1) persistent = false;
+        else rounds_wgs = (unsigned)ctx->num_cus * (unsigned)(occ > 4 ? 4 : occ);
+        if (rounds_wgs > 4096u) rounds_wgs = 4096u;       // GridBar: 64 groups of 64
+    }
     // one level of phase A; PayT = Pay4 / Pay8 (see there)
     auto run_level = [&](auto pay_tag, unsigned n_seg_now, Seg* seg_cur, Seg* seg_next, int level) {
         using PayT = decltype(pay_tag);
@@ -2138,6 +2275,19 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         hipLaunchKernelGGL(a_planes_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, P.ctl);
         PT* src = reinterpret_cast<PT*>(P.pay0); PT* dst = reinterpret_cast<PT*>(P.pay1);
         hipLaunchKernelGGL((a_bits_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.cent, P.bits21);
+        if (persistent) {
+            const unsigned n_wg = rounds_wgs < items_ub ? rounds_wgs : items_ub;
+            // rounds 0..20 (three barriers each, none after the last), the binning + evaluation, then the final shuffle
+            hipLaunchKernelGGL((a_rounds_kernel<PayT>), dim3(n_wg), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, 0, kCand, P.item_cnt, P.item_pre,
+                               P.falsepos, P.truepos, P.is_u, P.bits21, P.bar, bar_gen);
+            bar_gen += 3u * kCand - 1u;
+            hipLaunchKernelGGL((a_bin_kernel<PayT>), dim3((items_ub + kBinItems - 1) / kBinItems), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, dst, cur.boxes,
+                               P.is_u, P.bits21);          // 21 rounds: the arrangement is in the other buffer
+            hipLaunchKernelGGL(a_eval_kernel, dim3(n_seg_now), dim3(64), 0, st, seg_cur, P.ctl, cur.boxes);
+            hipLaunchKernelGGL((a_rounds_kernel<PayT>), dim3(n_wg), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, kCand, kCand + 1, P.item_cnt, P.item_pre,
+                               P.falsepos, P.truepos, P.is_u, P.bits21, P.bar, bar_gen);
+            bar_gen += 2u;
+        } else
         for (int c = 0; c <= kCand; ++c) {
             const int cc = c < kCand ? c : -1;       // -1: final re-shuffle with each segment's best plane
             if (c == kCand) {
@@ -2146,17 +2296,12 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
                 hipLaunchKernelGGL(a_eval_kernel, dim3(n_seg_now), dim3(64), 0, st, seg_cur, P.ctl, cur.boxes);
             }
             const int refresh = (c == 7 || c == 14 || c == kCand) ? 1 : 0;   // the rounds that start on another axis
-            if (single_pass) {
-                hipLaunchKernelGGL((a_rank1_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre, P.falsepos,
-                                   P.truepos, P.bits21, refresh, P.tiles, ++tile_epoch);
-            } else {
-                hipLaunchKernelGGL((a_count_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_cnt, P.bits21, refresh);
-                hipLaunchKernelGGL(a_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl, P.item_cnt, P.item_pre);
-                hipLaunchKernelGGL((a_ranks_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre,
-                                   P.falsepos, P.truepos);
-            }
+            hipLaunchKernelGGL((a_count_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_cnt, P.bits21, refresh);
+            hipLaunchKernelGGL(a_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl, P.item_cnt, P.item_pre);
+            hipLaunchKernelGGL((a_ranks_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre,
+                               P.falsepos, P.truepos);
             hipLaunchKernelGGL((a_apply_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, P.item_pre,
-                               P.falsepos, P.truepos, P.is_u, P.bits21, single_pass ? 1 : 0);
+                               P.falsepos, P.truepos, P.is_u, P.bits21);
             PT* t = src; src = dst; dst = t;
         }
         // 22 swaps: the arrangement is back in pay0
@@ -2170,10 +2315,10 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         if (wide_pay) run_level(Pay8{}, n_seg, seg_cur, seg_next, levels); else run_level(Pay4{}, n_seg, seg_cur, seg_next, levels);
         VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
         VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        if (h_ctl.err & ERR_LOOKBACK) {
-            // an item waited too long for its predecessors (workgroups not started in index order?): nothing of this build is
-            // kept - d_idx is untouched until the final permute - and it is redone with the three-kernel rounds
-            ctx->blas_three_kernel_rounds = true;
+        if (h_ctl.err & ERR_GRIDSYNC) {
+            // a grid barrier of the persistent rounds kernel expired (its workgroups were not all resident?): nothing of this
+            // build is kept - d_idx is untouched until the final permute - and it is redone with the four-kernel rounds
+            ctx->blas_four_kernel_rounds = true;
             return bvh_build_dev_impl(ctx, d_verts, n_vert, d_idx, n_tri, d_out, node_cap, out_n_nodes);
         }
         if (h_ctl.err & ERR_DEGENERATE)
@@ -2181,7 +2326,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
         n_seg = h_ctl.n_seg;
         Seg* t = seg_cur; seg_cur = seg_next; seg_next = t;
-        stats.kernel_launches += 9 + (single_pass ? 2 : 4) * (kCand + 1);
+        stats.kernel_launches += persistent ? 13 : 9 + 4 * (kCand + 1);
         if (++levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
     }
     stats.levels_phase_a = (uint32_t)levels;
