@@ -202,9 +202,6 @@ typedef enum VdOption {
     VD_OPT_TLAS_PROFILE = 17,     /* 1: the indexed build prints its in-kernel cycle counters             */
     VD_OPT_BLAS_WIDE_PAYLOAD = 30,/* 1: vd_bvh_build moves the 8-byte payload (what meshes above 2^25 triangles use) at
                                      any size (tests); default 0                                                  */
-    VD_OPT_BLAS_PERSISTENT_ROUNDS = 31, /* 0: the 22 shuffle rounds of a level of vd_bvh_build run as four kernels each
-                                     instead of one persistent kernel with grid barriers (A/B, tests; also what a
-                                     context falls back to by itself if a barrier ever times out); default 1      */
     VD_OPT_TRACE_SORT = 21,       /* 1: vd_trace* bin the rays first (sorted by origin cell + direction) and hand them
                                      out in that order; results are per ray, so only the order changes.  Default 0:
                                      measured slower on this part                                */

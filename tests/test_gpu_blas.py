@@ -42,17 +42,6 @@ def test_soup_sizes_vs_oracle(ctx, oracle, n_tri):
     assert np.array_equal(idx, want_idx)
 
 
-def test_four_kernel_rounds_vs_oracle(ctx, oracle, ctx_options):
-    """The 22 shuffle rounds of a phase-A level run inside one persistent kernel with grid barriers; the count / scan /
-    ranks / apply kernels are what a context falls back to if a barrier ever times out - kept bit-exact here."""
-    ctx_options("blas.persistent_rounds", 0)
-    for v, i in (synth.knot_mesh(256, 64), synth.triangle_soup(5000, seed=15), synth.knot_mesh(512, 128)):
-        want_nodes, want_idx = oracle.bvh_build(v, i)
-        nodes, idx = ctx.bvh_build(v, i)
-        assert fields_equal(nodes, want_nodes), diff_report(nodes, want_nodes)
-        assert np.array_equal(idx, want_idx)
-
-
 def test_wide_payload_path_vs_oracle(ctx, oracle, ctx_options):
     """Meshes above 2^25 triangles move an 8-byte {pos0, 21 predicate bits} payload through the rounds of phase A instead of
     the 4-byte {pos0, 7 bits of the current axis} one; VD_OPT_BLAS_WIDE_PAYLOAD forces that path at testable sizes."""

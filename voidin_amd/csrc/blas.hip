@@ -72,7 +72,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct TriBox { float mn[3]; float pad0; float mx[3]; float pad1; };   // 32 B, by triangle id
 struct TmpNode { float mn[3]; unsigned left_first; float mx[3]; unsigned count; };   // == VdBvhNode layout
 
-enum : unsigned { ERR_DEGENERATE = 1u, ERR_BAD_INDEX = 2u, ERR_INTERNAL = 4u, ERR_GRIDSYNC = 8u };
+enum : unsigned { ERR_DEGENERATE = 1u, ERR_BAD_INDEX = 2u, ERR_INTERNAL = 4u };
 constexpr unsigned kInteriorMark = 0x80000000u;   // phase B: TmpNode.count of a split node until the renumber (n stays in the low bits)
 
 __device__ __forceinline__ float pay_c(const u32x4& v, int axis) {
@@ -1188,7 +1188,7 @@ __global__ void a_items_fill_kernel(const Seg* segs, const LevelCtl* ctl, unsign
 // item is (wave, j, lane): position = rel0 + wave*256 + j*64 + lane.
 struct ItemCtx { unsigned seg, rel0, n_here; };
 __device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl, ItemCtx& ic, Seg const*& sg) {
-    if (blockIdx.x >= ctl->n_items || (ctl->err & ERR_GRIDSYNC)) return false;   // ERR_GRIDSYNC: the build is being redone (a_rounds_kernel)
+    if (blockIdx.x >= ctl->n_items) return false;
     ic.seg = item_seg[blockIdx.x];
     sg = segs + ic.seg;
     ic.rel0 = (blockIdx.x - sg->item_first) * kItem;
@@ -1437,292 +1437,6 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     }
 }
 
-// =============================================================================================
-// The rounds of a level as ONE persistent kernel.
-// A round is four dependent passes over the level's items (count -> scan -> ranks -> apply); as four kernels a round costs
-// ~49 us of which ~22 us are the four dependent launches (a kernel that does nothing takes 5-6 us here) - the rounds are
-// bound by launches, not by bytes (a 4-byte payload instead of 8 bought 1 ms of 25).  Here a grid of co-resident
-// workgroups, each owning every G-th item, runs rounds [r_begin, r_end) with three grid barriers per round; the workgroup
-// that arrives last at the first barrier of a round does the scan of the item counts before it releases the others.
-// Everything one workgroup writes and another reads (payload, rank tables, counts, the per-segment round state) moves
-// as agent-scope relaxed accesses - write-through stores, L1/L2-bypassing loads: the XCDs' L2s are not coherent with each
-// other inside a kernel, and a release fence per barrier would write back a whole L2 - ordered by `s_waitcnt vmcnt(0)`
-// before the arrival atomic (the protocol of the TLAS chain and the refit climb; tests/test_isa_protocols.py).
-// Co-residency is what the launch asks for (occupancy x CUs workgroups), not something the programming model promises:
-// every wait is bounded, on expiry ERR_GRIDSYNC is raised, every later kernel of the build returns at once, and the host
-// redoes the build with the four-kernel rounds (and keeps them for this context).
-// =============================================================================================
-template <typename T> __device__ __forceinline__ T ag_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T> __device__ __forceinline__ void ag_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned pay_ld(const unsigned* p) { return ag_ld(p); }
-__device__ __forceinline__ void pay_st(unsigned* p, unsigned v) { ag_st(p, v); }
-__device__ __forceinline__ u32x2 pay_ld(const u32x2* p) {
-    const vd_u64 w = ag_ld(reinterpret_cast<const vd_u64*>(p));
-    u32x2 v = {(unsigned)w, (unsigned)(w >> 32)};
-    return v;
-}
-__device__ __forceinline__ void pay_st(u32x2* p, u32x2 v) { ag_st(reinterpret_cast<vd_u64*>(p), ((vd_u64)v.y << 32) | v.x); }
-
-struct GridBar { unsigned arrive[64][16]; unsigned top, gen, pad[14]; };   // one 64-byte line per group of 64 workgroups
-constexpr unsigned kGridSpinLimit = 1u << 21;
-
-// Barrier over the n_wg workgroups of the grid; `elected` runs - by all threads of the LAST workgroup to arrive - before
-// anyone is released.  Returns false when the wait expired (ERR_GRIDSYNC is set).
-template <typename F>
-__device__ __forceinline__ bool grid_sync(GridBar* bar, unsigned n_wg, unsigned& gen, unsigned* err, F&& elected) {
-    __shared__ unsigned s_role;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's write-through stores have reached memory
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned role = 0;
-        const unsigned g = blockIdx.x >> 6, gsize = min(64u, n_wg - (g << 6)), n_groups = (n_wg + 63u) >> 6;
-        if (__hip_atomic_fetch_add(&bar->arrive[g][0], 1u, VD_RLX_AGENT) == gsize - 1u) {
-            ag_st(&bar->arrive[g][0], 0u);                 // nobody of this group arrives again before `gen` moves
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (__hip_atomic_fetch_add(&bar->top, 1u, VD_RLX_AGENT) == n_groups - 1u) { ag_st(&bar->top, 0u); role = 1u; }
-        }
-        s_role = role;
-    }
-    __syncthreads();
-    if (s_role == 1u) {
-        elected();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) ag_st(&bar->gen, gen + 1u);
-    } else if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (ag_ld(&bar->gen) != gen + 1u) {
-            if (++spins > kGridSpinLimit || ((spins & 255u) == 0u && (ag_ld(err) & ERR_GRIDSYNC))) { atomicOr(err, ERR_GRIDSYNC); s_role = 2u; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    __syncthreads();
-    gen += 1u;
-    return s_role != 2u;
-}
-
-// A workgroup handles kRB of its items side by side in every phase: the loads of all of them are in flight together (an
-// agent-scope load is a trip to the memory side, ~1-2 us, and an item is a chain of three or four of them) and there is
-// one workgroup barrier per phase and batch instead of one per item.  (One item at a time: 130 us per round, against
-// 49 us for the four kernels it replaces - whose 8 k workgroups hide that latency by sheer number.)
-constexpr int kRB = 4;
-struct RoundItem { const Seg* sg; unsigned item, seg, rel0, n_here, act, band, sh; bool valid; };
-
-template <typename P>
-__global__ __launch_bounds__(256, 4) void a_rounds_kernel(Seg* segs, const unsigned* __restrict__ item_seg, LevelCtl* ctl, typename P::T* pay_a,
-                                                          typename P::T* pay_b, int r_begin, int r_end, unsigned* item_cnt, unsigned* item_pre,
-                                                          unsigned* falsepos, unsigned* truepos, unsigned char* is_u_flag,
-                                                          const unsigned* __restrict__ bits21, GridBar* bar, unsigned gen0) {
-    typedef typename P::T PT;
-    __shared__ unsigned s_w[kRB][4], s_wave[4];
-    const unsigned n_items = ctl->n_items, n_seg = ctl->n_seg, n_wg = gridDim.x;
-    if (ctl->err & ERR_GRIDSYNC) return;
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, tid = threadIdx.x;
-    unsigned gen = gen0;
-    // the kRB items of a batch: item = base + k * n_wg (all uniform; the loads of the kRB chains overlap)
-    auto batch_info = [&](unsigned base, int r, int c, RoundItem (&it)[kRB]) {
-#pragma unroll
-        for (int k = 0; k < kRB; ++k) {
-            RoundItem& q = it[k];
-            q.item = base + (unsigned)k * n_wg;
-            q.valid = q.item < n_items;
-            q.seg = q.valid ? item_seg[q.item] : 0u;
-            q.sg = segs + q.seg;
-        }
-#pragma unroll
-        for (int k = 0; k < kRB; ++k) {
-            RoundItem& q = it[k];
-            q.rel0 = (q.item - q.sg->item_first) * kItem;
-            q.n_here = q.valid ? min((unsigned)kItem, q.sg->count - q.rel0) : 0u;
-            if (r % 7 == 0) { q.band = q.act = 0u; }
-            else { q.act = ag_ld(&q.sg->act[r % 3]); q.band = (r % 7 == 1) ? 0u : ag_ld(&q.sg->act[(r + 2) % 3]); }
-            q.sh = P::shift(c >= 0 ? (unsigned)c : q.sg->best);
-        }
-    };
-    // payload values and predicate ballots of the batch's positions that lie in the shuffled windows
-    auto batch_masks = [&](const RoundItem (&it)[kRB], const PT* pay, unsigned long long (&masks)[kRB][kPer], PT (&vals)[kRB][kPer]) {
-#pragma unroll
-        for (int k = 0; k < kRB; ++k)
-#pragma unroll
-            for (int j = 0; j < kPer; ++j) {
-                const unsigned x = wave * (unsigned)(kItem / 4) + j * 64u + lane;
-                if (x < it[k].n_here && it[k].rel0 + x >= it[k].act) vals[k][j] = pay_ld(pay + it[k].sg->start + it[k].rel0 + x);
-            }
-#pragma unroll
-        for (int k = 0; k < kRB; ++k)
-#pragma unroll
-            for (int j = 0; j < kPer; ++j) {
-                const unsigned x = wave * (unsigned)(kItem / 4) + j * 64u + lane;
-                const bool in = x < it[k].n_here && it[k].rel0 + x >= it[k].act;
-                masks[k][j] = __ballot(in && ((P::word(vals[k][j]) >> it[k].sh) & 1u));
-            }
-    };
-    for (int r = r_begin; r < r_end; ++r) {
-        const int c = r < kCand ? r : -1;
-        PT* src = (r & 1) ? pay_b : pay_a;
-        PT* dst = (r & 1) ? pay_a : pay_b;
-        const bool refresh = P::kRefresh && (r == 7 || r == 14 || r == kCand);
-        // ---- 1: true count of every item ----
-        for (unsigned base = blockIdx.x; base < n_items; base += n_wg * kRB) {
-            RoundItem it[kRB];
-            batch_info(base, r, c, it);
-            if (refresh) {                                   // rounds 7, 14, 21: the payload's bits become those of the new axis
-#pragma unroll
-                for (int k = 0; k < kRB; ++k) {
-                    const unsigned axis = (c >= 0 ? (unsigned)c : it[k].sg->best) / 7u;
-                    for (unsigned x = tid; x < it[k].n_here; x += 256u) {
-                        const unsigned a = it[k].sg->start + it[k].rel0 + x;
-                        const unsigned pos = P::pos(pay_ld(src + a));
-                        pay_st(src + a, P::make(pos, bits21[pos], axis));
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-            unsigned long long masks[kRB][kPer]; PT vals[kRB][kPer];
-            batch_masks(it, src, masks, vals);
-#pragma unroll
-            for (int k = 0; k < kRB; ++k) {
-                unsigned t = 0;
-#pragma unroll
-                for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[k][j]);
-                if (lane == 0u) s_w[k][wave] = t;
-            }
-            __syncthreads();
-            if (tid < (unsigned)kRB && it[0].item + tid * n_wg < n_items) ag_st(&item_cnt[it[0].item + tid * n_wg], s_w[tid][0] + s_w[tid][1] + s_w[tid][2] + s_w[tid][3]);
-            __syncthreads();
-        }
-        // ---- 2: exclusive scan of the counts + every segment's total, by the last workgroup to arrive ----
-        if (!grid_sync(bar, n_wg, gen, &ctl->err, [&]() {
-                const unsigned per = ((n_items + 255u) / 256u + 3u) & ~3u;
-                const unsigned lo = min(n_items, tid * per), hi = min(n_items, lo + per);
-                unsigned sum = 0;
-                for (unsigned i = lo; i < hi; ++i) sum += ag_ld(&item_cnt[i]);
-                unsigned incl = sum;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const unsigned t2 = __shfl_up(incl, off); if (lane >= (unsigned)off) incl += t2; }
-                if (lane == 63u) s_wave[wave] = incl;
-                __syncthreads();
-                unsigned run = incl - sum, total = 0;
-                for (unsigned w = 0; w < 4u; ++w) { if (w < wave) run += s_wave[w]; total += s_wave[w]; }
-                for (unsigned i = lo; i < hi; ++i) { const unsigned cnt = ag_ld(&item_cnt[i]); ag_st(&item_pre[i], run); run += cnt; }
-                if (tid == 0u) ag_st(&item_pre[n_items], total);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                for (unsigned i = tid; i < n_seg; i += 256u) {
-                    Seg& sg = segs[i];
-                    ag_st(&sg.ttot_cur, ag_ld(&item_pre[sg.item_first + sg.n_items]) - ag_ld(&item_pre[sg.item_first]));
-                }
-            })) return;
-        // ---- 3: rank -> position tables ----
-        for (unsigned base = blockIdx.x; base < n_items; base += n_wg * kRB) {
-            RoundItem it[kRB];
-            batch_info(base, r, c, it);
-            unsigned pre[kRB], ttot[kRB];
-#pragma unroll
-            for (int k = 0; k < kRB; ++k) {
-                pre[k] = it[k].valid ? ag_ld(&item_pre[it[k].item]) - ag_ld(&item_pre[it[k].sg->item_first]) : 0u;
-                ttot[k] = ag_ld(&it[k].sg->ttot_cur);
-            }
-            unsigned long long masks[kRB][kPer]; PT vals[kRB][kPer];
-            batch_masks(it, src, masks, vals);
-#pragma unroll
-            for (int k = 0; k < kRB; ++k) {
-                unsigned t = 0;
-#pragma unroll
-                for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[k][j]);
-                if (lane == 0u) s_w[k][wave] = t;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kRB; ++k) {
-                unsigned run = pre[k];
-                for (unsigned w = 0; w < wave; ++w) run += s_w[k][w];
-                const unsigned s = it[k].sg->start + it[k].act;
-#pragma unroll
-                for (int j = 0; j < kPer; ++j) {
-                    const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
-                    if (xr < it[k].n_here && it[k].rel0 + xr >= it[k].act) {
-                        const unsigned x = it[k].rel0 + xr - it[k].act;
-                        const bool p = (masks[k][j] >> lane) & 1ull;
-                        const unsigned tl = run + vd_mbcnt(masks[k][j]);
-                        if (p) ag_st(&truepos[s + (ttot[k] - tl - 1u)], x);     // index T: (T+1)-th true from the right
-                        else ag_st(&falsepos[s + (x - tl)], x);                 // index F: (F+1)-th false from the left
-                    }
-                    run += (unsigned)__popcll(masks[k][j]);
-                }
-            }
-            __syncthreads();
-        }
-        if (!grid_sync(bar, n_wg, gen, &ctl->err, []() {})) return;
-        // ---- 4: destinations, scatter, `u` ----
-        for (unsigned base = blockIdx.x; base < n_items; base += n_wg * kRB) {
-            RoundItem it[kRB];
-            batch_info(base, r, c, it);
-            unsigned pre[kRB], ttot[kRB];
-#pragma unroll
-            for (int k = 0; k < kRB; ++k) {
-                pre[k] = it[k].valid ? ag_ld(&item_pre[it[k].item]) - ag_ld(&item_pre[it[k].sg->item_first]) : 0u;
-                ttot[k] = ag_ld(&it[k].sg->ttot_cur);
-            }
-#pragma unroll
-            for (int k = 0; k < kRB; ++k)                    // the band the previous round froze: straight copy
-#pragma unroll
-                for (int j = 0; j < kPer; ++j) {
-                    const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane, xa = it[k].rel0 + xr;
-                    if (xr < it[k].n_here && xa >= it[k].band && xa < it[k].act) pay_st(dst + it[k].sg->start + xa, pay_ld(src + it[k].sg->start + xa));
-                }
-            unsigned long long masks[kRB][kPer]; PT vals[kRB][kPer];
-            batch_masks(it, src, masks, vals);
-#pragma unroll
-            for (int k = 0; k < kRB; ++k) {
-                unsigned t = 0;
-#pragma unroll
-                for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[k][j]);
-                if (lane == 0u) s_w[k][wave] = t;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kRB; ++k) {
-                unsigned run = pre[k];
-                for (unsigned w = 0; w < wave; ++w) run += s_w[k][w];
-                const unsigned n = it[k].sg->count - it[k].act, s = it[k].sg->start + it[k].act, tt = ttot[k], ftot = n - tt;
-#pragma unroll
-                for (int j = 0; j < kPer; ++j) {
-                    const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
-                    if (xr < it[k].n_here && it[k].rel0 + xr >= it[k].act) {
-                        const unsigned x = it[k].rel0 + xr - it[k].act;
-                        const bool p = (masks[k][j] >> lane) & 1ull;
-                        const unsigned tl = run + vd_mbcnt(masks[k][j]);
-                        const unsigned F = x - tl, T = tt - tl - (p ? 1u : 0u);
-                        const long long tF = F == 0u ? (long long)n : (F <= tt ? (long long)ag_ld(&truepos[s + F - 1u]) : -1ll);
-                        const bool left = (long long)x < tF;
-                        const unsigned fj = (T + 1u <= ftot) ? ag_ld(&falsepos[s + T]) : n;
-                        const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
-                        const bool is_u = fetch == n - 1u;
-                        unsigned dest;
-                        if (is_u) dest = tt - (p ? 1u : 0u);
-                        else if (left) dest = p ? x : (unsigned)tF - 1u;
-                        else dest = p ? fj : x - 1u;
-                        pay_st(dst + s + dest, vals[k][j]);
-                        if (is_u && c >= 0) {
-                            Seg& w = segs[it[k].seg];
-                            const unsigned upos = P::pos(vals[k][j]);
-                            ag_st(reinterpret_cast<vd_u64*>(&w.u_pay[c]), ((vd_u64)bits21[upos] << 32) | upos);
-                            ag_st(&w.u_p[c], p ? 1u : 0u); ag_st(&w.ttot[c], it[k].act + tt);
-                            ag_st(&w.act[(r + 1) % 3], it[k].act + tt - (p ? 1u : 0u));   // this trial's pivot: where the next round starts
-                            ag_st(&is_u_flag[upos], (unsigned char)1);
-                        }
-                    }
-                    run += (unsigned)__popcll(masks[k][j]);
-                }
-            }
-            __syncthreads();
-        }
-        if (r + 1 < r_end && !grid_sync(bar, n_wg, gen, &ctl->err, []() {})) return;
-    }
-}
-
 // binning over the non-u elements (one pass per level)
 template <typename P>
 __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
@@ -1735,7 +1449,6 @@ __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* i
     // segment changes: the flush is 144 same-address global atomics per workgroup (~5 ns each, serialised per address),
     // which at the top levels - one segment, 8 k items - used to be the floor of the kernel.
     __shared__ int s_bins[144][64];                    // entry = (axis * 8 + bin) * 6 + q; q < 3: min keys, q >= 3: max keys
-    if (ctl->err & ERR_GRIDSYNC) return;
     const unsigned n_items = ctl->n_items;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned cur_seg = kNone;
@@ -1787,7 +1500,7 @@ __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* i
 
 // one wave per segment: 21 costs -> best plane, stale pivot
 __global__ __launch_bounds__(64) void a_eval_kernel(Seg* segs, LevelCtl* ctl, const TriBox* __restrict__ boxes) {
-    if (blockIdx.x >= ctl->n_seg || (ctl->err & ERR_GRIDSYNC)) return;
+    if (blockIdx.x >= ctl->n_seg) return;
     Seg& sg = segs[blockIdx.x];
     const unsigned lane = threadIdx.x;
     vd_u64 key = ~0ull;
@@ -1858,7 +1571,7 @@ __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, Top
                                   unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap, MidRoot* mid, unsigned mid_cap,
                                   unsigned parity /* the set this level's a_child wrote */) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ctl->n_seg || (ctl->err & ERR_GRIDSYNC)) return;
+    if (i >= ctl->n_seg) return;
     const Seg& sg = segs[i];
     for (int c = 0; c < kCand; ++c) is_u_flag[sg.u_pay[c].x] = 0;
     const unsigned pair = atomicAdd(&ctl->n_top, 2u);
@@ -1909,6 +1622,8 @@ struct MidLds {
     u32x2 pay[kMidMax > 0 ? kMidMax : 1];
     unsigned short tpos[kMidMax > 0 ? kMidMax : 1], fpos[kMidMax > 0 ? kMidMax : 1];
     int bin_min[3][8][3], bin_max[3][8][3];
+    int bins16[144][16];                            // accumulation: entry = (axis * 8 + bin) * 6 + q, one copy per lane % 16 (same-
+                                                    // address LDS atomics serialise, and neighbours fall into the same few bins)
     int child_k[24];
     float pos[kCand + 3];
     u32x2 u_pay[kCand + 1];
@@ -2012,7 +1727,7 @@ __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot*
             for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(nd.cbk[k]); cbmax[k] = box_hi(nd.cbk[3 + k]); }
             L.pos[tid] = cand_pos(cbmin, cbmax, (int)tid);
         }
-        if (tid >= 64u && tid < 64u + 72u) { (&L.bin_min[0][0][0])[tid - 64u] = kBig; (&L.bin_max[0][0][0])[tid - 64u] = -kBig - 1; }
+        for (unsigned i2 = tid; i2 < 144u * 16u; i2 += kMidThreads) (&L.bins16[0][0])[i2] = ((i2 >> 4) % 6u) < 3u ? kBig : -kBig - 1;
         if (tid >= 192u && tid < 192u + 24u) L.child_k[tid - 192u] = ((tid - 192u) % 6u) < 3u ? kBig : -kBig - 1;
         __syncthreads();
         // predicate bits of the 21 planes
@@ -2044,11 +1759,21 @@ __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot*
             for (int a = 0; a < 3; ++a) {
                 const int b = 7 - __popc((v.y >> (7 * a)) & 0x7fu);
 #pragma unroll
+                int* row = &L.bins16[(a * 8 + b) * 6][lane & 15u];
+#pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    atomicMin(&L.bin_min[a][b][q], vd_key(bx.mn[q]));
-                    atomicMax(&L.bin_max[a][b][q], vd_key(bx.mx[q]));
+                    atomicMin(row + 16 * q, vd_key(bx.mn[q]));
+                    atomicMax(row + 16 * (3 + q), vd_key(bx.mx[q]));
                 }
             }
+        }
+        __syncthreads();
+        if (tid < 144u) {                              // the 16 copies of an entry -> the [axis][bin][3] arrays eval_candidate reads
+            const bool is_min = (tid % 6u) < 3u;
+            int v = L.bins16[tid][0];
+#pragma unroll
+            for (int k2 = 1; k2 < 16; ++k2) v = is_min ? min(v, L.bins16[tid][k2]) : max(v, L.bins16[tid][k2]);
+            if (is_min) (&L.bin_min[0][0][0])[(tid / 6u) * 3u + tid % 6u] = v; else (&L.bin_max[0][0][0])[(tid / 6u) * 3u + (tid % 6u - 3u)] = v;
         }
         __syncthreads();
         if (wave == 0u) {
@@ -2235,7 +1960,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     // ---- scratch layout ----
     Arena probe{nullptr, 0};
     auto layout = [&](Arena& a, bool) {
-        struct P { u32x2 *pay0, *pay1; f32x4 *cent, *cent1; TriBox *boxes, *boxes1; unsigned *bits21, *ids32; GridBar* bar;
+        struct P { u32x2 *pay0, *pay1; f32x4 *cent, *cent1; TriBox *boxes, *boxes1; unsigned *bits21, *ids32;
                    unsigned *falsepos, *truepos, *final_ids, *stack, *idx_copy;
                    unsigned char* is_u; Seg *seg0, *seg1; MidRoot* mid; unsigned *item_seg, *item_cnt, *item_pre; TopNode* top; SmallRoot* small;
                    unsigned* sub_interior; TmpNode* subnodes; unsigned short* submap; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair; } p;
@@ -2243,7 +1968,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         const size_t pay_words = wide_pay ? T : (T + 1) / 2;
         p.pay0 = a.take<u32x2>(pay_words); p.pay1 = a.take<u32x2>(pay_words);
         p.cent = a.take<f32x4>(T); p.boxes = a.take<TriBox>(T); p.cent1 = a.take<f32x4>(T); p.boxes1 = a.take<TriBox>(T);
-        p.bits21 = a.take<unsigned>(T); p.ids32 = a.take<unsigned>(T); p.bar = a.take<GridBar>(1);
+        p.bits21 = a.take<unsigned>(T); p.ids32 = a.take<unsigned>(T);
         p.falsepos = a.take<unsigned>(T); p.truepos = a.take<unsigned>(T);
         p.final_ids = a.take<unsigned>(T); p.stack = a.take<unsigned>(T); p.idx_copy = a.take<unsigned>(3 * T);
         p.is_u = a.take<unsigned char>(T);
@@ -2275,7 +2000,6 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         VD_HIP_CHECK(ctx, hipMemcpyAsync(P.root_keys, h_keys, sizeof(h_keys), hipMemcpyHostToDevice, st));
         VD_HIP_CHECK(ctx, hipMemsetAsync(P.ctl, 0, sizeof(LevelCtl), st));
         VD_HIP_CHECK(ctx, hipMemsetAsync(P.is_u, 0, T, st));
-        VD_HIP_CHECK(ctx, hipMemsetAsync(P.bar, 0, sizeof(GridBar), st));
         VD_HIP_CHECK(ctx, hipMemcpyAsync(P.idx_copy, d_idx, 3 * T * 4, hipMemcpyDeviceToDevice, st));
     }
     const unsigned tri_blocks = (unsigned)((T + 255) / 256);
@@ -2294,17 +2018,6 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     int levels = 0;
     stats.kernel_launches = 2;
     lap(stats.ms_precompute);
-    // the rounds of a level as one persistent kernel (a_rounds_kernel) unless this context has seen its grid barrier time
-    // out, or the option says otherwise; co-resident workgroups = what the occupancy query promises on this device
-    bool persistent = !ctx->blas_four_kernel_rounds && ctx->option(VD_OPT_BLAS_PERSISTENT_ROUNDS, 1) != 0;
-    unsigned rounds_wgs = 0, bar_gen = 0;
-    if (persistent) {
-        int occ = 0;
-        const void* fn = wide_pay ? reinterpret_cast<const void*>(a_rounds_kernel<Pay8>) : reinterpret_cast<const void*>(a_rounds_kernel<Pay4>);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, 0) != hipSuccess || occ < 1) persistent = false;
-        else rounds_wgs = (unsigned)ctx->num_cus * (unsigned)(occ > 8 ? 8 : occ);
-        if (rounds_wgs > 4096u) rounds_wgs = 4096u;       // GridBar: 64 groups of 64
-    }
     // one level of phase A; PayT = Pay4 / Pay8 (see there)
     auto run_level = [&](auto pay_tag, unsigned n_seg_now, Seg* seg_cur, Seg* seg_next, int level) {
         using PayT = decltype(pay_tag);
@@ -2319,19 +2032,6 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         hipLaunchKernelGGL(a_planes_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, P.ctl);
         PT* src = reinterpret_cast<PT*>(P.pay0); PT* dst = reinterpret_cast<PT*>(P.pay1);
         hipLaunchKernelGGL((a_bits_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.cent, P.bits21);
-        if (persistent) {
-            const unsigned n_wg = rounds_wgs < items_ub ? rounds_wgs : items_ub;
-            // rounds 0..20 (three barriers each, none after the last), the binning + evaluation, then the final shuffle
-            hipLaunchKernelGGL((a_rounds_kernel<PayT>), dim3(n_wg), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, 0, kCand, P.item_cnt, P.item_pre,
-                               P.falsepos, P.truepos, P.is_u, P.bits21, P.bar, bar_gen);
-            bar_gen += 3u * kCand - 1u;
-            hipLaunchKernelGGL((a_bin_kernel<PayT>), dim3((items_ub + kBinItems - 1) / kBinItems), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, dst, cur.boxes,
-                               P.is_u, P.bits21);          // 21 rounds: the arrangement is in the other buffer
-            hipLaunchKernelGGL(a_eval_kernel, dim3(n_seg_now), dim3(64), 0, st, seg_cur, P.ctl, cur.boxes);
-            hipLaunchKernelGGL((a_rounds_kernel<PayT>), dim3(n_wg), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, kCand, kCand + 1, P.item_cnt, P.item_pre,
-                               P.falsepos, P.truepos, P.is_u, P.bits21, P.bar, bar_gen);
-            bar_gen += 2u;
-        } else
         for (int c = 0; c <= kCand; ++c) {
             const int cc = c < kCand ? c : -1;       // -1: final re-shuffle with each segment's best plane
             if (c == kCand) {
@@ -2359,18 +2059,12 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         if (wide_pay) run_level(Pay8{}, n_seg, seg_cur, seg_next, levels); else run_level(Pay4{}, n_seg, seg_cur, seg_next, levels);
         VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
         VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        if (h_ctl.err & ERR_GRIDSYNC) {
-            // a grid barrier of the persistent rounds kernel expired (its workgroups were not all resident?): nothing of this
-            // build is kept - d_idx is untouched until the final permute - and it is redone with the four-kernel rounds
-            ctx->blas_four_kernel_rounds = true;
-            return bvh_build_dev_impl(ctx, d_verts, n_vert, d_idx, n_tri, d_out, node_cap, out_n_nodes);
-        }
         if (h_ctl.err & ERR_DEGENERATE)
             VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
         if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
         n_seg = h_ctl.n_seg;
         Seg* t = seg_cur; seg_cur = seg_next; seg_next = t;
-        stats.kernel_launches += persistent ? 13 : 9 + 4 * (kCand + 1);
+        stats.kernel_launches += 9 + 4 * (kCand + 1);
         if (++levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
     }
     stats.levels_phase_a = (uint32_t)levels;
