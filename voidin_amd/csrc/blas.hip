@@ -1758,7 +1758,6 @@ __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot*
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const int b = 7 - __popc((v.y >> (7 * a)) & 0x7fu);
-#pragma unroll
                 int* row = &L.bins16[(a * 8 + b) * 6][lane & 15u];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
