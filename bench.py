@@ -782,16 +782,26 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
     ds = ctx.device_scene(scene_host)
     d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
     d_any = torch.zeros(len(rays), dtype=torch.int32, device=dev)
+    # per-scene preparation (vd_trace_prepare_dev: de-indexed leaf triangles); the timed calls are the prepared ones, the
+    # plain entry points are timed beside them and must give the same bytes
+    acc = ctx.trace_prepare(ds)
     ctx.set_timing(True)
-    t_cl, t_any = [], []
+    t_cl, t_any, t_cl0, t_any0 = [], [], [], []
     for _ in range(3):
-        ctx.trace_dev(ds, d_rays, len(rays), d_hits); t_cl.append(ctx.last_gpu_ms())
-        ctx.trace_any_dev(ds, d_rays, len(rays), d_any); t_any.append(ctx.last_gpu_ms())
+        ctx.trace_dev(ds, d_rays, len(rays), d_hits); t_cl0.append(ctx.last_gpu_ms())
+        ctx.trace_any_dev(ds, d_rays, len(rays), d_any); t_any0.append(ctx.last_gpu_ms())
+    plain_bytes = (d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes())
+    for _ in range(3):
+        ctx.trace_prepared_dev(acc, d_rays, len(rays), d_hits); t_cl.append(ctx.last_gpu_ms())
+        ctx.trace_any_prepared_dev(acc, d_rays, len(rays), d_any); t_any.append(ctx.last_gpu_ms())
     ctx.set_timing(False)
     hits = d_hits.cpu().numpy()[: len(rays) * 16].view(abi.HIT)
     extra["trace"] = {"n_rays": len(rays), "scene": "2000 instances x 131k-triangle mesh",
                       "closest_hit_Mrays_per_s": round(len(rays) / min(t_cl) / 1e3, 1),
                       "occlusion_Mrays_per_s": round(len(rays) / min(t_any) / 1e3, 1),
+                      "without_vd_trace_prepare": {"closest_hit_Mrays_per_s": round(len(rays) / min(t_cl0) / 1e3, 1),
+                                                   "occlusion_Mrays_per_s": round(len(rays) / min(t_any0) / 1e3, 1),
+                                                   "same_bytes_as_prepared": bool(plain_bytes == (d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes()))},
                       "hit_fraction": round(float(hits["hit"].mean()), 3),
                       "occlusion_flags_equal_closest_hit": bool(np.array_equal(d_any.cpu().numpy().astype(np.uint32), hits["hit"]))}
     if not args.no_cpu_baseline:
@@ -808,6 +818,7 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
                                           "sample": f"every 4th ray of the same batch on {threads} threads ({len(sN)} rays), every 64th on 1 thread "
                                                     f"({len(s1)} rays), oracle vd_ref_trace",
                                           "gpu_equals_oracle_on_sample_hit_flags_and_dist_1e-5": ok}
+    acc.close()
     del ds, d_rays, d_hits, d_any
     # the reference's own harness shape (src/bin/bvh_gpu.rs:107-131): one large mesh + four small ones, 4 M primary rays
     inst2, infos2, B2, V2, I2 = synth.harness_scene(ctx.bvh_build)
@@ -815,15 +826,17 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
     rays2 = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 15), pitch_deg=0), 2048, 2048)
     ds2 = ctx.device_scene((tl2, inst2, infos2, B2, V2, I2))
     d_r2, d_h2 = ctx.upload(rays2), ctx.empty(len(rays2) * 16)
+    acc2 = ctx.trace_prepare(ds2)
     ctx.set_timing(True)
     t2 = []
     for _ in range(3):
-        ctx.trace_dev(ds2, d_r2, len(rays2), d_h2); t2.append(ctx.last_gpu_ms())
+        ctx.trace_prepared_dev(acc2, d_r2, len(rays2), d_h2); t2.append(ctx.last_gpu_ms())
     ctx.set_timing(False)
     h2 = d_h2.cpu().numpy()[: len(rays2) * 16].view(abi.HIT)
     extra["trace_harness_scene"] = {"n_rays": len(rays2), "scene": f"bvh_gpu.rs shape: {len(I2)//3} triangles, 5 instances",
                                     "closest_hit_Mrays_per_s": round(len(rays2) / min(t2) / 1e3, 1),
                                     "hit_fraction": round(float(h2["hit"].mean()), 3)}
+    acc2.close()
     del ds2, d_r2, d_h2
     # the CPU harness (src/bin/bvh_cpu.rs:39-96): per-pixel rays + Bvh::traverse_iter against ONE mesh, on the device;
     # the harness's own 64-triangle soup at 640 x 640, and the large mesh of the scene above at 2048 x 2048
@@ -845,6 +858,16 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
             ctx.traverse_iter_dev(d_nn, len(nn), d_vv, d_ix, d_pr, w * w, d_td); tt.append(ctx.last_gpu_ms())
         ctx.set_timing(False)
         res[tag] = {"Mrays_per_s": round(w * w / min(tt) / 1e3, 1), "hit_fraction": round(float((d_td >= 0).float().mean()), 3)}
+        # the recursive Bvh::traverse (blas.rs:211-245) on the same rays; where traverse_iter hits, the same distance
+        d_tr = torch.zeros(w * w, dtype=torch.float32, device=dev)
+        ctx.set_timing(True)
+        tr = []
+        for _ in range(3):
+            ctx.traverse_dev(d_nn, len(nn), d_vv, d_ix, d_pr, w * w, d_tr); tr.append(ctx.last_gpu_ms())
+        ctx.set_timing(False)
+        hit_it = d_td >= 0
+        res[tag]["recursive_traverse_Mrays_per_s"] = round(w * w / min(tr) / 1e3, 1)
+        res[tag]["recursive_equals_iter_where_it_hits"] = bool(torch.equal(d_tr[hit_it], d_td[hit_it]))
     extra["traverse_iter_cpu_harness"] = res
     # EXTENSION, no reference counterpart: depth pyramid of a 1920 x 1080 buffer + occlusion refinement
     # of the frustum mask of the headline's 10 M instances (a synthetic depth buffer: half the screen covered)
