@@ -96,6 +96,7 @@ int vd_ctx_destroy(VdCtx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scan_state) (void)hipFree(ctx->scan_state);
     if (ctx->expand_state) (void)hipFree(ctx->expand_state);
+    if (ctx->refit_state) (void)hipFree(ctx->refit_state);
     if (ctx->stage_in) (void)hipFree(ctx->stage_in);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
     if (ctx->stage_aux) (void)hipFree(ctx->stage_aux);

@@ -1067,22 +1067,39 @@ __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_ke
 // the number of memory-side round trips per level.
 // Launch 1: thread i < n recomputes leaf i+1; the same thread records, for the two children of interior node n+1+i,
 // {parent, sibling} and clears the node's handshake word.
+// Links live in a refit-only arena of the context that is zeroed when allocated and tagged per launch: an entry
+// {parent, sibling, epoch} counts only when its epoch is this launch's, so a node nobody links - the top of a chain -
+// is recognised without clearing anything between launches.  (The reference's chain DROPS a cluster whose unions all
+// reach 1e30 - an infinite leaf box: find_best_match answers the target itself, tlas.rs:88-104, the cluster is merged with
+// itself into a node nothing refers to and its slot goes to the last cluster, tlas.rs:62-79 - so tops other than node 2n
+// exist, and node 0 - a COPY of the node the chain ended on, tlas.rs:84 - is not always a copy of node 2n.)
+struct RefitRoot { unsigned node, epoch; };        // the interior node whose payload node 0 copies, found by the prep pass
 template <typename Node>
 __global__ __launch_bounds__(256) void tlas_refit_prep_kernel(const VdInstance* __restrict__ inst, unsigned n,
                                                               const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
-                                                              Node* __restrict__ nodes, uint2* __restrict__ up,
-                                                              unsigned* __restrict__ arrivals) {
+                                                              Node* __restrict__ nodes, uint4* __restrict__ up,
+                                                              unsigned* __restrict__ arrivals, RefitRoot* __restrict__ root, unsigned epoch) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const Box b = leaf_box(inst, meshes, n_mesh, nodes[i + 1].instance_idx);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { nodes[i + 1].min[c] = b.mn[c]; nodes[i + 1].max[c] = b.mx[c]; }
     const unsigned k = n + 1u + i;
-    unsigned l, r;
+    unsigned l, r, l0, r0;
     node_get_children(nodes[k], l, r);
-    up[l] = make_uint2(k, r);
-    up[r] = make_uint2(k, l);
+    node_get_children(nodes[0], l0, r0);
+    up[l] = make_uint4(k, r, epoch, 0u);
+    up[r] = make_uint4(k, l, epoch, 0u);
     arrivals[k] = 0u;
+    // node 0's box follows from its OWN payload, which a refit never touches: a leaf copy -> that instance's leaf box;
+    // otherwise the union of its children = the box of the interior node with the same children (node 2n in every
+    // ordinary build): the climber that finishes that node writes node 0 as well
+    if (l0 != 0u || r0 != 0u) { if (l == l0 && r == r0) *root = RefitRoot{k, epoch}; }
+    else if (i == 0u) {
+        const Box b0 = leaf_box(inst, meshes, n_mesh, nodes[0].instance_idx);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { nodes[0].min[c] = b0.mn[c]; nodes[0].max[c] = b0.mx[c]; }
+    }
 }
 
 template <typename Node> __device__ __forceinline__ Box load_box_plain(const Node* nodes, unsigned k) {
@@ -1118,13 +1135,15 @@ __device__ __forceinline__ Box box_union(const Box& a, const Box& b) {
 //    otherwise it publishes and the later of the two "readable" marks goes on (three round trips, as a plain
 //    arrival counter needs every time).  Nobody ever waits for another lane.
 template <typename Node>
-__global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigned n, const uint2* __restrict__ up,
-                                                            unsigned* arrivals) {
+__global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigned n, const uint4* __restrict__ up,
+                                                            unsigned* arrivals, const RefitRoot* __restrict__ root, unsigned epoch) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const unsigned c = i + 1u;
-    const uint2 u0 = up[c];
-    if (u0.y > n || c > u0.y) return;                     // sibling interior: its climber picks this leaf up; or the other leaf's lane
+    const RefitRoot rt = *root;
+    const unsigned root_src = rt.epoch == epoch ? rt.node : 0xffffffffu;
+    const uint4 u0 = up[c];
+    if (u0.z != epoch || u0.y > n || c > u0.y) return;    // no parent; sibling interior: its climber picks this leaf up; or the other leaf's lane
     unsigned k = u0.x;
     Box box = box_union(load_box_plain(nodes, c), load_box_plain(nodes, u0.y));
     for (;;) {
@@ -1133,13 +1152,13 @@ __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigne
             __hip_atomic_store(&nodes[k].min[q], box.mn[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&nodes[k].max[q], box.mx[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const uint2 u = up[k];                            // {parent, sibling}
+        if (k == root_src) {                              // node 0 copies this node's payload: same children, same box
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { nodes[0].min[q] = box.mn[q]; nodes[0].max[q] = box.mx[q]; }
+        }
+        const uint4 u = up[k];                            // {parent, sibling, epoch}
         const unsigned p = u.x, s = u.y;
-        // No parent: the reference's chain DROPS a cluster whose unions all have an area >= 1e30 or NaN (an infinite
-        // leaf box): find_best_match answers the target itself (tlas.rs:88-104), the cluster is merged with itself into
-        // a node nothing refers to, and its slot is given to the last cluster (tlas.rs:62-79).  Such a node is the top
-        // of an orphaned chain; its box has just been written, as the ascending recompute of SURVEY 8a T3 would.
-        if (p == 0xffffffffu) return;
+        if (u.z != epoch) return;                         // nobody linked this node in this launch: the top of a chain (node 2n, or an orphan)
         if (s == k) { k = p; continue; }                  // a cluster merged with itself (node 2n: the true root): same box
         if (s <= n) { box = box_union(box, load_box_plain(nodes, s)); k = p; continue; }
         const unsigned v = __hip_atomic_fetch_add(&arrivals[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1151,22 +1170,6 @@ __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigne
         box = box_union(box, load_box_agent(nodes, s));
         k = p;
     }
-}
-
-// Launch 3 (one lane): node 0.  tlas.rs:84 makes it a COPY of the node the chain ends on - node 2n in every ordinary
-// build, but any node when the chain ended on a stale slot (a cluster with an infinite box is dropped, and the root can
-// even be a single leaf) - so a refit recomputes its box from its OWN payload, like any other node: the leaf box of its
-// instance, or the union of its children's refitted boxes.  Its payload is never touched.
-template <typename Node>
-__global__ void tlas_refit_root_kernel(const VdInstance* __restrict__ inst, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
-                                       Node* __restrict__ nodes) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned l, r;
-    node_get_children(nodes[0], l, r);
-    const Box b = (l == 0u && r == 0u) ? leaf_box(inst, meshes, n_mesh, nodes[0].instance_idx)
-                                       : box_union(load_box_plain(nodes, l), load_box_plain(nodes, r));
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { nodes[0].min[c] = b.mn[c]; nodes[0].max[c] = b.mx[c]; }
 }
 
 template <typename Node>
@@ -1280,17 +1283,22 @@ template <typename Node>
 int tlas_refit_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                     Node* d_nodes) {
     const size_t total = 2 * (size_t)n + 1;
-    const size_t need = total * 12 + 256;
-    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
-    if (rc) return rc;
-    uint2* parent = reinterpret_cast<uint2*>(ctx->scratch);                    // {parent, sibling} per node
+    const size_t need = 256 + total * 16 + total * 4;
+    if (need > ctx->refit_state_bytes || !ctx->refit_state || ctx->refit_epoch == 0xffffffffu) {
+        int rc = vd_ensure(ctx, &ctx->refit_state, &ctx->refit_state_bytes, need);
+        if (rc) return rc;
+        VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->refit_state, 0, ctx->refit_state_bytes, ctx->stream));   // epoch 0 = never written
+        ctx->refit_epoch = 0u;
+    }
+    const unsigned epoch = ++ctx->refit_epoch;
+    char* base = reinterpret_cast<char*>(ctx->refit_state);
+    RefitRoot* root = reinterpret_cast<RefitRoot*>(base);
+    uint4* parent = reinterpret_cast<uint4*>(base + 256);                      // {parent, sibling, epoch} per node
     unsigned* arrivals = reinterpret_cast<unsigned*>(parent + total);
     vd_time_begin(ctx);
-    VD_HIP_CHECK(ctx, hipMemsetAsync(parent, 0xff, total * sizeof(uint2), ctx->stream));      // "no parent" until the prep pass links a node
     hipLaunchKernelGGL((tlas_refit_prep_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes, n_mesh,
-                       d_nodes, parent, arrivals);
-    hipLaunchKernelGGL((tlas_refit_up_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_nodes, n, parent, arrivals);
-    hipLaunchKernelGGL((tlas_refit_root_kernel<Node>), dim3(1), dim3(64), 0, ctx->stream, d_inst, d_meshes, n_mesh, d_nodes);
+                       d_nodes, parent, arrivals, root, epoch);
+    hipLaunchKernelGGL((tlas_refit_up_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_nodes, n, parent, arrivals, root, epoch);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;
