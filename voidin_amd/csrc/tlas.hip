@@ -1145,8 +1145,11 @@ __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigne
     const uint4 u0 = up[c];
     if (u0.z != epoch || u0.y > n || c > u0.y) return;    // no parent; sibling interior: its climber picks this leaf up; or the other leaf's lane
     unsigned k = u0.x;
+    uint4 u = up[k];                                      // {parent, sibling, epoch} of the node being finished
     Box box = box_union(load_box_plain(nodes, c), load_box_plain(nodes, u0.y));
     for (;;) {
+        // stores count in vmcnt on gfx950, and a wait for a load issued after them waits for them too: the loads a level
+        // needs - the next level's link and the sibling's box - are issued together, right after this level's link is in
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             __hip_atomic_store(&nodes[k].min[q], box.mn[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1156,11 +1159,11 @@ __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigne
 #pragma unroll
             for (int q = 0; q < 3; ++q) { nodes[0].min[q] = box.mn[q]; nodes[0].max[q] = box.mx[q]; }
         }
-        const uint4 u = up[k];                            // {parent, sibling, epoch}
-        const unsigned p = u.x, s = u.y;
         if (u.z != epoch) return;                         // nobody linked this node in this launch: the top of a chain (node 2n, or an orphan)
-        if (s == k) { k = p; continue; }                  // a cluster merged with itself (node 2n: the true root): same box
-        if (s <= n) { box = box_union(box, load_box_plain(nodes, s)); k = p; continue; }
+        const unsigned p = u.x, s = u.y;
+        const uint4 un = up[p];                           // the next level's link travels with the sibling's box
+        if (s == k) { k = p; u = un; continue; }          // a cluster merged with itself (node 2n: the true root): same box
+        if (s <= n) { box = box_union(box, load_box_plain(nodes, s)); k = p; u = un; continue; }
         const unsigned v = __hip_atomic_fetch_add(&arrivals[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v != 3u) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my box has reached memory
@@ -1168,7 +1171,7 @@ __global__ __launch_bounds__(256) void tlas_refit_up_kernel(Node* nodes, unsigne
             if (w < 4u) return;                           // the other side is not readable yet: its climber goes on
         }
         box = box_union(box, load_box_agent(nodes, s));
-        k = p;
+        k = p; u = un;
     }
 }
 
