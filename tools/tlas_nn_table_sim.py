@@ -1,8 +1,12 @@
+"""CPU simulation of a nearest-neighbour table for the TLAS chain (tlas.rs:56-105): hit rate against the refresh period,
+every hit checked against the true answer.   python tools/tlas_nn_table_sim.py   (NN_SIM_STORE=0: batches only)"""
 import sys, numpy as np, time
 sys.path.insert(0,'/root/repo')
 from oracle import np_restate as npr
 from voidin_amd import synth
 F=np.float32
+import os
+STORE = os.environ.get('NN_SIM_STORE', '1') != '0'     # 0: the table is filled by the refresh batches only
 def run(n, K, extent):
     meshes=synth.mesh_infos(); inst=synth.instances(n, seed=synth.SEED_BASE+6, extent=extent)
     bmin=np.zeros((2*n+1,3),F); bmax=np.zeros((2*n+1,3),F)
@@ -40,7 +44,7 @@ def run(n, K, extent):
             elif not uniq[x]: stats['miss_tie']+=1
             else: stats['miss_dead']+=1
         k,u=best(cnt,t)
-        if t<cnt: nn[x]=ni[k]; uniq[x]=u
+        if t<cnt and STORE: nn[x]=ni[k]; uniq[x]=u
         return k
     cnt,used,a=n,n+1,0
     batch(cnt); merges=0
@@ -56,6 +60,6 @@ def run(n, K, extent):
             b=cached_best(cnt,a,True)
         else: a,b=b,c
     return stats
-for n,K in ((4096,16),(4096,4),(4096,1)):
+for n,K in ((4096,0),(4096,256),(4096,64),(4096,16),(4096,4)):
     t=time.time(); s=run(n,K,300.0)
     print(n,K,s,"hit rate of non-post-merge queries %.2f"%(s['hit']/max(s['q'],1)), "%.1fs"%(time.time()-t),flush=True)
