@@ -345,8 +345,8 @@ def test_trace_supply_binning_and_prepared_triangles_are_order_only(ctx, oracle,
     d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
     d_any = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
     first = None
-    variants = [dict(sort=0, chunk=64), dict(sort=0), dict(sort_min=1), dict(sort_min=1, chunk=64), dict(sort_min=1, chunk=4096),
-                dict(sort_min=1, chunk=100)]
+    variants = [dict(), dict(chunk=64), dict(sort=1, sort_min=1), dict(sort=1, sort_min=1, chunk=64), dict(sort=1, sort_min=1, chunk=4096),
+                dict(sort=1, sort_min=1, chunk=100), dict(chunk=1000)]     # default: single rays from one counter, no binning
     for opts in variants:
         for k in ("sort", "sort_min", "chunk"):
             ctx_options("trace." + k, opts.get(k))

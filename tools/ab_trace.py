@@ -29,12 +29,11 @@ ds = ctx.device_scene((tl, inst_t, infos, nodes_b, tv, idx_b))
 acc = ctx.trace_prepare(ds)
 d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
 d_any = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
-variants = [("single rays nosort (r2 supply)", dict(sort=0, chunk=1), False), ("single rays nosort prep", dict(sort=0, chunk=1), True),
-            ("single rays sort prep", dict(chunk=1), True),
+variants = [("single rays (default)", dict(sort=0, chunk=1), False), ("single rays prep", dict(sort=0, chunk=1), True),
             ("chunk64 nosort", dict(sort=0, chunk=64), False), ("chunk64 nosort prep", dict(sort=0, chunk=64), True),
-            ("chunk nosort", dict(sort=0), False), ("chunk sort", dict(), False), ("chunk sort prep", dict(), True),
-            ("chunk64 sort prep", dict(chunk=64), True), ("chunk256 sort prep", dict(chunk=256), True),
-            ("chunk128 sort prep", dict(chunk=128), True)]
+             ("chunk64 sort", dict(sort=1, chunk=64), False),
+            ("chunk64 sort prep", dict(sort=1, chunk=64), True), ("chunk256 sort prep", dict(sort=1, chunk=256), True),
+            ("chunk128 sort prep", dict(sort=1, chunk=128), True)]
 ref_bytes = ref_any = None
 ctx.set_timing(True)
 for name, opts, prep in variants:

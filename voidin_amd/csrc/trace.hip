@@ -90,16 +90,20 @@ constexpr unsigned kRefillBelow = 56;   // draw new rays when fewer than this ma
 constexpr unsigned kWavesPerCu = 28;    // persistent grid = what is resident (7 waves per SIMD at 72 VGPRs): no wave starts late
 constexpr int kWgWaves = 7;             // waves per workgroup of the chunked form: 4 workgroups per CU
 // PREP: leaf triangles come de-indexed from Scene::tris (one contiguous fetch instead of indices[] -> verts[]).
-template <bool ANY, bool PREP, int WG_WAVES>
-__global__ __launch_bounds__(64 * WG_WAVES, 7)   // second argument (HIP): waves per SIMD = 28 per CU
-void trace_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
-                  unsigned* __restrict__ overflow) {
+// CHUNKS = false (default): idle lanes draw single rays from one global counter, one wave per workgroup - the round-2
+// form, kept apart so that it carries none of the chunk machinery (inside 7-wave workgroups with the chunk state live
+// the closest-hit walk spilled registers and lost 10 %: 38.5 -> 34.5 Mrays/s, same-session A/B against the round-2 library).
+template <bool ANY, bool PREP, bool CHUNKS>
+__device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restrict__ rays, const RaySource& src, VdHit* __restrict__ out,
+                                           unsigned* __restrict__ out_any, unsigned* __restrict__ overflow) {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned n_rays = src.n_rays;
     __shared__ vd_u64 s_word;              // chunked supply: {next, end} positions of the workgroup's current chunk
     unsigned p_next = 0, p_end = 0;        // a chunk this wave could not publish (another wave's was installed first)
-    if (threadIdx.x == 0) s_word = 0ull;
-    __syncthreads();
+    if (CHUNKS) {
+        if (threadIdx.x == 0) s_word = 0ull;
+        __syncthreads();
+    }
     unsigned stack[2 * kStack];            // BLAS entries sit above the TLAS entries of the same ray
     Ray world, ray;                        // `ray` is the active one (object space inside an instance)
     VdHit res;
@@ -128,13 +132,14 @@ void trace_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit*
             const unsigned long long idle = ~busy_mask;
             const unsigned want = (unsigned)__popcll(idle);
             unsigned base = 0, got = 0, done = 0;
-            {
+            if (!CHUNKS) {                                          // single rays from one global counter: the finest balance
+                if (lane == 0) base = atomicAdd(src.next_chunk, want);
+                base = __shfl(base, 0);
+                got = want;                                         // ids are checked against n_rays below (limit)
+                done = base + want >= n_rays ? 1u : 0u;
+            } else {
                 if (lane == 0) {
-                    if (src.chunk == 1u) {                              // single rays from one global counter: the finest balance
-                        base = atomicAdd(src.next_chunk, want);
-                        got = base < n_rays ? min(want, n_rays - base) : 0u;
-                        done = base + want >= n_rays ? 1u : 0u;
-                    } else if (p_next < p_end) { got = min(want, p_end - p_next); base = p_next; p_next += got; }
+                    if (p_next < p_end) { got = min(want, p_end - p_next); base = p_next; p_next += got; }
                     else for (;;) {
                         const vd_u64 old = __hip_atomic_load(&s_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         const unsigned nx = (unsigned)old, en = (unsigned)(old >> 32);
@@ -157,10 +162,15 @@ void trace_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit*
                 }
                 base = __shfl(base, 0); got = __shfl(got, 0); done = __shfl(done, 0);
             }
+            // the position drawn is checked against an explicit upper limit (`pos < limit`), never through a difference: written as
+            // `got = base < n_rays ? min(want, n_rays - base) : 0; if (k < got)` the one-wave kernel was compiled WITHOUT the
+            // `base < n_rays` guard (v_sub_u32 + v_min_u32, no clamp, no select: profiles/r03_trace_guard_isa.txt) and every
+            // draw past the end took `want` rays from beyond the array
+            const unsigned limit = CHUNKS ? base + got : n_rays;
             if (!busy) {
-                const unsigned k = vd_mbcnt(idle);
-                if (k < got) {
-                    const unsigned id = src.order ? src.order[base + k] : base + k;
+                const unsigned pos = base + vd_mbcnt(idle);
+                if (pos < limit && pos >= base) {
+                    const unsigned id = src.order ? src.order[pos] : pos;
                     const float4 a = reinterpret_cast<const float4*>(rays + id)[0], b = reinterpret_cast<const float4*>(rays + id)[1];
                     world.ex = a.x; world.ey = a.y; world.ez = a.z; world.dx = b.x; world.dy = b.y; world.dz = b.z;
                     world.ix = 1.0f / world.dx; world.iy = 1.0f / world.dy; world.iz = 1.0f / world.dz;   // ray_new: inv_dir = 1. / dir
@@ -253,6 +263,36 @@ void trace_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit*
     }
     if (ovf) atomicOr(overflow, 1u);
     if (bad_leaf) atomicOr(overflow, 2u);
+}
+
+// Entry points.  The single-ray form keeps the round-2 kernel's argument list (the six scene buffers, rays, count, outputs,
+// counter; + the triangle array when prepared): with the scene / supply structs of the chunked form as its arguments
+// (128 bytes of kernel arguments instead of 104) the one-wave-per-workgroup kernel faulted on this toolchain as soon as
+// more than ~100 k rays were in flight - same source, same ISA shape, only the argument block differs - while the
+// 7-wave workgroups of the chunked form run with the larger block.  Not understood; avoided.
+struct SceneArgs { const VdTlasNode* tlas; const VdInstance* inst; const VdMeshInfo* meshes; const VdBvhNode* bvh;
+                   const float* verts; const unsigned* indices; unsigned n_meshes; };
+template <bool ANY>
+__global__ __launch_bounds__(64, 7)   // second argument (HIP): waves per SIMD = 28 per CU
+void trace_single_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
+                         unsigned* __restrict__ overflow, unsigned* next_ray) {
+    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, nullptr};
+    const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray};
+    trace_body<ANY, false, false>(s, rays, src, out, out_any, overflow);
+}
+template <bool ANY>
+__global__ __launch_bounds__(64, 7)
+void trace_single_prep_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
+                              unsigned* __restrict__ overflow, unsigned* next_ray, const float* __restrict__ tris) {
+    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, tris};
+    const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray};
+    trace_body<ANY, true, false>(s, rays, src, out, out_any, overflow);
+}
+template <bool ANY, bool PREP>
+__global__ __launch_bounds__(64 * kWgWaves, 7)
+void trace_chunk_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
+                        unsigned* __restrict__ overflow) {
+    trace_body<ANY, PREP, true>(s, rays, src, out, out_any, overflow);
 }
 
 // Shadow rays of the reference's deferred pass (src/bin/raytraced_shadows.wgsl:97): origin = pos + nor * 0.0001,
@@ -583,18 +623,29 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);      // after sort_rays: the scratch may have grown
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 16, ctx->stream));
     {
-        // Default: single rays from one global counter (chunk = 1) - the finest balance.  Chunks of consecutive rays per
-        // workgroup (a CU-local window of the ray order) lose more to imbalance than they gain in locality: 64 rays per
-        // chunk 32.6, 256 rays 16.9 Mrays/s against 35.2 (same log).
-        const unsigned groups = (unsigned)ctx->num_cus * (kWavesPerCu / kWgWaves);
+        // Default: single rays from one global counter (chunk = 1), one wave per workgroup - the finest balance.  Chunks of
+        // consecutive rays per workgroup (a CU-local window of the ray order) lose more to imbalance than they gain in
+        // locality: 64 rays per chunk 32.6, 256 rays 16.9 Mrays/s against 35.2 in the same kernel (same log).
         unsigned chunk = (unsigned)ctx->option(VD_OPT_TRACE_CHUNK, 1);
-        if (chunk == 0u) chunk = 1u;
-        if (chunk != 1u) chunk = (chunk + 63u) & ~63u;     // 1: single rays from the global counter (no chunks)
-        const RaySource src{order, n_rays, chunk, (n_rays + chunk - 1u) / chunk, d_flag + 1};
-#define VD_TRACE_C(A, P) hipLaunchKernelGGL((trace_kernel<A, P, kWgWaves>), dim3(groups), dim3(64 * kWgWaves), 0, ctx->stream, s, d_rays, src, d_out, d_any, d_flag)
-        if (d_any) { if (d_tris) VD_TRACE_C(true, true); else VD_TRACE_C(true, false); }
-        else { if (d_tris) VD_TRACE_C(false, true); else VD_TRACE_C(false, false); }
+        if (chunk <= 1u && !order) {
+            const SceneArgs a{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes};
+            const unsigned waves = (unsigned)ctx->num_cus * kWavesPerCu;
+            if (d_tris) {
+                if (d_any) hipLaunchKernelGGL(trace_single_prep_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, d_tris);
+                else hipLaunchKernelGGL(trace_single_prep_kernel<false>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, d_tris);
+            } else {
+                if (d_any) hipLaunchKernelGGL(trace_single_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1);
+                else hipLaunchKernelGGL(trace_single_kernel<false>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1);
+            }
+        } else {
+            const unsigned groups = (unsigned)ctx->num_cus * (kWavesPerCu / kWgWaves);
+            chunk = chunk <= 1u ? 64u : ((chunk + 63u) & ~63u);      // binned rays are handed out in chunks (of 64 at least)
+            const RaySource src{order, n_rays, chunk, (n_rays + chunk - 1u) / chunk, d_flag + 1};
+#define VD_TRACE_C(A, P) hipLaunchKernelGGL((trace_chunk_kernel<A, P>), dim3(groups), dim3(64 * kWgWaves), 0, ctx->stream, s, d_rays, src, d_out, d_any, d_flag)
+            if (d_any) { if (d_tris) VD_TRACE_C(true, true); else VD_TRACE_C(true, false); }
+            else { if (d_tris) VD_TRACE_C(false, true); else VD_TRACE_C(false, false); }
 #undef VD_TRACE_C
+        }
     }
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
