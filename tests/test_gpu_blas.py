@@ -138,6 +138,29 @@ def test_generated_nan_centroids_agree_with_oracle(ctx, oracle):
         assert e.value.code == abi.VD_ERR_DEGENERATE
 
 
+def test_signalling_nan_vertices_agree_with_oracle(ctx, oracle):
+    """A SIGNALLING NaN (0x7fa00000) is a NaN to `a != a` on the CPU and must be one to the device's v_min_f32 / v_max_f32
+    too (the compiler canonicalises the operands first: in IEEE mode the bare instruction would quiet and RETURN it):
+    ignored by every box, false in every `<`, both sign bits."""
+    v, i = synth.triangle_soup(900, seed=79)
+    v = v.copy()
+    bits = v.view(np.uint32)
+    bits[7, 0] = 0x7FA00000; bits[55, 2] = 0xFFA00001; bits[300, 1] = 0x7F800001
+    assert np.isnan(v).sum() == 3
+    want_nodes, want_idx = oracle.bvh_build(v, i)
+    nodes, idx = ctx.bvh_build(v, i)
+    assert fields_equal(nodes, want_nodes), diff_report(nodes, want_nodes)
+    assert np.array_equal(idx, want_idx)
+    assert not np.isnan(nodes["min"]).any() and not np.isnan(nodes["max"]).any()
+    meshes = synth.mesh_infos()
+    inst = synth.instances(500, seed=synth.SEED_BASE + 61, extent=80.0)
+    t = inst["transform"].view(np.uint32)
+    t[17, 12] = 0x7FA00000; t[200, 0] = 0xFFA00000; t[333, 9] = 0x7F800001
+    got, want = ctx.tlas_build(inst, meshes), oracle.tlas_build(inst, meshes)
+    assert fields_equal(got, want)
+    assert ctx.tlas_refit(inst, meshes, got).tobytes() == oracle.tlas_refit(inst, meshes, want).tobytes() == want.tobytes()
+
+
 def test_builder_api_permutes_callers_indices(ctx):
     # BvhBuilder::new(&[Vec3], &mut [UVec3]).build() -> Bvh{nodes}; caller's slice permuted (blas.rs:95-100)
     g = golden("blas_soup64.npz")

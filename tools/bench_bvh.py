@@ -99,6 +99,25 @@ for r in range(3):
 assert rc == 0 and np.array_equal(d_any.cpu().numpy().astype(np.uint32), hits["hit"])
 print(f"trace_any (occlusion): {dta*1e3:.2f} ms = {len(rays)/dta/1e6:.1f} Mrays/s (flags equal vd_trace's)", flush=True)
 
+# the same scene behind vd_trace_prepare_dev (de-indexed leaf triangles; results must not change)
+ds_t = ctx.device_scene(scene_np)
+acc = ctx.trace_prepare(ds_t)
+d_hits_p = ctx.empty(len(rays) * 16)
+for r in range(3):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    ctx.trace_prepared_dev(acc, d_rays, len(rays), d_hits_p)
+    torch.cuda.synchronize(); dtp = time.perf_counter() - t
+assert np.array_equal(d_hits_p.cpu().numpy()[: len(rays) * 16], d_hits.cpu().numpy()[: len(rays) * 16])
+d_any_p = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
+for r in range(3):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    ctx.trace_any_prepared_dev(acc, d_rays, len(rays), d_any_p)
+    torch.cuda.synchronize(); dtap = time.perf_counter() - t
+assert torch.equal(d_any_p, d_any)
+print(f"trace, prepared leaves: {dtp*1e3:.2f} ms = {len(rays)/dtp/1e6:.1f} Mrays/s (hits bit-equal); "
+      f"occlusion {dtap*1e3:.2f} ms = {len(rays)/dtap/1e6:.1f} Mrays/s (flags equal)", flush=True)
+acc.close()
+
 # ---- the reference's own harness shape (src/bin/bvh_gpu.rs:107-131, camera at (0, 2.5, 15): bvh_gpu.rs:221) ----
 inst2, infos2, B, V, I = synth.harness_scene(ctx.bvh_build)
 tl2 = ctx.tlas_build(inst2, infos2)

@@ -16,15 +16,19 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in glob.glob('gpurun_out/prof_trace_l2/p*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if 'trace_kernel' in r['Kernel_Name']:
-            kind = 'occlusion' if 'Lb1E' in r['Kernel_Name'] or '<true>' in r['Kernel_Name'] else 'closest'
-            agg[(kind, r['Counter_Name'])].append(float(r['Counter_Value']))
-print('# rocprofv3 --pmc, one group per pass; per launch of trace_kernel (3 stress-scene launches then 3 harness-scene launches per kind are')
-print('# averaged separately below: the first three launches of a kind are the 1 M-ray stress scene, the rest the 4 M-ray harness scene)')
+        n = r['Kernel_Name']
+        if 'trace_single' in n or 'trace_chunk' in n:
+            kind = 'occlusion' if 'Lb1E' in n or '<true' in n else 'closest'
+            leaf = 'prepared' if '_prep' in n else 'indexed'
+            agg[(leaf, kind, r['Counter_Name'])].append(float(r['Counter_Value']))
+print('# rocprofv3 --pmc, one group per pass; per launch of the traversal kernel (trace_single_kernel / trace_single_prep_kernel).')
+print('# indexed: the first three launches of a kind are the 1 M-ray stress scene, the rest the 4 M-ray harness scene; prepared: stress scene only.')
+print('# per ray = the stress mean / 1 048 576 rays.')
 for k in sorted(agg):
     v = agg[k]
     a, b = v[:3], v[3:]
-    print(k[0], k[1], 'stress mean %.5g' % (sum(a) / len(a)), ('harness mean %.5g' % (sum(b) / len(b))) if b else '')
+    print(k[0], k[1], k[2], 'stress mean %.5g (%.4g per ray)' % (sum(a) / len(a), sum(a) / len(a) / 1048576.0),
+          ('harness mean %.5g' % (sum(b) / len(b))) if b else '')
 PY
 cat gpurun_out/round/${R}_trace_l2.txt
 for p in $O/p*.log; do grep -h "error\|Error" $p | head -2; done
