@@ -140,13 +140,13 @@ def test_generated_nan_centroids_agree_with_oracle(ctx, oracle):
 
 def test_signalling_nan_vertices_agree_with_oracle(ctx, oracle):
     """A SIGNALLING NaN (0x7fa00000) is a NaN to `a != a` on the CPU and must be one to the device's v_min_f32 / v_max_f32
-    too (the compiler canonicalises the operands first: in IEEE mode the bare instruction would quiet and RETURN it):
-    ignored by every box, false in every `<`, both sign bits."""
+    too: in IEEE mode the bare instruction quiets and RETURNS it (a NaN box; found by this test at vertex 55), so the
+    precompute pass quiets vertex coordinates as it loads them: ignored by every box, false in every `<`, both sign bits."""
     v, i = synth.triangle_soup(900, seed=79)
     v = v.copy()
     bits = v.view(np.uint32)
-    bits[7, 0] = 0x7FA00000; bits[55, 2] = 0xFFA00001; bits[300, 1] = 0x7F800001
-    assert np.isnan(v).sum() == 3
+    bits[7, 0] = 0x7FA00000; bits[55, 2] = 0xFFA00001; bits[300, 1] = 0x7F800001; bits[601, 2] = 0x7FA00001; bits[1202, 0] = 0xFF800001
+    assert np.isnan(v).sum() == 5
     want_nodes, want_idx = oracle.bvh_build(v, i)
     nodes, idx = ctx.bvh_build(v, i)
     assert fields_equal(nodes, want_nodes), diff_report(nodes, want_nodes)

@@ -43,6 +43,14 @@ for k,(i0,i1) in enumerate(zip(lv,ends_a)):
         d[key]+=t
     nxt=int(seq[lv[k+1]]['Start_Timestamp']) if k+1<len(lv) else int(seq[i1+1]['Start_Timestamp'])
     print(f"{k:5d} {span_l:8.3f} {sum(d.values()):7.3f}  {d['round']:8.3f} {d['bits']:12.3f} {d['bin']:8.3f} {d['child']:7.3f} {d['big']:9.3f} {d['other']:10.3f}   gap to next level {(nxt-int(part[-1]['End_Timestamp']))/1e3:.1f} us")
+# the round kernels by round index (levels 0..11, all triangles active): where inside a level the time goes
+for kn in ('a_count','a_scan_kernel','a_ranks','a_apply'):
+    per=collections.defaultdict(list)
+    for k,(i0,i1) in enumerate(zip(lv,ends_a)):
+        if k>11: break
+        calls=[r for r in seq[i0:i1+1] if kn in r['Kernel_Name']]
+        for c,r in enumerate(calls): per[c].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
+    if per: print(f"{kn:14s} us by call within the level:", ' '.join(f"{sum(v)/len(v):.1f}" for c,v in sorted(per.items())))
 big=[(g,seq[i]['Kernel_Name'][:40],seq[i+1]['Kernel_Name'][:40]) for i,g in enumerate(gaps) if g>30000]
 print("gaps > 30 us:",len(big), "sum %.2f ms"%(sum(b[0] for b in big)/1e6))
 for b in sorted(big, reverse=True)[:10]: print("  %.1f us after %s before %s"%(b[0]/1e3,b[1],b[2]))

@@ -157,12 +157,13 @@ __global__ __launch_bounds__(256) void blas_precompute_kernel(const float* __res
         TriBox bx; float ce[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            ce[k] = ((a[k] + b[k]) + c[k]) / 3.0f;          // blas.rs:80
+            const float ak = vd_quiet(a[k]), bk = vd_quiet(b[k]), ck = vd_quiet(c[k]);   // a signalling NaN becomes a quiet one
+            ce[k] = ((ak + bk) + ck) / 3.0f;                // blas.rs:80
             // the fold of blas.rs:184-204 starts from +-MAX_DIST and f32::min / max ignore a NaN vertex: a stored box
             // is the seeded fold over its own three vertices - never NaN - and min(1e30, .) is idempotent, so node
             // boxes reduced from these (box_lo / box_hi) equal the reference's fold over all vertices of the node
-            bx.mn[k] = vd_min_to(vd_min_to(vd_min_to(1e30f, a[k]), b[k]), c[k]);
-            bx.mx[k] = vd_max_to(vd_max_to(vd_max_to(-1e30f, a[k]), b[k]), c[k]);
+            bx.mn[k] = vd_min_to(vd_min_to(vd_min_to(1e30f, ak), bk), ck);
+            bx.mx[k] = vd_max_to(vd_max_to(vd_max_to(-1e30f, ak), bk), ck);
             k12[k] = min(k12[k], vd_key(bx.mn[k]));
             k12[3 + k] = max(k12[3 + k], vd_key(bx.mx[k]));
             k12[6 + k] = min(k12[6 + k], vd_key_lo(ce[k]));     // a NaN centroid (NaN vertex) drops out of `cb`
@@ -1202,12 +1203,15 @@ __device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_s
 template <typename P>
 __global__ __launch_bounds__(256) void a_bits_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                      typename P::T* __restrict__ pay, const f32x4* __restrict__ cent,
-                                                     unsigned* __restrict__ bits21) {
+                                                     unsigned* __restrict__ bits21, unsigned* __restrict__ item_cnt) {
     __shared__ float s_pos[kCand + 3];
+    __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     if (threadIdx.x < (unsigned)kCand) s_pos[threadIdx.x] = sg->pos[threadIdx.x];
+    if (threadIdx.x < 4u) s_w[threadIdx.x] = 0u;
     __syncthreads();
+    unsigned t0 = 0;        // trues of round 0 in this wave (lane 0 runs every iteration of its wave)
     for (unsigned x = threadIdx.x; x < ic.n_here; x += 256u) {
         const unsigned a = sg->start + ic.rel0 + x;
         const f32x4 c = cent[a];
@@ -1220,7 +1224,11 @@ __global__ __launch_bounds__(256) void a_bits_kernel(const Seg* segs, const unsi
         }
         bits21[a] = bits;
         pay[a] = P::make(a, bits, 0u);
+        t0 += (unsigned)__popcll(__ballot((bits & 1u) != 0u));
     }
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = t0;
+    __syncthreads();
+    if (threadIdx.x == 0) item_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];   // what a_count would find in round 0
 }
 
 __global__ void a_planes_kernel(Seg* segs, const LevelCtl* ctl) {
@@ -1340,10 +1348,12 @@ __global__ __launch_bounds__(1024) void a_scan_kernel(Seg* segs, const LevelCtl*
 template <typename P>
 __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                       const typename P::T* __restrict__ pay, int c, const unsigned* item_pre,
-                                                      unsigned* __restrict__ falsepos, unsigned* __restrict__ truepos) {
+                                                      unsigned* __restrict__ falsepos, unsigned* __restrict__ truepos,
+                                                      unsigned* __restrict__ cnt_next) {
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
+    if (cnt_next && threadIdx.x == 0) cnt_next[blockIdx.x] = 0u;      // a_apply of this round adds the next round's trues up in it
     const Window win = round_window(sg, c >= 0 ? c : kCand);
     if (ic.rel0 + ic.n_here <= win.act) return;             // wholly frozen
     unsigned long long masks[kPer]; typename P::T vals[kPer];
@@ -1372,27 +1382,93 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
     }
 }
 
-// round step 4: destinations, scatter, `u`
-template <typename P>
+// Counting into the items elements land in.  Landing positions are monotone along a wave within each of an element's
+// four classes, so a wave makes a handful of runs of lanes with the same item; a run's head adds the run to a small
+// tagged table in LDS (16 slots, item & 15; a slot already taken by another item sends the run straight to memory),
+// and the workgroup flushes the table with one device-scope atomic per slot: ~5 per workgroup instead of ~50 - the
+// counters of a level are 256 cache lines that every XCD adds to, and such atomics are resolved memory-side.
+#ifndef VD_LAND_LDS
+#define VD_LAND_LDS 1
+#endif
+struct LandTable { unsigned tag[16], val[16]; };
+__device__ __forceinline__ void land_init(LandTable& t) {
+    if (threadIdx.x < 16u) { t.tag[threadIdx.x] = 0xffffffffu; t.val[threadIdx.x] = 0u; }
+}
+__device__ __forceinline__ void land_add(LandTable& t, unsigned item, unsigned n, unsigned* __restrict__ cnt) {
+#if VD_LAND_LDS
+    const unsigned slot = item & 15u;
+    const unsigned old = atomicCAS(&t.tag[slot], 0xffffffffu, item);
+    if (old == 0xffffffffu || old == item) atomicAdd(&t.val[slot], n);
+    else
+#endif
+    __hip_atomic_fetch_add(cnt + item, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void land_flush(LandTable& t, unsigned* __restrict__ cnt) {   // after a barrier
+    if (threadIdx.x < 16u && t.val[threadIdx.x])
+        __hip_atomic_fetch_add(cnt + t.tag[threadIdx.x], t.val[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Called by the whole wave.
+__device__ __forceinline__ void count_runs(bool me, unsigned item, LandTable& t, unsigned* __restrict__ cnt) {
+    const unsigned long long part = __ballot(me);
+    if (part == 0ull) return;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane) - 1ull, below = part & lt;
+    const unsigned prev_item = __shfl(item, below ? 63 - __clzll((long long)below) : (int)lane);
+    const bool head = me && (below == 0ull || prev_item != item);
+    const unsigned long long heads = __ballot(head);
+    if (head) {
+        const unsigned long long above = heads & ~((2ull << lane) - 1ull);
+        const unsigned long long upto = above ? (1ull << __builtin_ctzll(above)) - 1ull : ~0ull;
+        land_add(t, item, (unsigned)__popcll(part & upto & ~lt), cnt);
+    }
+}
+
+// round step 4: destinations, scatter, `u` - and step 1 of the NEXT round: an element knows where it lands and what the
+// next round asks of it, so it adds itself to the true count of the item it lands in (`cnt_next`, zeroed by a_ranks).
+//   mode 1: the next round stays on this axis; its window is [pivot, n) = this round's falses and `u`;
+//   mode 2: the next round starts an axis: window = the whole segment, and the 4-byte payload swaps its seven bits for
+//           that axis' on the way - every position of the segment is rewritten and counted, the frozen prefix too;
+//   mode 0: the next round's predicate is not known yet (the final shuffle follows the cost evaluation): a_count runs.
+template <typename P, int mode>
 __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                       const typename P::T* __restrict__ src, typename P::T* __restrict__ dst, int c,
                                                       const unsigned* item_pre, const unsigned* __restrict__ falsepos,
                                                       const unsigned* __restrict__ truepos, unsigned char* __restrict__ is_u_flag,
-                                                      const unsigned* __restrict__ bits21) {
+                                                      const unsigned* __restrict__ bits21, unsigned* __restrict__ cnt_next) {
     __shared__ unsigned s_w[4];
+    __shared__ LandTable s_land;
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     const int r = c >= 0 ? c : kCand;
     const Window win = round_window(sg, r);
-    if (ic.rel0 + ic.n_here <= win.band) return;           // frozen before the previous round: both buffers agree
+    const unsigned copy_from = mode == 2 ? 0u : win.band;
+    if (ic.rel0 + ic.n_here <= copy_from) return;         // frozen before the previous round: both buffers agree
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (VD_LAND_LDS && mode != 0) land_init(s_land);      // first used after the barrier below (mode 2: after its own)
+    if (VD_LAND_LDS && mode == 2) __syncthreads();
+    const unsigned sh_next = P::shift((unsigned)(r + 1)), axis_next = (unsigned)(r + 1) / 7u;
     // the band the previous round froze: straight copy, so that `dst` holds the whole arrangement
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane, xa = ic.rel0 + xr;
-        if (xr < ic.n_here && xa >= win.band && xa < win.act) dst[sg->start + xa] = src[sg->start + xa];
+        bool pn = false;
+        if (xr < ic.n_here && xa >= copy_from && xa < win.act) {
+            typename P::T v = src[sg->start + xa];
+            if (mode == 2) {
+                if (P::kRefresh) v = P::make(P::pos(v), bits21[P::pos(v)], axis_next);
+                pn = (P::word(v) >> sh_next) & 1u;
+            }
+            dst[sg->start + xa] = v;
+        }
+        if (mode == 2) {
+            const unsigned np = (unsigned)__popcll(__ballot(pn));
+            if (np && lane == 0u) land_add(s_land, blockIdx.x, np, cnt_next);
+        }
     }
-    if (ic.rel0 + ic.n_here <= win.act) return;
+    if (ic.rel0 + ic.n_here <= win.act) {
+        if (VD_LAND_LDS && mode == 2) { __syncthreads(); land_flush(s_land, cnt_next); }
+        return;
+    }
     // predicates and TL are recomputed from the payload (cheaper than a per-position word through HBM)
     unsigned long long masks[kPer]; typename P::T vals[kPer];
     item_masks<P>(sg, ic, src, c, win.act, masks, vals);
@@ -1405,9 +1481,11 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     for (unsigned w = 0; w < wave; ++w) run += s_w[w];
     // everything below is partition_shuffle on the window [act, n): positions relative to act
     const unsigned n = sg->count - win.act, s = sg->start + win.act, ttot = sg->ttot_cur, ftot = n - ttot;
+    bool counts[kPer]; unsigned land[kPer];      // counted after the loop: the four gathers stay in flight together
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
+        counts[j] = false; land[j] = 0u;
         if (xr < ic.n_here && ic.rel0 + xr >= win.act) {
             const unsigned x = ic.rel0 + xr - win.act;
             const bool p = (masks[j] >> lane) & 1ull;
@@ -1422,11 +1500,19 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
             if (is_u) dest = ttot - (p ? 1u : 0u);
             else if (left) dest = p ? x : (unsigned)tF - 1u;
             else dest = p ? fj : x - 1u;
-            dst[s + dest] = vals[j];
+            typename P::T v = vals[j];
+            const unsigned upos = P::pos(v);
+            if (mode == 2) {
+                if (P::kRefresh) v = P::make(upos, bits21[upos], axis_next);
+                counts[j] = (P::word(v) >> sh_next) & 1u;
+            } else if (mode == 1) {
+                counts[j] = ((P::word(v) >> sh_next) & 1u) && (is_u || dest >= ttot);   // left of the pivot = frozen for the next round
+            }
+            land[j] = sg->item_first + (win.act + dest) / (unsigned)kItem;
+            dst[s + dest] = v;
             if (is_u && c >= 0) {
                 Seg& w = segs[ic.seg];
                 // counts as the reference sees them: examined trues of the WHOLE segment = frozen prefix + this window's
-                const unsigned upos = P::pos(vals[j]);
                 const u32x2 urec = {upos, bits21[upos]};               // the record keeps all 21 bits: the cost evaluation needs them
                 w.u_pay[c] = urec; w.u_p[c] = p ? 1u : 0u; w.ttot[c] = win.act + ttot;
                 w.act[(r + 1) % 3] = win.act + ttot - (p ? 1u : 0u);   // this trial's pivot: where the next round starts
@@ -1435,6 +1521,11 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
         }
         run += (unsigned)__popcll(masks[j]);
     }
+    if (mode != 0) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) count_runs(counts[j], land[j], s_land, cnt_next);
+    }
+    if (VD_LAND_LDS && mode != 0) { __syncthreads(); land_flush(s_land, cnt_next); }
 }
 
 // binning over the non-u elements (one pass per level)
@@ -1961,7 +2052,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     auto layout = [&](Arena& a, bool) {
         struct P { u32x2 *pay0, *pay1; f32x4 *cent, *cent1; TriBox *boxes, *boxes1; unsigned *bits21, *ids32;
                    unsigned *falsepos, *truepos, *final_ids, *stack, *idx_copy;
-                   unsigned char* is_u; Seg *seg0, *seg1; MidRoot* mid; unsigned *item_seg, *item_cnt, *item_pre; TopNode* top; SmallRoot* small;
+                   unsigned char* is_u; Seg *seg0, *seg1; MidRoot* mid; unsigned *item_seg, *item_cnt, *item_cnt1, *item_pre; TopNode* top; SmallRoot* small;
                    unsigned* sub_interior; TmpNode* subnodes; unsigned short* submap; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair; } p;
         // payload ping-pong: 4 bytes per triangle up to 2^25 triangles, 8 beyond (allocated for the width in use)
         const size_t pay_words = wide_pay ? T : (T + 1) / 2;
@@ -1972,7 +2063,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         p.final_ids = a.take<unsigned>(T); p.stack = a.take<unsigned>(T); p.idx_copy = a.take<unsigned>(3 * T);
         p.is_u = a.take<unsigned char>(T);
         p.seg0 = a.take<Seg>(seg_cap); p.seg1 = a.take<Seg>(seg_cap); p.mid = a.take<MidRoot>(mid_cap);
-        p.item_seg = a.take<unsigned>(item_cap); p.item_cnt = a.take<unsigned>(item_cap); p.item_pre = a.take<unsigned>(item_cap + 1);
+        p.item_seg = a.take<unsigned>(item_cap); p.item_cnt = a.take<unsigned>(item_cap); p.item_cnt1 = a.take<unsigned>(item_cap); p.item_pre = a.take<unsigned>(item_cap + 1);
         p.top = a.take<TopNode>(top_cap); p.small = a.take<SmallRoot>(small_cap); p.sub_interior = a.take<unsigned>(small_cap);
         p.subnodes = a.take<TmpNode>(2 * T + 2); p.submap = a.take<unsigned short>(2 * T + 2); p.ctl = a.take<LevelCtl>(1); p.root_keys = a.take<int>(16);
         p.tout = a.take<TopOut>(top_cap); p.root_pair = a.take<unsigned>(small_cap);
@@ -2030,7 +2121,8 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         hipLaunchKernelGGL(a_items_fill_kernel, dim3(n_seg_now), dim3(64), 0, st, seg_cur, P.ctl, P.item_seg);
         hipLaunchKernelGGL(a_planes_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, P.ctl);
         PT* src = reinterpret_cast<PT*>(P.pay0); PT* dst = reinterpret_cast<PT*>(P.pay1);
-        hipLaunchKernelGGL((a_bits_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.cent, P.bits21);
+        unsigned* const cnt[2] = {P.item_cnt, P.item_cnt1};      // round c counts in cnt[c & 1]
+        hipLaunchKernelGGL((a_bits_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.cent, P.bits21, cnt[0]);
         for (int c = 0; c <= kCand; ++c) {
             const int cc = c < kCand ? c : -1;       // -1: final re-shuffle with each segment's best plane
             if (c == kCand) {
@@ -2038,13 +2130,18 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
                                    P.is_u, P.bits21);
                 hipLaunchKernelGGL(a_eval_kernel, dim3(n_seg_now), dim3(64), 0, st, seg_cur, P.ctl, cur.boxes);
             }
-            const int refresh = (c == 7 || c == 14 || c == kCand) ? 1 : 0;   // the rounds that start on another axis
-            hipLaunchKernelGGL((a_count_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_cnt, P.bits21, refresh);
-            hipLaunchKernelGGL(a_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl, P.item_cnt, P.item_pre);
+            // the true counts of round c: from a_bits (c = 0), from the a_apply of round c - 1, or - the final shuffle, whose
+            // plane a_eval has only just chosen - from a_count, which also puts that axis' bits into the 4-byte payload
+            if (c == kCand)
+                hipLaunchKernelGGL((a_count_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, cnt[c & 1], P.bits21, 1);
+            const int mode = c + 1 >= kCand ? 0 : ((c + 1) % 7 == 0 ? 2 : 1);
+            unsigned* const cnt_next = mode ? cnt[(c + 1) & 1] : nullptr;
+            hipLaunchKernelGGL(a_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl, cnt[c & 1], P.item_pre);
             hipLaunchKernelGGL((a_ranks_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre,
-                               P.falsepos, P.truepos);
-            hipLaunchKernelGGL((a_apply_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, P.item_pre,
-                               P.falsepos, P.truepos, P.is_u, P.bits21);
+                               P.falsepos, P.truepos, cnt_next);
+            auto apply = mode == 0 ? a_apply_kernel<PayT, 0> : mode == 1 ? a_apply_kernel<PayT, 1> : a_apply_kernel<PayT, 2>;
+            hipLaunchKernelGGL(apply, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, P.item_pre,
+                               P.falsepos, P.truepos, P.is_u, P.bits21, cnt_next);
             PT* t = src; src = dst; dst = t;
         }
         // 22 swaps: the arrangement is back in pay0
@@ -2063,7 +2160,7 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
         n_seg = h_ctl.n_seg;
         Seg* t = seg_cur; seg_cur = seg_next; seg_next = t;
-        stats.kernel_launches += 9 + 4 * (kCand + 1);
+        stats.kernel_launches += 10 + 3 * (kCand + 1);
         if (++levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
     }
     stats.levels_phase_a = (uint32_t)levels;

@@ -116,10 +116,13 @@ __device__ __forceinline__ float vd_unkey(int k) {
 }
 __device__ __forceinline__ int vd_key_lo(float f) { return f != f ? 0x7fffffff : vd_key(f); }        // operand of a min
 __device__ __forceinline__ int vd_key_hi(float f) { return f != f ? (int)0x80000000 : vd_key(f); }   // operand of a max
-// IEEE minNum / maxNum as gfx950 executes them - one v_min_f32 / v_max_f32 (after a canonicalising v_max x, x that quiets
-// a signalling NaN): a NaN operand is ignored, both NaN -> NaN, and -0 orders below +0 (the ISA's LT_NEG_ZERO compare).
-// Exactly the semantics above, without the compare-and-select chains (which the compiler turned into six divergent
-// branches per box union: the refit climb went from 0.10 to 0.18 ms).
+// IEEE minNum / maxNum as gfx950 executes them - one v_min_f32 / v_max_f32: a QUIET NaN operand is ignored, both NaN ->
+// NaN, and -0 orders below +0 (the ISA's LT_NEG_ZERO compare).  Exactly the semantics above, without the
+// compare-and-select chains (which the compiler turned into six divergent branches per box union: the refit climb went
+// from 0.10 to 0.18 ms).  A SIGNALLING NaN is different: in IEEE mode the instruction quiets and RETURNS it, and the
+// compiler does not canonicalise the operands of fminf for us (LLVM leaves minnum(sNaN, x) open) - so raw user floats
+// pass through vd_quiet once where they are loaded (blas_precompute_kernel); everything arithmetic produces is quiet.
+__device__ __forceinline__ float vd_quiet(float x) { return __builtin_canonicalizef(x); }
 __device__ __forceinline__ float vd_min_to(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float vd_max_to(float a, float b) { return __builtin_fmaxf(a, b); }
 
