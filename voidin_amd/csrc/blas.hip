@@ -97,6 +97,13 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
+__device__ __forceinline__ unsigned wave_sum_u(unsigned u) {      // every stage leaves a group's sum in all of its lanes
+    int v = (int)u;
+    v += dpp_i<0xB1>(v); v += dpp_i<0x4E>(v); v += dpp_i<0x141>(v); v += dpp_i<0x140>(v);
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    return (unsigned)v;
+}
+
 // min / max over the aligned group of 8 lanes a lane belongs to, on the VALU (DPP) - the LDS crossbar is what the
 // shuffles of the trials already saturate.  row_half_mirror pairs lane i with 7 - i, then each quad holds four
 // pairs that cover all eight lanes: quad_perm [1,0,3,2] and [2,3,0,1] finish the reduction.
@@ -517,6 +524,25 @@ __device__ __forceinline__ void block_shuffle_helpers(WaveLds& L, WaveQueues& Q,
     }
 }
 
+// Phase B is a list of independent roots of 4..kSmallMax triangles, a workgroup each, and a root's time grows with its
+// size: dispatched largest first, the last workgroups to start are the short ones and the kernel's tail is short
+// (longest-processing-time order).  One workgroup: histogram of the counts, suffix sums, scatter.
+__global__ __launch_bounds__(1024) void b_order_kernel(const SmallRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
+                                                       unsigned* __restrict__ order) {
+    __shared__ unsigned s_bin[kSmallMax + 2];
+    const unsigned n = *n_roots_p, tid = threadIdx.x;
+    for (unsigned b = tid; b < (unsigned)kSmallMax + 2u; b += 1024u) s_bin[b] = 0u;
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += 1024u) atomicAdd(&s_bin[min(roots[i].count, (unsigned)kSmallMax + 1u)], 1u);
+    __syncthreads();
+    if (tid == 0) {           // first slot of each count, counting down from the largest
+        unsigned run = 0;
+        for (int b = kSmallMax + 1; b >= 0; --b) { const unsigned c = s_bin[b]; s_bin[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += 1024u) order[atomicAdd(&s_bin[min(roots[i].count, (unsigned)kSmallMax + 1u)], 1u)] = i;
+}
+
 #ifndef VD_SMALL_OCC
 #define VD_SMALL_OCC 6
 #endif
@@ -525,7 +551,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                        const unsigned* __restrict__ ids32, ArrSet set0, ArrSet set1,
                        TmpNode* __restrict__ subnodes, unsigned short* __restrict__ submap,
                        unsigned* __restrict__ sub_interior, unsigned* __restrict__ final_ids, unsigned* __restrict__ err,
-                       unsigned* __restrict__ dbg_cycles) {
+                       unsigned* __restrict__ dbg_cycles, const unsigned* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const unsigned tid = threadIdx.x, lane = vd_lane();
@@ -533,8 +559,8 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     WaveLds& L = *reinterpret_cast<WaveLds*>(smem);
     WaveQueues& Q = *reinterpret_cast<WaveQueues*>(smem + sizeof(WaveLds));
     WaveScratch& W = L.w[wave];
-    const unsigned root_i = blockIdx.x;
-    if (root_i >= *n_roots_p) return;
+    if (blockIdx.x >= *n_roots_p) return;
+    const unsigned root_i = order ? order[blockIdx.x] : blockIdx.x;     // largest roots first (b_order_kernel)
     const SmallRoot root = roots[root_i];
     const unsigned base = root.start, N = root.count;
     // per-triangle data: position order in the set the segment's last phase-A level wrote (pad & 1), through ids32 when
@@ -1144,6 +1170,8 @@ struct MidRoot { unsigned start, count, node, pad; int cbk[6]; int pad2[2]; };  
 
 struct LevelCtl {                     // device-side counters
     unsigned n_seg, n_seg_next, n_items, n_top, n_small, err, n_mid, pad1;
+    unsigned max_count, max_count_next;       // largest segment of this / the next level (the host picks the round kernels by it)
+    unsigned active, active_next;             // triangles in the segments of this / the next level
 };
 
 // one thread per segment: items per segment, centroid keys / bins reset
@@ -1344,13 +1372,37 @@ __global__ __launch_bounds__(1024) void a_scan_kernel(Seg* segs, const LevelCtl*
     }
 }
 
+// An item's prefix inside its segment and the segment's total.  With a_scan: two words of its output.  Without (SF, the
+// levels whose segments have <= 1024 items - all but the first few): every thread adds up to four of the segment's item
+// counts itself, two wave sums, and the result comes out of the barrier the kernel has anyway - the single-workgroup
+// scan between count and ranks (5.9 us, moves nothing) is not launched at those levels.
+template <bool SF>
+__device__ __forceinline__ void prefix_begin(const Seg* sg, const unsigned* __restrict__ item_pre, unsigned* s_red) {
+    if (!SF) return;
+    const unsigned mine = blockIdx.x - sg->item_first, ni = sg->n_items;
+    const unsigned* __restrict__ cn = item_pre + sg->item_first;       // SF: `item_pre` is the count array of the round
+    unsigned pa = 0, pb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned i = threadIdx.x + (unsigned)k * 256u;
+        if (i < ni) { const unsigned v = cn[i]; pb += v; pa += i < mine ? v : 0u; }
+    }
+    pa = wave_sum_u(pa); pb = wave_sum_u(pb);
+    if ((threadIdx.x & 63u) == 0u) { s_red[threadIdx.x >> 6] = pa; s_red[4u + (threadIdx.x >> 6)] = pb; }
+}
+template <bool SF>
+__device__ __forceinline__ void prefix_end(const Seg* sg, const unsigned* __restrict__ item_pre, const unsigned* s_red, unsigned& run, unsigned& ttot) {
+    if (SF) { run = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]); ttot = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]); }
+    else { run = item_pre[blockIdx.x] - item_pre[sg->item_first]; ttot = sg->ttot_cur; }
+}
+
 // round step 3: TL per position + rank -> position tables
-template <typename P>
+template <typename P, bool SF>
 __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                       const typename P::T* __restrict__ pay, int c, const unsigned* item_pre,
                                                       unsigned* __restrict__ falsepos, unsigned* __restrict__ truepos,
                                                       unsigned* __restrict__ cnt_next) {
-    __shared__ unsigned s_w[4];
+    __shared__ unsigned s_w[4], s_red[8];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     if (cnt_next && threadIdx.x == 0) cnt_next[blockIdx.x] = 0u;      // a_apply of this round adds the next round's trues up in it
@@ -1363,11 +1415,13 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
 #pragma unroll
     for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
     if (lane == 0u) s_w[wave] = t;
+    prefix_begin<SF>(sg, item_pre, s_red);
     __syncthreads();
-    unsigned run = item_pre[blockIdx.x] - item_pre[sg->item_first];
+    unsigned run, ttot;
+    prefix_end<SF>(sg, item_pre, s_red, run, ttot);
     for (unsigned w = 0; w < wave; ++w) run += s_w[w];
     // positions and table indices are relative to the window [act, n); the tables of the window start at s + act
-    const unsigned ttot = sg->ttot_cur, s = sg->start + win.act;
+    const unsigned s = sg->start + win.act;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
@@ -1429,13 +1483,13 @@ __device__ __forceinline__ void count_runs(bool me, unsigned item, LandTable& t,
 //   mode 2: the next round starts an axis: window = the whole segment, and the 4-byte payload swaps its seven bits for
 //           that axis' on the way - every position of the segment is rewritten and counted, the frozen prefix too;
 //   mode 0: the next round's predicate is not known yet (the final shuffle follows the cost evaluation): a_count runs.
-template <typename P, int mode>
+template <typename P, int mode, bool SF>
 __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                       const typename P::T* __restrict__ src, typename P::T* __restrict__ dst, int c,
                                                       const unsigned* item_pre, const unsigned* __restrict__ falsepos,
                                                       const unsigned* __restrict__ truepos, unsigned char* __restrict__ is_u_flag,
                                                       const unsigned* __restrict__ bits21, unsigned* __restrict__ cnt_next) {
-    __shared__ unsigned s_w[4];
+    __shared__ unsigned s_w[4], s_red[8];
     __shared__ LandTable s_land;
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
@@ -1476,11 +1530,13 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
 #pragma unroll
     for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
     if (lane == 0u) s_w[wave] = t;
+    prefix_begin<SF>(sg, item_pre, s_red);
     __syncthreads();
-    unsigned run = item_pre[blockIdx.x] - item_pre[sg->item_first];
+    unsigned run, ttot;
+    prefix_end<SF>(sg, item_pre, s_red, run, ttot);
     for (unsigned w = 0; w < wave; ++w) run += s_w[w];
     // everything below is partition_shuffle on the window [act, n): positions relative to act
-    const unsigned n = sg->count - win.act, s = sg->start + win.act, ttot = sg->ttot_cur, ftot = n - ttot;
+    const unsigned n = sg->count - win.act, s = sg->start + win.act, ftot = n - ttot;
     bool counts[kPer]; unsigned land[kPer];      // counted after the loop: the four gathers stay in flight together
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
@@ -1694,6 +1750,8 @@ __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, Top
         } else {
             t.kind = 1u;
             const unsigned ni = atomicAdd(&ctl->n_seg_next, 1u);
+            atomicMax(&ctl->max_count_next, t.count);
+            atomicAdd(&ctl->active_next, t.count);
             Seg& ns = next[ni];
             ns.start = t.start; ns.count = t.count; ns.node = pair + side;
             for (int q = 0; q < 6; ++q) ns.cbk[q] = sg.child_k[12 + side * 6 + q];
@@ -1791,11 +1849,11 @@ __device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, 
 
 __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
                                                                unsigned* __restrict__ ids32, ArrSet set0, ArrSet set1, LevelCtl* ctl, TopNode* top,
-                                                               SmallRoot* small, unsigned top_cap, unsigned small_cap) {
+                                                               SmallRoot* small, unsigned top_cap, unsigned small_cap, unsigned first) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MidLds& L = *reinterpret_cast<MidLds*>(smem);
-    if (blockIdx.x >= *n_roots_p) return;
-    const MidRoot root = roots[blockIdx.x];
+    if (first + blockIdx.x >= *n_roots_p) return;
+    const MidRoot root = roots[first + blockIdx.x];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // the segment's data sits, in position order, in the set its last phase-A level wrote (root.pad & 1)
     const f32x4* __restrict__ cent = (root.pad & 1u) ? set1.cent : set0.cent;
@@ -2016,7 +2074,7 @@ __global__ void c_root_kernel(TopNode* top, const int* root_keys, unsigned n_tri
         mid[0].start = 0; mid[0].count = n_tri; mid[0].node = 0; mid[0].pad = 0;
         for (int q = 0; q < 6; ++q) mid[0].cbk[q] = root_keys[6 + q];
     } else {
-        t.kind = 1u; segs[0].start = 0; segs[0].count = n_tri; segs[0].node = 0; ctl->n_seg = 1;
+        t.kind = 1u; segs[0].start = 0; segs[0].count = n_tri; segs[0].node = 0; ctl->n_seg = 1; ctl->max_count = n_tri; ctl->active = n_tri;
         for (int q = 0; q < 6; ++q) segs[0].cbk[q] = root_keys[6 + q];
     }
     top[0] = t;
@@ -2025,7 +2083,11 @@ __global__ void c_root_kernel(TopNode* top, const int* root_keys, unsigned n_tri
 }
 
 __global__ void a_level_swap_kernel(LevelCtl* ctl) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { ctl->n_seg = ctl->n_seg_next; ctl->n_seg_next = 0; ctl->n_items = 0; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctl->n_seg = ctl->n_seg_next; ctl->n_seg_next = 0; ctl->n_items = 0;
+        ctl->max_count = ctl->max_count_next; ctl->max_count_next = 0;
+        ctl->active = ctl->active_next; ctl->active_next = 0;
+    }
 }
 
 struct Arena {
@@ -2109,7 +2171,8 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     stats.kernel_launches = 2;
     lap(stats.ms_precompute);
     // one level of phase A; PayT = Pay4 / Pay8 (see there)
-    auto run_level = [&](auto pay_tag, unsigned n_seg_now, Seg* seg_cur, Seg* seg_next, int level) {
+    unsigned n_launch = 0;
+    auto run_level = [&](auto pay_tag, unsigned n_seg_now, Seg* seg_cur, Seg* seg_next, int level, bool scan_free) {
         using PayT = decltype(pay_tag);
         typedef typename PayT::T PT;
         const ArrSet cur = sets[level & 1], nxt = sets[(level + 1) & 1];
@@ -2136,12 +2199,16 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
                 hipLaunchKernelGGL((a_count_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, cnt[c & 1], P.bits21, 1);
             const int mode = c + 1 >= kCand ? 0 : ((c + 1) % 7 == 0 ? 2 : 1);
             unsigned* const cnt_next = mode ? cnt[(c + 1) & 1] : nullptr;
-            hipLaunchKernelGGL(a_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl, cnt[c & 1], P.item_pre);
-            hipLaunchKernelGGL((a_ranks_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, P.item_pre,
-                               P.falsepos, P.truepos, cnt_next);
-            auto apply = mode == 0 ? a_apply_kernel<PayT, 0> : mode == 1 ? a_apply_kernel<PayT, 1> : a_apply_kernel<PayT, 2>;
-            hipLaunchKernelGGL(apply, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, P.item_pre,
+            // prefixes: from a_scan, or - segments of <= 1024 items - added up by the workgroups themselves (prefix_begin)
+            const unsigned* pre = scan_free ? cnt[c & 1] : P.item_pre;
+            if (!scan_free) hipLaunchKernelGGL(a_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl, cnt[c & 1], P.item_pre);
+            auto ranks = scan_free ? a_ranks_kernel<PayT, true> : a_ranks_kernel<PayT, false>;
+            hipLaunchKernelGGL(ranks, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, pre, P.falsepos, P.truepos, cnt_next);
+            auto apply = scan_free ? (mode == 0 ? a_apply_kernel<PayT, 0, true> : mode == 1 ? a_apply_kernel<PayT, 1, true> : a_apply_kernel<PayT, 2, true>)
+                                   : (mode == 0 ? a_apply_kernel<PayT, 0, false> : mode == 1 ? a_apply_kernel<PayT, 1, false> : a_apply_kernel<PayT, 2, false>);
+            hipLaunchKernelGGL(apply, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, pre,
                                P.falsepos, P.truepos, P.is_u, P.bits21, cnt_next);
+            n_launch += scan_free ? 2u : 3u;
             PT* t = src; src = dst; dst = t;
         }
         // 22 swaps: the arrangement is back in pay0
@@ -2151,8 +2218,28 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
                            top_cap, small_cap, P.mid, mid_cap, (unsigned)((level + 1) & 1));
         hipLaunchKernelGGL(a_level_swap_kernel, dim3(1), dim3(64), 0, st, P.ctl);
     };
+    // The mid tier does not wait for the last levels: once most triangles have left phase A (segments <= kMidMax go to
+    // the mid list as they appear), the roots listed so far start on the second stream while the few launch-bound levels
+    // that remain run beside them; the rest of the list follows on the main stream.  Disjoint position ranges, shared
+    // lists appended by atomics - and no numbering depends on the order in which top nodes or small roots were listed.
+    unsigned mid_early = 0;
+    struct AuxJoin {          // an error return must not leave the early launch running over scratch the next call reuses
+        hipStream_t s = nullptr;
+        ~AuxJoin() { if (s) (void)hipStreamSynchronize(s); }
+    } aux_join;
+    auto launch_mid = [&](hipStream_t on, unsigned first, unsigned count) -> int {
+        if (!ctx->mid_lds_opt_in) {   // per context (= per device), not per process
+            VD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(blas_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds)));
+            ctx->mid_lds_opt_in = true;
+        }
+        hipLaunchKernelGGL(blas_mid_kernel, dim3(count), dim3(kMidThreads), sizeof(MidLds), on, P.mid, &P.ctl->n_mid, P.ids32, sets[0], sets[1],
+                           P.ctl, P.top, P.small, top_cap, small_cap, first);
+        stats.kernel_launches += 1;
+        return VD_OK;
+    };
     while (n_seg > 0) {
-        if (wide_pay) run_level(Pay8{}, n_seg, seg_cur, seg_next, levels); else run_level(Pay4{}, n_seg, seg_cur, seg_next, levels);
+        const bool scan_free = (h_ctl.max_count + kItem - 1) / kItem <= 1024u;
+        if (wide_pay) run_level(Pay8{}, n_seg, seg_cur, seg_next, levels, scan_free); else run_level(Pay4{}, n_seg, seg_cur, seg_next, levels, scan_free);
         VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
         VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
         if (h_ctl.err & ERR_DEGENERATE)
@@ -2160,34 +2247,40 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
         n_seg = h_ctl.n_seg;
         Seg* t = seg_cur; seg_cur = seg_next; seg_next = t;
-        stats.kernel_launches += 10 + 3 * (kCand + 1);
+        stats.kernel_launches += 10 + n_launch; n_launch = 0;
         if (++levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
+        if (!mid_early && n_seg > 0 && h_ctl.n_mid > 0 && (size_t)h_ctl.active * 2 <= T) {
+            if (!ctx->aux_stream) VD_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+            if (!ctx->ev_aux) VD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
+            const int rc_m = launch_mid(ctx->aux_stream, 0u, h_ctl.n_mid);    // the stream was synchronised just above
+            if (rc_m) return rc_m;
+            VD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_aux, ctx->aux_stream));
+            mid_early = h_ctl.n_mid;
+            aux_join.s = ctx->aux_stream;
+        }
     }
     stats.levels_phase_a = (uint32_t)levels;
     lap(stats.ms_phase_a);
 
     // ---- mid tier: segments of kSmallMax < n <= kMidMax, one workgroup each, down to small roots ----
     if (h_ctl.n_mid) {
-        if (!ctx->mid_lds_opt_in) {   // per context (= per device), not per process
-            VD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(blas_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MidLds)));
-            ctx->mid_lds_opt_in = true;
-        }
-        hipLaunchKernelGGL(blas_mid_kernel, dim3(h_ctl.n_mid), dim3(kMidThreads), sizeof(MidLds), st, P.mid, &P.ctl->n_mid, P.ids32, sets[0], sets[1],
-                           P.ctl, P.top, P.small, top_cap, small_cap);
+        if (h_ctl.n_mid > mid_early) { const int rc_m = launch_mid(st, mid_early, h_ctl.n_mid - mid_early); if (rc_m) return rc_m; }
+        if (mid_early) VD_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_aux, 0));
         VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
         VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
         if (h_ctl.err & ERR_DEGENERATE)
             VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
         if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
-        stats.kernel_launches += 1;
+        aux_join.s = nullptr;     // the main stream waited for the early launch and the host for the main stream
     }
     lap(stats.ms_mid);
     // ---- phase B ----
     const unsigned n_small = h_ctl.n_small, n_top = h_ctl.n_top;
     stats.n_top_nodes = n_top; stats.n_small_roots = n_small; stats.n_mid_roots = h_ctl.n_mid;
     if (n_small) {
+        hipLaunchKernelGGL(b_order_kernel, dim3(1), dim3(1024), 0, st, P.small, &P.ctl->n_small, P.root_pair);   // root_pair is free until phase C
         hipLaunchKernelGGL(blas_small_kernel, dim3(n_small), dim3(64 * kSubWaves), sizeof(WaveLds) + sizeof(WaveQueues), st, P.small, &P.ctl->n_small, P.ids32,
-                           sets[0], sets[1], P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err, P.stack);
+                           sets[0], sets[1], P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err, P.stack, P.root_pair);
         ctx->dbg_ptr = P.stack; ctx->dbg_count = 2 * n_small;
     }
     // ---- phase C: DFS numbering of the top tree on the host ----

@@ -106,6 +106,7 @@ int vd_ctx_destroy(VdCtx* ctx) {
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
+    if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return VD_OK;

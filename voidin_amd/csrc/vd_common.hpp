@@ -16,7 +16,7 @@ struct VdCtx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // stream in use (own or caller's)
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr, ev_aux = nullptr;
     bool timed_mid = false;
     bool timed = false;
     bool timing_enabled = false;        // event pairs around kernels cost a few us of GPU idle each: opt-in
