@@ -208,6 +208,8 @@ typedef enum VdOption {
     VD_OPT_TRACE_SORT_MIN = 22,   /* fewest rays a call bins when VD_OPT_TRACE_SORT is on; default 65536          */
     VD_OPT_TRACE_CHUNK = 23,      /* 1 (default): idle lanes draw single rays from one counter; >= 64: consecutive
                                      rays per workgroup in chunks of this size (measured slower: imbalance)      */
+    VD_OPT_TRACE_YIELD = 24,      /* lanes of a wave that wait (at a BLAS leaf, or with a finished ray) before the wave
+                                     leaves its stepping loop to serve them; default 16                          */
     VD_OPT_COUNT_ = 32
 } VdOption;
 int         vd_ctx_set_option(VdCtx* ctx, int option /* VdOption */, int64_t value);

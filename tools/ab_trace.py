@@ -34,11 +34,14 @@ variants = [("single rays (default)", dict(sort=0, chunk=1), False), ("single ra
              ("chunk64 sort", dict(sort=1, chunk=64), False),
             ("chunk64 sort prep", dict(sort=1, chunk=64), True), ("chunk256 sort prep", dict(sort=1, chunk=256), True),
             ("chunk128 sort prep", dict(sort=1, chunk=128), True)]
+if os.environ.get("AB_YIELD"):        # sweep of VD_OPT_TRACE_YIELD on the default supply
+    variants = [("yield %2d%s" % (y, " prep" if pr else ""), dict(sort=0, chunk=1, **{"yield": y}), pr)
+                for y in [int(v) for v in os.environ["AB_YIELD"].split(",")] for pr in (False, True)]
 ref_bytes = ref_any = None
 ctx.set_timing(True)
 for name, opts, prep in variants:
-    for k in ("sort", "chunk"):
-        ctx.set_option("trace." + k, opts.get(k))
+    for k in ("sort", "chunk", "yield"):
+        ctx.set_option("trace." + k, opts.get(k, -1))
     t_cl, t_any = [], []
     for _ in range(args.reps):
         if prep:

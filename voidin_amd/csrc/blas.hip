@@ -56,6 +56,7 @@ constexpr int kBig = 0x7fffffff;
 #endif
 constexpr int kItem = VD_ITEM;          // phase A: positions per workgroup item (256 lanes x kPer)
 constexpr int kPer = kItem / 256;       // positions per lane: position = rel0 + wave * (kItem / 4) + j * 64 + lane
+constexpr unsigned kMidEarlyMin = 256;  // mid-tier roots that make an early launch worth it (one per CU)
 constexpr int kBinItems = 8;            // a_bin_kernel: consecutive items per workgroup
 #ifndef VD_MID_MAX
 #define VD_MID_MAX 2048
@@ -1436,33 +1437,12 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
     }
 }
 
-// Counting into the items elements land in.  Landing positions are monotone along a wave within each of an element's
-// four classes, so a wave makes a handful of runs of lanes with the same item; a run's head adds the run to a small
-// tagged table in LDS (16 slots, item & 15; a slot already taken by another item sends the run straight to memory),
-// and the workgroup flushes the table with one device-scope atomic per slot: ~5 per workgroup instead of ~50 - the
-// counters of a level are 256 cache lines that every XCD adds to, and such atomics are resolved memory-side.
-#ifndef VD_LAND_LDS
-#define VD_LAND_LDS 1
-#endif
-struct LandTable { unsigned tag[16], val[16]; };
-__device__ __forceinline__ void land_init(LandTable& t) {
-    if (threadIdx.x < 16u) { t.tag[threadIdx.x] = 0xffffffffu; t.val[threadIdx.x] = 0u; }
-}
-__device__ __forceinline__ void land_add(LandTable& t, unsigned item, unsigned n, unsigned* __restrict__ cnt) {
-#if VD_LAND_LDS
-    const unsigned slot = item & 15u;
-    const unsigned old = atomicCAS(&t.tag[slot], 0xffffffffu, item);
-    if (old == 0xffffffffu || old == item) atomicAdd(&t.val[slot], n);
-    else
-#endif
-    __hip_atomic_fetch_add(cnt + item, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void land_flush(LandTable& t, unsigned* __restrict__ cnt) {   // after a barrier
-    if (threadIdx.x < 16u && t.val[threadIdx.x])
-        __hip_atomic_fetch_add(cnt + t.tag[threadIdx.x], t.val[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Called by the whole wave.
-__device__ __forceinline__ void count_runs(bool me, unsigned item, LandTable& t, unsigned* __restrict__ cnt) {
+// Counting into the items elements land in.  Most counted elements land in the item they came from (a false the back
+// pointer examined moves one position: partition_shuffle, blas.rs:168-182): those are a ballot and a popcount into a
+// wave-uniform register, one atomic per wave at the end.  The others - falses the front pointer threw to the far end,
+// `u`, and in mode 2 the trues that fill their holes - land monotonically along a wave within each class, so a wave
+// makes a handful of runs of lanes with the same item, and a run's head adds the run.  Called by the whole wave.
+__device__ __forceinline__ void count_runs(bool me, unsigned item, unsigned* __restrict__ cnt) {
     const unsigned long long part = __ballot(me);
     if (part == 0ull) return;
     const unsigned lane = threadIdx.x & 63u;
@@ -1473,7 +1453,7 @@ __device__ __forceinline__ void count_runs(bool me, unsigned item, LandTable& t,
     if (head) {
         const unsigned long long above = heads & ~((2ull << lane) - 1ull);
         const unsigned long long upto = above ? (1ull << __builtin_ctzll(above)) - 1ull : ~0ull;
-        land_add(t, item, (unsigned)__popcll(part & upto & ~lt), cnt);
+        __hip_atomic_fetch_add(cnt + item, (unsigned)__popcll(part & upto & ~lt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1490,7 +1470,6 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
                                                       const unsigned* __restrict__ truepos, unsigned char* __restrict__ is_u_flag,
                                                       const unsigned* __restrict__ bits21, unsigned* __restrict__ cnt_next) {
     __shared__ unsigned s_w[4], s_red[8];
-    __shared__ LandTable s_land;
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
     const int r = c >= 0 ? c : kCand;
@@ -1498,8 +1477,7 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     const unsigned copy_from = mode == 2 ? 0u : win.band;
     if (ic.rel0 + ic.n_here <= copy_from) return;         // frozen before the previous round: both buffers agree
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (VD_LAND_LDS && mode != 0) land_init(s_land);      // first used after the barrier below (mode 2: after its own)
-    if (VD_LAND_LDS && mode == 2) __syncthreads();
+    unsigned own_cnt = 0;                                  // elements counted into this very item (wave-uniform)
     const unsigned sh_next = P::shift((unsigned)(r + 1)), axis_next = (unsigned)(r + 1) / 7u;
     // the band the previous round froze: straight copy, so that `dst` holds the whole arrangement
 #pragma unroll
@@ -1514,13 +1492,10 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
             }
             dst[sg->start + xa] = v;
         }
-        if (mode == 2) {
-            const unsigned np = (unsigned)__popcll(__ballot(pn));
-            if (np && lane == 0u) land_add(s_land, blockIdx.x, np, cnt_next);
-        }
+        if (mode == 2) own_cnt += (unsigned)__popcll(__ballot(pn));
     }
     if (ic.rel0 + ic.n_here <= win.act) {
-        if (VD_LAND_LDS && mode == 2) { __syncthreads(); land_flush(s_land, cnt_next); }
+        if (mode == 2 && own_cnt && lane == 0u) __hip_atomic_fetch_add(cnt_next + blockIdx.x, own_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     // predicates and TL are recomputed from the payload (cheaper than a per-position word through HBM)
@@ -1579,9 +1554,13 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     }
     if (mode != 0) {
 #pragma unroll
-        for (int j = 0; j < kPer; ++j) count_runs(counts[j], land[j], s_land, cnt_next);
+        for (int j = 0; j < kPer; ++j) {
+            const bool mine = counts[j] && land[j] == blockIdx.x;
+            own_cnt += (unsigned)__popcll(__ballot(mine));
+            count_runs(counts[j] && !mine, land[j], cnt_next);
+        }
+        if (own_cnt && lane == 0u) __hip_atomic_fetch_add(cnt_next + blockIdx.x, own_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (VD_LAND_LDS && mode != 0) { __syncthreads(); land_flush(s_land, cnt_next); }
 }
 
 // binning over the non-u elements (one pass per level)
@@ -2218,9 +2197,9 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
                            top_cap, small_cap, P.mid, mid_cap, (unsigned)((level + 1) & 1));
         hipLaunchKernelGGL(a_level_swap_kernel, dim3(1), dim3(64), 0, st, P.ctl);
     };
-    // The mid tier does not wait for the last levels: once most triangles have left phase A (segments <= kMidMax go to
-    // the mid list as they appear), the roots listed so far start on the second stream while the few launch-bound levels
-    // that remain run beside them; the rest of the list follows on the main stream.  Disjoint position ranges, shared
+    // The mid tier does not wait for the last levels: segments <= kMidMax go to the mid list as they appear, and after
+    // every level the roots listed since the last launch start on the second stream, beside the levels that remain
+    // (those stream through HBM, the mid tier computes out of LDS); the rest of the list follows on the main stream.  Disjoint position ranges, shared
     // lists appended by atomics - and no numbering depends on the order in which top nodes or small roots were listed.
     unsigned mid_early = 0;
     struct AuxJoin {          // an error return must not leave the early launch running over scratch the next call reuses
@@ -2249,10 +2228,10 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         Seg* t = seg_cur; seg_cur = seg_next; seg_next = t;
         stats.kernel_launches += 10 + n_launch; n_launch = 0;
         if (++levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
-        if (!mid_early && n_seg > 0 && h_ctl.n_mid > 0 && (size_t)h_ctl.active * 2 <= T) {
+        if (n_seg > 0 && h_ctl.n_mid >= mid_early + kMidEarlyMin) {     // enough new roots to be worth a launch beside the next level
             if (!ctx->aux_stream) VD_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
             if (!ctx->ev_aux) VD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
-            const int rc_m = launch_mid(ctx->aux_stream, 0u, h_ctl.n_mid);    // the stream was synchronised just above
+            const int rc_m = launch_mid(ctx->aux_stream, mid_early, h_ctl.n_mid - mid_early);    // the stream was synchronised just above
             if (rc_m) return rc_m;
             VD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_aux, ctx->aux_stream));
             mid_early = h_ctl.n_mid;

@@ -10,6 +10,7 @@
 // triangles do not occur (BvhBuilder stops at <= 3: blas.rs:108) and are not representable in a stack entry.
 #include "vd_common.hpp"
 
+#include <algorithm>
 #include <new>
 
 // vd_trace_prepare_dev: per-scene data derived once from the six trace buffers
@@ -66,6 +67,8 @@ struct Scene {
     const VdTlasNode* tlas; const VdInstance* inst; const VdMeshInfo* meshes; const VdBvhNode* bvh;
     const float* verts; const unsigned* indices; unsigned n_meshes;
     const float* tris;          // vd_trace_prepare_dev: 9 floats per triangle in index-buffer order (nullptr: not prepared)
+    const float4* irec;         // entry records, 8 x float4 per TLAS node (entry_records_kernel)
+    unsigned yield;             // waiting lanes at which a wave leaves the stepping loop (VD_OPT_TRACE_YIELD)
 };
 
 // Where a wave's rays come from.  `order` (nullptr = identity) lists the ray ids in the order they are handed out (the
@@ -86,6 +89,7 @@ struct RaySource { const unsigned* order; unsigned n_rays, chunk, n_chunks; unsi
 // ANY: occlusion query - the lane stops at the first accepted triangle and only `hit` is reported.  That flag is
 // the same as the closest-hit traversal's: until something is accepted nothing is pruned by distance, so both walks
 // visit the same nodes up to that point (the reference's shadow pass uses only `.hit`: raytraced_shadows.wgsl:97-102).
+constexpr long long kYieldDefault = 1;   // see the stepping loop (sweep in profiles/r03_ab_trace.log: 1 is best)
 constexpr unsigned kRefillBelow = 56;   // draw new rays when fewer than this many lanes are busy
 constexpr unsigned kWavesPerCu = 28;    // persistent grid = what is resident (7 waves per SIMD at 72 VGPRs): no wave starts late
 constexpr int kWgWaves = 7;             // waves per workgroup of the chunked form: 4 workgroups per CU
@@ -108,9 +112,9 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
     Ray world, ray;                        // `ray` is the active one (object space inside an instance)
     VdHit res;
     unsigned ray_id = 0;
-    bool busy = false, exhausted = false, ovf = false, bad_leaf = false, in_blas = false;
+    bool busy = false, exhausted = false, ovf = false, bad_leaf = false, bad_entry = false, in_blas = false;
     unsigned head = 0, blas_base = 0;
-    unsigned instance_idx = 0, bvh_index = 0, base_index = 0, vertex_offset = 0;
+    unsigned tl_leaf = 0, bvh_index = 0, base_index = 0, vertex_offset = 0;   // tl_leaf: the TLAS leaf node the ray is inside
     uint2 cn = make_uint2(0u, 0u);         // payload of the current node
     bool ray_done = false;
 
@@ -124,7 +128,8 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
     for (;;) {
         // ---- retire finished rays, refill idle lanes ----
         if (busy && ray_done) {
-            if (ANY) out_any[ray_id] = res.hit; else out[ray_id] = res;
+            if (ANY) out_any[ray_id] = res.hit;
+            else { if (res.hit) res.instance = s.tlas[res.instance].instance_idx; out[ray_id] = res; }   // hits carry the leaf node until here
             busy = false;
         }
         const unsigned long long busy_mask = __ballot(busy);
@@ -177,31 +182,92 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                     ray = world;
                     res.dist = kMaxDist; res.hit = 0u; res.instance = 0xffffffffu; res.triangle = 0xffffffffu;
                     const VdTlasNode root = s.tlas[0];
-                    cn = make_uint2(root.left_right, root.instance_idx);
+                    cn = make_uint2(root.left_right, 0u);          // .y of a TLAS leaf = its node index
                     ray_id = id; busy = true; ray_done = false; in_blas = false; head = 0; blas_base = 0;
                 }
             }
             if (done) exhausted = true;     // wave-uniform
         }
         if (!__ballot(busy)) break;
-        // ---- interior steps (bvh.wgsl:56-74 and 104-121) ----
-        while (busy && !ray_done && (in_blas ? cn.y == 0u : cn.x != 0u)) {
+        // ---- interior steps (bvh.wgsl:56-74 and 104-121) and instance entries (bvh.wgsl:78-87) ----
+        // A TLAS leaf is an instance to enter: instance -> inv_transform + mesh -> MeshInfo -> the mesh's root node -> its two
+        // children is a chain of four dependent fetches, taken 140 times per ray on the stress scene (2000 overlapping
+        // instances; 1.9 BLAS steps per entry: most entries end at the root's children) against 475 interior steps.  The
+        // entry record of the leaf (entry_records_kernel: one 128-byte line per TLAS node, rewritten at every call) holds
+        // all of it, so an entry is ONE trip to L2 (and a second read of the same line out of L1) and runs the root's step in
+        // the same iteration - same values, same arithmetic.
+        // The wave leaves the loop to serve the lanes that wait - at a BLAS leaf, or finished - once `yield` of them do
+        // (or nobody steps any more): leaves are rare next to steps (13 against 615 per ray on the stress scene), so waiting
+        // for every lane to reach one would idle most of the wave, and serving each at once would run the triangle code
+        // for one lane at a time.
+        const unsigned n_busy = (unsigned)__popcll(__ballot(busy));
+        for (;;) {
+            // PREP: a lane at a BLAS leaf steps too - its fetch is one de-indexed triangle (36 contiguous bytes), in flight
+            // together with the other lanes' node pairs and entry records: one trip to memory per iteration whatever the
+            // lanes are doing.  (Indexed leaves are two dependent fetches of another shape: served outside the loop.)
+            const bool leaf = in_blas && cn.y != 0u;
+            const bool stepping = busy && !ray_done && (PREP || !leaf);
+            const unsigned n_step = (unsigned)__popcll(__ballot(stepping));
+            if (n_step == 0u || n_busy - n_step >= s.yield) break;
+            if (!stepping) continue;
+            const bool enter = !in_blas && cn.x == 0u;
             const char* p0; const char* p1;
-            if (in_blas) {
+            unsigned idx0 = 0u, idx1 = 0u;
+            if (PREP && leaf) {               // triangle cn.x of the mesh: the vertices fetch_vertex (bvh.wgsl:30-33) returns
+                p0 = reinterpret_cast<const char*>(s.tris + 9u * ((size_t)(base_index / 3u) + cn.x));
+                p1 = p0 + sizeof(VdBvhNode);
+            } else if (enter) {               // the first half of the leaf's entry record: matrix rows + mesh words
+                p0 = reinterpret_cast<const char*>(s.irec + 8u * (size_t)cn.y);
+                p1 = p0 + sizeof(VdBvhNode);
+            } else if (in_blas) {
                 p0 = reinterpret_cast<const char*>(s.bvh + (bvh_index + cn.x));
                 p1 = p0 + sizeof(VdBvhNode);
             } else {
-                p0 = reinterpret_cast<const char*>(s.tlas + (cn.x & 0xffffu));
-                p1 = reinterpret_cast<const char*>(s.tlas + (cn.x >> 16u));
+                idx0 = cn.x & 0xffffu; idx1 = cn.x >> 16u;
+                p0 = reinterpret_cast<const char*>(s.tlas + idx0);
+                p1 = reinterpret_cast<const char*>(s.tlas + idx1);
             }
-            const float4 a0 = reinterpret_cast<const float4*>(p0)[0], a1 = reinterpret_cast<const float4*>(p0)[1];
-            const float4 b0 = reinterpret_cast<const float4*>(p1)[0], b1 = reinterpret_cast<const float4*>(p1)[1];
+            // one set of registers for either kind of lane: an entering lane's matrix rows travel with the other lanes' child pairs
+            float4 a0 = reinterpret_cast<const float4*>(p0)[0], a1 = reinterpret_cast<const float4*>(p0)[1];
+            float4 b0 = reinterpret_cast<const float4*>(p1)[0], b1 = reinterpret_cast<const float4*>(p1)[1];
+            if (PREP && leaf) {               // bvh.wgsl:48-55, one triangle per iteration, in leaf order
+                const float v0[3] = {a0.x, a0.y, a0.z}, v1[3] = {a0.w, a1.x, a1.y}, v2[3] = {a1.z, a1.w, b0.x};
+                float hit = res.dist;
+                if (intersect_trig(ray, v0, v1, v2, hit)) {
+                    res.dist = hit; res.hit = 1u; res.instance = tl_leaf; res.triangle = cn.x;
+                    if (ANY) { ray_done = true; continue; }
+                }
+                if (--cn.y == 0u) pop(); else ++cn.x;
+                continue;
+            }
+            if (enter) {
+                // (inv_transform * vec4(eye, 1.)).xyz and (inv_transform * vec4(dir, 0.)).xyz; a0, a1, b0 = rows 0..2 of the matrix
+                tl_leaf = cn.y;
+                ray.ex = ((a0.x * world.ex + a0.y * world.ey) + a0.z * world.ez) + a0.w * 1.0f;
+                ray.ey = ((a1.x * world.ex + a1.y * world.ey) + a1.z * world.ez) + a1.w * 1.0f;
+                ray.ez = ((b0.x * world.ex + b0.y * world.ey) + b0.z * world.ez) + b0.w * 1.0f;
+                ray.dx = ((a0.x * world.dx + a0.y * world.dy) + a0.z * world.dz) + a0.w * 0.0f;
+                ray.dy = ((a1.x * world.dx + a1.y * world.dy) + a1.z * world.dz) + a1.w * 0.0f;
+                ray.dz = ((b0.x * world.dx + b0.y * world.dy) + b0.z * world.dz) + b0.w * 0.0f;
+                ray.ix = 1.0f / ray.dx; ray.iy = 1.0f / ray.dy; ray.iz = 1.0f / ray.dz;
+                bvh_index = __float_as_uint(b1.x); base_index = __float_as_uint(b1.y); vertex_offset = __float_as_uint(b1.z);
+                const unsigned rw = __float_as_uint(b1.w);             // the mesh's root: left_first | count << 30 (traverse_bvh starts there)
+                if (rw == 0xffffffffu) { bad_entry = true; ray_done = true; continue; }   // instance / mesh / root outside the scene's buffers
+                in_blas = true;
+                blas_base = head;
+                cn = make_uint2(rw & 0x3fffffffu, rw >> 30);
+                if (cn.y != 0u) continue;                                // a mesh of <= 3 triangles: its root is a leaf
+                // the root's children: the second half of the same 128-byte line (in L1 by now)
+                a0 = reinterpret_cast<const float4*>(p0)[4]; a1 = reinterpret_cast<const float4*>(p0)[5];
+                b0 = reinterpret_cast<const float4*>(p0)[6]; b1 = reinterpret_cast<const float4*>(p0)[7];
+            }
             const float mn0[3] = {a0.x, a0.y, a0.z}, mx0[3] = {a1.x, a1.y, a1.z};
             const float mn1[3] = {b0.x, b0.y, b0.z}, mx1[3] = {b1.x, b1.y, b1.z};
             float min_dist = intersect_aabb(ray, mn0, mx0, res.dist);
             float max_dist = intersect_aabb(ray, mn1, mx1, res.dist);
-            uint2 near = make_uint2(__float_as_uint(a0.w), __float_as_uint(a1.w));
-            uint2 far = make_uint2(__float_as_uint(b0.w), __float_as_uint(b1.w));
+            // payload of a child: BLAS {left_first, count}; TLAS {left_right, its own node index}
+            uint2 near = make_uint2(__float_as_uint(a0.w), in_blas ? __float_as_uint(a1.w) : idx0);
+            uint2 far = make_uint2(__float_as_uint(b0.w), in_blas ? __float_as_uint(b1.w) : idx1);
             if (min_dist > max_dist) {
                 const uint2 tu = near; near = far; far = tu;
                 const float tf = min_dist; min_dist = max_dist; max_dist = tf;
@@ -216,26 +282,8 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             }
             cn = near;
         }
-        if (!busy || ray_done) continue;
-        if (!in_blas) {
-            // ---- TLAS leaf: instance_intersect (bvh.wgsl:78-87) ----
-            instance_idx = cn.y;
-            const VdInstance* I = s.inst + instance_idx;
-            const VdMeshInfo mesh = s.meshes[min(I->mesh, s.n_meshes - 1u)];
-            bvh_index = mesh.bvh_index; base_index = mesh.base_index; vertex_offset = (unsigned)mesh.vertex_offset;
-            const float* M = I->inv_transform;
-            ray.ex = ((M[0] * world.ex + M[4] * world.ey) + M[8] * world.ez) + M[12] * 1.0f;
-            ray.ey = ((M[1] * world.ex + M[5] * world.ey) + M[9] * world.ez) + M[13] * 1.0f;
-            ray.ez = ((M[2] * world.ex + M[6] * world.ey) + M[10] * world.ez) + M[14] * 1.0f;
-            ray.dx = ((M[0] * world.dx + M[4] * world.dy) + M[8] * world.dz) + M[12] * 0.0f;
-            ray.dy = ((M[1] * world.dx + M[5] * world.dy) + M[9] * world.dz) + M[13] * 0.0f;
-            ray.dz = ((M[2] * world.dx + M[6] * world.dy) + M[10] * world.dz) + M[14] * 0.0f;
-            ray.ix = 1.0f / ray.dx; ray.iy = 1.0f / ray.dy; ray.iz = 1.0f / ray.dz;
-            const VdBvhNode root = s.bvh[bvh_index];               // traverse_bvh starts at the mesh's root
-            cn = make_uint2(root.left_first, root.count);
-            in_blas = true;
-            blas_base = head;
-        } else {
+        if (PREP || !busy || ray_done || !(in_blas && cn.y != 0u)) continue;     // only lanes at an indexed BLAS leaf go on
+        {
             // ---- BLAS leaf (bvh.wgsl:48-55) ----
             for (unsigned k = 0; k < cn.y; ++k) {
                 const unsigned idx = cn.x + k;
@@ -254,7 +302,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                 }
                 float hit = res.dist;
                 if (intersect_trig(ray, a0, a1, a2, hit)) {
-                    res.dist = hit; res.hit = 1u; res.instance = instance_idx; res.triangle = idx;
+                    res.dist = hit; res.hit = 1u; res.instance = tl_leaf; res.triangle = idx;
                     if (ANY) break;
                 }
             }
@@ -263,6 +311,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
     }
     if (ovf) atomicOr(overflow, 1u);
     if (bad_leaf) atomicOr(overflow, 2u);
+    if (bad_entry) atomicOr(overflow, 4u);
 }
 
 // Entry points.  The single-ray form keeps the round-2 kernel's argument list (the six scene buffers, rays, count, outputs,
@@ -271,12 +320,12 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
 // more than ~100 k rays were in flight - same source, same ISA shape, only the argument block differs - while the
 // 7-wave workgroups of the chunked form run with the larger block.  Not understood; avoided.
 struct SceneArgs { const VdTlasNode* tlas; const VdInstance* inst; const VdMeshInfo* meshes; const VdBvhNode* bvh;
-                   const float* verts; const unsigned* indices; unsigned n_meshes; };
+                   const float* verts; const unsigned* indices; unsigned n_meshes, yield; const float4* irec; };
 template <bool ANY>
 __global__ __launch_bounds__(64, 7)   // second argument (HIP): waves per SIMD = 28 per CU
 void trace_single_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                          unsigned* __restrict__ overflow, unsigned* next_ray) {
-    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, nullptr};
+    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, nullptr, a.irec, a.yield};
     const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray};
     trace_body<ANY, false, false>(s, rays, src, out, out_any, overflow);
 }
@@ -284,7 +333,7 @@ template <bool ANY>
 __global__ __launch_bounds__(64, 7)
 void trace_single_prep_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                               unsigned* __restrict__ overflow, unsigned* next_ray, const float* __restrict__ tris) {
-    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, tris};
+    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, tris, a.irec, a.yield};
     const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray};
     trace_body<ANY, true, false>(s, rays, src, out, out_any, overflow);
 }
@@ -565,6 +614,45 @@ __global__ __launch_bounds__(64 * kSortWaves) void rs_scatter_kernel(const unsig
     }
 }
 
+// Entry records: everything `instance_intersect` (bvh.wgsl:78-87) and the first step of `traverse_bvh` (bvh.wgsl:35-76)
+// read when a ray enters the instance of a TLAS leaf, gathered into one 128-byte line per TLAS node:
+//   [0..2] rows 0..2 of inv_transform (row r = {M[r], M[4 + r], M[8 + r], M[12 + r]}: the operands of
+//          (inv_transform * vec4(p, w)).r in source order)
+//   [3]    {bvh_index, base_index, vertex_offset, root.left_first | root.count << 30} of the instance's mesh
+//   [4..7] the 64 bytes of the root's two children (bvh_nodes[bvh_index + root.left_first], + 1) when it has any.
+// Written at the start of EVERY trace call from the scene's own buffers (<= 65 536 nodes: a few microseconds), so
+// instances, TLAS nodes and meshes may change between calls as before.  A leaf whose instance, mesh root or children lie
+// outside the buffers gets .w = 0xffffffff in [3]: a ray that ENTERS it reports VD_ERR_INVALID_ARG (unreachable slots of
+// a TLAS array may hold anything).
+__global__ __launch_bounds__(256) void entry_records_kernel(const VdTlasNode* __restrict__ tlas, unsigned n_nodes, const VdInstance* __restrict__ inst,
+                                                            unsigned n_inst, const VdMeshInfo* __restrict__ meshes, unsigned n_meshes,
+                                                            const VdBvhNode* __restrict__ bvh, unsigned n_bvh, float4* __restrict__ rec) {
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n_nodes) return;
+    const VdTlasNode node = tlas[k];
+    if (node.left_right != 0u) return;                  // interior: never entered
+    float4* R = rec + 8u * (size_t)k;
+    const float4 poison = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
+    if (node.instance_idx >= n_inst) { R[3] = poison; return; }
+    const VdInstance* I = inst + node.instance_idx;
+    const VdMeshInfo mesh = meshes[min(I->mesh, n_meshes - 1u)];
+    const float* M = I->inv_transform;
+    R[0] = make_float4(M[0], M[4], M[8], M[12]);
+    R[1] = make_float4(M[1], M[5], M[9], M[13]);
+    R[2] = make_float4(M[2], M[6], M[10], M[14]);
+    if (mesh.bvh_index >= n_bvh) { R[3] = poison; return; }
+    const VdBvhNode root = bvh[mesh.bvh_index];
+    if (root.count > 3u || root.left_first >= (1u << 30)) { R[3] = poison; return; }    // not a BvhBuilder tree (blas.rs:108)
+    if (root.count == 0u) {
+        const size_t c = (size_t)mesh.bvh_index + root.left_first;
+        if (c + 1u >= n_bvh) { R[3] = poison; return; }
+        const float4* src = reinterpret_cast<const float4*>(bvh + c);
+        R[4] = src[0]; R[5] = src[1]; R[6] = src[2]; R[7] = src[3];
+    }
+    R[3] = make_float4(__uint_as_float(mesh.bvh_index), __uint_as_float(mesh.base_index), __uint_as_float((unsigned)mesh.vertex_offset),
+                       __uint_as_float(root.left_first | (root.count << 30)));
+}
+
 // De-indexed leaf triangles: tris[9 * (base_index / 3 + t)] = the three vertices fetch_vertex (bvh.wgsl:30-33) returns for
 // triangle t of the mesh, i.e. vertices[vertex_offset + indices[base_index + 3 t + c]].
 __global__ __launch_bounds__(256) void prepare_tris_kernel(const VdMeshInfo* __restrict__ meshes, const float* __restrict__ verts,
@@ -584,13 +672,13 @@ __global__ __launch_bounds__(256) void prepare_tris_kernel(const VdMeshInfo* __r
     }
 }
 
-// order = the ray ids sorted by ray key (scratch of the context, past the first 256 bytes); nullptr when not worth it
-int sort_rays(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n, const unsigned** out_order) {
+// order = the ray ids sorted by ray key (scratch of the context from byte `at`: past the flags and the entry records)
+int sort_rays(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n, const unsigned** out_order, size_t at) {
     const unsigned n_units = (n + kSortUnit - 1u) / kSortUnit;
     const size_t arr = ((size_t)n * 4 + 255) & ~(size_t)255, tab = ((size_t)256 * n_units * 4 + 255) & ~(size_t)255;
-    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256 + 4 * arr + tab);
+    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, at + 4 * arr + tab);
     if (rc) return rc;
-    char* base = reinterpret_cast<char*>(ctx->scratch) + 256;
+    char* base = reinterpret_cast<char*>(ctx->scratch) + at;
     unsigned* k[2] = {reinterpret_cast<unsigned*>(base), reinterpret_cast<unsigned*>(base + arr)};
     unsigned* v[2] = {reinterpret_cast<unsigned*>(base + 2 * arr), reinterpret_cast<unsigned*>(base + 3 * arr)};
     unsigned* table = reinterpret_cast<unsigned*>(base + 4 * arr);
@@ -610,25 +698,31 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
                  uint32_t* d_any = nullptr) {
     // idle waves keep drawing from the ray counter after the last ray: leave it room below 2^32
     if (n_rays > 0xf0000000u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: more than 0xf0000000 rays in one call");
-    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, 256);
+    // scratch: [256 B flags and counters][entry records, 128 B per TLAS node][ray binning arrays]
+    const size_t rec_bytes = (size_t)128 * sc->n_tlas_nodes, sort_at = 256 + rec_bytes;
+    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, sort_at);
     if (rc) return rc;
-    Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, d_tris};
     // Binning is OFF by default: measured on the stress scene (tools/ab_trace.py, profiles/r03_ab_trace.log) rays handed
     // out in sorted order are SLOWER (32.0 against 35.7 Mrays/s): the walk is bound by the slowest of a wave's 64 fetches,
     // not by the L1 hit rate, and sorting puts the expensive rays of the dense screen centre side by side in time.
     const bool sorted = ctx->option(VD_OPT_TRACE_SORT, 0) != 0 && n_rays >= (unsigned)ctx->option(VD_OPT_TRACE_SORT_MIN, 65536);
     vd_time_begin(ctx);
     const unsigned* order = nullptr;
-    if (sorted) { rc = sort_rays(ctx, sc, d_rays, n_rays, &order); if (rc) return rc; }
+    if (sorted) { rc = sort_rays(ctx, sc, d_rays, n_rays, &order, sort_at); if (rc) return rc; }
     unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);      // after sort_rays: the scratch may have grown
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 16, ctx->stream));
+    float4* d_rec = reinterpret_cast<float4*>(reinterpret_cast<char*>(ctx->scratch) + 256);
+    const unsigned yield = (unsigned)std::max<long long>(1, ctx->option(VD_OPT_TRACE_YIELD, kYieldDefault));
+    hipLaunchKernelGGL(entry_records_kernel, dim3((sc->n_tlas_nodes + 255u) / 256u), dim3(256), 0, ctx->stream, sc->tlas_nodes, sc->n_tlas_nodes,
+                       sc->instances, sc->n_instances, sc->meshes, sc->n_meshes, sc->bvh_nodes, sc->n_bvh_nodes, d_rec);
+    Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, d_tris, d_rec, yield};
     {
         // Default: single rays from one global counter (chunk = 1), one wave per workgroup - the finest balance.  Chunks of
         // consecutive rays per workgroup (a CU-local window of the ray order) lose more to imbalance than they gain in
         // locality: 64 rays per chunk 32.6, 256 rays 16.9 Mrays/s against 35.2 in the same kernel (same log).
         unsigned chunk = (unsigned)ctx->option(VD_OPT_TRACE_CHUNK, 1);
         if (chunk <= 1u && !order) {
-            const SceneArgs a{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes};
+            const SceneArgs a{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, yield, d_rec};
             const unsigned waves = (unsigned)ctx->num_cus * kWavesPerCu;
             if (d_tris) {
                 if (d_any) hipLaunchKernelGGL(trace_single_prep_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, d_tris);
@@ -651,6 +745,7 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     VD_HIP_CHECK(ctx, hipGetLastError());
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->host_pinned[0] & 4u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: a TLAS leaf's instance, its mesh's root or the root's children lie outside the scene's buffers");
     if (ctx->host_pinned[0] & 2u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: BVH leaf with more than 3 triangles (BvhBuilder never makes one: blas.rs:108)");
     if (ctx->host_pinned[0]) VD_FAIL(ctx, VD_ERR_STACK_OVERFLOW, "vd_trace: traversal stack (128 entries per ray) exceeded");
     return VD_OK;
