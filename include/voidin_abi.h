@@ -210,6 +210,7 @@ typedef enum VdOption {
                                      rays per workgroup in chunks of this size (measured slower: imbalance)      */
     VD_OPT_TRACE_YIELD = 24,      /* lanes of a wave that wait (at a BLAS leaf, or with a finished ray) before the wave
                                      leaves its stepping loop to serve them; default 16                          */
+    VD_OPT_TRACE_WAVES = 25,      /* persistent waves per CU of the single-ray supply (1..28); default 28          */
     VD_OPT_COUNT_ = 32
 } VdOption;
 int         vd_ctx_set_option(VdCtx* ctx, int option /* VdOption */, int64_t value);

@@ -346,9 +346,11 @@ def test_trace_supply_binning_and_prepared_triangles_are_order_only(ctx, oracle,
     d_any = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
     first = None
     variants = [dict(), dict(chunk=64), dict(sort=1, sort_min=1), dict(sort=1, sort_min=1, chunk=64), dict(sort=1, sort_min=1, chunk=4096),
-                dict(sort=1, sort_min=1, chunk=100), dict(chunk=1000)]     # default: single rays from one counter, no binning
+                dict(sort=1, sort_min=1, chunk=100), dict(chunk=1000),     # default: single rays from one counter, no binning
+                # when a wave leaves its stepping loop to serve waiting lanes, and how many waves a CU runs
+                {"yield": 4}, {"yield": 64}, {"yield": 64, "chunk": 64}, dict(waves=3)]
     for opts in variants:
-        for k in ("sort", "sort_min", "chunk"):
+        for k in ("sort", "sort_min", "chunk", "yield", "waves"):
             ctx_options("trace." + k, opts.get(k))
         for prep in (False, True):
             d_hits.zero_(); d_any.fill_(9)
@@ -363,6 +365,9 @@ def test_trace_supply_binning_and_prepared_triangles_are_order_only(ctx, oracle,
                 assert np.array_equal(got["hit"], want["hit"]) and want["hit"].sum() > 300
                 hit = want["hit"] == 1
                 assert got["dist"][hit].tobytes() == want["dist"][hit].tobytes()          # bit-equal in fact (tolerance: 1e-5)
+                # which instance and which triangle: the walk carries the TLAS leaf and resolves the instance when the ray retires
+                assert np.array_equal(got["instance"][hit], want["instance"][hit])
+                assert np.array_equal(got["triangle"][hit], want["triangle"][hit])
             assert got.tobytes() == first, (opts, prep)
             assert np.array_equal(d_any.cpu().numpy().astype(np.uint32), want["hit"]), (opts, prep)
     acc.close()
@@ -372,6 +377,65 @@ def test_trace_supply_binning_and_prepared_triangles_are_order_only(ctx, oracle,
     with pytest.raises(VoidinError) as e:
         ctx.trace_prepare(bad)
     assert e.value.code == abi.VD_ERR_INVALID_ARG
+
+
+def test_trace_records_survive_stale_slots_and_report_bad_leaves(ctx, oracle):
+    """The per-call records of the walk (trace.hip, records_kernel): the two children of a TLAS node sit side by side at
+    the LEFT child's index, tagged with the right child's.  An unreachable slot of the TLAS array may name the same left
+    child with another right child (the reference's array keeps such slots: tlas.rs:62-84) - whichever of the two wrote
+    the slot, the walk must notice a foreign tag and read the nodes themselves.  And a leaf whose instance index or whose
+    mesh's BLAS root lies outside the scene's buffers is an error when a ray enters it, not a wild read."""
+    import torch
+    v, i = synth.knot_mesh(64, 16)
+    nodes, idx = oracle.bvh_build(v, i)
+    infos = np.zeros(1, dtype=abi.MESH_INFO)
+    infos[0]["min"], infos[0]["max"] = synth.mesh_bounds(v)
+    infos[0]["index_count"] = len(idx)
+    inst = synth.instances(200, n_mesh=1, seed=synth.SEED_BASE + 33, extent=40.0, scale_range=(0.5, 2.0))
+    tl = oracle.tlas_build(inst, infos)
+    rays = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 45), pitch_deg=0), 160, 160)
+    want, _ = oracle.trace((tl, inst, infos, nodes, v, idx), rays, threads=8)
+    assert want["hit"].sum() > 500
+    # reachable nodes, and slots nobody reaches
+    reach = np.zeros(len(tl), dtype=bool); todo = [0]
+    while todo:
+        k = todo.pop(); reach[k] = True
+        lr = int(tl["left_right"][k])
+        if lr: todo += [lr & 0xffff, lr >> 16]
+    free = np.nonzero(~reach)[0]
+    interior = np.nonzero(reach & (tl["left_right"] != 0))[0]
+    assert len(free) >= 1 and len(interior) > 50
+    stale = tl.copy()
+    for n, k in enumerate(free[:64]):                     # every free slot claims some real node's left child, with another partner
+        lr = int(tl["left_right"][interior[(7 * n) % len(interior)]])
+        stale["left_right"][k] = (lr & 0xffff) | (int(interior[(3 * n + 1) % len(interior)]) << 16)
+    d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
+    d_any = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
+    for tlas_nodes in (tl, stale):
+        ds = ctx.device_scene((tlas_nodes, inst, infos, nodes, v, idx))
+        for rep in range(3):                              # which writer wins a contested slot may differ from launch to launch
+            ctx.trace_dev(ds, d_rays, len(rays), d_hits); ctx.trace_any_dev(ds, d_rays, len(rays), d_any)
+            got = d_hits.cpu().numpy().view(abi.HIT)[: len(rays)]
+            hit = want["hit"] == 1
+            assert np.array_equal(got["hit"], want["hit"])
+            for f in ("dist", "instance", "triangle"):
+                assert got[f][hit].tobytes() == want[f][hit].tobytes(), f
+            assert np.array_equal(d_any.cpu().numpy().astype(np.uint32), want["hit"])
+    # a leaf that names an instance past the buffer / a mesh whose BLAS root is past the node buffer: VD_ERR_INVALID_ARG
+    leaf = int(np.nonzero(reach & (tl["left_right"] == 0))[0][0])
+    bad_leaf = tl.copy(); bad_leaf["instance_idx"][leaf] = len(inst) + 5
+    bad_mesh = infos.copy(); bad_mesh[0]["bvh_index"] = len(nodes) + 7
+    # rays aimed at every instance: some ray enters the poisoned leaf
+    dirs = np.array([(0, 0, -1), (0, 0, 1), (0, -1, 0), (0, 1, 0), (-1, 0, 0), (1, 0, 0)], dtype=np.float32)
+    aim = np.zeros(len(inst) * 6, dtype=abi.RAY)          # from six sides: something in front may hide the leaf from one of them
+    for k, d in enumerate(dirs):
+        aim["eye"][k::6] = inst["transform"][:, 12:15] - 30.0 * d; aim["dir"][k::6] = d
+    d_aim, d_h2 = ctx.upload(aim), ctx.empty(len(aim) * 16)
+    for scene in ((bad_leaf, inst, infos, nodes, v, idx), (tl, inst, bad_mesh, nodes, v, idx)):
+        with pytest.raises(VoidinError) as e:
+            ctx.trace_dev(ctx.device_scene(scene), d_aim, len(aim), d_h2)
+        assert e.value.code == abi.VD_ERR_INVALID_ARG
+    ctx.trace_dev(ctx.device_scene((tl, inst, infos, nodes, v, idx)), d_aim, len(aim), d_h2)      # the context is fine afterwards
 
 
 def test_trace_axis_aligned_and_degenerate_rays(ctx, oracle):

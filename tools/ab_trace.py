@@ -37,10 +37,13 @@ variants = [("single rays (default)", dict(sort=0, chunk=1), False), ("single ra
 if os.environ.get("AB_YIELD"):        # sweep of VD_OPT_TRACE_YIELD on the default supply
     variants = [("yield %2d%s" % (y, " prep" if pr else ""), dict(sort=0, chunk=1, **{"yield": y}), pr)
                 for y in [int(v) for v in os.environ["AB_YIELD"].split(",")] for pr in (False, True)]
+if os.environ.get("AB_WAVES"):        # sweep of VD_OPT_TRACE_WAVES on the default supply
+    variants = [("waves/CU %2d%s" % (w, " prep" if pr else ""), dict(sort=0, chunk=1, waves=w), pr)
+                for w in [int(v) for v in os.environ["AB_WAVES"].split(",")] for pr in (False, True)]
 ref_bytes = ref_any = None
 ctx.set_timing(True)
 for name, opts, prep in variants:
-    for k in ("sort", "chunk", "yield"):
+    for k in ("sort", "chunk", "yield", "waves"):
         ctx.set_option("trace." + k, opts.get(k, -1))
     t_cl, t_any = [], []
     for _ in range(args.reps):
@@ -50,6 +53,20 @@ for name, opts, prep in variants:
         else:
             ctx.trace_dev(ds, d_rays, len(rays), d_hits); t_cl.append(ctx.last_gpu_ms())
             ctx.trace_any_dev(ds, d_rays, len(rays), d_any); t_any.append(ctx.last_gpu_ms())
+    if hasattr(ctx.lib, "vd_debug_trace_counters") and os.environ.get("AB_COUNTERS"):      # tuning build: what the waves did (last call = occlusion)
+        import ctypes as C
+        for kind in ("closest", "occlusion"):
+            if kind == "closest":
+                (ctx.trace_prepared_dev(acc, d_rays, len(rays), d_hits) if prep else ctx.trace_dev(ds, d_rays, len(rays), d_hits))
+            else:
+                (ctx.trace_any_prepared_dev(acc, d_rays, len(rays), d_any) if prep else ctx.trace_any_dev(ds, d_rays, len(rays), d_any))
+            c = (C.c_uint64 * 8)()
+            ctx.lib.vd_debug_trace_counters.argtypes = [C.c_void_p, C.c_void_p]
+            ctx.lib.vd_debug_trace_counters(ctx.h, c)
+            n = len(rays)
+            print(f"    {kind}: outer iterations {c[0]}, stepping iterations {c[1]} ({c[1] / (256 * 28):.0f} per wave), lanes per iteration {c[2] / max(1, c[1]):.1f}, "
+                  f"lane-steps per ray {c[2] / n:.0f} (leaf {c[3] / n:.1f}, entry {c[4] / n:.1f}, TLAS interior {c[5] / n:.1f}); longest ray {c[6]} steps; "
+                  f"iterations after the last ray was handed out: {c[7] / (256 * 28):.0f} per wave")
     b, a = d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes()
     if ref_bytes is None:
         ref_bytes, ref_any = b, a

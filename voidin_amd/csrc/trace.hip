@@ -19,6 +19,7 @@ struct VdTraceAccel { VdTraceScene scene; float* tris = nullptr; };
 namespace {
 
 constexpr int kStack = 64;
+constexpr int kLdsStack = 20;            // stack entries per ray kept in LDS: 5 KB per wave, 28 waves per CU = 140 of the 160 KB
 constexpr float kMaxDist = 1e30f;
 
 struct Ray { float ex, ey, ez, dx, dy, dz, ix, iy, iz; };
@@ -67,7 +68,9 @@ struct Scene {
     const VdTlasNode* tlas; const VdInstance* inst; const VdMeshInfo* meshes; const VdBvhNode* bvh;
     const float* verts; const unsigned* indices; unsigned n_meshes;
     const float* tris;          // vd_trace_prepare_dev: 9 floats per triangle in index-buffer order (nullptr: not prepared)
-    const float4* irec;         // entry records, 8 x float4 per TLAS node (entry_records_kernel)
+    const float4* irec;         // entry records, 4 x float4 per TLAS node (records_kernel)
+    const float4* tpair;        // child pairs of the TLAS, 4 x float4 per node, at the LEFT child's index
+    const float4* mrec;         // mesh records, 8 x float4 per mesh
     unsigned yield;             // waiting lanes at which a wave leaves the stepping loop (VD_OPT_TRACE_YIELD)
 };
 
@@ -108,7 +111,12 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
         if (threadIdx.x == 0) s_word = 0ull;
         __syncthreads();
     }
-    unsigned stack[2 * kStack];            // BLAS entries sit above the TLAS entries of the same ray
+    // The first kLdsStack entries of a ray's stack live in LDS ([slot][lane]: a lane always hits its own bank), the rest in
+    // the private array.  A private array indexed by a per-lane depth is scratch memory, and 64 lanes at 64 depths are 64
+    // lines per push and per pop - as many as the node fetch itself, out of the same L1 miss bandwidth that bounds the walk.
+    __shared__ unsigned s_stack[CHUNKS ? kWgWaves : 1][kLdsStack][64];
+    unsigned* const lds_stack = &s_stack[CHUNKS ? (threadIdx.x >> 6) : 0u][0][lane];
+    unsigned stack[2 * kStack - kLdsStack];  // BLAS entries sit above the TLAS entries of the same ray
     Ray world, ray;                        // `ray` is the active one (object space inside an instance)
     VdHit res;
     unsigned ray_id = 0;
@@ -117,17 +125,24 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
     unsigned tl_leaf = 0, bvh_index = 0, base_index = 0, vertex_offset = 0;   // tl_leaf: the TLAS leaf node the ray is inside
     uint2 cn = make_uint2(0u, 0u);         // payload of the current node
     bool ray_done = false;
+#ifdef VD_TUNING
+    unsigned dbg_outer = 0, dbg_iter = 0, dbg_lanes = 0, dbg_kind[3] = {0, 0, 0}, dbg_ray_steps = 0, dbg_ray_max = 0, dbg_drain = 0;
+#endif
 
     auto pop = [&]() {                     // leave the current node
         if (in_blas && head == blas_base) { in_blas = false; ray = world; }
         if (head == 0u) { ray_done = true; return; }
-        const unsigned w = stack[--head];
+        --head;
+        const unsigned w = head < (unsigned)kLdsStack ? lds_stack[head * 64u] : stack[head - (unsigned)kLdsStack];
         if (in_blas) cn = make_uint2(w & 0x3fffffffu, w >> 30);
         else cn = (w & 0xffffu) ? make_uint2(w, 0xffffffffu) : make_uint2(0u, w >> 16);
     };
     for (;;) {
         // ---- retire finished rays, refill idle lanes ----
         if (busy && ray_done) {
+#ifdef VD_TUNING
+            dbg_ray_max = max(dbg_ray_max, dbg_ray_steps); dbg_ray_steps = 0;
+#endif
             if (ANY) out_any[ray_id] = res.hit;
             else { if (res.hit) res.instance = s.tlas[res.instance].instance_idx; out[ray_id] = res; }   // hits carry the leaf node until here
             busy = false;
@@ -201,6 +216,9 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
         // for every lane to reach one would idle most of the wave, and serving each at once would run the triangle code
         // for one lane at a time.
         const unsigned n_busy = (unsigned)__popcll(__ballot(busy));
+#ifdef VD_TUNING
+        ++dbg_outer;
+#endif
         for (;;) {
             // PREP: a lane at a BLAS leaf steps too - its fetch is one de-indexed triangle (36 contiguous bytes), in flight
             // together with the other lanes' node pairs and entry records: one trip to memory per iteration whatever the
@@ -209,6 +227,11 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             const bool stepping = busy && !ray_done && (PREP || !leaf);
             const unsigned n_step = (unsigned)__popcll(__ballot(stepping));
             if (n_step == 0u || n_busy - n_step >= s.yield) break;
+#ifdef VD_TUNING
+            ++dbg_iter; dbg_lanes += n_step; if (stepping) ++dbg_ray_steps; if (exhausted) ++dbg_drain;
+            dbg_kind[0] += (unsigned)__popcll(__ballot(stepping && leaf)); dbg_kind[1] += (unsigned)__popcll(__ballot(stepping && !leaf && !in_blas && cn.x == 0u));
+            dbg_kind[2] += (unsigned)__popcll(__ballot(stepping && !leaf && !in_blas && cn.x != 0u));
+#endif
             if (!stepping) continue;
             const bool enter = !in_blas && cn.x == 0u;
             const char* p0; const char* p1;
@@ -216,16 +239,16 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             if (PREP && leaf) {               // triangle cn.x of the mesh: the vertices fetch_vertex (bvh.wgsl:30-33) returns
                 p0 = reinterpret_cast<const char*>(s.tris + 9u * ((size_t)(base_index / 3u) + cn.x));
                 p1 = p0 + sizeof(VdBvhNode);
-            } else if (enter) {               // the first half of the leaf's entry record: matrix rows + mesh words
-                p0 = reinterpret_cast<const char*>(s.irec + 8u * (size_t)cn.y);
+            } else if (enter) {               // the leaf's entry record: matrix rows + mesh id
+                p0 = reinterpret_cast<const char*>(s.irec + 4u * (size_t)cn.y);
                 p1 = p0 + sizeof(VdBvhNode);
             } else if (in_blas) {
                 p0 = reinterpret_cast<const char*>(s.bvh + (bvh_index + cn.x));
                 p1 = p0 + sizeof(VdBvhNode);
             } else {
-                idx0 = cn.x & 0xffffu; idx1 = cn.x >> 16u;
-                p0 = reinterpret_cast<const char*>(s.tlas + idx0);
-                p1 = reinterpret_cast<const char*>(s.tlas + idx1);
+                idx0 = cn.x & 0xffffu; idx1 = cn.x >> 16u;       // both children as ONE line: the pair record at the left child's index
+                p0 = reinterpret_cast<const char*>(s.tpair + 4u * (size_t)idx0);
+                p1 = p0 + sizeof(VdTlasNode);
             }
             // one set of registers for either kind of lane: an entering lane's matrix rows travel with the other lanes' child pairs
             float4 a0 = reinterpret_cast<const float4*>(p0)[0], a1 = reinterpret_cast<const float4*>(p0)[1];
@@ -250,16 +273,24 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                 ray.dy = ((a1.x * world.dx + a1.y * world.dy) + a1.z * world.dz) + a1.w * 0.0f;
                 ray.dz = ((b0.x * world.dx + b0.y * world.dy) + b0.z * world.dz) + b0.w * 0.0f;
                 ray.ix = 1.0f / ray.dx; ray.iy = 1.0f / ray.dy; ray.iz = 1.0f / ray.dz;
-                bvh_index = __float_as_uint(b1.x); base_index = __float_as_uint(b1.y); vertex_offset = __float_as_uint(b1.z);
-                const unsigned rw = __float_as_uint(b1.w);             // the mesh's root: left_first | count << 30 (traverse_bvh starts there)
-                if (rw == 0xffffffffu) { bad_entry = true; ray_done = true; continue; }   // instance / mesh / root outside the scene's buffers
+                if (__float_as_uint(b1.y) != 0u) { bad_entry = true; ray_done = true; continue; }   // the leaf's instance lies outside the buffer
+                // the mesh's words and its root's children: the mesh record (a handful of lines that stay in L1)
+                const float4* Mr = s.mrec + 8u * (size_t)__float_as_uint(b1.x);
+                const float4 idv = Mr[0];
+                a0 = Mr[4]; a1 = Mr[5]; b0 = Mr[6]; b1 = Mr[7];
+                bvh_index = __float_as_uint(idv.x); base_index = __float_as_uint(idv.y); vertex_offset = __float_as_uint(idv.z);
+                const unsigned rw = __float_as_uint(idv.w);            // the mesh's root: left_first | count << 30 (traverse_bvh starts there)
+                if (rw == 0xffffffffu) { bad_entry = true; ray_done = true; continue; }   // mesh root / its children outside the buffer
                 in_blas = true;
                 blas_base = head;
                 cn = make_uint2(rw & 0x3fffffffu, rw >> 30);
                 if (cn.y != 0u) continue;                                // a mesh of <= 3 triangles: its root is a leaf
-                // the root's children: the second half of the same 128-byte line (in L1 by now)
-                a0 = reinterpret_cast<const float4*>(p0)[4]; a1 = reinterpret_cast<const float4*>(p0)[5];
-                b0 = reinterpret_cast<const float4*>(p0)[6]; b1 = reinterpret_cast<const float4*>(p0)[7];
+            } else if (!in_blas && __float_as_uint(a1.w) != idx1) {
+                // the pair record at idx0 was written for another right child: some unreachable slot of the TLAS array names
+                // the same left child (records_kernel) - read the two nodes themselves
+                const float4* n0 = reinterpret_cast<const float4*>(s.tlas + idx0);
+                const float4* n1 = reinterpret_cast<const float4*>(s.tlas + idx1);
+                a0 = n0[0]; a1 = n0[1]; b0 = n1[0]; b1 = n1[1];
             }
             const float mn0[3] = {a0.x, a0.y, a0.z}, mx0[3] = {a1.x, a1.y, a1.z};
             const float mn1[3] = {b0.x, b0.y, b0.z}, mx1[3] = {b1.x, b1.y, b1.z};
@@ -278,7 +309,9 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             if (in_blas ? max_dist <= res.dist : max_dist < res.dist) {
                 if (head + 1u > 2u * (unsigned)kStack) { ovf = true; ray_done = true; continue; }
                 if (in_blas && far.y > 3u) bad_leaf = true;   // not representable in a stack entry
-                stack[head++] = in_blas ? (far.x | (far.y << 30)) : (far.x != 0u ? far.x : (far.y << 16));
+                const unsigned w = in_blas ? (far.x | (far.y << 30)) : (far.x != 0u ? far.x : (far.y << 16));
+                if (head < (unsigned)kLdsStack) lds_stack[head * 64u] = w; else stack[head - (unsigned)kLdsStack] = w;
+                ++head;
             }
             cn = near;
         }
@@ -309,6 +342,15 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             if (ANY && res.hit) ray_done = true; else pop();
         }
     }
+#ifdef VD_TUNING
+    if (lane == 0) {       // wave totals -> the words after the flag and the ray counter (vd_debug_trace_counters)
+        atomicAdd(overflow + 4, dbg_outer); atomicAdd(overflow + 5, dbg_iter);
+        atomicAdd(reinterpret_cast<unsigned long long*>(overflow + 6), (unsigned long long)dbg_lanes);
+        atomicAdd(overflow + 8, dbg_kind[0]); atomicAdd(overflow + 9, dbg_kind[1]); atomicAdd(overflow + 10, dbg_kind[2]);
+        atomicAdd(overflow + 12, dbg_drain);
+    }
+    atomicMax(overflow + 11, dbg_ray_max);
+#endif
     if (ovf) atomicOr(overflow, 1u);
     if (bad_leaf) atomicOr(overflow, 2u);
     if (bad_entry) atomicOr(overflow, 4u);
@@ -320,12 +362,12 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
 // more than ~100 k rays were in flight - same source, same ISA shape, only the argument block differs - while the
 // 7-wave workgroups of the chunked form run with the larger block.  Not understood; avoided.
 struct SceneArgs { const VdTlasNode* tlas; const VdInstance* inst; const VdMeshInfo* meshes; const VdBvhNode* bvh;
-                   const float* verts; const unsigned* indices; unsigned n_meshes, yield; const float4* irec; };
+                   const float* verts; const unsigned* indices; unsigned n_meshes, yield; const float4* irec; const float4* tpair; const float4* mrec; };
 template <bool ANY>
 __global__ __launch_bounds__(64, 7)   // second argument (HIP): waves per SIMD = 28 per CU
 void trace_single_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                          unsigned* __restrict__ overflow, unsigned* next_ray) {
-    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, nullptr, a.irec, a.yield};
+    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, nullptr, a.irec, a.tpair, a.mrec, a.yield};
     const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray};
     trace_body<ANY, false, false>(s, rays, src, out, out_any, overflow);
 }
@@ -333,7 +375,7 @@ template <bool ANY>
 __global__ __launch_bounds__(64, 7)
 void trace_single_prep_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                               unsigned* __restrict__ overflow, unsigned* next_ray, const float* __restrict__ tris) {
-    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, tris, a.irec, a.yield};
+    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, tris, a.irec, a.tpair, a.mrec, a.yield};
     const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray};
     trace_body<ANY, true, false>(s, rays, src, out, out_any, overflow);
 }
@@ -614,43 +656,70 @@ __global__ __launch_bounds__(64 * kSortWaves) void rs_scatter_kernel(const unsig
     }
 }
 
-// Entry records: everything `instance_intersect` (bvh.wgsl:78-87) and the first step of `traverse_bvh` (bvh.wgsl:35-76)
-// read when a ray enters the instance of a TLAS leaf, gathered into one 128-byte line per TLAS node:
-//   [0..2] rows 0..2 of inv_transform (row r = {M[r], M[4 + r], M[8 + r], M[12 + r]}: the operands of
-//          (inv_transform * vec4(p, w)).r in source order)
-//   [3]    {bvh_index, base_index, vertex_offset, root.left_first | root.count << 30} of the instance's mesh
-//   [4..7] the 64 bytes of the root's two children (bvh_nodes[bvh_index + root.left_first], + 1) when it has any.
+// Per-call records: what the walk reads at a TLAS step and when it enters an instance, re-laid so that each is ONE line.
+// The bound of this kernel family is the number of distinct lines a CU can fetch (tools/probe_gather.hip:
+// profiles/r03_probe_gather.log), so the lines per ray are what counts:
+//   tpair[idx0]  (64 B) the two children of a TLAS node - tlas[idx0], tlas[idx1] - side by side at the LEFT child's index
+//                (a TLAS step used to fetch two nodes at unrelated indices = two lines).  The left copy's unused
+//                instance_idx word holds idx1 as a tag: a slot written for another right child (an unreachable slot of
+//                the array naming the same left child) is detected and the step reads the two nodes themselves;
+//   irec[k]      (64 B) for a TLAS leaf k: rows 0..2 of its instance's inv_transform (row r = {M[r], M[4 + r], M[8 + r],
+//                M[12 + r]}: the operands of (inv_transform * vec4(p, w)).r in source order), {mesh id, bad-instance flag};
+//   mrec[m]      (128 B) per mesh: {bvh_index, base_index, vertex_offset, root.left_first | root.count << 30} and the 64
+//                bytes of the root's two children: `instance_intersect` (bvh.wgsl:78-87) + the first step of `traverse_bvh`
+//                (bvh.wgsl:35-76) used to be instance -> MeshInfo -> root -> children, four dependent fetches, 140 times
+//                per ray on the stress scene; few meshes, so these lines stay in L1.
 // Written at the start of EVERY trace call from the scene's own buffers (<= 65 536 nodes: a few microseconds), so
-// instances, TLAS nodes and meshes may change between calls as before.  A leaf whose instance, mesh root or children lie
-// outside the buffers gets .w = 0xffffffff in [3]: a ray that ENTERS it reports VD_ERR_INVALID_ARG (unreachable slots of
-// a TLAS array may hold anything).
-__global__ __launch_bounds__(256) void entry_records_kernel(const VdTlasNode* __restrict__ tlas, unsigned n_nodes, const VdInstance* __restrict__ inst,
-                                                            unsigned n_inst, const VdMeshInfo* __restrict__ meshes, unsigned n_meshes,
-                                                            const VdBvhNode* __restrict__ bvh, unsigned n_bvh, float4* __restrict__ rec) {
+// instances, TLAS nodes and meshes may change between calls as before.  A mesh whose root or root children lie outside
+// the buffers gets 0xffffffff as its root word: a ray that ENTERS it reports VD_ERR_INVALID_ARG.
+constexpr unsigned kTlasSlots = 65536;              // 16-bit child indices (bvh.wgsl:105-106)
+__global__ __launch_bounds__(256) void records_kernel(const VdTlasNode* __restrict__ tlas, unsigned n_nodes, const VdInstance* __restrict__ inst,
+                                                      unsigned n_inst, const VdMeshInfo* __restrict__ meshes, unsigned n_meshes,
+                                                      const VdBvhNode* __restrict__ bvh, unsigned n_bvh, float4* __restrict__ irec,
+                                                      float4* __restrict__ tpair, float4* __restrict__ mrec) {
     const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k < n_meshes) {
+        const VdMeshInfo mesh = meshes[k];
+        float4* R = mrec + 8u * (size_t)k;
+        unsigned rw = 0xffffffffu;
+        if (mesh.bvh_index < n_bvh) {
+            const VdBvhNode root = bvh[mesh.bvh_index];
+            if (root.count <= 3u && root.left_first < (1u << 30)) {        // else: not a BvhBuilder tree (blas.rs:108)
+                if (root.count != 0u) rw = root.left_first | (root.count << 30);
+                else {
+                    const size_t c = (size_t)mesh.bvh_index + root.left_first;
+                    if (c + 1u < n_bvh) {
+                        const float4* src = reinterpret_cast<const float4*>(bvh + c);
+                        R[4] = src[0]; R[5] = src[1]; R[6] = src[2]; R[7] = src[3];
+                        rw = root.left_first;
+                    }
+                }
+            }
+        }
+        R[0] = make_float4(__uint_as_float(mesh.bvh_index), __uint_as_float(mesh.base_index), __uint_as_float((unsigned)mesh.vertex_offset),
+                           __uint_as_float(rw));
+    }
     if (k >= n_nodes) return;
     const VdTlasNode node = tlas[k];
-    if (node.left_right != 0u) return;                  // interior: never entered
-    float4* R = rec + 8u * (size_t)k;
-    const float4 poison = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu));
-    if (node.instance_idx >= n_inst) { R[3] = poison; return; }
+    if (node.left_right != 0u) {
+        const unsigned idx0 = node.left_right & 0xffffu, idx1 = node.left_right >> 16u;
+        if (idx0 < n_nodes && idx1 < n_nodes) {
+            const float4* c0 = reinterpret_cast<const float4*>(tlas + idx0);
+            const float4* c1 = reinterpret_cast<const float4*>(tlas + idx1);
+            float4 lo = c0[1]; lo.w = __uint_as_float(idx1);
+            float4* P = tpair + 4u * (size_t)idx0;
+            P[0] = c0[0]; P[1] = lo; P[2] = c1[0]; P[3] = c1[1];
+        }
+        return;
+    }
+    float4* R = irec + 4u * (size_t)k;
+    if (node.instance_idx >= n_inst) { R[3] = make_float4(0.0f, __uint_as_float(1u), 0.0f, 0.0f); return; }
     const VdInstance* I = inst + node.instance_idx;
-    const VdMeshInfo mesh = meshes[min(I->mesh, n_meshes - 1u)];
     const float* M = I->inv_transform;
     R[0] = make_float4(M[0], M[4], M[8], M[12]);
     R[1] = make_float4(M[1], M[5], M[9], M[13]);
     R[2] = make_float4(M[2], M[6], M[10], M[14]);
-    if (mesh.bvh_index >= n_bvh) { R[3] = poison; return; }
-    const VdBvhNode root = bvh[mesh.bvh_index];
-    if (root.count > 3u || root.left_first >= (1u << 30)) { R[3] = poison; return; }    // not a BvhBuilder tree (blas.rs:108)
-    if (root.count == 0u) {
-        const size_t c = (size_t)mesh.bvh_index + root.left_first;
-        if (c + 1u >= n_bvh) { R[3] = poison; return; }
-        const float4* src = reinterpret_cast<const float4*>(bvh + c);
-        R[4] = src[0]; R[5] = src[1]; R[6] = src[2]; R[7] = src[3];
-    }
-    R[3] = make_float4(__uint_as_float(mesh.bvh_index), __uint_as_float(mesh.base_index), __uint_as_float((unsigned)mesh.vertex_offset),
-                       __uint_as_float(root.left_first | (root.count << 30)));
+    R[3] = make_float4(__uint_as_float(min(I->mesh, n_meshes - 1u)), __uint_as_float(0u), 0.0f, 0.0f);
 }
 
 // De-indexed leaf triangles: tris[9 * (base_index / 3 + t)] = the three vertices fetch_vertex (bvh.wgsl:30-33) returns for
@@ -698,8 +767,9 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
                  uint32_t* d_any = nullptr) {
     // idle waves keep drawing from the ray counter after the last ray: leave it room below 2^32
     if (n_rays > 0xf0000000u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: more than 0xf0000000 rays in one call");
-    // scratch: [256 B flags and counters][entry records, 128 B per TLAS node][ray binning arrays]
-    const size_t rec_bytes = (size_t)128 * sc->n_tlas_nodes, sort_at = 256 + rec_bytes;
+    // scratch: [256 B flags and counters][TLAS child pairs, 64 B x 65 536][entry records, 64 B per TLAS node][mesh records][ray binning arrays]
+    const size_t pair_bytes = (size_t)64 * kTlasSlots, irec_bytes = (size_t)64 * sc->n_tlas_nodes, mrec_bytes = (size_t)128 * sc->n_meshes;
+    const size_t sort_at = 256 + pair_bytes + ((irec_bytes + 255) & ~(size_t)255) + ((mrec_bytes + 255) & ~(size_t)255);
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, sort_at);
     if (rc) return rc;
     // Binning is OFF by default: measured on the stress scene (tools/ab_trace.py, profiles/r03_ab_trace.log) rays handed
@@ -710,20 +780,23 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     const unsigned* order = nullptr;
     if (sorted) { rc = sort_rays(ctx, sc, d_rays, n_rays, &order, sort_at); if (rc) return rc; }
     unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);      // after sort_rays: the scratch may have grown
-    VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 16, ctx->stream));
-    float4* d_rec = reinterpret_cast<float4*>(reinterpret_cast<char*>(ctx->scratch) + 256);
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 64, ctx->stream));
+    float4* d_pair = reinterpret_cast<float4*>(reinterpret_cast<char*>(ctx->scratch) + 256);
+    float4* d_rec = reinterpret_cast<float4*>(reinterpret_cast<char*>(d_pair) + pair_bytes);
+    float4* d_mrec = reinterpret_cast<float4*>(reinterpret_cast<char*>(d_rec) + ((irec_bytes + 255) & ~(size_t)255));
     const unsigned yield = (unsigned)std::max<long long>(1, ctx->option(VD_OPT_TRACE_YIELD, kYieldDefault));
-    hipLaunchKernelGGL(entry_records_kernel, dim3((sc->n_tlas_nodes + 255u) / 256u), dim3(256), 0, ctx->stream, sc->tlas_nodes, sc->n_tlas_nodes,
-                       sc->instances, sc->n_instances, sc->meshes, sc->n_meshes, sc->bvh_nodes, sc->n_bvh_nodes, d_rec);
-    Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, d_tris, d_rec, yield};
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_pair, 0xff, pair_bytes, ctx->stream));      // no slot carries a tag yet
+    hipLaunchKernelGGL(records_kernel, dim3((std::max(sc->n_tlas_nodes, sc->n_meshes) + 255u) / 256u), dim3(256), 0, ctx->stream, sc->tlas_nodes,
+                       sc->n_tlas_nodes, sc->instances, sc->n_instances, sc->meshes, sc->n_meshes, sc->bvh_nodes, sc->n_bvh_nodes, d_rec, d_pair, d_mrec);
+    Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, d_tris, d_rec, d_pair, d_mrec, yield};
     {
         // Default: single rays from one global counter (chunk = 1), one wave per workgroup - the finest balance.  Chunks of
         // consecutive rays per workgroup (a CU-local window of the ray order) lose more to imbalance than they gain in
         // locality: 64 rays per chunk 32.6, 256 rays 16.9 Mrays/s against 35.2 in the same kernel (same log).
         unsigned chunk = (unsigned)ctx->option(VD_OPT_TRACE_CHUNK, 1);
         if (chunk <= 1u && !order) {
-            const SceneArgs a{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, yield, d_rec};
-            const unsigned waves = (unsigned)ctx->num_cus * kWavesPerCu;
+            const SceneArgs a{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, yield, d_rec, d_pair, d_mrec};
+            const unsigned waves = (unsigned)ctx->num_cus * (unsigned)std::min<long long>(kWavesPerCu, std::max<long long>(1, ctx->option(VD_OPT_TRACE_WAVES, kWavesPerCu)));
             if (d_tris) {
                 if (d_any) hipLaunchKernelGGL(trace_single_prep_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, d_tris);
                 else hipLaunchKernelGGL(trace_single_prep_kernel<false>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, d_tris);
@@ -759,6 +832,18 @@ bool scene_ok(const VdTraceScene* s) {
 }  // namespace
 
 extern "C" {
+
+#ifdef VD_TUNING
+// tuning build only: {outer iterations, stepping-loop iterations, stepping lanes (64 bit), leaf / entry / TLAS-interior lane-steps} of the last trace call
+int vd_debug_trace_counters(VdCtx* ctx, uint64_t* out /*[8]*/) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx || !out || !ctx->scratch) return VD_ERR_INVALID_ARG;
+    unsigned h[16];
+    if (hipMemcpy(h, ctx->scratch, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return VD_ERR_HIP;
+    out[0] = h[4]; out[1] = h[5]; out[2] = (uint64_t)h[6] | ((uint64_t)h[7] << 32); out[3] = h[8]; out[4] = h[9]; out[5] = h[10]; out[6] = h[11]; out[7] = h[12];
+    return VD_OK;
+}
+#endif
 
 int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out) {
     VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
