@@ -24,12 +24,15 @@ def stats(path):
 
 def k(st, name):
     v = st.get(name)
-    if not v:                                  # template arguments changed between rounds: first kernel with that prefix
-        v = next((x for key, x in sorted(st.items()) if key.startswith(name)), None)
+    if not v:                                  # template arguments changed between rounds: all instantiations with that prefix together
+        v = [x[0] for key, x in sorted(st.items()) if key.startswith(name)]
     if not v:
         return "n/a"
-    c, avg, mn, pct = v[0]
-    return f"avg {avg:.1f} µs over {c} launches (min {mn:.1f})"
+    c = sum(x[0] for x in v)
+    avg = sum(x[0] * x[1] for x in v) / c
+    mn = min(x[2] for x in v)
+    more = f", {len(v)} instantiations" if len(v) > 1 else ""
+    return f"avg {avg:.1f} µs over {c} launches (min {mn:.1f}{more})"
 
 
 def round_section(tag):
@@ -102,7 +105,7 @@ def round_section(tag):
               f"`{tag}_bench_bvh.log`): `a_apply_kernel` {k(st, 'a_apply_kernel')}, `a_ranks_kernel` {k(st, 'a_ranks_kernel')}, `a_count_kernel` "
               f"{k(st, 'a_count_kernel')}, `a_scan_kernel` {k(st, 'a_scan_kernel')}, `a_bin_kernel` {k(st, 'a_bin_kernel')}, `a_child_kernel` {k(st, 'a_child_kernel')}, "
               f"`blas_mid_kernel` {k(st, 'blas_mid_kernel')}, `blas_small_kernel` {k(st, 'blas_small_kernel')}."]
-    for extra in sorted(glob.glob(os.path.join(P, f"{tag}_*.log"))):
+    for extra in sorted(glob.glob(os.path.join(P, f"{tag}_*.log")) + glob.glob(os.path.join(P, f"{tag}_*.txt"))):
         base = os.path.basename(extra)
         if base.endswith("bench_bvh.log") or base.split("_", 1)[1] not in NOTES:
             continue
@@ -119,6 +122,14 @@ NOTES = {
     "expand_pipe_experiment.log": "measured and NOT kept: persistent register-prefetch form of the 80 M-instance expansion",
     "blas_item_sweep.log": "phase A item size sweep (`-DVD_ITEM`), 8.4 M triangles",
     "blas_big_tier_experiment.log": "measured and NOT kept: an LDS tier for 2049..8192-prim segments (in-kernel cycles per phase)",
+    "ab_trace.log": "`tools/ab_trace.py`: ray supply (single rays / chunks), ray binning, de-indexed leaves on the stress scene (before the loop was restructured)",
+    "ab_trace_loop.log": "`tools/ab_trace.py` after the stepping loop was restructured: VD_OPT_TRACE_YIELD and VD_OPT_TRACE_WAVES sweeps; tuning-build counters "
+                         "(lanes per iteration, lane-steps per ray, longest ray, iterations after the last ray was handed out) at 1 M rays and at 64 / 1024 / 16 384 rays alone",
+    "probe_gather.log": "`tools/probe_gather.hip`: what a CU pays for 64 divergent 64-byte fetches per wave-step (own 4 x 16 B / quad-cooperative / two lines), 28 waves per CU, "
+                        "working sets in L2 / MALL / HBM",
+    "trace_l2.txt": "`tools/gpu_prof_trace_l2.sh`: L1 / L2 / fabric counters of the traversal kernels per launch and per ray (rocprofv3 --pmc, one group per pass)",
+    "trace_guard_isa.txt": "the toolchain finding behind the explicit `pos < limit` in the ray refill (ISA excerpt)",
+    "tlas_nn_table_sim.log": "`tools/tlas_nn_table_sim.py`: hit rates of a nearest-neighbour table in the literal TLAS chain, by refresh interval",
 }
 
 
