@@ -384,7 +384,12 @@ typedef struct VdTraceScene {
  * out[i].dist matches the WGSL result within 1e-5 relative; a ray has 128 stack entries
  * for its TLAS + BLAS walk, pushing far children only (reference: 24 per walk, unchecked);
  * overflow is reported as VD_ERR_STACK_OVERFLOW.  BLAS leaves hold at most 3 triangles
- * (what BvhBuilder makes, blas.rs:108); anything else is VD_ERR_INVALID_ARG.             */
+ * (what BvhBuilder makes, blas.rs:108); anything else is VD_ERR_INVALID_ARG, and so is a TLAS
+ * leaf a ray ENTERS whose instance index, whose mesh's BLAS root or whose root's children lie
+ * outside the scene's buffers (unreachable slots of the TLAS array may hold anything).  Every
+ * call first re-lays what the walk reads at a TLAS step and at an instance entry into one
+ * cache line each (<= 65 536 TLAS nodes: a few microseconds, in the context's scratch), from
+ * the scene's own buffers - nothing is cached across calls.                                   */
 int vd_trace(VdCtx* ctx, const VdTraceScene* scene, const VdRay* rays, uint32_t n_rays,
              VdHit* out);
 int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene /* struct on host, pointers on device */,

@@ -3,7 +3,7 @@
 // Replaces `traverse_tlas(ray)` (reference: shaders/utils/bvh.wgsl:89-123) and its callees
 // `instance_intersect` (bvh.wgsl:78-87), `traverse_bvh` (bvh.wgsl:35-76), `fetch_vertex`
 // (bvh.wgsl:30-33), `intersect_aabb` / `intersect_trig` (shaders/utils/intersections.wgsl:13-45).
-// One lane per ray at a time, persistent waves that refill (see trace_kernel); the arithmetic order is the WGSL
+// One lane per ray at a time, persistent waves that refill (see trace_body); the arithmetic order is the WGSL
 // source order with no FMA, so hit distances are reproduced to the bit on the oracle's evaluation model (tolerance
 // in tests: 1e-5).  The reference's 24-entry stack is unchecked (shaders/utils/stack.wgsl:1-20); here one 128-entry
 // stack serves the TLAS and the BLAS walk of a ray and overflow is reported, not ignored.  Leaves of more than 3
@@ -83,12 +83,12 @@ struct Scene {
 struct RaySource { const unsigned* order; unsigned n_rays, chunk, n_chunks; unsigned* next_chunk; };
 
 // A fixed grid of waves; a lane whose ray is finished draws the next ray from a counter, so a wave stays full while
-// rays of very different cost (a few node visits to tens of thousands) pass through it, and there is no tail of
-// half-empty waves (one wave per 64 consecutive rays, nested TLAS/BLAS loops: 33 instead of 39 Mrays/s closest hit,
-// 50 instead of 62 Mrays/s occlusion on the bench scene).  To let a lane restart at any point the TLAS walk and the per-instance BLAS walk
-// are ONE state machine over ONE stack (TLAS and BLAS nodes share the 32-byte {min, u32, max, u32} layout), with the
-// interior steps in an inner loop that lanes sitting at a leaf sit out.  Each ray still sees exactly the reference's
-// sequence of node visits and triangle tests (bvh.wgsl:35-123); only the interleaving across lanes changes.
+// rays of very different cost (a few node visits to thousands) pass through it.  To let a lane restart at any point the
+// TLAS walk and the per-instance BLAS walk are ONE state machine over ONE stack (TLAS and BLAS nodes share the 32-byte
+// {min, u32, max, u32} layout).  Every busy lane makes ONE fetch per iteration of the stepping loop, whatever it is
+// doing - an interior node's child pair, the entry record of the instance it enters, a de-indexed triangle - into one set
+// of registers (see the loop).  Each ray still sees exactly the reference's sequence of node visits and triangle tests
+// (bvh.wgsl:35-123); only the interleaving across lanes changes.
 // ANY: occlusion query - the lane stops at the first accepted triangle and only `hit` is reported.  That flag is
 // the same as the closest-hit traversal's: until something is accepted nothing is pruned by distance, so both walks
 // visit the same nodes up to that point (the reference's shadow pass uses only `.hit`: raytraced_shadows.wgsl:97-102).
