@@ -791,6 +791,13 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
         ctx.trace_dev(ds, d_rays, len(rays), d_hits); t_cl0.append(ctx.last_gpu_ms())
         ctx.trace_any_dev(ds, d_rays, len(rays), d_any); t_any0.append(ctx.last_gpu_ms())
     plain_bytes = (d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes())
+    t_cli, t_anyi = [], []                        # the indexed leaves (indices[] -> vertices[]): what a plain call walks when it cannot de-index
+    ctx.set_option("trace.auto_prepare", 0)
+    for _ in range(2):
+        ctx.trace_dev(ds, d_rays, len(rays), d_hits); t_cli.append(ctx.last_gpu_ms())
+        ctx.trace_any_dev(ds, d_rays, len(rays), d_any); t_anyi.append(ctx.last_gpu_ms())
+    ctx.set_option("trace.auto_prepare", None)
+    indexed_bytes = (d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes())
     for _ in range(3):
         ctx.trace_prepared_dev(acc, d_rays, len(rays), d_hits); t_cl.append(ctx.last_gpu_ms())
         ctx.trace_any_prepared_dev(acc, d_rays, len(rays), d_any); t_any.append(ctx.last_gpu_ms())
@@ -801,7 +808,11 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
                       "occlusion_Mrays_per_s": round(len(rays) / min(t_any) / 1e3, 1),
                       "without_vd_trace_prepare": {"closest_hit_Mrays_per_s": round(len(rays) / min(t_cl0) / 1e3, 1),
                                                    "occlusion_Mrays_per_s": round(len(rays) / min(t_any0) / 1e3, 1),
+                                                   "note": "the plain vd_trace_dev / vd_trace_any_dev: they de-index the leaves themselves, per call",
                                                    "same_bytes_as_prepared": bool(plain_bytes == (d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes()))},
+                      "indexed_leaves": {"closest_hit_Mrays_per_s": round(len(rays) / min(t_cli) / 1e3, 1),
+                                         "occlusion_Mrays_per_s": round(len(rays) / min(t_anyi) / 1e3, 1),
+                                         "same_bytes_as_prepared": bool(indexed_bytes == (d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes()))},
                       "hit_fraction": round(float(hits["hit"].mean()), 3),
                       "occlusion_flags_equal_closest_hit": bool(np.array_equal(d_any.cpu().numpy().astype(np.uint32), hits["hit"]))}
     if not args.no_cpu_baseline:

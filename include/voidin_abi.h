@@ -211,6 +211,9 @@ typedef enum VdOption {
     VD_OPT_TRACE_YIELD = 24,      /* lanes of a wave that wait (at a BLAS leaf, or with a finished ray) before the wave
                                      leaves its stepping loop to serve them; default 16                          */
     VD_OPT_TRACE_WAVES = 25,      /* persistent waves per CU of the single-ray supply (1..28); default 28          */
+    VD_OPT_TRACE_AUTO_PREPARE = 27,/* 1 (default): a vd_trace_dev / vd_trace_any_dev call de-indexes the leaf triangles
+                                     itself (what vd_trace_prepare_dev does once per scene) when that is cheap next to
+                                     the walk: n_rays * 8 >= triangles <= 16 M; 0: never                         */
     VD_OPT_COUNT_ = 32
 } VdOption;
 int         vd_ctx_set_option(VdCtx* ctx, int option /* VdOption */, int64_t value);

@@ -348,9 +348,11 @@ def test_trace_supply_binning_and_prepared_triangles_are_order_only(ctx, oracle,
     variants = [dict(), dict(chunk=64), dict(sort=1, sort_min=1), dict(sort=1, sort_min=1, chunk=64), dict(sort=1, sort_min=1, chunk=4096),
                 dict(sort=1, sort_min=1, chunk=100), dict(chunk=1000),     # default: single rays from one counter, no binning
                 # when a wave leaves its stepping loop to serve waiting lanes, and how many waves a CU runs
-                {"yield": 4}, {"yield": 64}, {"yield": 64, "chunk": 64}, dict(waves=3)]
+                {"yield": 4}, {"yield": 64}, {"yield": 64, "chunk": 64}, dict(waves=3),
+                # the plain calls de-index the leaves themselves by default; without that they walk the indexed leaves
+                dict(auto_prepare=0), {"auto_prepare": 0, "yield": 4}]
     for opts in variants:
-        for k in ("sort", "sort_min", "chunk", "yield", "waves"):
+        for k in ("sort", "sort_min", "chunk", "yield", "waves", "auto_prepare"):
             ctx_options("trace." + k, opts.get(k))
         for prep in (False, True):
             d_hits.zero_(); d_any.fill_(9)
@@ -436,6 +438,35 @@ def test_trace_records_survive_stale_slots_and_report_bad_leaves(ctx, oracle):
             ctx.trace_dev(ctx.device_scene(scene), d_aim, len(aim), d_h2)
         assert e.value.code == abi.VD_ERR_INVALID_ARG
     ctx.trace_dev(ctx.device_scene((tl, inst, infos, nodes, v, idx)), d_aim, len(aim), d_h2)      # the context is fine afterwards
+
+
+def test_trace_falls_back_to_indexed_leaves_when_a_mesh_cannot_be_deindexed(ctx, oracle):
+    """A plain vd_trace_dev de-indexes the leaf triangles itself (36 B per triangle, index-buffer order) - which needs every
+    mesh's base_index to be a multiple of 3.  The reference's fetch_vertex (bvh.wgsl:30-33) has no such need: with an index
+    buffer that starts one word late the call must notice on the device and walk the indexed leaves instead - same hits."""
+    v, i = synth.knot_mesh(48, 12)
+    nodes, idx = oracle.bvh_build(v, i)
+    infos = np.zeros(1, dtype=abi.MESH_INFO)
+    infos[0]["min"], infos[0]["max"] = synth.mesh_bounds(v)
+    infos[0]["index_count"], infos[0]["base_index"] = len(idx), 1
+    idx1 = np.concatenate([np.zeros(1, dtype=np.uint32), idx])
+    inst = synth.instances(60, n_mesh=1, seed=synth.SEED_BASE + 34, extent=25.0, scale_range=(0.5, 2.0))
+    tl = oracle.tlas_build(inst, infos)
+    rays = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 30), pitch_deg=0), 128, 128)
+    scene = (tl, inst, infos, nodes, v, idx1)
+    want, _ = oracle.trace(scene, rays, threads=8)
+    assert want["hit"].sum() > 300
+    ds = ctx.device_scene(scene)
+    d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
+    ctx.trace_dev(ds, d_rays, len(rays), d_hits)
+    got = d_hits.cpu().numpy().view(abi.HIT)[: len(rays)]
+    hit = want["hit"] == 1
+    assert np.array_equal(got["hit"], want["hit"])
+    for f in ("dist", "instance", "triangle"):
+        assert got[f][hit].tobytes() == want[f][hit].tobytes(), f
+    with pytest.raises(VoidinError) as e:                    # the explicit per-scene call says why it cannot
+        ctx.trace_prepare(ds)
+    assert e.value.code == abi.VD_ERR_INVALID_ARG
 
 
 def test_trace_axis_aligned_and_degenerate_rays(ctx, oracle):

@@ -366,7 +366,8 @@ struct SceneArgs { const VdTlasNode* tlas; const VdInstance* inst; const VdMeshI
 template <bool ANY>
 __global__ __launch_bounds__(64, 7)   // second argument (HIP): waves per SIMD = 28 per CU
 void trace_single_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
-                         unsigned* __restrict__ overflow, unsigned* next_ray) {
+                         unsigned* __restrict__ overflow, unsigned* next_ray, const unsigned* __restrict__ gate) {
+    if (gate && *gate == 0u) return;          // the call de-indexed the leaves itself and that went well: the other kernel runs
     const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, nullptr, a.irec, a.tpair, a.mrec, a.yield};
     const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray};
     trace_body<ANY, false, false>(s, rays, src, out, out_any, overflow);
@@ -374,7 +375,9 @@ void trace_single_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n
 template <bool ANY>
 __global__ __launch_bounds__(64, 7)
 void trace_single_prep_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
-                              unsigned* __restrict__ overflow, unsigned* next_ray, const float* __restrict__ tris) {
+                              unsigned* __restrict__ overflow, unsigned* next_ray, const float* __restrict__ tris,
+                              const unsigned* __restrict__ gate) {
+    if (gate && *gate != 0u) return;          // the call's own de-indexing met an index range it cannot use: the indexed kernel runs
     const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, tris, a.irec, a.tpair, a.mrec, a.yield};
     const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray};
     trace_body<ANY, true, false>(s, rays, src, out, out_any, overflow);
@@ -769,7 +772,18 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     if (n_rays > 0xf0000000u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: more than 0xf0000000 rays in one call");
     // scratch: [256 B flags and counters][TLAS child pairs, 64 B x 65 536][entry records, 64 B per TLAS node][mesh records][ray binning arrays]
     const size_t pair_bytes = (size_t)64 * kTlasSlots, irec_bytes = (size_t)64 * sc->n_tlas_nodes, mrec_bytes = (size_t)128 * sc->n_meshes;
-    const size_t sort_at = 256 + pair_bytes + ((irec_bytes + 255) & ~(size_t)255) + ((mrec_bytes + 255) & ~(size_t)255);
+    const size_t tris_at = 256 + pair_bytes + ((irec_bytes + 255) & ~(size_t)255) + ((mrec_bytes + 255) & ~(size_t)255);
+    // A call that was not given prepared leaves de-indexes them itself when that is cheap next to the walk (one pass over the
+    // index buffer, 36 B per triangle into the scratch: 5 us for the stress scene's 131 k triangles, 20 us for the harness
+    // scene's 1.2 M) - the plain vd_trace_dev then walks at the prepared rate.  Not for few rays over a big scene, not
+    // above 16 M triangles, not with the binned / chunked supplies; VD_OPT_TRACE_AUTO_PREPARE = 0 turns it off.
+    const size_t n_tri = sc->n_indices / 3u;
+    const bool single = ctx->option(VD_OPT_TRACE_CHUNK, 1) <= 1 &&
+                        !(ctx->option(VD_OPT_TRACE_SORT, 0) != 0 && n_rays >= (unsigned)ctx->option(VD_OPT_TRACE_SORT_MIN, 65536));
+    const bool auto_prep = !d_tris && single && ctx->option(VD_OPT_TRACE_AUTO_PREPARE, 1) != 0 && n_tri > 0 && sc->n_vertices > 0 &&
+                           n_tri <= ((size_t)1 << 24) && (size_t)n_rays * 8u >= n_tri;
+    const size_t tris_bytes = auto_prep ? (((size_t)36 * n_tri + 64 + 255) & ~(size_t)255) : 0;
+    const size_t sort_at = tris_at + tris_bytes;
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, sort_at);
     if (rc) return rc;
     // Binning is OFF by default: measured on the stress scene (tools/ab_trace.py, profiles/r03_ab_trace.log) rays handed
@@ -788,6 +802,13 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_pair, 0xff, pair_bytes, ctx->stream));      // no slot carries a tag yet
     hipLaunchKernelGGL(records_kernel, dim3((std::max(sc->n_tlas_nodes, sc->n_meshes) + 255u) / 256u), dim3(256), 0, ctx->stream, sc->tlas_nodes,
                        sc->n_tlas_nodes, sc->instances, sc->n_instances, sc->meshes, sc->n_meshes, sc->bvh_nodes, sc->n_bvh_nodes, d_rec, d_pair, d_mrec);
+    const unsigned* gate = nullptr;
+    if (auto_prep) {
+        float* t = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->scratch) + tris_at);
+        hipLaunchKernelGGL(prepare_tris_kernel, dim3(256, sc->n_meshes), dim3(256), 0, ctx->stream, sc->meshes, sc->vertices, sc->indices, sc->n_indices,
+                           sc->n_vertices, t, d_flag + 2);
+        d_tris = t; gate = d_flag + 2;        // non-zero: some mesh's index range cannot be de-indexed - the indexed kernel takes the call
+    }
     Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, d_tris, d_rec, d_pair, d_mrec, yield};
     {
         // Default: single rays from one global counter (chunk = 1), one wave per workgroup - the finest balance.  Chunks of
@@ -798,11 +819,12 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
             const SceneArgs a{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, yield, d_rec, d_pair, d_mrec};
             const unsigned waves = (unsigned)ctx->num_cus * (unsigned)std::min<long long>(kWavesPerCu, std::max<long long>(1, ctx->option(VD_OPT_TRACE_WAVES, kWavesPerCu)));
             if (d_tris) {
-                if (d_any) hipLaunchKernelGGL(trace_single_prep_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, d_tris);
-                else hipLaunchKernelGGL(trace_single_prep_kernel<false>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, d_tris);
-            } else {
-                if (d_any) hipLaunchKernelGGL(trace_single_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1);
-                else hipLaunchKernelGGL(trace_single_kernel<false>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1);
+                if (d_any) hipLaunchKernelGGL(trace_single_prep_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, d_tris, gate);
+                else hipLaunchKernelGGL(trace_single_prep_kernel<false>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, d_tris, gate);
+            }
+            if (!d_tris || gate) {
+                if (d_any) hipLaunchKernelGGL(trace_single_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, gate);
+                else hipLaunchKernelGGL(trace_single_kernel<false>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, gate);
             }
         } else {
             const unsigned groups = (unsigned)ctx->num_cus * (kWavesPerCu / kWgWaves);
