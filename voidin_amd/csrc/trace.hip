@@ -770,8 +770,9 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
                  uint32_t* d_any = nullptr) {
     // idle waves keep drawing from the ray counter after the last ray: leave it room below 2^32
     if (n_rays > 0xf0000000u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: more than 0xf0000000 rays in one call");
-    // scratch: [256 B flags and counters][TLAS child pairs, 64 B x 65 536][entry records, 64 B per TLAS node][mesh records][ray binning arrays]
-    const size_t pair_bytes = (size_t)64 * kTlasSlots, irec_bytes = (size_t)64 * sc->n_tlas_nodes, mrec_bytes = (size_t)128 * sc->n_meshes;
+    // scratch: [256 B flags and counters][TLAS child pairs, 64 B x 65 536][entry records, 64 B x 65 536][mesh records][de-indexed triangles][ray binning arrays]
+    // (pairs and entry records for all 65 536 indices a 16-bit child field can name: a stray index reads a poisoned slot, not beyond)
+    const size_t pair_bytes = (size_t)64 * kTlasSlots, irec_bytes = (size_t)64 * kTlasSlots, mrec_bytes = (size_t)128 * sc->n_meshes;
     const size_t tris_at = 256 + pair_bytes + ((irec_bytes + 255) & ~(size_t)255) + ((mrec_bytes + 255) & ~(size_t)255);
     // A call that was not given prepared leaves de-indexes them itself when that is cheap next to the walk (one pass over the
     // index buffer, 36 B per triangle into the scratch: 5 us for the stress scene's 131 k triangles, 20 us for the harness
@@ -799,7 +800,7 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     float4* d_rec = reinterpret_cast<float4*>(reinterpret_cast<char*>(d_pair) + pair_bytes);
     float4* d_mrec = reinterpret_cast<float4*>(reinterpret_cast<char*>(d_rec) + ((irec_bytes + 255) & ~(size_t)255));
     const unsigned yield = (unsigned)std::max<long long>(1, ctx->option(VD_OPT_TRACE_YIELD, kYieldDefault));
-    VD_HIP_CHECK(ctx, hipMemsetAsync(d_pair, 0xff, pair_bytes, ctx->stream));      // no slot carries a tag yet
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_pair, 0xff, pair_bytes + irec_bytes, ctx->stream));      // no pair slot carries a tag yet, every entry record says "bad"
     hipLaunchKernelGGL(records_kernel, dim3((std::max(sc->n_tlas_nodes, sc->n_meshes) + 255u) / 256u), dim3(256), 0, ctx->stream, sc->tlas_nodes,
                        sc->n_tlas_nodes, sc->instances, sc->n_instances, sc->meshes, sc->n_meshes, sc->bvh_nodes, sc->n_bvh_nodes, d_rec, d_pair, d_mrec);
     const unsigned* gate = nullptr;
