@@ -65,3 +65,19 @@ def test_no_cpu_fallback_in_product_package():
                 txt = open(os.path.join(dp, f)).read()
                 assert "vd_ref_" not in txt and "np_restate" not in txt and "libvd_oracle" not in txt, f
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_option_ids_of_the_python_mirror_are_the_headers():
+    """voidin_amd/abi.py names the VdOption ids by hand; every enumerator of include/voidin_abi.h must be there with its value
+    (an option the mirror does not know is one no test or A/B script can reach), and no id may be used twice."""
+    import re
+    from voidin_amd import abi
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "voidin_abi.h")).read()
+    body = text[text.index("typedef enum VdOption"):text.index("} VdOption;")]
+    header = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(VD_OPT_[A-Z0-9_]+)\s*=\s*(\d+)", body)}
+    count = header.pop("VD_OPT_COUNT_")
+    assert header and max(header.values()) < count
+    assert len(set(header.values())) == len(header)
+    mirror = {"VD_OPT_" + k.replace(".", "_").upper(): v for k, v in abi.OPTIONS.items()}
+    assert mirror == header, (sorted(set(header) ^ set(mirror)), {k: (header.get(k), mirror.get(k)) for k in header if header.get(k) != mirror.get(k)})
+    assert set(abi.OPTION_ENV.values()) <= set(abi.OPTIONS)
