@@ -60,13 +60,13 @@ for name, opts, prep in variants:
                 (ctx.trace_prepared_dev(acc, d_rays, len(rays), d_hits) if prep else ctx.trace_dev(ds, d_rays, len(rays), d_hits))
             else:
                 (ctx.trace_any_prepared_dev(acc, d_rays, len(rays), d_any) if prep else ctx.trace_any_dev(ds, d_rays, len(rays), d_any))
-            c = (C.c_uint64 * 8)()
+            c = (C.c_uint64 * 11)()
             ctx.lib.vd_debug_trace_counters.argtypes = [C.c_void_p, C.c_void_p]
             ctx.lib.vd_debug_trace_counters(ctx.h, c)
             n = len(rays)
             print(f"    {kind}: outer iterations {c[0]}, stepping iterations {c[1]} ({c[1] / (256 * 28):.0f} per wave), lanes per iteration {c[2] / max(1, c[1]):.1f}, "
                   f"lane-steps per ray {c[2] / n:.0f} (leaf {c[3] / n:.1f}, entry {c[4] / n:.1f}, TLAS interior {c[5] / n:.1f}); longest ray {c[6]} steps; "
-                  f"iterations after the last ray was handed out: {c[7] / (256 * 28):.0f} per wave")
+                  f"iterations after the last ray was handed out: {c[7] / (256 * 28):.0f} per wave; the longest wave: {c[8]} iterations; most iterations of a wave with one busy lane: {c[9]}, with two to four: {c[10]}")
     b, a = d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes()
     if ref_bytes is None:
         ref_bytes, ref_any = b, a

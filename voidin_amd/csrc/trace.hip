@@ -126,7 +126,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
     uint2 cn = make_uint2(0u, 0u);         // payload of the current node
     bool ray_done = false;
 #ifdef VD_TUNING
-    unsigned dbg_outer = 0, dbg_iter = 0, dbg_lanes = 0, dbg_kind[3] = {0, 0, 0}, dbg_ray_steps = 0, dbg_ray_max = 0, dbg_drain = 0;
+    unsigned dbg_outer = 0, dbg_iter = 0, dbg_lanes = 0, dbg_kind[3] = {0, 0, 0}, dbg_ray_steps = 0, dbg_ray_max = 0, dbg_drain = 0, dbg_lone = 0, dbg_few = 0;
 #endif
 
     auto pop = [&]() {                     // leave the current node
@@ -229,6 +229,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             if (n_step == 0u || n_busy - n_step >= s.yield) break;
 #ifdef VD_TUNING
             ++dbg_iter; dbg_lanes += n_step; if (stepping) ++dbg_ray_steps; if (exhausted) ++dbg_drain;
+            if (n_busy == 1u) ++dbg_lone; else if (n_busy <= 4u) ++dbg_few;
             dbg_kind[0] += (unsigned)__popcll(__ballot(stepping && leaf)); dbg_kind[1] += (unsigned)__popcll(__ballot(stepping && !leaf && !in_blas && cn.x == 0u));
             dbg_kind[2] += (unsigned)__popcll(__ballot(stepping && !leaf && !in_blas && cn.x != 0u));
 #endif
@@ -348,6 +349,9 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
         atomicAdd(reinterpret_cast<unsigned long long*>(overflow + 6), (unsigned long long)dbg_lanes);
         atomicAdd(overflow + 8, dbg_kind[0]); atomicAdd(overflow + 9, dbg_kind[1]); atomicAdd(overflow + 10, dbg_kind[2]);
         atomicAdd(overflow + 12, dbg_drain);
+        atomicMax(overflow + 13, dbg_iter);                 // the wave that iterates longest ...
+        atomicMax(overflow + 14, dbg_lone);                 // ... and the longest stretches with one / two to four busy lanes
+        atomicMax(overflow + 15, dbg_few);
     }
     atomicMax(overflow + 11, dbg_ray_max);
 #endif
@@ -858,12 +862,12 @@ extern "C" {
 
 #ifdef VD_TUNING
 // tuning build only: {outer iterations, stepping-loop iterations, stepping lanes (64 bit), leaf / entry / TLAS-interior lane-steps} of the last trace call
-int vd_debug_trace_counters(VdCtx* ctx, uint64_t* out /*[8]*/) {
+int vd_debug_trace_counters(VdCtx* ctx, uint64_t* out /*[11]*/) {
     VdDeviceGuard vd_guard_(ctx);
     if (!ctx || !out || !ctx->scratch) return VD_ERR_INVALID_ARG;
     unsigned h[16];
     if (hipMemcpy(h, ctx->scratch, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return VD_ERR_HIP;
-    out[0] = h[4]; out[1] = h[5]; out[2] = (uint64_t)h[6] | ((uint64_t)h[7] << 32); out[3] = h[8]; out[4] = h[9]; out[5] = h[10]; out[6] = h[11]; out[7] = h[12];
+    out[0] = h[4]; out[1] = h[5]; out[2] = (uint64_t)h[6] | ((uint64_t)h[7] << 32); out[3] = h[8]; out[4] = h[9]; out[5] = h[10]; out[6] = h[11]; out[7] = h[12]; out[8] = h[13]; out[9] = h[14]; out[10] = h[15];
     return VD_OK;
 }
 #endif
