@@ -469,6 +469,67 @@ def test_trace_falls_back_to_indexed_leaves_when_a_mesh_cannot_be_deindexed(ctx,
     assert e.value.code == abi.VD_ERR_INVALID_ARG
 
 
+def test_trace_many_small_scenes_vs_oracle(ctx, oracle, ctx_options):
+    """Thirty small scenes of every shape the walk's state machine has a special case for: meshes of one, two and three
+    triangles (the BLAS root is a leaf), a single instance (the TLAS root is a leaf), several meshes side by side (non-zero
+    bvh_index / base_index / vertex_offset), rays from everywhere in all directions (from inside boxes too).  Hit flag,
+    distance, instance and triangle against the oracle, the plain call (de-indexing its leaves itself), the indexed
+    leaves and the prepared scene; the occlusion query's flags on each."""
+    import torch
+    rng = np.random.default_rng(20261003)
+    pool = [synth.triangle_soup(1, seed=5), synth.triangle_soup(2, seed=6), synth.triangle_soup(3, seed=7), synth.triangle_soup(10, seed=8),
+            synth.uv_sphere(1.0, 3), synth.knot_mesh(24, 8), synth.plane_mesh(2.0, 2.0)]
+    built = [(v, *oracle.bvh_build(v, i)) for v, i in pool]            # (verts, nodes, reordered indices)
+    total_hits = 0
+    for scene_no in range(30):
+        picks = rng.choice(len(built), size=int(rng.integers(1, 4)), replace=False)
+        V, I, B = [], [], []
+        infos = np.zeros(len(picks), dtype=abi.MESH_INFO)
+        vo = bo = no = 0
+        for k, m in enumerate(picks):
+            v, nodes, idx = built[m]
+            infos[k]["min"], infos[k]["max"] = synth.mesh_bounds(v)
+            infos[k]["index_count"], infos[k]["base_index"] = len(idx), bo
+            infos[k]["vertex_offset"], infos[k]["bvh_index"] = vo, no
+            V.append(v); I.append(idx); B.append(nodes)
+            vo += len(v); bo += len(idx); no += len(nodes)
+        V, I, B = np.concatenate(V), np.concatenate(I), np.concatenate(B)
+        n_inst = int(rng.choice([1, 1, 2, 3, 7, 40]))
+        inst = synth.instances(n_inst, n_mesh=len(picks), seed=synth.SEED_BASE + 100 + scene_no, extent=12.0, scale_range=(0.5, 3.0))
+        tl = oracle.tlas_build(inst, infos)
+        n_rays = 1500
+        rays = np.zeros(n_rays, dtype=abi.RAY)
+        eye = rng.normal(size=(n_rays, 3)).astype(np.float32) * rng.choice([0.5, 6.0, 25.0], size=(n_rays, 1)).astype(np.float32)
+        target = rng.normal(size=(n_rays, 3)).astype(np.float32) * 5.0
+        d = target - eye
+        d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-6).astype(np.float32)
+        axis = rng.integers(0, n_rays, size=60)
+        d[axis] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, size=60)] * rng.choice([-1.0, 1.0], size=(60, 1)).astype(np.float32)
+        rays["eye"], rays["dir"] = eye, d.astype(np.float32)
+        scene = (tl, inst, infos, B, V, I)
+        want, _ = oracle.trace(scene, rays, threads=8)
+        hit = want["hit"] == 1
+        total_hits += int(hit.sum())
+        ds = ctx.device_scene(scene)
+        acc = ctx.trace_prepare(ds)
+        d_rays, d_hits = ctx.upload(rays), ctx.empty(n_rays * 16)
+        d_any = torch.zeros(n_rays, dtype=torch.int32, device="cuda")
+        for mode in ("plain", "indexed", "prepared"):
+            ctx_options("trace.auto_prepare", 0 if mode == "indexed" else None)
+            d_hits.zero_(); d_any.fill_(7)
+            if mode == "prepared":
+                ctx.trace_prepared_dev(acc, d_rays, n_rays, d_hits); ctx.trace_any_prepared_dev(acc, d_rays, n_rays, d_any)
+            else:
+                ctx.trace_dev(ds, d_rays, n_rays, d_hits); ctx.trace_any_dev(ds, d_rays, n_rays, d_any)
+            got = d_hits.cpu().numpy().view(abi.HIT)[:n_rays]
+            assert np.array_equal(got["hit"], want["hit"]), (scene_no, mode)
+            for f in ("dist", "instance", "triangle"):
+                assert got[f][hit].tobytes() == want[f][hit].tobytes(), (scene_no, mode, f)
+            assert np.array_equal(d_any.cpu().numpy().astype(np.uint32), want["hit"]), (scene_no, mode)
+        acc.close()
+    assert total_hits > 2000
+
+
 def test_trace_axis_aligned_and_degenerate_rays(ctx, oracle):
     """The WGSL walk multiplies by inv_dir = 1 / dir: rays with zero direction components give inf and 0 * inf = NaN
     in the slab test, which must flow through min / max as in the restated shader (WGSL min / max = IEEE minNum /
