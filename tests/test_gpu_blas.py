@@ -199,3 +199,26 @@ def test_device_entry_point_and_determinism(ctx, oracle):
         outs.append((d_n.cpu().numpy()[: n_nodes * 32].view(abi.BVH_NODE), d_i.cpu().numpy().view(np.uint32)[: 3 * n_tri]))
     assert fields_equal(outs[0][0], want_nodes) and np.array_equal(outs[0][1], want_idx)
     assert outs[0][0].tobytes() == outs[1][0].tobytes() and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_denormal_vertex_coordinates_survive_the_quieting_pass(ctx, oracle):
+    """blas_precompute_kernel passes every vertex coordinate through a canonicalising v_max x, x (signalling NaNs); that
+    instruction must leave f32 denormals alone (the kernels run with denormals preserved, like the x86 oracle): a mesh
+    squeezed into the denormal range around zero, and one with a few denormal coordinates among ordinary ones, build the
+    oracle's tree bit for bit."""
+    v, i = synth.triangle_soup(700, seed=81)
+    tiny = (v * np.float32(1e-39)).astype(np.float32)                      # every coordinate denormal (|x| < 1.2e-38)
+    assert (np.abs(tiny[tiny != 0]) < np.float32(1.1754944e-38)).all() and (tiny != 0).sum() > 1000
+    mixed = v.copy(); mixed[::13] = tiny[::13]; mixed[5, 1] = np.float32(-1e-45)
+    for vv in (tiny, mixed):
+        try:
+            want_nodes, want_idx = oracle.bvh_build(vv, i)
+        except oracle.OracleError as e:                                     # all-denormal extents: areas underflow to 0 -> no split passes
+            assert e.code == abi.VD_ERR_DEGENERATE
+            with pytest.raises(VoidinError) as g:
+                ctx.bvh_build(vv, i)
+            assert g.value.code == abi.VD_ERR_DEGENERATE
+            continue
+        nodes, idx = ctx.bvh_build(vv, i)
+        assert fields_equal(nodes, want_nodes), diff_report(nodes, want_nodes)
+        assert np.array_equal(idx, want_idx)
