@@ -120,34 +120,37 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
     Ray world, ray;                        // `ray` is the active one (object space inside an instance)
     VdHit res;
     unsigned ray_id = 0;
-    bool busy = false, exhausted = false, ovf = false, bad_leaf = false, bad_entry = false, in_blas = false;
+    // ((st & kBusy) != 0u) / ((st & kDone) != 0u) / ((st & kInBlas) != 0u) live as bits of one per-lane word: as `bool`s they are lane masks in scalar registers, and every
+    // assignment under divergent control flow is mask algebra (550 of the loop's 1060 instructions were s_and / s_or / s_andn2)
+    unsigned st = 0;
+    constexpr unsigned kBusy = 1u, kDone = 2u, kInBlas = 4u, kOvf = 8u, kBadLeaf = 16u, kBadEntry = 32u;
+    bool exhausted = false;               // wave-uniform
     unsigned head = 0, blas_base = 0;
     unsigned tl_leaf = 0, bvh_index = 0, base_index = 0, vertex_offset = 0;   // tl_leaf: the TLAS leaf node the ray is inside
     uint2 cn = make_uint2(0u, 0u);         // payload of the current node
-    bool ray_done = false;
 #ifdef VD_TUNING
     unsigned dbg_outer = 0, dbg_iter = 0, dbg_lanes = 0, dbg_kind[3] = {0, 0, 0}, dbg_ray_steps = 0, dbg_ray_max = 0, dbg_drain = 0, dbg_lone = 0, dbg_few = 0;
 #endif
 
     auto pop = [&]() {                     // leave the current node
-        if (in_blas && head == blas_base) { in_blas = false; ray = world; }
-        if (head == 0u) { ray_done = true; return; }
+        if (((st & kInBlas) != 0u) && head == blas_base) { st &= ~kInBlas; ray = world; }
+        if (head == 0u) { st |= kDone; return; }
         --head;
         const unsigned w = head < (unsigned)kLdsStack ? lds_stack[head * 64u] : stack[head - (unsigned)kLdsStack];
-        if (in_blas) cn = make_uint2(w & 0x3fffffffu, w >> 30);
+        if (((st & kInBlas) != 0u)) cn = make_uint2(w & 0x3fffffffu, w >> 30);
         else cn = (w & 0xffffu) ? make_uint2(w, 0xffffffffu) : make_uint2(0u, w >> 16);
     };
     for (;;) {
         // ---- retire finished rays, refill idle lanes ----
-        if (busy && ray_done) {
+        if (((st & kBusy) != 0u) && ((st & kDone) != 0u)) {
 #ifdef VD_TUNING
             dbg_ray_max = max(dbg_ray_max, dbg_ray_steps); dbg_ray_steps = 0;
 #endif
             if (ANY) out_any[ray_id] = res.hit;
             else { if (res.hit) res.instance = s.tlas[res.instance].instance_idx; out[ray_id] = res; }   // hits carry the leaf node until here
-            busy = false;
+            st &= ~kBusy;
         }
-        const unsigned long long busy_mask = __ballot(busy);
+        const unsigned long long busy_mask = __ballot(((st & kBusy) != 0u));
         if (!exhausted && (unsigned)__popcll(busy_mask) < kRefillBelow) {
             const unsigned long long idle = ~busy_mask;
             const unsigned want = (unsigned)__popcll(idle);
@@ -187,7 +190,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             // `base < n_rays` guard (v_sub_u32 + v_min_u32, no clamp, no select: profiles/r03_trace_guard_isa.txt) and every
             // draw past the end took `want` rays from beyond the array
             const unsigned limit = CHUNKS ? base + got : n_rays;
-            if (!busy) {
+            if (!((st & kBusy) != 0u)) {
                 const unsigned pos = base + vd_mbcnt(idle);
                 if (pos < limit && pos >= base) {
                     const unsigned id = src.order ? src.order[pos] : pos;
@@ -198,12 +201,12 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                     res.dist = kMaxDist; res.hit = 0u; res.instance = 0xffffffffu; res.triangle = 0xffffffffu;
                     const VdTlasNode root = s.tlas[0];
                     cn = make_uint2(root.left_right, 0u);          // .y of a TLAS leaf = its node index
-                    ray_id = id; busy = true; ray_done = false; in_blas = false; head = 0; blas_base = 0;
+                    ray_id = id; st |= kBusy; st &= ~kDone; st &= ~kInBlas; head = 0; blas_base = 0;
                 }
             }
             if (done) exhausted = true;     // wave-uniform
         }
-        if (!__ballot(busy)) break;
+        if (!__ballot(((st & kBusy) != 0u))) break;
         // ---- interior steps (bvh.wgsl:56-74 and 104-121) and instance entries (bvh.wgsl:78-87) ----
         // A TLAS leaf is an instance to enter: instance -> inv_transform + mesh -> MeshInfo -> the mesh's root node -> its two
         // children is a chain of four dependent fetches, taken 140 times per ray on the stress scene (2000 overlapping
@@ -215,7 +218,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
         // (or nobody steps any more): leaves are rare next to steps (13 against 615 per ray on the stress scene), so waiting
         // for every lane to reach one would idle most of the wave, and serving each at once would run the triangle code
         // for one lane at a time.
-        const unsigned n_busy = (unsigned)__popcll(__ballot(busy));
+        const unsigned n_busy = (unsigned)__popcll(__ballot(((st & kBusy) != 0u)));
 #ifdef VD_TUNING
         ++dbg_outer;
 #endif
@@ -223,18 +226,18 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             // PREP: a lane at a BLAS leaf steps too - its fetch is one de-indexed triangle (36 contiguous bytes), in flight
             // together with the other lanes' node pairs and entry records: one trip to memory per iteration whatever the
             // lanes are doing.  (Indexed leaves are two dependent fetches of another shape: served outside the loop.)
-            const bool leaf = in_blas && cn.y != 0u;
-            const bool stepping = busy && !ray_done && (PREP || !leaf);
+            const bool leaf = ((st & kInBlas) != 0u) && cn.y != 0u;
+            const bool stepping = ((st & kBusy) != 0u) && !((st & kDone) != 0u) && (PREP || !leaf);
             const unsigned n_step = (unsigned)__popcll(__ballot(stepping));
             if (n_step == 0u || n_busy - n_step >= s.yield) break;
 #ifdef VD_TUNING
             ++dbg_iter; dbg_lanes += n_step; if (stepping) ++dbg_ray_steps; if (exhausted) ++dbg_drain;
             if (n_busy == 1u) ++dbg_lone; else if (n_busy <= 4u) ++dbg_few;
-            dbg_kind[0] += (unsigned)__popcll(__ballot(stepping && leaf)); dbg_kind[1] += (unsigned)__popcll(__ballot(stepping && !leaf && !in_blas && cn.x == 0u));
-            dbg_kind[2] += (unsigned)__popcll(__ballot(stepping && !leaf && !in_blas && cn.x != 0u));
+            dbg_kind[0] += (unsigned)__popcll(__ballot(stepping && leaf)); dbg_kind[1] += (unsigned)__popcll(__ballot(stepping && !leaf && !((st & kInBlas) != 0u) && cn.x == 0u));
+            dbg_kind[2] += (unsigned)__popcll(__ballot(stepping && !leaf && !((st & kInBlas) != 0u) && cn.x != 0u));
 #endif
             if (!stepping) continue;
-            const bool enter = !in_blas && cn.x == 0u;
+            const bool enter = !((st & kInBlas) != 0u) && cn.x == 0u;
             const char* p0; const char* p1;
             unsigned idx0 = 0u, idx1 = 0u;
             if (PREP && leaf) {               // triangle cn.x of the mesh: the vertices fetch_vertex (bvh.wgsl:30-33) returns
@@ -243,7 +246,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             } else if (enter) {               // the leaf's entry record: matrix rows + mesh id
                 p0 = reinterpret_cast<const char*>(s.irec + 4u * (size_t)cn.y);
                 p1 = p0 + sizeof(VdBvhNode);
-            } else if (in_blas) {
+            } else if (((st & kInBlas) != 0u)) {
                 p0 = reinterpret_cast<const char*>(s.bvh + (bvh_index + cn.x));
                 p1 = p0 + sizeof(VdBvhNode);
             } else {
@@ -259,7 +262,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                 float hit = res.dist;
                 if (intersect_trig(ray, v0, v1, v2, hit)) {
                     res.dist = hit; res.hit = 1u; res.instance = tl_leaf; res.triangle = cn.x;
-                    if (ANY) { ray_done = true; continue; }
+                    if (ANY) { st |= kDone; continue; }
                 }
                 if (--cn.y == 0u) pop(); else ++cn.x;
                 continue;
@@ -274,19 +277,19 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                 ray.dy = ((a1.x * world.dx + a1.y * world.dy) + a1.z * world.dz) + a1.w * 0.0f;
                 ray.dz = ((b0.x * world.dx + b0.y * world.dy) + b0.z * world.dz) + b0.w * 0.0f;
                 ray.ix = 1.0f / ray.dx; ray.iy = 1.0f / ray.dy; ray.iz = 1.0f / ray.dz;
-                if (__float_as_uint(b1.y) != 0u) { bad_entry = true; ray_done = true; continue; }   // the leaf's instance lies outside the buffer
+                if (__float_as_uint(b1.y) != 0u) { st |= kBadEntry; st |= kDone; continue; }   // the leaf's instance lies outside the buffer
                 // the mesh's words and its root's children: the mesh record (a handful of lines that stay in L1)
                 const float4* Mr = s.mrec + 8u * (size_t)__float_as_uint(b1.x);
                 const float4 idv = Mr[0];
                 a0 = Mr[4]; a1 = Mr[5]; b0 = Mr[6]; b1 = Mr[7];
                 bvh_index = __float_as_uint(idv.x); base_index = __float_as_uint(idv.y); vertex_offset = __float_as_uint(idv.z);
                 const unsigned rw = __float_as_uint(idv.w);            // the mesh's root: left_first | count << 30 (traverse_bvh starts there)
-                if (rw == 0xffffffffu) { bad_entry = true; ray_done = true; continue; }   // mesh root / its children outside the buffer
-                in_blas = true;
+                if (rw == 0xffffffffu) { st |= kBadEntry; st |= kDone; continue; }   // mesh root / its children outside the buffer
+                st |= kInBlas;
                 blas_base = head;
                 cn = make_uint2(rw & 0x3fffffffu, rw >> 30);
                 if (cn.y != 0u) continue;                                // a mesh of <= 3 triangles: its root is a leaf
-            } else if (!in_blas && __float_as_uint(a1.w) != idx1) {
+            } else if (!((st & kInBlas) != 0u) && __float_as_uint(a1.w) != idx1) {
                 // the pair record at idx0 was written for another right child: some unreachable slot of the TLAS array names
                 // the same left child (records_kernel) - read the two nodes themselves
                 const float4* n0 = reinterpret_cast<const float4*>(s.tlas + idx0);
@@ -298,8 +301,8 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             float min_dist = intersect_aabb(ray, mn0, mx0, res.dist);
             float max_dist = intersect_aabb(ray, mn1, mx1, res.dist);
             // payload of a child: BLAS {left_first, count}; TLAS {left_right, its own node index}
-            uint2 near = make_uint2(__float_as_uint(a0.w), in_blas ? __float_as_uint(a1.w) : idx0);
-            uint2 far = make_uint2(__float_as_uint(b0.w), in_blas ? __float_as_uint(b1.w) : idx1);
+            uint2 near = make_uint2(__float_as_uint(a0.w), ((st & kInBlas) != 0u) ? __float_as_uint(a1.w) : idx0);
+            uint2 far = make_uint2(__float_as_uint(b0.w), ((st & kInBlas) != 0u) ? __float_as_uint(b1.w) : idx1);
             if (min_dist > max_dist) {
                 const uint2 tu = near; near = far; far = tu;
                 const float tf = min_dist; min_dist = max_dist; max_dist = tf;
@@ -307,16 +310,16 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             if (min_dist >= res.dist) { pop(); continue; }
             // far child: the BLAS loop keeps it on `<=` (a missed child, 1e30, is pushed while nothing is hit yet),
             // the TLAS loop on `<`
-            if (in_blas ? max_dist <= res.dist : max_dist < res.dist) {
-                if (head + 1u > 2u * (unsigned)kStack) { ovf = true; ray_done = true; continue; }
-                if (in_blas && far.y > 3u) bad_leaf = true;   // not representable in a stack entry
-                const unsigned w = in_blas ? (far.x | (far.y << 30)) : (far.x != 0u ? far.x : (far.y << 16));
+            if (((st & kInBlas) != 0u) ? max_dist <= res.dist : max_dist < res.dist) {
+                if (head + 1u > 2u * (unsigned)kStack) { st |= kOvf; st |= kDone; continue; }
+                if (((st & kInBlas) != 0u) && far.y > 3u) st |= kBadLeaf;   // not representable in a stack entry
+                const unsigned w = ((st & kInBlas) != 0u) ? (far.x | (far.y << 30)) : (far.x != 0u ? far.x : (far.y << 16));
                 if (head < (unsigned)kLdsStack) lds_stack[head * 64u] = w; else stack[head - (unsigned)kLdsStack] = w;
                 ++head;
             }
             cn = near;
         }
-        if (PREP || !busy || ray_done || !(in_blas && cn.y != 0u)) continue;     // only lanes at an indexed BLAS leaf go on
+        if (PREP || !((st & kBusy) != 0u) || ((st & kDone) != 0u) || !(((st & kInBlas) != 0u) && cn.y != 0u)) continue;     // only lanes at an indexed BLAS leaf go on
         {
             // ---- BLAS leaf (bvh.wgsl:48-55) ----
             for (unsigned k = 0; k < cn.y; ++k) {
@@ -340,7 +343,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                     if (ANY) break;
                 }
             }
-            if (ANY && res.hit) ray_done = true; else pop();
+            if (ANY && res.hit) st |= kDone; else pop();
         }
     }
 #ifdef VD_TUNING
@@ -350,14 +353,14 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
         atomicAdd(overflow + 8, dbg_kind[0]); atomicAdd(overflow + 9, dbg_kind[1]); atomicAdd(overflow + 10, dbg_kind[2]);
         atomicAdd(overflow + 12, dbg_drain);
         atomicMax(overflow + 13, dbg_iter);                 // the wave that iterates longest ...
-        atomicMax(overflow + 14, dbg_lone);                 // ... and the longest stretches with one / two to four busy lanes
+        atomicMax(overflow + 14, dbg_lone);                 // ... and the longest stretches with one / two to four ((st & kBusy) != 0u) lanes
         atomicMax(overflow + 15, dbg_few);
     }
     atomicMax(overflow + 11, dbg_ray_max);
 #endif
-    if (ovf) atomicOr(overflow, 1u);
-    if (bad_leaf) atomicOr(overflow, 2u);
-    if (bad_entry) atomicOr(overflow, 4u);
+    if (st & kOvf) atomicOr(overflow, 1u);
+    if (st & kBadLeaf) atomicOr(overflow, 2u);
+    if (st & kBadEntry) atomicOr(overflow, 4u);
 }
 
 // Entry points.  The single-ray form keeps the round-2 kernel's argument list (the six scene buffers, rays, count, outputs,
