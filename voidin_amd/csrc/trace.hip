@@ -257,6 +257,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             // one set of registers for either kind of lane: an entering lane's matrix rows travel with the other lanes' child pairs
             float4 a0 = reinterpret_cast<const float4*>(p0)[0], a1 = reinterpret_cast<const float4*>(p0)[1];
             float4 b0 = reinterpret_cast<const float4*>(p1)[0], b1 = reinterpret_cast<const float4*>(p1)[1];
+            bool do_pop = false;              // one pop site for both kinds of lane
             if (PREP && leaf) {               // bvh.wgsl:48-55, one triangle per iteration, in leaf order
                 const float v0[3] = {a0.x, a0.y, a0.z}, v1[3] = {a0.w, a1.x, a1.y}, v2[3] = {a1.z, a1.w, b0.x};
                 float hit = res.dist;
@@ -264,9 +265,8 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                     res.dist = hit; res.hit = 1u; res.instance = tl_leaf; res.triangle = cn.x;
                     if (ANY) { st |= kDone; continue; }
                 }
-                if (--cn.y == 0u) pop(); else ++cn.x;
-                continue;
-            }
+                if (--cn.y == 0u) do_pop = true; else ++cn.x;
+            } else {
             if (enter) {
                 // (inv_transform * vec4(eye, 1.)).xyz and (inv_transform * vec4(dir, 0.)).xyz; a0, a1, b0 = rows 0..2 of the matrix
                 tl_leaf = cn.y;
@@ -307,7 +307,8 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                 const uint2 tu = near; near = far; far = tu;
                 const float tf = min_dist; min_dist = max_dist; max_dist = tf;
             }
-            if (min_dist >= res.dist) { pop(); continue; }
+            if (min_dist >= res.dist) do_pop = true;
+            else {
             // far child: the BLAS loop keeps it on `<=` (a missed child, 1e30, is pushed while nothing is hit yet),
             // the TLAS loop on `<`
             if (((st & kInBlas) != 0u) ? max_dist <= res.dist : max_dist < res.dist) {
@@ -318,6 +319,9 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                 ++head;
             }
             cn = near;
+            }
+            }
+            if (do_pop) pop();
         }
         if (PREP || !((st & kBusy) != 0u) || ((st & kDone) != 0u) || !(((st & kInBlas) != 0u) && cn.y != 0u)) continue;     // only lanes at an indexed BLAS leaf go on
         {
