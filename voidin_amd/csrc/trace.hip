@@ -115,7 +115,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
     // the private array.  A private array indexed by a per-lane depth is scratch memory, and 64 lanes at 64 depths are 64
     // lines per push and per pop - as many as the node fetch itself, out of the same L1 miss bandwidth that bounds the walk.
     __shared__ unsigned s_stack[CHUNKS ? kWgWaves : 1][kLdsStack][64];
-    unsigned* const lds_stack = &s_stack[CHUNKS ? (threadIdx.x >> 6) : 0u][0][lane];
+    const unsigned wv = CHUNKS ? (threadIdx.x >> 6) : 0u;     // (indexed, not through a pointer: a 64-bit pointer was spilled and reloaded at every push)
     unsigned stack[2 * kStack - kLdsStack];  // BLAS entries sit above the TLAS entries of the same ray
     Ray world, ray;                        // `ray` is the active one (object space inside an instance)
     VdHit res;
@@ -136,7 +136,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
         if (((st & kInBlas) != 0u) && head == blas_base) { st &= ~kInBlas; ray = world; }
         if (head == 0u) { st |= kDone; return; }
         --head;
-        const unsigned w = head < (unsigned)kLdsStack ? lds_stack[head * 64u] : stack[head - (unsigned)kLdsStack];
+        const unsigned w = head < (unsigned)kLdsStack ? s_stack[wv][head][lane] : stack[head - (unsigned)kLdsStack];
         if (((st & kInBlas) != 0u)) cn = make_uint2(w & 0x3fffffffu, w >> 30);
         else cn = (w & 0xffffu) ? make_uint2(w, 0xffffffffu) : make_uint2(0u, w >> 16);
     };
@@ -311,11 +311,13 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             else {
             // far child: the BLAS loop keeps it on `<=` (a missed child, 1e30, is pushed while nothing is hit yet),
             // the TLAS loop on `<`
-            if (((st & kInBlas) != 0u) ? max_dist <= res.dist : max_dist < res.dist) {
+            const bool blas_now = (st & kInBlas) != 0u;
+            if (max_dist < res.dist || (blas_now && max_dist == res.dist)) {
                 if (head + 1u > 2u * (unsigned)kStack) { st |= kOvf; st |= kDone; continue; }
-                if (((st & kInBlas) != 0u) && far.y > 3u) st |= kBadLeaf;   // not representable in a stack entry
-                const unsigned w = ((st & kInBlas) != 0u) ? (far.x | (far.y << 30)) : (far.x != 0u ? far.x : (far.y << 16));
-                if (head < (unsigned)kLdsStack) lds_stack[head * 64u] = w; else stack[head - (unsigned)kLdsStack] = w;
+                if (blas_now && far.y > 3u) st |= kBadLeaf;   // not representable in a stack entry
+                const unsigned w_blas = far.x | (far.y << 30), w_tlas = far.x != 0u ? far.x : (far.y << 16);
+                const unsigned w = blas_now ? w_blas : w_tlas;
+                if (head < (unsigned)kLdsStack) s_stack[wv][head][lane] = w; else stack[head - (unsigned)kLdsStack] = w;
                 ++head;
             }
             cn = near;
