@@ -19,7 +19,7 @@ struct VdTraceAccel { VdTraceScene scene; float* tris = nullptr; };
 namespace {
 
 constexpr int kStack = 64;
-constexpr int kLdsStack = 20;            // stack entries per ray kept in LDS: 5 KB per wave, 28 waves per CU = 140 of the 160 KB
+constexpr int kLdsStack = 24;            // stack entries per ray kept in LDS: 6 KB per wave, 24 waves per CU = 144 of the 160 KB
 constexpr float kMaxDist = 1e30f;
 
 struct Ray { float ex, ey, ez, dx, dy, dz, ix, iy, iz; };
@@ -94,11 +94,11 @@ struct RaySource { const unsigned* order; unsigned n_rays, chunk, n_chunks; unsi
 // visit the same nodes up to that point (the reference's shadow pass uses only `.hit`: raytraced_shadows.wgsl:97-102).
 constexpr long long kYieldDefault = 1;   // see the stepping loop (sweep in profiles/r03_ab_trace.log: 1 is best)
 constexpr unsigned kRefillBelow = 56;   // draw new rays when fewer than this many lanes are busy
-constexpr unsigned kWavesPerCu = 28;    // persistent grid = what is resident (7 waves per SIMD at 72 VGPRs): no wave starts late
-constexpr int kWgWaves = 7;             // waves per workgroup of the chunked form: 4 workgroups per CU
+constexpr unsigned kWavesPerCu = 24;    // persistent grid = what is resident (6 waves per SIMD at <= 84 VGPRs: the walk holds ~76, and with 72 it spilled): no wave starts late
+constexpr int kWgWaves = 6;             // waves per workgroup of the chunked form: 4 workgroups per CU
 // PREP: leaf triangles come de-indexed from Scene::tris (one contiguous fetch instead of indices[] -> verts[]).
 // CHUNKS = false (default): idle lanes draw single rays from one global counter, one wave per workgroup - the round-2
-// form, kept apart so that it carries none of the chunk machinery (inside 7-wave workgroups with the chunk state live
+// form, kept apart so that it carries none of the chunk machinery (inside multi-wave workgroups with the chunk state live
 // the closest-hit walk spilled registers and lost 10 %: 38.5 -> 34.5 Mrays/s, same-session A/B against the round-2 library).
 template <bool ANY, bool PREP, bool CHUNKS>
 __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restrict__ rays, const RaySource& src, VdHit* __restrict__ out,
@@ -369,15 +369,12 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
     if (st & kBadEntry) atomicOr(overflow, 4u);
 }
 
-// Entry points.  The single-ray form keeps the round-2 kernel's argument list (the six scene buffers, rays, count, outputs,
-// counter; + the triangle array when prepared): with the scene / supply structs of the chunked form as its arguments
-// (128 bytes of kernel arguments instead of 104) the one-wave-per-workgroup kernel faulted on this toolchain as soon as
-// more than ~100 k rays were in flight - same source, same ISA shape, only the argument block differs - while the
-// 7-wave workgroups of the chunked form run with the larger block.  Not understood; avoided.
+// Entry points.  The single-ray form takes the scene's buffers as plain kernel arguments (one wave per workgroup, the
+// persistent grid = 24 waves per CU); the chunked form takes the scene / supply structs.
 struct SceneArgs { const VdTlasNode* tlas; const VdInstance* inst; const VdMeshInfo* meshes; const VdBvhNode* bvh;
                    const float* verts; const unsigned* indices; unsigned n_meshes, yield; const float4* irec; const float4* tpair; const float4* mrec; };
 template <bool ANY>
-__global__ __launch_bounds__(64, 7)   // second argument (HIP): waves per SIMD = 28 per CU
+__global__ __launch_bounds__(64, 6)   // second argument (HIP): waves per SIMD = 24 per CU
 void trace_single_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                          unsigned* __restrict__ overflow, unsigned* next_ray, const unsigned* __restrict__ gate) {
     if (gate && *gate == 0u) return;          // the call de-indexed the leaves itself and that went well: the other kernel runs
@@ -386,7 +383,7 @@ void trace_single_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n
     trace_body<ANY, false, false>(s, rays, src, out, out_any, overflow);
 }
 template <bool ANY>
-__global__ __launch_bounds__(64, 7)
+__global__ __launch_bounds__(64, 6)
 void trace_single_prep_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                               unsigned* __restrict__ overflow, unsigned* next_ray, const float* __restrict__ tris,
                               const unsigned* __restrict__ gate) {
@@ -396,7 +393,7 @@ void trace_single_prep_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsig
     trace_body<ANY, true, false>(s, rays, src, out, out_any, overflow);
 }
 template <bool ANY, bool PREP>
-__global__ __launch_bounds__(64 * kWgWaves, 7)
+__global__ __launch_bounds__(64 * kWgWaves, 6)
 void trace_chunk_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                         unsigned* __restrict__ overflow) {
     trace_body<ANY, PREP, true>(s, rays, src, out, out_any, overflow);
