@@ -17,18 +17,17 @@ agg = collections.defaultdict(list)
 for f in glob.glob('gpurun_out/prof_trace_l2/p*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        if 'trace_single' in n or 'trace_chunk' in n:
+        if 'trace_single_prep' in n:                      # plain calls de-index their leaves per call and run this kernel too (the indexed one returns at once)
             kind = 'occlusion' if 'Lb1E' in n or '<true' in n else 'closest'
-            leaf = 'prepared' if '_prep' in n else 'indexed'
-            agg[(leaf, kind, r['Counter_Name'])].append(float(r['Counter_Value']))
-print('# rocprofv3 --pmc, one group per pass; per launch of the traversal kernel (trace_single_kernel / trace_single_prep_kernel).')
-print('# indexed: the first three launches of a kind are the 1 M-ray stress scene, the rest the 4 M-ray harness scene; prepared: stress scene only.')
-print('# per ray = the stress mean / 1 048 576 rays.')
+            agg[(kind, r['Counter_Name'])].append(float(r['Counter_Value']))
+print('# rocprofv3 --pmc, one group per pass; per launch of trace_single_prep_kernel (tools/bench_bvh.py: the plain vd_trace_dev / vd_trace_any_dev de-index')
+print('# their leaves per call, so they run the same kernel as the prepared scene).  Launch order per kind: 3 x stress scene plain, 3 x stress scene prepared,')
+print('# then (closest hit only) 3 x the 4 M-ray harness scene.  per ray = the stress mean / 1 048 576 rays.')
 for k in sorted(agg):
     v = agg[k]
-    a, b = v[:3], v[3:]
-    print(k[0], k[1], k[2], 'stress mean %.5g (%.4g per ray)' % (sum(a) / len(a), sum(a) / len(a) / 1048576.0),
-          ('harness mean %.5g' % (sum(b) / len(b))) if b else '')
+    a, b = v[:6], v[6:]
+    print(k[0], k[1], 'stress mean %.5g (%.4g per ray)' % (sum(a) / len(a), sum(a) / len(a) / 1048576.0),
+          ('harness mean %.5g (%.4g per ray)' % (sum(b) / len(b), sum(b) / len(b) / 4194304.0)) if b else '')
 PY
 cat gpurun_out/round/${R}_trace_l2.txt
 for p in $O/p*.log; do grep -h "error\|Error" $p | head -2; done
