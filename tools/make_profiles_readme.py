@@ -105,6 +105,29 @@ def round_section(tag):
               f"`{tag}_bench_bvh.log`): `a_apply_kernel` {k(st, 'a_apply_kernel')}, `a_ranks_kernel` {k(st, 'a_ranks_kernel')}, `a_count_kernel` "
               f"{k(st, 'a_count_kernel')}, `a_scan_kernel` {k(st, 'a_scan_kernel')}, `a_bin_kernel` {k(st, 'a_bin_kernel')}, `a_child_kernel` {k(st, 'a_child_kernel')}, "
               f"`blas_mid_kernel` {k(st, 'blas_mid_kernel')}, `blas_small_kernel` {k(st, 'blas_small_kernel')}."]
+    bp, bl = os.path.join(P, f"{tag}_bvh_pmc.json"), os.path.join(P, f"{tag}_blas_levels.log")
+    if os.path.exists(bp) and os.path.exists(bl):
+        # HBM traffic of one 8.4 M-triangle build per kernel (PMC) over that kernel's time in one build (kernel trace): GB/s per kernel
+        pm = json.load(open(bp))
+        kern = pm.get("kernels", {})
+        times = {}
+        for line in open(bl):
+            m = re.match(r"\s+(?:void )?(\S.*?)\s+calls\s+(\d+) total\s+([0-9.]+) ms", line)
+            if m:
+                times[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)))
+        rows = []
+        for name, v in kern.items():
+            key = next((t for t in times if name.startswith(t) or t.startswith(name[:28])), None)
+            if key is None:
+                continue
+            gb = (v["read_MB"] + v["write_MB"]) / 1e3
+            ms = times[key][1]
+            if ms > 0.2:
+                rows.append((gb / ms, f"`{name}` {gb:.1f} GB in {ms:.2f} ms = {gb / ms:.1f} TB/s"))
+        if rows:
+            tot = pm.get("total", {})
+            L += [f"* `{tag}_bvh_pmc.json` + `{tag}_blas_levels.log` (HBM bytes per build by PMC, read = 2 x FETCH_SIZE, write = WRITE_SIZE; kernel time of one build): "
+                  + "; ".join(r[1] for r in sorted(rows, reverse=True)) + f"; the whole build {tot.get('sum_MB', 0) / 1e3:.1f} GB."]
     for extra in sorted(glob.glob(os.path.join(P, f"{tag}_*.log")) + glob.glob(os.path.join(P, f"{tag}_*.txt"))):
         base = os.path.basename(extra)
         if base.endswith("bench_bvh.log") or base.split("_", 1)[1] not in NOTES:
