@@ -210,7 +210,7 @@ typedef enum VdOption {
                                      rays per workgroup in chunks of this size (measured slower: imbalance)      */
     VD_OPT_TRACE_YIELD = 24,      /* lanes of a wave that wait (at a BLAS leaf, or with a finished ray) before the wave
                                      leaves its stepping loop to serve them; default 16                          */
-    VD_OPT_TRACE_WAVES = 25,      /* persistent waves per CU of the single-ray supply (1..28); default 28          */
+    VD_OPT_TRACE_WAVES = 25,      /* persistent waves per CU of the single-ray supply (1..24); default 24          */
     VD_OPT_TRACE_AUTO_PREPARE = 27,/* 1 (default): a vd_trace_dev / vd_trace_any_dev call de-indexes the leaf triangles
                                      itself (what vd_trace_prepare_dev does once per scene) when that is cheap next to
                                      the walk: n_rays * 8 >= triangles <= 16 M; 0: never                         */
