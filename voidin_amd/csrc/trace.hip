@@ -811,8 +811,9 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     float4* d_mrec = reinterpret_cast<float4*>(reinterpret_cast<char*>(d_rec) + ((irec_bytes + 255) & ~(size_t)255));
     const unsigned yield = (unsigned)std::max<long long>(1, ctx->option(VD_OPT_TRACE_YIELD, kYieldDefault));
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_pair, 0xff, pair_bytes + irec_bytes, ctx->stream));      // no pair slot carries a tag yet, every entry record says "bad"
-    hipLaunchKernelGGL(records_kernel, dim3((std::max(sc->n_tlas_nodes, sc->n_meshes) + 255u) / 256u), dim3(256), 0, ctx->stream, sc->tlas_nodes,
-                       sc->n_tlas_nodes, sc->instances, sc->n_instances, sc->meshes, sc->n_meshes, sc->bvh_nodes, sc->n_bvh_nodes, d_rec, d_pair, d_mrec);
+    const unsigned n_rec = std::min(sc->n_tlas_nodes, kTlasSlots);      // nodes past 65 535 cannot be named by a 16-bit child field
+    hipLaunchKernelGGL(records_kernel, dim3((std::max(n_rec, sc->n_meshes) + 255u) / 256u), dim3(256), 0, ctx->stream, sc->tlas_nodes,
+                       n_rec, sc->instances, sc->n_instances, sc->meshes, sc->n_meshes, sc->bvh_nodes, sc->n_bvh_nodes, d_rec, d_pair, d_mrec);
     const unsigned* gate = nullptr;
     if (auto_prep) {
         float* t = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->scratch) + tris_at);
