@@ -47,7 +47,7 @@ def cull_cases():
 
 
 def cube_obj():
-    """tests/golden/cube.obj is a byte copy of /root/reference/assets/cube/cube.obj - the only mesh asset the reference
+    """tests/golden/cube.obj is a byte copy of /root/reference/assets/cube/cube.obj - the only OBJ asset the reference
     still ships (216 v / 218 mixed quad + triangle faces): ObjModel::load's fan triangulation + single-index vertices."""
     from voidin_amd.obj import ObjModel
     src = "/root/reference/assets/cube/cube.obj"
@@ -210,8 +210,46 @@ def occlusion_case():
     print("occlusion: frustum", pop(frustum), "-> kept", pop(m_np))
 
 
+def helmet_case():
+    """The one real mesh the reference checkout carries: assets/glTF-Sample-Models/2.0/DamagedHelmet/glTF-Binary/
+    DamagedHelmet.glb (14 556 vertices, 15 452 triangles), which the default demo loads and places at
+    translation(0, 0, 9) * scale(3) (src/bin/model.rs:100-106; camera at (2, 5, 12), pitch -20 deg: model.rs:235).
+    The fixture holds what GltfDocument::import hands to MeshPool::add - the POSITION accessor's Vec3s and the indices as
+    u32 (gltf_model/mod.rs:118-150) - checksums of the C oracle's BLAS over it (15 k triangles are too many for the numpy
+    restatement's Python loops: this one fixture freezes the C oracle alone), the instance, its one-leaf TLAS and the
+    oracle's hits for 160 x 160 primary rays from that camera.  No reference file is copied: geometry arrays only."""
+    import zlib
+    from voidin_amd.gltf import GltfDocument
+    src = "/root/reference/assets/glTF-Sample-Models/2.0/DamagedHelmet/glTF-Binary/DamagedHelmet.glb"
+    if not os.path.exists(src):
+        print("helmet_case: reference asset not present, fixture left as it is")
+        return
+    doc = GltfDocument.load(src)
+    (prim,) = doc.primitives()
+    v, i = prim.arrays()
+    assert v.shape == (14556, 3) and i.shape == (46356,)
+    nodes, idx = ref.bvh_build(v, i)
+    T = np.eye(4); T[:3, 3] = (0.0, 0.0, 9.0)
+    ((M, _, _),) = doc.scene_instances(T @ np.diag([3.0, 3.0, 3.0, 1.0]))
+    inst = synth.instance_from_matrix(M.T.reshape(16), mesh=0).reshape(1)
+    infos = np.zeros(1, dtype=abi.MESH_INFO)
+    infos[0]["min"], infos[0]["max"] = synth.mesh_bounds(v)
+    infos[0]["index_count"] = len(idx)
+    tl = ref.tlas_build(inst, infos)
+    cam = synth.camera_uniform(eye=(2.0, 5.0, 12.0), pitch_deg=-20.0)
+    rays = synth.primary_rays(cam, 160, 160)
+    hits, _ = ref.trace((tl, inst, infos, nodes, v, idx), rays, threads=8)
+    assert 2000 < hits["hit"].sum() < len(rays)
+    np.savez_compressed(os.path.join(OUT, "helmet.npz"), vertices=v, indices=i, n_nodes=np.uint32(len(nodes)),
+                        nodes_crc=np.uint32(zlib.crc32(nodes.tobytes())), indices_out_crc=np.uint32(zlib.crc32(idx.tobytes())),
+                        instances=inst, meshes=infos, tlas=tl, camera=cam, width=np.uint32(160), height=np.uint32(160),
+                        hit=hits["hit"].astype(np.uint8), dist=hits["dist"], triangle=hits["triangle"])
+    print("helmet: nodes", len(nodes), "hits", int(hits["hit"].sum()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    helmet_case()
     cull_cases()
     blas_cases()
     builtin_pool_case()
