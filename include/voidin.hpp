@@ -22,6 +22,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <array>
 #include <vector>
 
 #include "voidin_abi.h"
@@ -57,6 +58,8 @@ class Gpu {
     void check(int rc) const { if (rc != VD_OK) throw Error(rc, vd_last_error(ctx_)); }
     void set_stream(void* hip_stream) { check(vd_ctx_set_stream(ctx_, hip_stream)); }
     void synchronize() { check(vd_ctx_synchronize(ctx_)); }
+    // per-context tuning (VdOption in voidin_abi.h); a negative value restores the default
+    void set_option(VdOption option, int64_t value) { check(vd_ctx_set_option(ctx_, (int)option, value)); }
 
    private:
     VdCtx* ctx_ = nullptr;
@@ -392,6 +395,65 @@ inline std::vector<VdHit> traverse_tlas(const Gpu& gpu, const VdTraceScene& scen
     gpu.check(vd_trace(gpu.ctx(), &scene, rays.data(), (uint32_t)rays.size(), out.data()));
     return out;
 }
+
+// The trace bind group the reference builds once per scene (app.rs:255-287): the six device buffers of a scene plus the
+// de-indexed leaf triangles vd_trace_prepare_dev derives from them.  Rebuild it where that bind group is rebuilt (meshes,
+// vertices or indices changed); instances and TLAS nodes may change between calls.  All pointers are device memory.
+class TraceScene {
+   public:
+    TraceScene(const Gpu& gpu, const VdTraceScene& d_scene) : gpu_(gpu) { gpu.check(vd_trace_prepare_dev(gpu.ctx(), &d_scene, &accel_)); }
+    ~TraceScene() { if (accel_) vd_trace_release(gpu_.ctx(), accel_); }
+    TraceScene(const TraceScene&) = delete;
+    TraceScene& operator=(const TraceScene&) = delete;
+    // traverse_tlas(ray) for a batch (bvh.wgsl:89-123); d_out: n_rays hits
+    void trace(const VdRay* d_rays, uint32_t n_rays, VdHit* d_out) const { gpu_.check(vd_trace_prepared_dev(gpu_.ctx(), accel_, d_rays, n_rays, d_out)); }
+    // the shadow pass's test (raytraced_shadows.wgsl:97-102): d_hit[i] = traverse_tlas(ray i).hit
+    void trace_any(const VdRay* d_rays, uint32_t n_rays, uint32_t* d_hit) const {
+        gpu_.check(vd_trace_any_prepared_dev(gpu_.ctx(), accel_, d_rays, n_rays, d_hit));
+    }
+
+   private:
+    const Gpu& gpu_;
+    VdTraceAccel* accel_ = nullptr;
+};
+
+// EmitDraws over an instance-sharded scene, one process per GPU (INTEGRATION.md 7 has the Rust form).  Rank 0
+// makes the communicator id and hands it to the others through the host's own channel; every rank then constructs this
+// with its rank.  `record` = cull the own shard -> RCCL all-gather (1 bit per instance) on the context's stream -> expand:
+// every GPU ends with the ordered draw list of the whole scene, no host round trip.
+class DistEmitDraws {
+   public:
+    using Id = std::array<uint8_t, VD_DIST_ID_BYTES>;
+    static Id unique_id() {
+        Id id{};
+        const int rc = vd_dist_unique_id(id.data());
+        if (rc != VD_OK) throw Error(rc, "vd_dist_unique_id: RCCL could not be loaded");
+        return id;
+    }
+    DistEmitDraws(Gpu& gpu, const Id& id, int rank, int world) : gpu_(gpu) { gpu.check(vd_dist_create(gpu.ctx(), id.data(), rank, world, &dist_)); }
+    ~DistEmitDraws() { if (dist_) vd_dist_destroy(dist_); }
+    DistEmitDraws(const DistEmitDraws&) = delete;
+    DistEmitDraws& operator=(const DistEmitDraws&) = delete;
+    VdDistInfo info() const { VdDistInfo i{}; gpu_.check(vd_dist_info(dist_, &i)); return i; }
+    // per scene (mesh assignment is static in the reference's scenes): this rank's shard of n_total instances
+    void set_scene(const Instance* d_shard_instances, uint32_t n_local, uint32_t n_total, uint32_t n_mesh) {
+        gpu_.check(vd_dist_set_scene_dev(dist_, d_shard_instances, n_local, n_total, n_mesh));
+    }
+    // per frame: d_out holds n_total commands, *d_out_count the survivors of the whole scene
+    void record(const CameraUniform& camera, const MeshInfo* d_meshes, uint32_t n_mesh, const Instance* d_shard_instances,
+                DrawIndexedIndirect* d_out, uint32_t* d_out_count) {
+        gpu_.check(vd_dist_step_full_dev(dist_, &camera, d_meshes, n_mesh, d_shard_instances, d_out, d_out_count));
+    }
+    // the literal exchange of the 20-byte commands (blocks: the sizes are data dependent)
+    void record_draws(const CameraUniform& camera, const MeshInfo* d_meshes, uint32_t n_mesh, const Instance* d_shard_instances,
+                      DrawIndexedIndirect* d_out, uint32_t* d_out_count) {
+        gpu_.check(vd_dist_step_draws_dev(dist_, &camera, d_meshes, n_mesh, d_shard_instances, d_out, d_out_count));
+    }
+
+   private:
+    Gpu& gpu_;
+    VdDist* dist_ = nullptr;
+};
 
 // EXTENSION (no reference counterpart: README.md:33 only links "Two-Pass Occlusion Culling"): the second pass of that
 // scheme.  `build` turns the depth buffer the first pass rendered into a min pyramid; `refine` clears, in a frustum

@@ -180,6 +180,66 @@ int main() {
         REQUIRE(n_h > 100 && n_h < dist.size());
     }
 
+    // round 3: the prepared scene (TraceScene = the trace bind group built once per scene), a per-context option, and the
+    // sharded EmitDraws with one rank - everything on device copies of the scene's buffers
+    {
+        auto up = [&](const void* h, size_t bytes) { void* d = nullptr; if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess) std::abort();
+                                                      if (h && bytes && hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) std::abort(); return d; };
+        VdTraceScene ds = scene;
+        ds.tlas_nodes = (const VdTlasNode*)up(scene.tlas_nodes, sizeof(VdTlasNode) * scene.n_tlas_nodes);
+        ds.instances = (const VdInstance*)up(scene.instances, sizeof(VdInstance) * scene.n_instances);
+        ds.meshes = (const VdMeshInfo*)up(scene.meshes, sizeof(VdMeshInfo) * scene.n_meshes);
+        ds.bvh_nodes = (const VdBvhNode*)up(scene.bvh_nodes, sizeof(VdBvhNode) * scene.n_bvh_nodes);
+        ds.vertices = (const float*)up(scene.vertices, 12 * (size_t)scene.n_vertices);
+        ds.indices = (const uint32_t*)up(scene.indices, 4 * (size_t)scene.n_indices);
+        VdRay* d_rays = (VdRay*)up(rays.data(), sizeof(VdRay) * rays.size());
+        VdHit* d_hits = (VdHit*)up(nullptr, sizeof(VdHit) * rays.size());
+        uint32_t* d_any = (uint32_t*)up(nullptr, 4 * rays.size());
+        std::vector<VdHit> got(rays.size());
+        std::vector<uint32_t> any(rays.size());
+        {
+            voidin::TraceScene ts(gpu, ds);
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) gpu.set_option(VD_OPT_TRACE_YIELD, 8);              // when a wave serves its waiting lanes: order only
+                ts.trace(d_rays, (uint32_t)rays.size(), d_hits);
+                ts.trace_any(d_rays, (uint32_t)rays.size(), d_any);
+                gpu.synchronize();
+                REQUIRE(hipMemcpy(got.data(), d_hits, sizeof(VdHit) * rays.size(), hipMemcpyDeviceToHost) == hipSuccess);
+                REQUIRE(hipMemcpy(any.data(), d_any, 4 * rays.size(), hipMemcpyDeviceToHost) == hipSuccess);
+                for (size_t i = 0; i < rays.size(); ++i) {
+                    REQUIRE(got[i].hit == hits[i].hit && any[i] == hits[i].hit);
+                    if (got[i].hit) REQUIRE(std::memcmp(&got[i], &hits[i], sizeof(VdHit)) == 0);      // the host-pointer call's bytes
+                }
+            }
+            gpu.set_option(VD_OPT_TRACE_YIELD, -1);
+        }
+        // one-rank DistEmitDraws == EmitDraws' compacted list (the RCCL library is bound at run time; skipped when it is not there)
+        bool have_rccl = true;
+        voidin::DistEmitDraws::Id id{};
+        try { id = voidin::DistEmitDraws::unique_id(); } catch (const voidin::Error& e) { have_rccl = false; REQUIRE(e.code == VD_ERR_COMM); }
+        if (have_rccl) {
+            voidin::DistEmitDraws dd(gpu, id, 0, 1);
+            REQUIRE(dd.info().world == 1);
+            const uint32_t n = (uint32_t)inst.size();
+            VdDrawIndexedIndirect* d_a = (VdDrawIndexedIndirect*)up(nullptr, 20 * (size_t)n);
+            VdDrawIndexedIndirect* d_b = (VdDrawIndexedIndirect*)up(nullptr, 20 * (size_t)n);
+            uint32_t* d_cnt = (uint32_t*)up(nullptr, 16);
+            dd.set_scene(ds.instances, n, n, scene.n_meshes);
+            dd.record(cam, ds.meshes, scene.n_meshes, ds.instances, d_a, d_cnt);
+            gpu.check(vd_cull_compact_dev(gpu.ctx(), &cam, ds.meshes, scene.n_meshes, ds.instances, n, d_b, d_cnt + 1, 0));
+            gpu.synchronize();
+            uint32_t c2[2] = {0, 0};
+            REQUIRE(hipMemcpy(c2, d_cnt, 8, hipMemcpyDeviceToHost) == hipSuccess);
+            REQUIRE(c2[0] == c2[1] && c2[0] == count);
+            std::vector<char> la(20 * (size_t)c2[0]), lb(20 * (size_t)c2[0]);
+            REQUIRE(hipMemcpy(la.data(), d_a, la.size(), hipMemcpyDeviceToHost) == hipSuccess);
+            REQUIRE(hipMemcpy(lb.data(), d_b, lb.size(), hipMemcpyDeviceToHost) == hipSuccess);
+            REQUIRE(la == lb);
+            hipFree(d_a); hipFree(d_b); hipFree(d_cnt);
+        }
+        std::printf("round-3 mirror: prepared trace == vd_trace (two yields), DistEmitDraws(world 1) %s\n", have_rccl ? "== EmitDraws" : "skipped (no RCCL)");
+    }
+
     // error behaviour: degenerate input is an error code, not a crash (blas.rs:137-140 would panic)
     std::vector<voidin::Vec3> tv = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}};
     std::vector<uint32_t> ti; for (int k = 0; k < 5; ++k) { ti.push_back(0); ti.push_back(1); ti.push_back(2); }
