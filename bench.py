@@ -849,6 +849,36 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
                                     "hit_fraction": round(float(h2["hit"].mean()), 3)}
     acc2.close()
     del ds2, d_r2, d_h2
+    # the one real mesh the reference checkout carries, as its default demo places and views it (src/bin/model.rs:100-106, :235):
+    # tests/golden/helmet.npz = the arrays GltfDocument::import hands to MeshPool::add + the oracle's tree checksums and hits
+    hp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "helmet.npz")
+    if os.path.exists(hp):
+        import zlib
+        g = np.load(hp)
+        hv, hi = np.ascontiguousarray(g["vertices"]), np.ascontiguousarray(g["indices"])
+        tb = []
+        for _ in range(3):
+            t = time.perf_counter(); hn, hidx = ctx.bvh_build(hv, hi); tb.append(time.perf_counter() - t)
+        htl = ctx.tlas_build(g["instances"], g["meshes"])
+        hrays = synth.primary_rays(g["camera"], 1024, 1024)
+        hds = ctx.device_scene((htl, g["instances"], g["meshes"], hn, hv, hidx))
+        d_hr, d_hh = ctx.upload(hrays), ctx.empty(len(hrays) * 16)
+        ctx.set_timing(True)
+        th = []
+        for _ in range(3):
+            ctx.trace_dev(hds, d_hr, len(hrays), d_hh); th.append(ctx.last_gpu_ms())
+        ctx.set_timing(False)
+        small = synth.primary_rays(g["camera"], int(g["width"]), int(g["height"]))
+        d_sr, d_sh = ctx.upload(small), ctx.empty(len(small) * 16)
+        ctx.trace_dev(hds, d_sr, len(small), d_sh)
+        sh = d_sh.cpu().numpy()[: len(small) * 16].view(abi.HIT)
+        hit = g["hit"] == 1
+        extra["reference_helmet"] = {"mesh": "DamagedHelmet.glb of the reference's assets: 14556 vertices, 15452 triangles",
+                                     "blas_build_ms_host_arrays": round(min(tb) * 1e3, 3),
+                                     "blas_equals_oracle_checksums": bool(zlib.crc32(hn.tobytes()) == int(g["nodes_crc"]) and zlib.crc32(hidx.tobytes()) == int(g["indices_out_crc"])),
+                                     "demo_view_1024x1024_Mrays_per_s": round(len(hrays) / min(th) / 1e3, 1),
+                                     "demo_view_hits_equal_oracle_fixture": bool(np.array_equal(sh["hit"], g["hit"]) and sh["dist"][hit].tobytes() == g["dist"][hit].tobytes())}
+        del hds, d_hr, d_hh, d_sr, d_sh
     # the CPU harness (src/bin/bvh_cpu.rs:39-96): per-pixel rays + Bvh::traverse_iter against ONE mesh, on the device;
     # the harness's own 64-triangle soup at 640 x 640, and the large mesh of the scene above at 2048 x 2048
     cam_h = synth.camera_uniform(eye=(0, 0, 15), pitch_deg=0)
