@@ -285,26 +285,42 @@ def run_rank(args):
     del d_all_idx
 
     # N > 1: the sharded scene.  d_all = the whole scene's list (full / draws / indices), on every rank.
-    sv, rccl_info = None, None
+    sv, rccl_info, data_group = None, None, None
     if distributed and exchange == "rccl":
         try:
             sv = vdist.RcclVisibility(ctx, n_total, d_m, n_mesh, d_i)
             ok = 1
         except Exception as e:      # VD_ERR_COMM: RCCL not loadable / communicator refused -> every rank falls back together
             ok, why = 0, repr(e)
-        flag = torch.tensor([ok], dtype=torch.int32)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            if rank == 0:
-                print(f"bench.py: C-ABI RCCL exchange unavailable ({why if not ok else 'another rank failed'}); "
-                      f"falling back to torch.distributed over {backend}", file=sys.stderr, flush=True)
+            # The data path stays RCCL or the run fails: the control-plane group here is gloo, and a host-staged number
+            # under an "RCCL" headline would be worse than no number.  Fall back to torch.distributed's own RCCL group.
             if sv is not None:
                 sv.close()
-            sv, exchange = None, "torch (fallback)"
+            sv = None
+            if rank == 0:
+                print(f"bench.py: C-ABI RCCL exchange unavailable ({why if not ok else 'another rank failed'}); "
+                      "trying torch.distributed over a new nccl (= RCCL) group", file=sys.stderr, flush=True)
+            try:
+                data_group = dist.new_group(backend="nccl", device_id=dev) if backend != "nccl" else None
+                probe = torch.zeros(world, dtype=torch.int32, device=dev)
+                dist.all_gather_into_tensor(probe, torch.ones(1, dtype=torch.int32, device=dev), group=data_group)
+                torch.cuda.synchronize()
+                good = int(probe.sum().item()) == world
+            except Exception as e:
+                good, why = False, repr(e)
+            flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                raise SystemExit(f"bench.py: rank {rank}: no RCCL data path (C-ABI exchange and torch.distributed/nccl both failed: "
+                                 f"{why if not good else 'another rank failed'}); refusing to time a gloo exchange under --exchange rccl")
+            exchange = "torch (fallback, nccl group)"
         else:
             rccl_info = {"version": int(sv.info.rccl_version), "library": sv.info.rccl_library.decode()}
     if distributed and sv is None:
-        sv = vdist.ShardedVisibility(ctx, n_total, d_m, n_mesh, d_i)
+        sv = vdist.ShardedVisibility(ctx, n_total, d_m, n_mesh, d_i, group=data_group)
     via_c = distributed and exchange == "rccl"
     d_all = ctx.empty(n_total * 20) if distributed else None
     d_cnt_all = torch.zeros(4, dtype=torch.int32, device=dev) if distributed else None
@@ -323,8 +339,6 @@ def run_rank(args):
             elif mode == "draws":
                 sv.step_draws(cam, d_all, d_cnt_all)
             elif mode == "indices":
-                if via_c:
-                    raise SystemExit("bench.py: --gather indices has no C-ABI form; use --exchange torch")
                 sv.step_indices(cam, d_all, d_cnt_all)
             else:
                 sv.step_shard(cam, d_out, d_cnt)
@@ -367,7 +381,7 @@ def run_rank(args):
             legs = (lambda: sv.cull_to_mask(cam), sv.allgather_masks, lambda: sv.expand_all(d_all, d_cnt_all))
         else:
             legs = (lambda: ctx.cull_mask_dev(cam, d_m, n_mesh, d_i, n, sv.d_mask),
-                    lambda: dist.all_gather_into_tensor(sv.d_mask_all, sv.d_mask),
+                    lambda: dist.all_gather_into_tensor(sv.d_mask_all, sv.d_mask, group=data_group),
                     lambda: ctx.expand_mask_dev(sv.d_mask_all, n_total, sv.S, sv.d_mesh_ids, d_m, n_mesh, d_all, d_cnt_all, id_bytes=sv.id_bytes))
         breakdown = {
             "cull_to_mask_ms": leg(legs[0]),
@@ -376,7 +390,7 @@ def run_rank(args):
             "mask_bytes_per_rank": int(sv.wps * 8),
             "note": "gather=full: every GPU materialises the whole list, so the expansion leg does not shrink with N (DESIGN.md 6)"}
         gather_modes = {}
-        for m_ in (("full", "draws", "shard") if via_c else ("full", "draws", "indices", "shard")):
+        for m_ in ("full", "draws", "indices", "shard"):
             t_ = ms_per_step if m_ == mode else timed(step_fn(m_), args.steps, 2)
             gather_modes[m_] = {"ms_per_step": round(t_, 4), "M_inst_per_s": round(n_total / t_ / 1e3, 1)}
         gather_modes["note"] = ("full/draws/indices: every GPU ends with the whole ordered list (wire: 1 bit per instance / 20 B per survivor / "
@@ -388,7 +402,8 @@ def run_rank(args):
             inst_w = synth.instances(n_w, seed=synth.SEED_BASE + 3, offset=rank * n_w, with_inverse=False, **kw)
             d_iw = ctx.upload(inst_w)
             del inst_w
-            sv_w = (vdist.RcclVisibility if via_c else vdist.ShardedVisibility)(ctx, n_w * world, d_m, n_mesh, d_iw)
+            sv_w = (vdist.RcclVisibility(ctx, n_w * world, d_m, n_mesh, d_iw) if via_c else
+                    vdist.ShardedVisibility(ctx, n_w * world, d_m, n_mesh, d_iw, group=data_group))
             d_all_w, d_cnt_w = ctx.empty(n_w * world * 20), torch.zeros(4, dtype=torch.int32, device=dev)
             t_full = timed(lambda: sv_w.step(cam, d_all_w, d_cnt_w), args.steps, 2)
             t_shard = timed(lambda: sv_w.step_shard(cam, d_all_w, d_cnt_w), args.steps, 2)
@@ -564,6 +579,13 @@ def run_rank(args):
             line["config"]["rccl"] = rccl_info
         if breakdown:
             line["step_breakdown"] = breakdown
+            line["scaling_ceiling"]["mask_allgather_ms_measured"] = breakdown["mask_allgather_ms"]
+            line["scaling_ceiling"]["mask_allgather_ms_assumed"] = 0.025
+        if gather_modes:
+            # both ends of the design space in every N > 1 line, whatever --gather selected for `value`: `full` = every GPU
+            # holds the whole list (cannot scale past the list write), `shard` = each GPU holds its own part (can)
+            line["value_full"] = gather_modes["full"]["M_inst_per_s"]
+            line["value_shard"] = gather_modes["shard"]["M_inst_per_s"]
         print(json.dumps(line), flush=True)
     if via_c:
         sv.close()

@@ -449,6 +449,11 @@ class DistEmitDraws {
                       DrawIndexedIndirect* d_out, uint32_t* d_out_count) {
         gpu_.check(vd_dist_step_draws_dev(dist_, &camera, d_meshes, n_mesh, d_shard_instances, d_out, d_out_count));
     }
+    // the same exchange with 4-byte survivor indices on the wire (SURVEY.md 8e's option; blocks like record_draws)
+    void record_indices(const CameraUniform& camera, const MeshInfo* d_meshes, uint32_t n_mesh, const Instance* d_shard_instances,
+                        DrawIndexedIndirect* d_out, uint32_t* d_out_count) {
+        gpu_.check(vd_dist_step_indices_dev(dist_, &camera, d_meshes, n_mesh, d_shard_instances, d_out, d_out_count));
+    }
 
    private:
     Gpu& gpu_;

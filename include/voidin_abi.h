@@ -213,7 +213,9 @@ typedef enum VdOption {
     VD_OPT_TRACE_WAVES = 25,      /* persistent waves per CU of the single-ray supply (1..24); default 24          */
     VD_OPT_TRACE_AUTO_PREPARE = 27,/* 1 (default): a vd_trace_dev / vd_trace_any_dev call de-indexes the leaf triangles
                                      itself (what vd_trace_prepare_dev does once per scene) when that is cheap next to
-                                     the walk: n_rays * 8 >= triangles <= 16 M; 0: never                         */
+                                     the walk: n_rays * 8 >= triangles <= 2 Mi, at most 65 535 meshes.  The 36 B per
+                                     triangle live in the context's grow-only scratch (<= 72 MB, kept until
+                                     vd_ctx_destroy); 2: up to 16 Mi triangles (576 MB); 0: never                */
     VD_OPT_COUNT_ = 32
 } VdOption;
 int         vd_ctx_set_option(VdCtx* ctx, int option /* VdOption */, int64_t value);
@@ -489,9 +491,18 @@ int vd_traverse(VdCtx* ctx, const VdBvhNode* nodes, uint32_t n_nodes, const floa
  *   vd_dist_step_draws_dev  the literal exchange of the 20-byte commands: compact the own shard, all-gather
  *                           the counts (read back on the host: the sizes are data dependent), exact-size
  *                           grouped ncclSend / ncclRecv straight into every peer's final buffer.
+ *   vd_dist_step_indices_dev  the same exchange with 4-byte survivor indices on the wire (SURVEY.md §8e's option;
+ *                           5x fewer bytes than the commands, fewer than the bitmask when < 1 in 32 survives):
+ *                           vd_cull_mask_dev -> vd_mask_to_indices_dev (global indices) -> counts (host read
+ *                           back) -> grouped ncclSend / ncclRecv -> vd_indices_to_draws_dev.  Its two index
+ *                           buffers (4 B per shard slot + 4 B per scene slot) are allocated on first use.
  *   vd_dist_allgather_dev   plain byte all-gather on the ctx stream (d_recv holds world * bytes_per_rank).
- * RCCL is bound at run time: the copy already loaded in the process if there is one, else
- * $VD_RCCL_LIB, else librccl.so.1 / /opt/rocm/lib; failure is VD_ERR_COMM, never an abort.            */
+ * All three steps leave the same bytes in d_out[0..*d_out_count) on every rank: vd_cull_compact of the
+ * whole scene.  A failed ncclSend / ncclRecv closes its group before VD_ERR_COMM is returned, so the
+ * communicator's thread is never left with an open group.
+ * RCCL is bound at run time: $VD_RCCL_LIB if the host sets it (an explicit choice wins - the tests bind
+ * their test double this way), else the copy already loaded in the process, else librccl.so.1 /
+ * /opt/rocm/lib; failure is VD_ERR_COMM, never an abort.                                             */
 #define VD_DIST_ID_BYTES 128
 typedef struct VdDist VdDist;
 typedef struct VdDistInfo {
@@ -517,6 +528,9 @@ int vd_dist_step_full_dev(VdDist* dist, const VdCameraUniform* camera /* host */
 int vd_dist_step_draws_dev(VdDist* dist, const VdCameraUniform* camera /* host */, const VdMeshInfo* d_meshes,
                            uint32_t n_mesh, const VdInstance* d_shard_instances, VdDrawIndexedIndirect* d_out,
                            uint32_t* d_out_count);
+int vd_dist_step_indices_dev(VdDist* dist, const VdCameraUniform* camera /* host */, const VdMeshInfo* d_meshes,
+                             uint32_t n_mesh, const VdInstance* d_shard_instances, VdDrawIndexedIndirect* d_out,
+                             uint32_t* d_out_count);
 int vd_dist_allgather_dev(VdDist* dist, const void* d_send, void* d_recv, uint64_t bytes_per_rank);
 
 /* ------------------------------------------------------------------------------------ */

@@ -227,6 +227,28 @@ def test_tlas_refit_after_motion(ctx, oracle):
         assert np.array_equal(got["max"][k], np.maximum(got["max"][l], got["max"][r]))
 
 
+def test_tlas_refit_arena_survives_a_change_of_instance_count(oracle):
+    """The refit arena (epoch-tagged links, then the arrival words) is laid out by n.  Refits at n1 followed by refits
+    at a slightly larger n2 on the SAME context (capacity unchanged) must not read n1's arrival words as n2's link
+    records: six refits at each size, every one compared with the oracle, both orders, on a context of its own."""
+    from voidin_amd.runtime import Context
+    meshes = synth.mesh_infos()
+    own = Context(0)
+    try:
+        for sizes in ((1000, 1150, 1000, 1249), (4096, 4097, 3500)):
+            for n in sizes:
+                inst = synth.instances(n, seed=synth.SEED_BASE + 70 + n % 7, extent=150.0)
+                nodes = own.tlas_build(inst, meshes)
+                for k in range(6):
+                    moved = inst.copy()
+                    moved["transform"][:: 3 + k, 12:15] += np.float32(0.37 * (k + 1))
+                    got = own.tlas_refit(moved, meshes, nodes)
+                    want = oracle.tlas_refit(moved, meshes, nodes)
+                    assert got.tobytes() == want.tobytes(), (sizes, n, k)
+    finally:
+        own.close()
+
+
 def test_tlas_overflow_and_bad_args(ctx):
     meshes = synth.mesh_infos()
     inst = np.zeros(abi.TLAS_MAX_INSTANCES + 1, abi.INSTANCE)

@@ -170,6 +170,7 @@ PROTOTYPES = {
     "vd_dist_set_scene_dev": (_I, [_P, _P, _U, _U, _U]),
     "vd_dist_step_full_dev": (_I, [_P, _P, _P, _U, _P, _P, _P]),
     "vd_dist_step_draws_dev": (_I, [_P, _P, _P, _U, _P, _P, _P]),
+    "vd_dist_step_indices_dev": (_I, [_P, _P, _P, _U, _P, _P, _P]),
     "vd_dist_allgather_dev": (_I, [_P, _P, _P, C.c_uint64]),
 }
 

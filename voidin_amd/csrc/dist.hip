@@ -10,10 +10,13 @@
 //                           ~40x slower than HBM, so the wire carries a bit per instance, not a 20-byte command.
 //   vd_dist_step_draws_dev  the literal exchange: compact the own shard, all-gather the counts, then an exact-size direct
 //                           exchange of the 20-byte commands (grouped ncclSend / ncclRecv, one xGMI link per peer).
+//   vd_dist_step_indices_dev  the same exchange with 4-byte survivor indices on the wire (SURVEY.md 8e's option):
+//                           cull_mask -> mask_to_indices -> counts -> exact-size exchange -> indices_to_draws.
 //
 // RCCL is bound at run time (dlopen), not at link time: a host process usually has a copy loaded already (rccl-sys in a
 // Rust host, torch's bundled librccl in the Python tests) and a second copy under another soname would bring its own
-// global state; the copy already in the process is preferred, then VD_RCCL_LIB, then the ROCm install.
+// global state.  Order: $VD_RCCL_LIB when the host sets it (an explicit choice overrides everything - it is how the
+// tests bind their test double, tests/cpp/fake_rccl.cpp), else the copy already in the process, else the ROCm install.
 #include "vd_common.hpp"
 
 #include <dlfcn.h>
@@ -46,7 +49,7 @@ const char* load_rccl() {   // nullptr = ok, else what went wrong
     const char* env = getenv("VD_RCCL_LIB");
     struct Cand { const char* name; int flags; };
     const Cand cands[] = {
-        {env, RTLD_NOW | RTLD_LOCAL},
+        {env, RTLD_NOW | RTLD_LOCAL},                 // the host's explicit choice, if any
         {"librccl.so", RTLD_NOW | RTLD_NOLOAD},       // a copy the host process already holds (torch, rccl-sys)
         {"librccl.so.1", RTLD_NOW | RTLD_NOLOAD},
         {"librccl.so.1", RTLD_NOW | RTLD_LOCAL},
@@ -94,7 +97,9 @@ struct VdDist {
     uint64_t* d_mask_all = nullptr;   // wps * world words
     void* d_mesh_ids = nullptr;       // shard * world rows of id_bytes
     VdDrawIndexedIndirect* d_local = nullptr;   // draws mode: own shard's compacted commands (shard slots)
-    uint32_t* d_counts = nullptr;     // draws mode: [world] survivor counts + [1] own count
+    uint32_t* d_idx = nullptr;        // indices mode: own shard's survivor indices (shard slots), made on first use
+    uint32_t* d_idx_all = nullptr;    // indices mode: all survivors' indices (shard * world slots)
+    uint32_t* d_counts = nullptr;     // draws / indices mode: [world] survivor counts + [1] own count
     uint32_t* h_counts = nullptr;     // pinned mirror
 };
 
@@ -113,7 +118,9 @@ static void dist_free_scene(VdDist* d) {
     if (d->d_mask_all) (void)hipFree(d->d_mask_all);
     if (d->d_mesh_ids) (void)hipFree(d->d_mesh_ids);
     if (d->d_local) (void)hipFree(d->d_local);
-    d->d_mask = d->d_mask_all = nullptr; d->d_mesh_ids = nullptr; d->d_local = nullptr;
+    if (d->d_idx) (void)hipFree(d->d_idx);
+    if (d->d_idx_all) (void)hipFree(d->d_idx_all);
+    d->d_mask = d->d_mask_all = nullptr; d->d_mesh_ids = nullptr; d->d_local = nullptr; d->d_idx = d->d_idx_all = nullptr;
     d->n_total = 0;
 }
 
@@ -240,43 +247,110 @@ int vd_dist_step_full_dev(VdDist* d, const VdCameraUniform* camera, const VdMesh
     return vd_expand_mask_dev(ctx, d->d_mask_all, d->n_total, d->shard, d->d_mesh_ids, d->id_bytes, d_meshes, n_mesh, d_out, d_out_count);
 }
 
+// The variable-size leg shared by the draws and the indices steps: all-gather the survivor counts (d_own -> d_counts,
+// read back: the sizes are data dependent, one host round trip), then the exact-size direct exchange - every rank's
+// `rec`-byte records go straight to their final offset in every peer's `d_dst` (one xGMI link per peer), the own
+// records by a device copy.  *out_total = survivors of the whole scene.
+static int exchange_records(VdDist* d, const void* d_own_records, size_t rec, void* d_dst, uint64_t* out_total) {
+    VdCtx* ctx = d->ctx;
+    uint32_t* d_own = d->d_counts + d->world;
+    VD_RCCL_CHECK(d, g_rccl.AllGather(d_own, d->d_counts, 1, ncclUint32, d->comm, ctx->stream));
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(d->h_counts, d->d_counts, 4 * (size_t)d->world, hipMemcpyDeviceToHost, ctx->stream));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t off = 0, my_off = 0;
+    for (int q = 0; q < d->world; ++q) {
+        if (q == d->rank) my_off = off;
+        if (d->h_counts[q] > d->shard) VD_FAIL(ctx, VD_ERR_COMM, "vd_dist_step: a gathered count exceeds the shard size");
+        off += d->h_counts[q];
+    }
+    const uint64_t total = off;
+    if (total > d->n_total) VD_FAIL(ctx, VD_ERR_COMM, "vd_dist_step: gathered counts exceed the scene");
+    const uint32_t mine = d->h_counts[d->rank];
+    char* dst = static_cast<char*>(d_dst);
+    if (mine) VD_HIP_CHECK(ctx, hipMemcpyAsync(dst + rec * my_off, d_own_records, rec * mine, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d->world > 1) {
+        // a failed ncclSend / ncclRecv must not leave the group open on this thread (every later collective would be
+        // queued into it and never issued): remember the first error, still issue the operations of the other peers
+        // (they are served instead of left waiting), ALWAYS close the group, then report
+        VD_RCCL_CHECK(d, g_rccl.GroupStart());
+        ncclResult_t first = ncclSuccess;
+        const char* what = "";
+        uint64_t o = 0;
+        for (int q = 0; q < d->world; ++q) {
+            const uint32_t cq = d->h_counts[q];
+            if (q != d->rank) {
+                if (mine) {
+                    const ncclResult_t r = g_rccl.Send(d_own_records, rec * mine, ncclUint8, q, d->comm, ctx->stream);
+                    if (r != ncclSuccess && first == ncclSuccess) { first = r; what = "ncclSend"; }
+                }
+                if (cq) {
+                    const ncclResult_t r = g_rccl.Recv(dst + rec * o, rec * cq, ncclUint8, q, d->comm, ctx->stream);
+                    if (r != ncclSuccess && first == ncclSuccess) { first = r; what = "ncclRecv"; }
+                }
+            }
+            o += cq;
+        }
+        const ncclResult_t end = g_rccl.GroupEnd();
+        if (first != ncclSuccess || end != ncclSuccess) {
+            snprintf(ctx->err, sizeof(ctx->err), "vd_dist_step: %s -> %s (group closed; peers of a failed exchange time out in RCCL)",
+                     first != ncclSuccess ? what : "ncclGroupEnd", g_rccl.GetErrorString(first != ncclSuccess ? first : end));
+            return VD_ERR_COMM;
+        }
+    }
+    *out_total = total;
+    return VD_OK;
+}
+
 int vd_dist_step_draws_dev(VdDist* d, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                            const VdInstance* d_shard_instances, VdDrawIndexedIndirect* d_out, uint32_t* d_out_count) {
     if (!d) return VD_ERR_INVALID_ARG;
     VdCtx* ctx = d->ctx;
     VdDeviceGuard vd_guard_(ctx);
     if (!d->n_total) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_dist_step: vd_dist_set_scene_dev first");
+    if (n_mesh != d->n_mesh) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_dist_step: n_mesh differs from the scene's");
     if (!d_out || !d_out_count) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_dist_step_draws: null output");
     uint32_t* d_own = d->d_counts + d->world;
     int rc = VD_OK;
     if (d->n_local) rc = vd_cull_compact_shard_dev(ctx, camera, d_meshes, n_mesh, d_shard_instances, d->n_local, d->first, d->d_local, d_own, 0);
     else hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, ctx->stream, d_own, 0u);
     if (rc) return rc;
-    VD_RCCL_CHECK(d, g_rccl.AllGather(d_own, d->d_counts, 1, ncclUint32, d->comm, ctx->stream));
-    // the sizes are data dependent: one host round trip
-    VD_HIP_CHECK(ctx, hipMemcpyAsync(d->h_counts, d->d_counts, 4 * (size_t)d->world, hipMemcpyDeviceToHost, ctx->stream));
-    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    uint64_t off = 0, my_off = 0;
-    for (int q = 0; q < d->world; ++q) { if (q == d->rank) my_off = off; off += d->h_counts[q]; }
-    const uint64_t total = off;
-    if (total > d->n_total) VD_FAIL(ctx, VD_ERR_COMM, "vd_dist_step_draws: gathered counts exceed the scene");
-    const size_t rec = sizeof(VdDrawIndexedIndirect);
-    const uint32_t mine = d->h_counts[d->rank];
-    if (mine) VD_HIP_CHECK(ctx, hipMemcpyAsync(d_out + my_off, d->d_local, rec * mine, hipMemcpyDeviceToDevice, ctx->stream));
-    if (d->world > 1) {
-        // exact-size direct exchange: every rank sends its list straight into every peer's final buffer
-        VD_RCCL_CHECK(d, g_rccl.GroupStart());
-        uint64_t o = 0;
-        for (int q = 0; q < d->world; ++q) {
-            const uint32_t cq = d->h_counts[q];
-            if (q != d->rank) {
-                if (mine) VD_RCCL_CHECK(d, g_rccl.Send(d->d_local, rec * mine, ncclUint8, q, d->comm, ctx->stream));
-                if (cq) VD_RCCL_CHECK(d, g_rccl.Recv(d_out + o, rec * cq, ncclUint8, q, d->comm, ctx->stream));
-            }
-            o += cq;
+    uint64_t total = 0;
+    rc = exchange_records(d, d->d_local, sizeof(VdDrawIndexedIndirect), d_out, &total);
+    if (rc) return rc;
+    hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, ctx->stream, d_out_count, (unsigned)total);
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    return VD_OK;
+}
+
+int vd_dist_step_indices_dev(VdDist* d, const VdCameraUniform* camera, const VdMeshInfo* d_meshes, uint32_t n_mesh,
+                             const VdInstance* d_shard_instances, VdDrawIndexedIndirect* d_out, uint32_t* d_out_count) {
+    if (!d) return VD_ERR_INVALID_ARG;
+    VdCtx* ctx = d->ctx;
+    VdDeviceGuard vd_guard_(ctx);
+    if (!d->n_total) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_dist_step: vd_dist_set_scene_dev first");
+    if (n_mesh != d->n_mesh) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_dist_step: n_mesh differs from the scene's");
+    if (!d_out || !d_out_count) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_dist_step_indices: null output");
+    if (!d->d_idx) {   // first use of this mode on the scene: 4 B per shard slot + 4 B per scene slot
+        const size_t rows = (size_t)d->shard * (size_t)d->world;
+        if (hipMalloc(reinterpret_cast<void**>(&d->d_idx), 4 * (size_t)(d->shard ? d->shard : 1) + 16) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&d->d_idx_all), 4 * (rows ? rows : 1) + 16) != hipSuccess) {
+            if (d->d_idx) (void)hipFree(d->d_idx);
+            d->d_idx = d->d_idx_all = nullptr;
+            VD_FAIL(ctx, VD_ERR_OOM, "vd_dist_step_indices: index buffers");
         }
-        VD_RCCL_CHECK(d, g_rccl.GroupEnd());
     }
+    uint32_t* d_own = d->d_counts + d->world;
+    int rc = VD_OK;
+    if (d->n_local) {
+        rc = vd_cull_mask_dev(ctx, camera, d_meshes, n_mesh, d_shard_instances, d->n_local, d->d_mask);
+        if (!rc) rc = vd_mask_to_indices_dev(ctx, d->d_mask, d->n_local, d->first, d->d_idx, d_own);
+    } else hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, ctx->stream, d_own, 0u);
+    if (rc) return rc;
+    uint64_t total = 0;
+    rc = exchange_records(d, d->d_idx, sizeof(uint32_t), d->d_idx_all, &total);
+    if (rc) return rc;
+    if (total) rc = vd_indices_to_draws_dev(ctx, d->d_idx_all, (uint32_t)total, d->d_mesh_ids, d->id_bytes, d->shard * (uint32_t)d->world, d_meshes, n_mesh, d_out);
+    if (rc) return rc;
     hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, ctx->stream, d_out_count, (unsigned)total);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;

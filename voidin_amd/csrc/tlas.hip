@@ -1287,11 +1287,15 @@ int tlas_refit_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
                     Node* d_nodes) {
     const size_t total = 2 * (size_t)n + 1;
     const size_t need = 256 + total * 16 + total * 4;
-    if (need > ctx->refit_state_bytes || !ctx->refit_state || ctx->refit_epoch == 0xffffffffu) {
+    // The arrival words sit behind the link records, so their offset depends on n: after refits at n1 a refit at another
+    // n in the same arena would read old arrival words (values up to 4 / 6 = plausible small epochs) as link records.
+    // A change of n therefore starts the arena over, like a reallocation or an epoch wrap does.
+    if (need > ctx->refit_state_bytes || !ctx->refit_state || ctx->refit_epoch == 0xffffffffu || n != ctx->refit_n) {
         int rc = vd_ensure(ctx, &ctx->refit_state, &ctx->refit_state_bytes, need);
         if (rc) return rc;
         VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->refit_state, 0, ctx->refit_state_bytes, ctx->stream));   // epoch 0 = never written
         ctx->refit_epoch = 0u;
+        ctx->refit_n = n;
     }
     const unsigned epoch = ++ctx->refit_epoch;
     char* base = reinterpret_cast<char*>(ctx->refit_state);

@@ -675,7 +675,10 @@ __global__ __launch_bounds__(64 * kSortWaves) void rs_scatter_kernel(const unsig
 //   tpair[idx0]  (64 B) the two children of a TLAS node - tlas[idx0], tlas[idx1] - side by side at the LEFT child's index
 //                (a TLAS step used to fetch two nodes at unrelated indices = two lines).  The left copy's unused
 //                instance_idx word holds idx1 as a tag: a slot written for another right child (an unreachable slot of
-//                the array naming the same left child) is detected and the step reads the two nodes themselves;
+//                the array naming the same left child) is detected and the step reads the two nodes themselves.  When
+//                several slots name one left child, exactly ONE writes the record - the lowest node index
+//                (pair_owner_kernel: atomicMin into an owner word, then records_kernel writes only as the owner) - so a
+//                record is never a mixture of two writers' stores;
 //   irec[k]      (64 B) for a TLAS leaf k: rows 0..2 of its instance's inv_transform (row r = {M[r], M[4 + r], M[8 + r],
 //                M[12 + r]}: the operands of (inv_transform * vec4(p, w)).r in source order), {mesh id, bad-instance flag};
 //   mrec[m]      (128 B) per mesh: {bvh_index, base_index, vertex_offset, root.left_first | root.count << 30} and the 64
@@ -686,10 +689,17 @@ __global__ __launch_bounds__(64 * kSortWaves) void rs_scatter_kernel(const unsig
 // instances, TLAS nodes and meshes may change between calls as before.  A mesh whose root or root children lie outside
 // the buffers gets 0xffffffff as its root word: a ray that ENTERS it reports VD_ERR_INVALID_ARG.
 constexpr unsigned kTlasSlots = 65536;              // 16-bit child indices (bvh.wgsl:105-106)
+__global__ __launch_bounds__(256) void pair_owner_kernel(const VdTlasNode* __restrict__ tlas, unsigned n_nodes, unsigned* __restrict__ owner) {
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n_nodes) return;
+    const unsigned lr = tlas[k].left_right;
+    if (lr != 0u && (lr & 0xffffu) < n_nodes && (lr >> 16u) < n_nodes) atomicMin(owner + (lr & 0xffffu), k);
+}
+
 __global__ __launch_bounds__(256) void records_kernel(const VdTlasNode* __restrict__ tlas, unsigned n_nodes, const VdInstance* __restrict__ inst,
                                                       unsigned n_inst, const VdMeshInfo* __restrict__ meshes, unsigned n_meshes,
                                                       const VdBvhNode* __restrict__ bvh, unsigned n_bvh, float4* __restrict__ irec,
-                                                      float4* __restrict__ tpair, float4* __restrict__ mrec) {
+                                                      float4* __restrict__ tpair, float4* __restrict__ mrec, const unsigned* __restrict__ owner) {
     const unsigned k = blockIdx.x * 256u + threadIdx.x;
     if (k < n_meshes) {
         const VdMeshInfo mesh = meshes[k];
@@ -716,7 +726,7 @@ __global__ __launch_bounds__(256) void records_kernel(const VdTlasNode* __restri
     const VdTlasNode node = tlas[k];
     if (node.left_right != 0u) {
         const unsigned idx0 = node.left_right & 0xffffu, idx1 = node.left_right >> 16u;
-        if (idx0 < n_nodes && idx1 < n_nodes) {
+        if (idx0 < n_nodes && idx1 < n_nodes && owner[idx0] == k) {
             const float4* c0 = reinterpret_cast<const float4*>(tlas + idx0);
             const float4* c1 = reinterpret_cast<const float4*>(tlas + idx1);
             float4 lo = c0[1]; lo.w = __uint_as_float(idx1);
@@ -782,17 +792,21 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     if (n_rays > 0xf0000000u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: more than 0xf0000000 rays in one call");
     // scratch: [256 B flags and counters][TLAS child pairs, 64 B x 65 536][entry records, 64 B x 65 536][mesh records][de-indexed triangles][ray binning arrays]
     // (pairs and entry records for all 65 536 indices a 16-bit child field can name: a stray index reads a poisoned slot, not beyond)
-    const size_t pair_bytes = (size_t)64 * kTlasSlots, irec_bytes = (size_t)64 * kTlasSlots, mrec_bytes = (size_t)128 * sc->n_meshes;
-    const size_t tris_at = 256 + pair_bytes + ((irec_bytes + 255) & ~(size_t)255) + ((mrec_bytes + 255) & ~(size_t)255);
+    const size_t pair_bytes = (size_t)64 * kTlasSlots, irec_bytes = (size_t)64 * kTlasSlots, owner_bytes = (size_t)4 * kTlasSlots;
+    const size_t mrec_bytes = (size_t)128 * sc->n_meshes;
+    const size_t tris_at = 256 + pair_bytes + irec_bytes + owner_bytes + ((mrec_bytes + 255) & ~(size_t)255);
     // A call that was not given prepared leaves de-indexes them itself when that is cheap next to the walk (one pass over the
     // index buffer, 36 B per triangle into the scratch: 5 us for the stress scene's 131 k triangles, 20 us for the harness
     // scene's 1.2 M) - the plain vd_trace_dev then walks at the prepared rate.  Not for few rays over a big scene, not
-    // above 16 M triangles, not with the binned / chunked supplies; VD_OPT_TRACE_AUTO_PREPARE = 0 turns it off.
+    // with the binned / chunked supplies, not with more meshes than one launch's gridDim.y, and only up to 2 Mi triangles
+    // (72 MB of the context's grow-only scratch, kept for its lifetime); VD_OPT_TRACE_AUTO_PREPARE = 2 raises that to
+    // 16 Mi (576 MB), 0 turns it off.  vd_trace_prepare_dev is the explicit form without a limit.
     const size_t n_tri = sc->n_indices / 3u;
     const bool single = ctx->option(VD_OPT_TRACE_CHUNK, 1) <= 1 &&
                         !(ctx->option(VD_OPT_TRACE_SORT, 0) != 0 && n_rays >= (unsigned)ctx->option(VD_OPT_TRACE_SORT_MIN, 65536));
-    const bool auto_prep = !d_tris && single && ctx->option(VD_OPT_TRACE_AUTO_PREPARE, 1) != 0 && n_tri > 0 && sc->n_vertices > 0 &&
-                           n_tri <= ((size_t)1 << 24) && (size_t)n_rays * 8u >= n_tri;
+    const long long auto_opt = ctx->option(VD_OPT_TRACE_AUTO_PREPARE, 1);
+    const bool auto_prep = !d_tris && single && auto_opt != 0 && n_tri > 0 && sc->n_vertices > 0 && sc->n_meshes <= 65535u &&
+                           n_tri <= ((size_t)1 << (auto_opt >= 2 ? 24 : 21)) && (size_t)n_rays * 8u >= n_tri;
     const size_t tris_bytes = auto_prep ? (((size_t)36 * n_tri + 64 + 255) & ~(size_t)255) : 0;
     const size_t sort_at = tris_at + tris_bytes;
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, sort_at);
@@ -808,12 +822,14 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 64, ctx->stream));
     float4* d_pair = reinterpret_cast<float4*>(reinterpret_cast<char*>(ctx->scratch) + 256);
     float4* d_rec = reinterpret_cast<float4*>(reinterpret_cast<char*>(d_pair) + pair_bytes);
-    float4* d_mrec = reinterpret_cast<float4*>(reinterpret_cast<char*>(d_rec) + ((irec_bytes + 255) & ~(size_t)255));
+    unsigned* d_owner = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d_rec) + irec_bytes);
+    float4* d_mrec = reinterpret_cast<float4*>(reinterpret_cast<char*>(d_owner) + owner_bytes);
     const unsigned yield = (unsigned)std::max<long long>(1, ctx->option(VD_OPT_TRACE_YIELD, kYieldDefault));
-    VD_HIP_CHECK(ctx, hipMemsetAsync(d_pair, 0xff, pair_bytes + irec_bytes, ctx->stream));      // no pair slot carries a tag yet, every entry record says "bad"
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_pair, 0xff, pair_bytes + irec_bytes + owner_bytes, ctx->stream));      // no pair slot carries a tag or has an owner yet, every entry record says "bad"
     const unsigned n_rec = std::min(sc->n_tlas_nodes, kTlasSlots);      // nodes past 65 535 cannot be named by a 16-bit child field
+    hipLaunchKernelGGL(pair_owner_kernel, dim3((n_rec + 255u) / 256u), dim3(256), 0, ctx->stream, sc->tlas_nodes, n_rec, d_owner);
     hipLaunchKernelGGL(records_kernel, dim3((std::max(n_rec, sc->n_meshes) + 255u) / 256u), dim3(256), 0, ctx->stream, sc->tlas_nodes,
-                       n_rec, sc->instances, sc->n_instances, sc->meshes, sc->n_meshes, sc->bvh_nodes, sc->n_bvh_nodes, d_rec, d_pair, d_mrec);
+                       n_rec, sc->instances, sc->n_instances, sc->meshes, sc->n_meshes, sc->bvh_nodes, sc->n_bvh_nodes, d_rec, d_pair, d_mrec, d_owner);
     const unsigned* gate = nullptr;
     if (auto_prep) {
         float* t = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->scratch) + tris_at);
@@ -912,8 +928,9 @@ int vd_trace_prepare_dev(VdCtx* ctx, const VdTraceScene* d_scene, VdTraceAccel**
     unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);
     (void)hipMemsetAsync(d_flag, 0, 4, ctx->stream);
     (void)hipMemsetAsync(a->tris, 0, 36 * n_tri + 64, ctx->stream);      // index ranges no mesh covers
-    hipLaunchKernelGGL(prepare_tris_kernel, dim3(256, d_scene->n_meshes), dim3(256), 0, ctx->stream, d_scene->meshes, d_scene->vertices, d_scene->indices,
-                       d_scene->n_indices, d_scene->n_vertices, a->tris, d_flag);
+    for (unsigned m0 = 0; m0 < d_scene->n_meshes; m0 += 65535u)      // gridDim.y carries the mesh: 65 535 per launch
+        hipLaunchKernelGGL(prepare_tris_kernel, dim3(256, std::min(d_scene->n_meshes - m0, 65535u)), dim3(256), 0, ctx->stream, d_scene->meshes + m0,
+                           d_scene->vertices, d_scene->indices, d_scene->n_indices, d_scene->n_vertices, a->tris, d_flag);
     hipError_t e = hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess || ctx->host_pinned[0]) {

@@ -210,6 +210,12 @@ class RcclVisibility:
         self.ctx._chk(self.lib.vd_dist_step_draws_dev(self.h, cam.ctypes.data, self._abi.ptr(self.d_meshes), self.n_mesh,
                                                       self._abi.ptr(self.d_inst), self._abi.ptr(d_out), self._abi.ptr(d_count)))
 
+    def step_indices(self, camera, d_out, d_count):
+        """Full list on every rank; wire = 4 B per survivor (counts read back on the host)."""
+        cam = self._cam(camera)
+        self.ctx._chk(self.lib.vd_dist_step_indices_dev(self.h, cam.ctypes.data, self._abi.ptr(self.d_meshes), self.n_mesh,
+                                                        self._abi.ptr(self.d_inst), self._abi.ptr(d_out), self._abi.ptr(d_count)))
+
     def step_shard(self, camera, d_out_local, d_count_local):
         self.ctx.cull_compact_dev(camera, self.d_meshes, self.n_mesh, self.d_inst, self.n_local, d_out_local, d_count_local,
                                   False, self.lo)
