@@ -901,6 +901,54 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
                                      "demo_view_1024x1024_Mrays_per_s": round(len(hrays) / min(th) / 1e3, 1),
                                      "demo_view_hits_equal_oracle_fixture": bool(np.array_equal(sh["hit"], g["hit"]) and sh["dist"][hit].tobytes() == g["dist"][hit].tobytes())}
         del hds, d_hr, d_hh, d_sr, d_sh
+        # K meshes in ONE build (vd_bvh_build_batch_dev; MeshPool::add for a whole scene, mesh/mod.rs:309-351): 64 copies of the
+        # helmet, and a Sponza-class load of 400 meshes of 1 k - 50 k triangles; device arrays, packed node buffer; every mesh's
+        # nodes are compared (CRC) with the single build's
+        def batch_leg(meshes, reps=3):
+            K = len(meshes)
+            items = (abi.BvhBatchItem * K)()
+            dev_v = [ctx.upload(np.ascontiguousarray(v, dtype=np.float32)) for v, _ in meshes]
+            host_i = [np.ascontiguousarray(i, dtype=np.uint32).reshape(-1) for _, i in meshes]
+            dev_i = [ctx.upload(i) for i in host_i]
+            n_tri = sum(len(i) // 3 for i in host_i)
+            d_nodes = ctx.empty(2 * n_tri * 32 + 64 * K)
+            best = None
+            for _ in range(reps):
+                for m in range(K):
+                    dev_i[m].copy_(torch.from_numpy(host_i[m].view(np.uint8)))       # the build permutes the indices in place
+                    items[m].verts_xyz, items[m].indices_inout, items[m].out_nodes = abi.ptr(dev_v[m]), abi.ptr(dev_i[m]), None
+                    items[m].n_vert, items[m].n_tri, items[m].node_cap = len(meshes[m][0]), len(host_i[m]) // 3, 0
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                ctx.bvh_build_batch_dev(items, K, d_nodes, 2 * n_tri + 2 * K, 0)
+                dt = time.perf_counter() - t
+                best = dt if best is None else min(best, dt)
+            nodes = d_nodes.cpu().numpy()
+            crcs = [zlib.crc32(nodes[items[m].out_first_node * 32: (items[m].out_first_node + items[m].out_n_nodes) * 32].tobytes()) for m in range(K)]
+            return best, n_tri, crcs, ctx.bvh_last_build_stats()
+        t64, n64, crc64, st64 = batch_leg([(hv, hi)] * 64)
+        rng = np.random.default_rng(5)
+        many = []
+        for k in range(400):
+            t_ = int(np.exp(rng.uniform(np.log(1000), np.log(50_000))))
+            u_ = max(8, int(np.sqrt(2 * t_)))
+            many.append(synth.knot_mesh(u_, max(4, t_ // (2 * u_)), seed=synth.SEED_BASE + 100 + k))
+        t400, n400, crc400, st400 = batch_leg(many, reps=2)
+        t_single = time.perf_counter()
+        ok400 = True
+        for k in range(0, 400, 8):                                                   # every 8th mesh against its single build
+            sn_, _ = ctx.bvh_build(*many[k])
+            ok400 = ok400 and zlib.crc32(sn_.tobytes()) == crc400[k]
+        t_single = (time.perf_counter() - t_single) / 50
+        extra["bvh_build_batch"] = {
+            "helmet_x64": {"ms_total": round(t64 * 1e3, 3), "ms_per_mesh_amortised": round(t64 * 1e3 / 64, 4), "Mprims_per_s": round(n64 / t64 / 1e6, 1),
+                           "levels_phase_a": st64["levels_phase_a"], "kernel_launches": st64["kernel_launches"],
+                           "every_mesh_equals_the_single_build": bool(all(c == int(g["nodes_crc"]) for c in crc64))},
+            "meshes_400_of_1k_to_50k": {"triangles": n400, "ms_total": round(t400 * 1e3, 2), "Mprims_per_s": round(n400 / t400 / 1e6, 1),
+                                        "levels_phase_a": st400["levels_phase_a"], "kernel_launches": st400["kernel_launches"],
+                                        "single_build_ms_per_mesh_host_arrays": round(t_single * 1e3, 3),
+                                        "sampled_meshes_equal_their_single_builds": bool(ok400)},
+            "note": "device arrays, packed node buffer, wall clock around the blocking call; single helmet build for comparison: reference_helmet.blas_build_ms_host_arrays"}
     # the CPU harness (src/bin/bvh_cpu.rs:39-96): per-pixel rays + Bvh::traverse_iter against ONE mesh, on the device;
     # the harness's own 64-triangle soup at 640 x 640, and the large mesh of the scene above at 2048 x 2048
     cam_h = synth.camera_uniform(eye=(0, 0, 15), pitch_deg=0)

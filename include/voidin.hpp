@@ -208,6 +208,46 @@ class MeshPool {
         return (uint32_t)mesh_info_cpu.size() - 1;     // MeshId
     }
 
+    // MeshPool::add for a whole scene: the same bookkeeping for every mesh, ONE batched BLAS build (vd_bvh_build_batch)
+    // instead of a build per mesh - a load of hundreds of small meshes pays the builder's fixed cost once.  The meshes'
+    // index slices are permuted in place, as `add` does.  Returns the MeshId of the first mesh added (ids are consecutive).
+    uint32_t add_many(const MeshRef* meshes, size_t n_meshes) {
+        const uint32_t first_id = (uint32_t)mesh_info_cpu.size();
+        if (n_meshes == 0) return first_id;
+        std::vector<VdBvhBatchItem> items(n_meshes);
+        size_t node_room = 0;
+        for (size_t m = 0; m < n_meshes; ++m) {
+            items[m] = VdBvhBatchItem{};
+            items[m].verts_xyz = &meshes[m].vertices->x; items[m].n_vert = (uint32_t)meshes[m].n_vertices;
+            items[m].indices_inout = meshes[m].indices; items[m].n_tri = (uint32_t)(meshes[m].n_indices / 3);
+            items[m].out_nodes = nullptr;                       // packed: bvh_index = bvh_nodes.len() (mesh/mod.rs:320-345)
+            node_room += 2 * (meshes[m].n_indices / 3) + 2;     // the reference allocates 2 * T nodes (blas.rs:52)
+        }
+        const uint32_t first_node = (uint32_t)bvh_nodes.size();
+        bvh_nodes.resize(first_node + node_room);
+        uint32_t end = first_node;
+        gpu_.check(vd_bvh_build_batch(gpu_.ctx(), items.data(), (uint32_t)n_meshes, bvh_nodes.data(), bvh_nodes.size(), first_node, &end));
+        bvh_nodes.resize(end);                                  // nodes.truncate(pool) of every mesh (blas.rs:93)
+        for (size_t m = 0; m < n_meshes; ++m) {
+            const MeshRef& mesh = meshes[m];
+            MeshInfo info{};
+            float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+            for (size_t i = 0; i < mesh.n_vertices; ++i) {
+                const float p[3] = {mesh.vertices[i].x, mesh.vertices[i].y, mesh.vertices[i].z};
+                for (int k = 0; k < 3; ++k) { mn[k] = p[k] < mn[k] ? p[k] : mn[k]; mx[k] = p[k] > mx[k] ? p[k] : mx[k]; }
+            }
+            std::memcpy(info.min, mn, 12); std::memcpy(info.max, mx, 12);
+            info.index_count = (uint32_t)mesh.n_indices;
+            info.base_index = (uint32_t)indices.size();
+            info.vertex_offset = (int32_t)vertices.size();
+            info.bvh_index = items[m].out_first_node;
+            vertices.insert(vertices.end(), mesh.vertices, mesh.vertices + mesh.n_vertices);
+            indices.insert(indices.end(), mesh.indices, mesh.indices + mesh.n_indices);
+            mesh_info_cpu.push_back(info);
+        }
+        return first_id;
+    }
+
     // MeshPool::generate_tlas (mesh/mod.rs:279-286)
     void generate_tlas(const std::vector<Instance>& instances) {
         if (instances.empty()) return;

@@ -341,6 +341,38 @@ int vd_bvh_build_dev(VdCtx* ctx, const float* d_verts_xyz, uint32_t n_vert,
                      uint32_t* d_indices_inout, uint32_t n_tri,
                      VdBvhNode* d_out_nodes, uint32_t node_cap, uint32_t* out_n_nodes /* host */);
 
+/* Batched BLAS build (NEW): K meshes in ONE build.  MeshPool::add builds one BLAS per mesh at load
+ * (crates/pools/src/mesh/mod.rs:309-351: Sponza-class scenes are hundreds of small meshes) and a
+ * single build has a fixed cost of launches and host round trips that dwarfs a 15 k-triangle mesh.
+ * Here the meshes' triangles lie side by side in one position space and every pass of the builder -
+ * the level loop (one host round trip per level for the WHOLE batch), the mid tier, the small
+ * subtrees - runs once for all of them; meshes of <= 2048 / <= 512 triangles start in those tiers
+ * directly.  Each mesh's nodes and permuted indices are exactly what vd_bvh_build gives for that
+ * mesh alone (mesh-local node ids and leaf positions, node 1 all-zero).
+ *   items          host array; per mesh: vertices, mesh-local indices (permuted in place), and either
+ *                  its own node array (out_nodes, node_cap) or out_nodes = NULL = PACKED: the mesh's
+ *                  nodes follow the previous packed mesh's in `packed_nodes`, from `packed_first` on -
+ *                  MeshPool's `bvh_index = bvh_nodes.len()` bookkeeping (mesh/mod.rs:320-345);
+ *                  written back: out_n_nodes, out_first_node (= MeshInfo.bvh_index when packed), status
+ *   packed_nodes   shared node buffer of `packed_cap` nodes (may be NULL when no item is packed)
+ *   out_packed_end one past the last packed node written (host pointer, may be NULL)
+ * _dev: every pointer inside the items and packed_nodes are device pointers; blocks like
+ * vd_bvh_build_dev.  An error fails the whole batch (nothing is to be used); items[m].status names the
+ * mesh when the error has one (bad index, capacity).                                              */
+typedef struct VdBvhBatchItem {
+    const float* verts_xyz;        /* n_vert * 3 floats                                     */
+    uint32_t*    indices_inout;    /* n_tri * 3 u32, mesh-local                             */
+    VdBvhNode*   out_nodes;        /* NULL = packed                                         */
+    uint32_t     n_vert, n_tri, node_cap;
+    uint32_t     out_n_nodes;      /* written                                               */
+    uint32_t     out_first_node;   /* written                                               */
+    int32_t      status;           /* written                                               */
+} VdBvhBatchItem;
+int vd_bvh_build_batch(VdCtx* ctx, VdBvhBatchItem* items, uint32_t n_items, VdBvhNode* packed_nodes,
+                       uint64_t packed_cap, uint32_t packed_first, uint32_t* out_packed_end);
+int vd_bvh_build_batch_dev(VdCtx* ctx, VdBvhBatchItem* items, uint32_t n_items, VdBvhNode* d_packed_nodes,
+                           uint64_t packed_cap, uint32_t packed_first, uint32_t* out_packed_end);
+
 /* ------------------------------------------------------------------------------------ */
 /* TLAS build / refit                                               */
 /* ------------------------------------------------------------------------------------ */

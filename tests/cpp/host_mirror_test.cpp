@@ -53,6 +53,22 @@ int main() {
     REQUIRE(pool.bvh_nodes.size() == 2 + ref_n);
     REQUIRE(std::memcmp(pool.bvh_nodes.data() + 2, ref_nodes.data(), ref_n * sizeof(VdBvhNode)) == 0);
     REQUIRE(soup_i == ref_i);
+    {
+        // MeshPool::add_many: the same two meshes (and the plane once more) through ONE batched build == add() three times
+        voidin::MeshPool pool2(gpu), pool3(gpu);
+        std::vector<uint32_t> pi_a = {0, 1, 2, 0, 2, 3}, pi_b = pi_a, pi_c = pi_a, pi_d = pi_a, si_a, si_b;
+        for (int t = 0; t < 900; ++t) for (int k = 0; k < 3; ++k) { si_a.push_back(3 * t + k); si_b.push_back(3 * t + k); }
+        pool2.add({plane_v.data(), plane_v.size(), pi_a.data(), pi_a.size()});
+        pool2.add({soup_v.data(), soup_v.size(), si_a.data(), si_a.size()});
+        pool2.add({plane_v.data(), plane_v.size(), pi_b.data(), pi_b.size()});
+        const voidin::MeshRef many[3] = {{plane_v.data(), plane_v.size(), pi_c.data(), pi_c.size()}, {soup_v.data(), soup_v.size(), si_b.data(), si_b.size()},
+                                         {plane_v.data(), plane_v.size(), pi_d.data(), pi_d.size()}};
+        REQUIRE(pool3.add_many(many, 3) == 0);
+        REQUIRE(pool3.mesh_info_cpu.size() == 3 && pool3.bvh_nodes.size() == pool2.bvh_nodes.size() && pool3.indices == pool2.indices);
+        REQUIRE(std::memcmp(pool3.bvh_nodes.data(), pool2.bvh_nodes.data(), pool2.bvh_nodes.size() * sizeof(VdBvhNode)) == 0);
+        REQUIRE(std::memcmp(pool3.mesh_info_cpu.data(), pool2.mesh_info_cpu.data(), 3 * sizeof(voidin::MeshInfo)) == 0);
+        REQUIRE(si_b == ref_i);
+    }
 
     // instances: translate + uniform scale, Instance::new computes inv_transform (shared.rs:90-98)
     voidin::InstancePool ipool;

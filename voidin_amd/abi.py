@@ -98,6 +98,13 @@ class DistInfo(C.Structure):
                 ("_pad", C.c_int32), ("rccl_library", C.c_char * 128)]
 
 
+class BvhBatchItem(C.Structure):
+    """VdBvhBatchItem (include/voidin_abi.h, "Batched BLAS build")."""
+    _fields_ = [("verts_xyz", C.c_void_p), ("indices_inout", C.c_void_p), ("out_nodes", C.c_void_p),
+                ("n_vert", C.c_uint32), ("n_tri", C.c_uint32), ("node_cap", C.c_uint32),
+                ("out_n_nodes", C.c_uint32), ("out_first_node", C.c_uint32), ("status", C.c_int32)]
+
+
 class BvhBuildStats(C.Structure):
     """VdBvhBuildStats (include/voidin_abi.h, instrumentation)."""
     _fields_ = [("ms_precompute", C.c_float), ("ms_phase_a", C.c_float), ("ms_mid", C.c_float), ("ms_phase_b", C.c_float),
@@ -132,6 +139,8 @@ PROTOTYPES = {
     "vd_compact_draws_dev": (_I, [_P, _P, _U, _P, _P]),
     "vd_bvh_build": (_I, [_P, _P, _U, _P, _U, _P, _U, _P]),
     "vd_bvh_build_dev": (_I, [_P, _P, _U, _P, _U, _P, _U, _P]),
+    "vd_bvh_build_batch": (_I, [_P, _P, _U, _P, C.c_uint64, _U, _P]),
+    "vd_bvh_build_batch_dev": (_I, [_P, _P, _U, _P, C.c_uint64, _U, _P]),
     "vd_tlas_build": (_I, [_P, _P, _U, _P, _U, _P]),
     "vd_tlas_build_dev": (_I, [_P, _P, _U, _P, _U, _P]),
     "vd_tlas_build_wide": (_I, [_P, _P, _U, _P, _U, _P]),

@@ -143,26 +143,55 @@ __device__ __forceinline__ float cand_pos(const float* cbmin, const float* cbmax
 // same-address global atomics are serialised chip-wide (~2-5 ns each), and one workgroup per 256 triangles made
 // 393 k of them at 8.4 M triangles - most of this kernel's 0.9 ms.
 constexpr int kPreTris = 8;
-__global__ __launch_bounds__(256) void blas_precompute_kernel(const float* __restrict__ verts, const unsigned* __restrict__ idx,
-                                                              unsigned n_tri, unsigned n_vert,
+constexpr unsigned kChunk = 256u * kPreTris;      // triangles per workgroup of the precompute and of the final index permute
+
+// One build takes K meshes (vd_bvh_build_batch*; vd_bvh_build* is K = 1).  Their triangles are laid side by side in ONE
+// position space - mesh m owns positions [base, base + n_tri) - so every later pass (the level loop over a forest of
+// segments, the mid tier, the small subtrees) runs once for the whole batch; only the passes that touch the caller's
+// buffers (here, and the copy-out) look the mesh up: workgroup -> chunk of kChunk triangles -> mesh, by bisection over
+// the meshes' first chunks.
+struct MeshDesc {
+    const float* verts; const unsigned* idx_in; unsigned* idx_out; VdBvhNode* out;
+    unsigned n_vert, n_tri, base, chunk0;
+};
+__device__ __forceinline__ unsigned mesh_of_chunk(const MeshDesc* __restrict__ meshes, unsigned n_meshes, unsigned chunk) {
+    unsigned lo = 0, hi = n_meshes;              // largest m with meshes[m].chunk0 <= chunk
+    while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (meshes[mid].chunk0 <= chunk) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void blas_precompute_kernel(const MeshDesc* __restrict__ meshes, unsigned n_meshes,
+                                                              unsigned* __restrict__ idx_copy,
                                                               f32x4* __restrict__ cent, TriBox* __restrict__ boxes,
-                                                              int* __restrict__ root_keys /*[12]: box, centroid box*/,
-                                                              unsigned* __restrict__ err) {
+                                                              int* __restrict__ root_keys /*[16] per mesh: box, centroid box*/,
+                                                              unsigned* __restrict__ err, unsigned* __restrict__ bad_mesh) {
     __shared__ int s_k[12];
+    __shared__ unsigned s_m;
     if (threadIdx.x < 12) s_k[threadIdx.x] = (threadIdx.x % 6) < 3 ? kBig : -kBig - 1;
+    if (threadIdx.x == 0) s_m = mesh_of_chunk(meshes, n_meshes, blockIdx.x);
     __syncthreads();
+    const unsigned m = s_m;
+    const MeshDesc md = meshes[m];
+    const float* __restrict__ verts = md.verts;
+    const unsigned* __restrict__ idx = md.idx_in;
+    const unsigned n_tri = md.n_tri, n_vert = md.n_vert, chunk = blockIdx.x - md.chunk0;
     int k12[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) k12[q] = (q % 6) < 3 ? kBig : -kBig - 1;
     bool bad = false;
 #pragma unroll 2
     for (int r = 0; r < kPreTris; ++r) {
-        const unsigned t = (blockIdx.x * (unsigned)kPreTris + (unsigned)r) * 256u + threadIdx.x;   // coalesced per round
+        const unsigned t = (chunk * (unsigned)kPreTris + (unsigned)r) * 256u + threadIdx.x;   // coalesced per round
         if (t >= n_tri) break;
+        const unsigned g = md.base + t;                     // the triangle's position / id in the batch
         const unsigned i0 = idx[3u * (size_t)t], i1 = idx[3u * (size_t)t + 1], i2 = idx[3u * (size_t)t + 2];
-        if (i0 >= n_vert || i1 >= n_vert || i2 >= n_vert) { bad = true; continue; }
-        const float* a = verts + 3u * (size_t)i0; const float* b = verts + 3u * (size_t)i1; const float* c = verts + 3u * (size_t)i2;
+        idx_copy[3u * (size_t)g] = i0; idx_copy[3u * (size_t)g + 1] = i1; idx_copy[3u * (size_t)g + 2] = i2;   // the permute's source (blas.rs:95-100 clones too)
         TriBox bx; float ce[3];
+        if (i0 >= n_vert || i1 >= n_vert || i2 >= n_vert) {
+            bad = true;
+            for (int k = 0; k < 3; ++k) { ce[k] = 0.0f; bx.mn[k] = 0.0f; bx.mx[k] = 0.0f; }
+        } else {
+        const float* a = verts + 3u * (size_t)i0; const float* b = verts + 3u * (size_t)i1; const float* c = verts + 3u * (size_t)i2;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float ak = vd_quiet(a[k]), bk = vd_quiet(b[k]), ck = vd_quiet(c[k]);   // a signalling NaN becomes a quiet one
@@ -177,12 +206,13 @@ __global__ __launch_bounds__(256) void blas_precompute_kernel(const float* __res
             k12[6 + k] = min(k12[6 + k], vd_key_lo(ce[k]));     // a NaN centroid (NaN vertex) drops out of `cb`
             k12[9 + k] = max(k12[9 + k], vd_key_hi(ce[k]));
         }
+        }
         bx.pad0 = bx.pad1 = 0.0f;
-        const f32x4 c4 = {ce[0], ce[1], ce[2], __uint_as_float(t)};   // .w: the triangle's id travels with its centroid
-        cent[t] = c4;
-        boxes[t] = bx;
+        const f32x4 c4 = {ce[0], ce[1], ce[2], __uint_as_float(g)};   // .w: the triangle's id travels with its centroid
+        cent[g] = c4;
+        boxes[g] = bx;
     }
-    if (bad) atomicOr(err, ERR_BAD_INDEX);
+    if (bad) { atomicOr(err, ERR_BAD_INDEX); atomicMin(bad_mesh, m); }
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
         const int v = (q % 6) < 3 ? wave_min_i(k12[q]) : wave_max_i(k12[q]);
@@ -190,8 +220,8 @@ __global__ __launch_bounds__(256) void blas_precompute_kernel(const float* __res
     }
     __syncthreads();
     if (threadIdx.x < 12) {
-        if ((threadIdx.x % 6) < 3) atomicMin(&root_keys[threadIdx.x], s_k[threadIdx.x]);
-        else atomicMax(&root_keys[threadIdx.x], s_k[threadIdx.x]);
+        if ((threadIdx.x % 6) < 3) atomicMin(&root_keys[16u * m + threadIdx.x], s_k[threadIdx.x]);
+        else atomicMax(&root_keys[16u * m + threadIdx.x], s_k[threadIdx.x]);
     }
 }
 
@@ -1987,24 +2017,31 @@ __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot*
 // =============================================================================================
 // Phase C: copy-out.
 // =============================================================================================
-struct TopOut { unsigned final_index, pair; };   // pair = final left_first for interior nodes
+struct TopOut { unsigned final_index, pair, mesh; };   // pair = final left_first for interior nodes; mesh: whose node array
 
-__global__ void c_top_kernel(const TopNode* top, const TopOut* tout, unsigned n_top, VdBvhNode* out) {
+__global__ void c_top_kernel(const TopNode* top, const TopOut* tout, unsigned n_top, const MeshDesc* __restrict__ meshes) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_top || (i == 1u)) return;          // tmp slot 1 is unused (mirrors the reference's node 1)
+    if (i >= n_top) return;
     const TopNode t = top[i];
+    const MeshDesc md = meshes[tout[i].mesh];
     VdBvhNode n;
+    if (t.kind == 3u) {                            // tmp slot 2m + 1 mirrors the reference's never-used node 1: all-zero (blas.rs:52,90)
+        memset(&n, 0, sizeof(n));
+        md.out[1] = n;
+        return;
+    }
     for (int q = 0; q < 3; ++q) { n.min[q] = t.mn[q]; n.max[q] = t.mx[q]; }
-    if (t.kind == 0u) { n.left_first = t.start; n.count = t.count; }
+    if (t.kind == 0u) { n.left_first = t.start - md.base; n.count = t.count; }      // leaf: position in the MESH's index buffer
     else { n.left_first = tout[i].pair; n.count = 0u; }
-    out[tout[i].final_index] = n;
+    md.out[tout[i].final_index] = n;
 }
 
 __global__ __launch_bounds__(256) void c_sub_kernel(const SmallRoot* roots, const unsigned* sub_interior, const unsigned* root_pair,
                                                     unsigned n_roots, const TmpNode* subnodes, const unsigned short* submap,
-                                                    VdBvhNode* out) {
+                                                    const TopOut* tout, const MeshDesc* __restrict__ meshes) {
     const unsigned r = blockIdx.x;
     if (r >= n_roots) return;
+    const MeshDesc md = meshes[tout[roots[r].top_node].mesh];
     const TmpNode* src = subnodes + 2u * (size_t)roots[r].start;
     const unsigned short* nmap = submap + 2u * (size_t)roots[r].start;
     const unsigned n_nodes = 2u * sub_interior[r], off = root_pair[r];
@@ -2013,14 +2050,14 @@ __global__ __launch_bounds__(256) void c_sub_kernel(const SmallRoot* roots, cons
         VdBvhNode n;
         for (int q = 0; q < 3; ++q) { n.min[q] = t.mn[q]; n.max[q] = t.mx[q]; }
         n.count = t.count;
-        n.left_first = t.count == 0u ? t.left_first + off : t.left_first;   // interior: local pair -> final pair
-        out[off + nmap[j]] = n;
+        n.left_first = t.count == 0u ? t.left_first + off : t.left_first - md.base;   // interior: local pair -> final pair; leaf: batch position -> mesh position
+        md.out[off + nmap[j]] = n;
     }
 }
 
 __global__ void c_ids_big_leaves_kernel(const TopNode* top, unsigned n_top, const unsigned* ids32, ArrSet set0, ArrSet set1, unsigned* final_ids) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_top || i == 1u) return;
+    if (i >= n_top) return;
     const TopNode t = top[i];
     if (t.kind != 0u) return;
     const f32x4* cent = (t.pad & 1u) ? set1.cent : set0.cent;
@@ -2030,35 +2067,59 @@ __global__ void c_ids_big_leaves_kernel(const TopNode* top, unsigned n_top, cons
     }
 }
 
-__global__ void c_permute_kernel(const unsigned* __restrict__ final_ids, const unsigned* __restrict__ idx_in,
-                                 unsigned* __restrict__ idx_out, unsigned n_tri) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_tri) return;
-    const unsigned t = final_ids[i];                                      // blas.rs:95-100
-    idx_out[3u * (size_t)i] = idx_in[3u * (size_t)t];
-    idx_out[3u * (size_t)i + 1] = idx_in[3u * (size_t)t + 1];
-    idx_out[3u * (size_t)i + 2] = idx_in[3u * (size_t)t + 2];
+// blas.rs:95-100 per mesh: indices[i] = old_indices[tri_ids[i]]; ids and the copy are batch-wide, the result is the mesh's own buffer
+__global__ __launch_bounds__(256) void c_permute_kernel(const unsigned* __restrict__ final_ids, const unsigned* __restrict__ idx_in,
+                                                        const MeshDesc* __restrict__ meshes, unsigned n_meshes) {
+    __shared__ unsigned s_m;
+    if (threadIdx.x == 0) s_m = mesh_of_chunk(meshes, n_meshes, blockIdx.x);
+    __syncthreads();
+    const MeshDesc md = meshes[s_m];
+    const unsigned chunk = blockIdx.x - md.chunk0;
+#pragma unroll 2
+    for (int r = 0; r < kPreTris; ++r) {
+        const unsigned i = (chunk * (unsigned)kPreTris + (unsigned)r) * 256u + threadIdx.x;
+        if (i >= md.n_tri) break;
+        const unsigned t = final_ids[md.base + i];
+        md.idx_out[3u * (size_t)i] = idx_in[3u * (size_t)t];
+        md.idx_out[3u * (size_t)i + 1] = idx_in[3u * (size_t)t + 1];
+        md.idx_out[3u * (size_t)i + 2] = idx_in[3u * (size_t)t + 2];
+    }
 }
 
-__global__ void c_root_kernel(TopNode* top, const int* root_keys, unsigned n_tri, SmallRoot* small, LevelCtl* ctl, Seg* segs, MidRoot* mid) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one thread per mesh: its root (tmp node 2m; 2m + 1 is the reference's unused slot) and the tier that takes it
+__global__ void c_root_kernel(TopNode* top, const int* root_keys, const MeshDesc* __restrict__ meshes, unsigned n_meshes, SmallRoot* small,
+                              LevelCtl* ctl, Seg* segs, MidRoot* mid) {
+    const unsigned m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_meshes) return;
+    if (m == 0u) ctl->n_top = 2u * n_meshes;      // the level loop appends child pairs behind the roots
+    const int* rk = root_keys + 16u * m;
+    const unsigned n_tri = meshes[m].n_tri, base = meshes[m].base;
     TopNode t;
-    for (int q = 0; q < 3; ++q) { t.mn[q] = box_lo(root_keys[q]); t.mx[q] = box_hi(root_keys[3 + q]); }
-    t.start = 0; t.count = n_tri; t.left = 0; t.small = 0; t.pad = 0;
-    ctl->n_top = 2; ctl->n_small = 0; ctl->n_seg = 0; ctl->n_seg_next = 0; ctl->n_items = 0; ctl->n_mid = 0;
+    for (int q = 0; q < 3; ++q) { t.mn[q] = box_lo(rk[q]); t.mx[q] = box_hi(rk[3 + q]); }
+    t.start = base; t.count = n_tri; t.left = 0; t.small = 0; t.pad = 0;
     if (n_tri <= 3u) t.kind = 0u;
-    else if (n_tri <= (unsigned)kSmallMax) { t.kind = 2u; small[0] = SmallRoot{0u, n_tri, 0u, 0u}; ctl->n_small = 1; }
-    else if (n_tri <= (unsigned)kMidMax) {
-        t.kind = 1u; ctl->n_mid = 1;
-        mid[0].start = 0; mid[0].count = n_tri; mid[0].node = 0; mid[0].pad = 0;
-        for (int q = 0; q < 6; ++q) mid[0].cbk[q] = root_keys[6 + q];
+    else if (n_tri <= (unsigned)kSmallMax) {
+        t.kind = 2u;
+        const unsigned si = atomicAdd(&ctl->n_small, 1u);
+        small[si] = SmallRoot{base, n_tri, 2u * m, 0u};
+        t.small = si;
+    } else if (n_tri <= (unsigned)kMidMax) {
+        t.kind = 1u;
+        MidRoot& r = mid[atomicAdd(&ctl->n_mid, 1u)];
+        r.start = base; r.count = n_tri; r.node = 2u * m; r.pad = 0;
+        for (int q = 0; q < 6; ++q) r.cbk[q] = rk[6 + q];
     } else {
-        t.kind = 1u; segs[0].start = 0; segs[0].count = n_tri; segs[0].node = 0; ctl->n_seg = 1; ctl->max_count = n_tri; ctl->active = n_tri;
-        for (int q = 0; q < 6; ++q) segs[0].cbk[q] = root_keys[6 + q];
+        t.kind = 1u;
+        Seg& sg = segs[atomicAdd(&ctl->n_seg, 1u)];
+        sg.start = base; sg.count = n_tri; sg.node = 2u * m;
+        for (int q = 0; q < 6; ++q) sg.cbk[q] = rk[6 + q];
+        atomicMax(&ctl->max_count, n_tri);
+        atomicAdd(&ctl->active, n_tri);
     }
-    top[0] = t;
+    top[2u * m] = t;
     TopNode z; memset(&z, 0, sizeof(z));
-    top[1] = z;
+    z.kind = 3u;
+    top[2u * m + 1u] = z;
 }
 
 __global__ void a_level_swap_kernel(LevelCtl* ctl) {
@@ -2079,14 +2140,25 @@ struct Arena {
     }
 };
 
-int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32_t* d_idx, uint32_t n_tri,
-                       VdBvhNode* d_out, uint32_t node_cap, uint32_t* out_n_nodes) {
-    const size_t T = n_tri;
+// One mesh of a build, host side.  d_out == nullptr: packed - the mesh's nodes follow the previous mesh's in the batch's
+// shared node buffer (MeshPool's `bvh_index = bvh_nodes.len()` bookkeeping, mesh/mod.rs:320-345).
+struct BuildMesh {
+    const float* d_verts; uint32_t n_vert; uint32_t* d_idx; uint32_t n_tri; VdBvhNode* d_out; uint32_t node_cap;
+    uint32_t out_n_nodes, out_first;
+};
+
+int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_packed, uint64_t packed_cap, uint32_t packed_first,
+                         uint32_t* out_failed_mesh) {
+    size_t T = 0;
+    unsigned n_chunks = 0;
+    for (uint32_t m = 0; m < K; ++m) { T += hm[m].n_tri; n_chunks += (hm[m].n_tri + kChunk - 1u) / kChunk; }
+    if (T > 0x3fffffffu) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_bvh_build: more than 2^30 - 1 triangles in one build");
+    const uint32_t n_tri = (uint32_t)T;
     const unsigned seg_cap = (unsigned)(T / kSmallMax + 2);
     const unsigned mid_cap = seg_cap;
     const unsigned item_cap = (unsigned)(T / kItem + seg_cap + 2);
     const unsigned small_cap = (unsigned)(T / 4 + 2);
-    const unsigned top_cap = (unsigned)(2 * (size_t)small_cap + 4 * (size_t)seg_cap + 64);
+    const unsigned top_cap = (unsigned)(2 * (size_t)small_cap + 4 * (size_t)seg_cap + 2 * (size_t)K + 64);
     const bool wide_pay = T > kPay4Max || ctx->option(VD_OPT_BLAS_WIDE_PAYLOAD, 0) != 0;
     // ---- scratch layout ----
     Arena probe{nullptr, 0};
@@ -2094,7 +2166,8 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         struct P { u32x2 *pay0, *pay1; f32x4 *cent, *cent1; TriBox *boxes, *boxes1; unsigned *bits21, *ids32;
                    unsigned *falsepos, *truepos, *final_ids, *stack, *idx_copy;
                    unsigned char* is_u; Seg *seg0, *seg1; MidRoot* mid; unsigned *item_seg, *item_cnt, *item_cnt1, *item_pre; TopNode* top; SmallRoot* small;
-                   unsigned* sub_interior; TmpNode* subnodes; unsigned short* submap; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair; } p;
+                   unsigned* sub_interior; TmpNode* subnodes; unsigned short* submap; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair;
+                   MeshDesc* meshes; unsigned* bad_mesh; } p;
         // payload ping-pong: 4 bytes per triangle up to 2^25 triangles, 8 beyond (allocated for the width in use)
         const size_t pay_words = wide_pay ? T : (T + 1) / 2;
         p.pay0 = a.take<u32x2>(pay_words); p.pay1 = a.take<u32x2>(pay_words);
@@ -2106,8 +2179,9 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         p.seg0 = a.take<Seg>(seg_cap); p.seg1 = a.take<Seg>(seg_cap); p.mid = a.take<MidRoot>(mid_cap);
         p.item_seg = a.take<unsigned>(item_cap); p.item_cnt = a.take<unsigned>(item_cap); p.item_cnt1 = a.take<unsigned>(item_cap); p.item_pre = a.take<unsigned>(item_cap + 1);
         p.top = a.take<TopNode>(top_cap); p.small = a.take<SmallRoot>(small_cap); p.sub_interior = a.take<unsigned>(small_cap);
-        p.subnodes = a.take<TmpNode>(2 * T + 2); p.submap = a.take<unsigned short>(2 * T + 2); p.ctl = a.take<LevelCtl>(1); p.root_keys = a.take<int>(16);
+        p.subnodes = a.take<TmpNode>(2 * T + 2); p.submap = a.take<unsigned short>(2 * T + 2); p.ctl = a.take<LevelCtl>(1); p.root_keys = a.take<int>(16 * (size_t)K);
         p.tout = a.take<TopOut>(top_cap); p.root_pair = a.take<unsigned>(small_cap);
+        p.meshes = a.take<MeshDesc>(K); p.bad_mesh = a.take<unsigned>(1);
         return p;
     };
     (void)layout(probe, false);
@@ -2126,25 +2200,44 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     };
 
     vd_time_begin(ctx);
+    // pinned staging, first use: [MeshDesc K][root keys 16 K] (phase C lays it out again for its own tables)
+    const size_t off_keys = sizeof(MeshDesc) * (size_t)K;
     {
-        int h_keys[16] = {kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1, kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1, 0, 0, 0, 0};
-        VD_HIP_CHECK(ctx, hipMemcpyAsync(P.root_keys, h_keys, sizeof(h_keys), hipMemcpyHostToDevice, st));
-        VD_HIP_CHECK(ctx, hipMemsetAsync(P.ctl, 0, sizeof(LevelCtl), st));
-        VD_HIP_CHECK(ctx, hipMemsetAsync(P.is_u, 0, T, st));
-        VD_HIP_CHECK(ctx, hipMemcpyAsync(P.idx_copy, d_idx, 3 * T * 4, hipMemcpyDeviceToDevice, st));
+        int rc_s = vd_ensure_host(ctx, off_keys + 64 * (size_t)K + 64);
+        if (rc_s) return rc_s;
     }
-    const unsigned tri_blocks = (unsigned)((T + 255) / 256);
-    hipLaunchKernelGGL(blas_precompute_kernel, dim3((unsigned)((T + 256 * kPreTris - 1) / (256 * kPreTris))), dim3(256), 0, st, d_verts, P.idx_copy, n_tri, n_vert,
-                       P.cent, P.boxes, P.root_keys, &P.ctl->err);
+    MeshDesc* h_desc = reinterpret_cast<MeshDesc*>(ctx->host_stage);
+    {
+        int* h_keys = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->host_stage) + off_keys);
+        unsigned base = 0, chunk0 = 0;
+        for (uint32_t m = 0; m < K; ++m) {
+            h_desc[m] = MeshDesc{hm[m].d_verts, hm[m].d_idx, hm[m].d_idx, hm[m].d_out, hm[m].n_vert, hm[m].n_tri, base, chunk0};
+            base += hm[m].n_tri; chunk0 += (hm[m].n_tri + kChunk - 1u) / kChunk;
+            static const int init[16] = {kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1, kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1, 0, 0, 0, 0};
+            memcpy(h_keys + 16 * (size_t)m, init, sizeof(init));
+        }
+        VD_HIP_CHECK(ctx, hipMemcpyAsync(P.meshes, h_desc, sizeof(MeshDesc) * (size_t)K, hipMemcpyHostToDevice, st));
+        VD_HIP_CHECK(ctx, hipMemcpyAsync(P.root_keys, h_keys, 64 * (size_t)K, hipMemcpyHostToDevice, st));
+        VD_HIP_CHECK(ctx, hipMemsetAsync(P.ctl, 0, sizeof(LevelCtl), st));
+        VD_HIP_CHECK(ctx, hipMemsetAsync(P.bad_mesh, 0xff, 4, st));
+        VD_HIP_CHECK(ctx, hipMemsetAsync(P.is_u, 0, T, st));
+    }
+    hipLaunchKernelGGL(blas_precompute_kernel, dim3(n_chunks), dim3(256), 0, st, P.meshes, K, P.idx_copy, P.cent, P.boxes, P.root_keys, &P.ctl->err, P.bad_mesh);
     const ArrSet sets[2] = {ArrSet{P.cent, P.boxes}, ArrSet{P.cent1, P.boxes1}};
-    hipLaunchKernelGGL(c_root_kernel, dim3(1), dim3(64), 0, st, P.top, P.root_keys, n_tri, P.small, P.ctl, P.seg0, P.mid);
+    hipLaunchKernelGGL(c_root_kernel, dim3((K + 63u) / 64u), dim3(64), 0, st, P.top, P.root_keys, P.meshes, K, P.small, P.ctl, P.seg0, P.mid);
 
     // ---- phase A: level loop ----
     Seg* seg_cur = P.seg0; Seg* seg_next = P.seg1;
     LevelCtl h_ctl;
+    unsigned h_bad = kNone;
     VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, P.bad_mesh, 4, hipMemcpyDeviceToHost, st));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    if (h_ctl.err & ERR_BAD_INDEX) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_bvh_build: index >= n_vert");
+    if (h_ctl.err & ERR_BAD_INDEX) {
+        if (out_failed_mesh) *out_failed_mesh = h_bad;
+        snprintf(ctx->err, sizeof(ctx->err), "vd_bvh_build: index >= n_vert (mesh %u of the build)", h_bad);
+        return VD_ERR_INVALID_ARG;
+    }
     unsigned n_seg = h_ctl.n_seg;
     int levels = 0;
     stats.kernel_launches = 2;
@@ -2269,7 +2362,8 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     // [TopNode n_top][TopOut n_top][order n_top][sub n_small][root_pair n_small]
     const size_t off_out = sizeof(TopNode) * (size_t)n_top, off_ord = off_out + sizeof(TopOut) * (size_t)n_top;
     const size_t off_sub = off_ord + 4 * (size_t)n_top, off_rp = off_sub + 4 * (size_t)(n_small ? n_small : 1);
-    int rc_h = vd_ensure_host(ctx, off_rp + 4 * (size_t)(n_small ? n_small : 1));
+    const size_t off_desc = (off_rp + 4 * (size_t)(n_small ? n_small : 1) + 15) & ~(size_t)15;
+    int rc_h = vd_ensure_host(ctx, off_desc + sizeof(MeshDesc) * (size_t)K);
     if (rc_h) return rc_h;
     if (!ctx->aux_stream) VD_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     char* hs = reinterpret_cast<char*>(ctx->host_stage);
@@ -2278,22 +2372,30 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
     unsigned* h_ord = reinterpret_cast<unsigned*>(hs + off_ord);
     unsigned* h_sub = reinterpret_cast<unsigned*>(hs + off_sub);
     unsigned* h_root_pair = reinterpret_cast<unsigned*>(hs + off_rp);
+    h_desc = reinterpret_cast<MeshDesc*>(hs + off_desc);          // the staging may have moved: written again below
     VD_HIP_CHECK(ctx, hipMemcpyAsync(h_top, P.top, sizeof(TopNode) * n_top, hipMemcpyDeviceToHost, ctx->aux_stream));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->aux_stream));
+    // pre-order walk of every mesh's tree, one after the other: an interior node takes the next pair when visited
+    // (blas.rs:110-112); h_ord records the visits, mesh boundaries in ord_end
+    std::vector<unsigned> ord_end(K);
     unsigned n_ord = 0;
     {
-        // pre-order walk: an interior node takes the next pair when visited (blas.rs:110-112)
         std::vector<unsigned> stk;
-        stk.push_back(0);
-        while (!stk.empty()) {
-            const unsigned v = stk.back(); stk.pop_back();
-            const TopNode& t = h_top[v];
-            if (t.kind == 0u) continue;
-            h_ord[n_ord++] = v;
-            if (t.kind == 1u) {
-                stk.push_back(t.left + 1);
-                stk.push_back(t.left);
+        for (uint32_t m = 0; m < K; ++m) {
+            stk.push_back(2u * m);
+            while (!stk.empty()) {
+                const unsigned v = stk.back(); stk.pop_back();
+                const TopNode& t = h_top[v];
+                h_out[v].mesh = m;
+                if (t.kind == 0u) continue;
+                h_ord[n_ord++] = v;
+                if (t.kind == 1u) {
+                    stk.push_back(t.left + 1);
+                    stk.push_back(t.left);
+                }
             }
+            h_out[2u * m + 1u].mesh = m; h_out[2u * m + 1u].final_index = 1u; h_out[2u * m + 1u].pair = 0u;
+            ord_end[m] = n_ord;
         }
     }
     if (n_small) VD_HIP_CHECK(ctx, hipMemcpyAsync(h_sub, P.sub_interior, 4 * (size_t)n_small, hipMemcpyDeviceToHost, st));
@@ -2303,36 +2405,61 @@ int bvh_build_dev_impl(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32
         VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
     if (h_ctl.err & ERR_INTERNAL) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: phase B work list stalled");
     lap(stats.ms_phase_b);
-    unsigned pool = 2;
-    h_out[0].final_index = 0;
-    for (unsigned k = 0; k < n_ord; ++k) {
-        const unsigned v = h_ord[k];
-        const TopNode& t = h_top[v];
-        const unsigned pair = pool;
-        h_out[v].pair = pair;
-        if (t.kind == 2u) {
-            h_root_pair[t.small] = pair;
-            pool += 2u * h_sub[t.small];
-        } else {
-            pool += 2;
-            h_out[t.left].final_index = pair;
-            h_out[t.left + 1].final_index = pair + 1;
+    uint64_t packed_at = packed_first;
+    {
+        unsigned k = 0, base = 0, chunk0 = 0;
+        for (uint32_t m = 0; m < K; ++m) {
+            unsigned pool = 2;
+            h_out[2u * m].final_index = 0;
+            for (; k < ord_end[m]; ++k) {
+                const unsigned v = h_ord[k];
+                const TopNode& t = h_top[v];
+                const unsigned pair = pool;
+                h_out[v].pair = pair;
+                if (t.kind == 2u) {
+                    h_root_pair[t.small] = pair;
+                    pool += 2u * h_sub[t.small];
+                } else {
+                    pool += 2;
+                    h_out[t.left].final_index = pair;
+                    h_out[t.left + 1].final_index = pair + 1;
+                }
+            }
+            VdBvhNode* out = hm[m].d_out;
+            hm[m].out_n_nodes = pool; hm[m].out_first = 0;
+            if (out) {
+                if (pool > hm[m].node_cap) {
+                    if (out_failed_mesh) *out_failed_mesh = m;
+                    snprintf(ctx->err, sizeof(ctx->err), "vd_bvh_build: node_cap too small (mesh %u of the build needs %u nodes)", m, pool);
+                    return VD_ERR_INVALID_ARG;
+                }
+            } else {
+                if (packed_at + pool > packed_cap) {
+                    if (out_failed_mesh) *out_failed_mesh = m;
+                    snprintf(ctx->err, sizeof(ctx->err), "vd_bvh_build_batch: the packed node buffer is full at mesh %u", m);
+                    return VD_ERR_INVALID_ARG;
+                }
+                out = d_packed + packed_at;
+                hm[m].out_first = (uint32_t)packed_at;
+                packed_at += pool;
+            }
+            h_desc[m] = MeshDesc{hm[m].d_verts, hm[m].d_idx, hm[m].d_idx, out, hm[m].n_vert, hm[m].n_tri, base, chunk0};
+            base += hm[m].n_tri; chunk0 += (hm[m].n_tri + kChunk - 1u) / kChunk;
         }
     }
-    if (pool > node_cap) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_bvh_build: node_cap too small");
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(P.meshes, h_desc, sizeof(MeshDesc) * (size_t)K, hipMemcpyHostToDevice, st));      // now with every mesh's node array
     VD_HIP_CHECK(ctx, hipMemcpyAsync(P.tout, h_out, sizeof(TopOut) * n_top, hipMemcpyHostToDevice, st));
     if (n_small) VD_HIP_CHECK(ctx, hipMemcpyAsync(P.root_pair, h_root_pair, 4 * (size_t)n_small, hipMemcpyHostToDevice, st));
-    VD_HIP_CHECK(ctx, hipMemsetAsync(d_out, 0, sizeof(VdBvhNode) * 2, st));   // node 1 stays all-zero (blas.rs:52,90)
-    hipLaunchKernelGGL(c_top_kernel, dim3((n_top + 63) / 64), dim3(64), 0, st, P.top, P.tout, n_top, d_out);
-    if (n_small) hipLaunchKernelGGL(c_sub_kernel, dim3(n_small), dim3(256), 0, st, P.small, P.sub_interior, P.root_pair, n_small, P.subnodes, P.submap, d_out);
+    hipLaunchKernelGGL(c_top_kernel, dim3((n_top + 63) / 64), dim3(64), 0, st, P.top, P.tout, n_top, P.meshes);
+    if (n_small) hipLaunchKernelGGL(c_sub_kernel, dim3(n_small), dim3(256), 0, st, P.small, P.sub_interior, P.root_pair, n_small, P.subnodes, P.submap, P.tout, P.meshes);
     hipLaunchKernelGGL(c_ids_big_leaves_kernel, dim3((n_top + 63) / 64), dim3(64), 0, st, P.top, n_top, P.ids32, sets[0], sets[1], P.final_ids);
-    hipLaunchKernelGGL(c_permute_kernel, dim3(tri_blocks), dim3(256), 0, st, P.final_ids, P.idx_copy, d_idx, n_tri);
+    hipLaunchKernelGGL(c_permute_kernel, dim3(n_chunks), dim3(256), 0, st, P.final_ids, P.idx_copy, P.meshes, K);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     VD_HIP_CHECK(ctx, hipStreamSynchronize(st));   // the pinned staging is reused by the next build
     stats.kernel_launches += (n_small ? 2 : 0) + 3;
     lap(stats.ms_phase_c);
-    *out_n_nodes = pool;
+    (void)n_tri;
     return VD_OK;
 }
 
@@ -2370,7 +2497,12 @@ int vd_bvh_build_dev(VdCtx* ctx, const float* d_verts, uint32_t n_vert, uint32_t
                      uint32_t node_cap, uint32_t* out_n_nodes) {
     VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_build_args(ctx, d_verts, n_vert, d_idx, n_tri, d_out, node_cap, out_n_nodes);
-    return rc ? rc : bvh_build_dev_impl(ctx, d_verts, n_vert, d_idx, n_tri, d_out, node_cap, out_n_nodes);
+    if (rc) return rc;
+    BuildMesh one{d_verts, n_vert, d_idx, n_tri, d_out, node_cap, 0u, 0u};
+    rc = bvh_build_batch_impl(ctx, &one, 1u, nullptr, 0, 0u, nullptr);
+    if (rc) return rc;
+    *out_n_nodes = one.out_n_nodes;
+    return VD_OK;
 }
 
 int vd_bvh_build(VdCtx* ctx, const float* verts, uint32_t n_vert, uint32_t* idx, uint32_t n_tri, VdBvhNode* out,
@@ -2389,13 +2521,117 @@ int vd_bvh_build(VdCtx* ctx, const float* verts, uint32_t n_vert, uint32_t* idx,
     if (rc) return rc;
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->stage_in, verts, vb, hipMemcpyHostToDevice, ctx->stream));
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->stage_aux, idx, ib, hipMemcpyHostToDevice, ctx->stream));
-    rc = bvh_build_dev_impl(ctx, reinterpret_cast<const float*>(ctx->stage_in), n_vert, reinterpret_cast<uint32_t*>(ctx->stage_aux),
-                            n_tri, reinterpret_cast<VdBvhNode*>(ctx->stage_out), node_cap, out_n_nodes);
+    BuildMesh one{reinterpret_cast<const float*>(ctx->stage_in), n_vert, reinterpret_cast<uint32_t*>(ctx->stage_aux), n_tri,
+                  reinterpret_cast<VdBvhNode*>(ctx->stage_out), node_cap, 0u, 0u};
+    rc = bvh_build_batch_impl(ctx, &one, 1u, nullptr, 0, 0u, nullptr);
     if (rc) return rc;
+    *out_n_nodes = one.out_n_nodes;
     VD_HIP_CHECK(ctx, hipMemcpyAsync(idx, ctx->stage_aux, ib, hipMemcpyDeviceToHost, ctx->stream));
     VD_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->stage_out, sizeof(VdBvhNode) * (size_t)*out_n_nodes, hipMemcpyDeviceToHost, ctx->stream));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return VD_OK;
+}
+
+// K meshes in ONE build (header: "Batched BLAS build").
+static int batch_args(VdCtx* ctx, const VdBvhBatchItem* items, uint32_t n_items, const VdBvhNode* packed, uint64_t packed_cap, uint32_t packed_first,
+                      std::vector<BuildMesh>& hm) {
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!items || n_items == 0) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_bvh_build_batch: no items");
+    if (n_items > (1u << 24)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_bvh_build_batch: more than 2^24 meshes");
+    hm.resize(n_items);
+    uint64_t total = 0;
+    for (uint32_t m = 0; m < n_items; ++m) {
+        const VdBvhBatchItem& it = items[m];
+        if (!it.verts_xyz || !it.indices_inout || it.n_tri == 0 || it.n_vert == 0) {
+            snprintf(ctx->err, sizeof(ctx->err), "vd_bvh_build_batch: item %u: null pointer or zero count", m);
+            return VD_ERR_INVALID_ARG;
+        }
+        if (it.out_nodes ? it.node_cap < 2u : (!packed || packed_first > packed_cap)) {
+            snprintf(ctx->err, sizeof(ctx->err), "vd_bvh_build_batch: item %u: no room for its nodes (out_nodes with node_cap >= 2, or a packed buffer)", m);
+            return VD_ERR_INVALID_ARG;
+        }
+        total += it.n_tri;
+        hm[m] = BuildMesh{it.verts_xyz, it.n_vert, it.indices_inout, it.n_tri, it.out_nodes, it.node_cap, 0u, 0u};
+    }
+    if (total > 0x3fffffffu) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_bvh_build_batch: more than 2^30 - 1 triangles in one build");
+    return VD_OK;
+}
+
+int vd_bvh_build_batch_dev(VdCtx* ctx, VdBvhBatchItem* items, uint32_t n_items, VdBvhNode* d_packed_nodes, uint64_t packed_cap,
+                           uint32_t packed_first, uint32_t* out_packed_end) {
+    VdDeviceGuard vd_guard_(ctx);
+    std::vector<BuildMesh> hm;
+    int rc = batch_args(ctx, items, n_items, d_packed_nodes, packed_cap, packed_first, hm);
+    if (rc) return rc;
+    uint32_t failed = 0xffffffffu;
+    rc = bvh_build_batch_impl(ctx, hm.data(), n_items, d_packed_nodes, packed_cap, packed_first, &failed);
+    uint32_t end = packed_first;
+    for (uint32_t m = 0; m < n_items; ++m) {
+        items[m].out_n_nodes = rc ? 0u : hm[m].out_n_nodes;
+        items[m].out_first_node = rc ? 0u : hm[m].out_first;
+        items[m].status = rc ? (failed == 0xffffffffu || failed == m ? rc : VD_OK) : VD_OK;
+        if (!rc && !items[m].out_nodes) end = hm[m].out_first + hm[m].out_n_nodes;
+    }
+    if (out_packed_end) *out_packed_end = end;
+    return rc;
+}
+
+int vd_bvh_build_batch(VdCtx* ctx, VdBvhBatchItem* items, uint32_t n_items, VdBvhNode* packed_nodes, uint64_t packed_cap,
+                       uint32_t packed_first, uint32_t* out_packed_end) {
+    VdDeviceGuard vd_guard_(ctx);
+    std::vector<BuildMesh> hm;
+    int rc = batch_args(ctx, items, n_items, packed_nodes, packed_cap, packed_first, hm);
+    if (rc) return rc;
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // staging: [vertices of all meshes][indices of all meshes] in, [nodes: 2 * n_tri per mesh, the reference's own bound] out
+    size_t vb = 0, ib = 0, nb = 0;
+    for (uint32_t m = 0; m < n_items; ++m) {
+        vb += ((size_t)items[m].n_vert * 12 + 255) & ~(size_t)255;
+        ib += ((size_t)items[m].n_tri * 12 + 255) & ~(size_t)255;
+        nb += sizeof(VdBvhNode) * (2 * (size_t)items[m].n_tri + 2);
+    }
+    rc = vd_ensure(ctx, &ctx->stage_in, &ctx->stage_in_bytes, vb + 256);
+    if (rc) return rc;
+    rc = vd_ensure(ctx, &ctx->stage_aux, &ctx->stage_aux_bytes, ib + 256);
+    if (rc) return rc;
+    rc = vd_ensure(ctx, &ctx->stage_out, &ctx->stage_out_bytes, nb + 256);
+    if (rc) return rc;
+    char* dv = reinterpret_cast<char*>(ctx->stage_in); char* di = reinterpret_cast<char*>(ctx->stage_aux);
+    VdBvhNode* dn = reinterpret_cast<VdBvhNode*>(ctx->stage_out);
+    for (uint32_t m = 0; m < n_items; ++m) {
+        VD_HIP_CHECK(ctx, hipMemcpyAsync(dv, items[m].verts_xyz, (size_t)items[m].n_vert * 12, hipMemcpyHostToDevice, ctx->stream));
+        VD_HIP_CHECK(ctx, hipMemcpyAsync(di, items[m].indices_inout, (size_t)items[m].n_tri * 12, hipMemcpyHostToDevice, ctx->stream));
+        hm[m].d_verts = reinterpret_cast<const float*>(dv); hm[m].d_idx = reinterpret_cast<uint32_t*>(di);
+        hm[m].d_out = dn; hm[m].node_cap = 2u * items[m].n_tri + 2u;
+        dv += ((size_t)items[m].n_vert * 12 + 255) & ~(size_t)255;
+        di += ((size_t)items[m].n_tri * 12 + 255) & ~(size_t)255;
+        dn += 2 * (size_t)items[m].n_tri + 2;
+    }
+    uint32_t failed = 0xffffffffu;
+    rc = bvh_build_batch_impl(ctx, hm.data(), n_items, nullptr, 0, 0u, &failed);
+    uint64_t at = packed_first;
+    for (uint32_t m = 0; m < n_items && !rc; ++m) {        // room on the caller's side
+        const uint32_t need = hm[m].out_n_nodes;
+        if (items[m].out_nodes ? need > items[m].node_cap : at + need > packed_cap) {
+            snprintf(ctx->err, sizeof(ctx->err), "vd_bvh_build_batch: item %u needs %u nodes: node_cap / packed_cap too small", m, need);
+            rc = VD_ERR_INVALID_ARG; failed = m;
+        }
+        if (!items[m].out_nodes) at += need;
+    }
+    at = packed_first;
+    for (uint32_t m = 0; m < n_items; ++m) {
+        items[m].status = rc ? (failed == 0xffffffffu || failed == m ? rc : VD_OK) : VD_OK;
+        items[m].out_n_nodes = rc ? 0u : hm[m].out_n_nodes;
+        items[m].out_first_node = 0u;
+        if (rc) continue;
+        VdBvhNode* dst = items[m].out_nodes;
+        if (!dst) { dst = packed_nodes + at; items[m].out_first_node = (uint32_t)at; at += hm[m].out_n_nodes; }
+        VD_HIP_CHECK(ctx, hipMemcpyAsync(items[m].indices_inout, hm[m].d_idx, (size_t)items[m].n_tri * 12, hipMemcpyDeviceToHost, ctx->stream));
+        VD_HIP_CHECK(ctx, hipMemcpyAsync(dst, hm[m].d_out, sizeof(VdBvhNode) * (size_t)hm[m].out_n_nodes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (out_packed_end) *out_packed_end = (uint32_t)at;
+    return rc;
 }
 
 }  // extern "C"

@@ -182,6 +182,37 @@ class Context:
                                             abi.ptr(d_nodes), node_cap, C.addressof(n_nodes)))
         return n_nodes.value
 
+    def bvh_build_batch(self, meshes, packed=True):
+        """K meshes in ONE build (vd_bvh_build_batch; MeshPool::add for a whole scene, mesh/mod.rs:309-351).
+        meshes: [(vertices (V,3) f32, indices (3T,) u32)].  packed: one shared node array, each mesh's nodes behind the
+        previous mesh's -> (nodes, [(first_node, n_nodes, permuted indices)]); else [(nodes, permuted indices)]."""
+        K = len(meshes)
+        items = (abi.BvhBatchItem * K)()
+        keep = []
+        for m, (v, i) in enumerate(meshes):
+            v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 3)
+            idx = np.array(i, dtype=np.uint32).reshape(-1).copy()
+            n_tri = len(idx) // 3
+            own = None if packed else np.zeros(max(2 * n_tri, 2), dtype=abi.BVH_NODE)
+            keep.append((v, idx, own))
+            items[m].verts_xyz, items[m].indices_inout = v.ctypes.data, idx.ctypes.data
+            items[m].out_nodes = None if packed else own.ctypes.data
+            items[m].n_vert, items[m].n_tri, items[m].node_cap = len(v), n_tri, 0 if packed else len(own)
+        cap = sum(max(2 * (len(k[1]) // 3), 2) for k in keep) if packed else 0
+        shared = np.zeros(max(cap, 1), dtype=abi.BVH_NODE)
+        end = C.c_uint32(0)
+        self._chk(self.lib.vd_bvh_build_batch(self.h, C.addressof(items), K, shared.ctypes.data if packed else None, cap, 0, C.addressof(end)))
+        if packed:
+            return shared[: end.value].copy(), [(int(items[m].out_first_node), int(items[m].out_n_nodes), keep[m][1]) for m in range(K)]
+        return [(keep[m][2][: items[m].out_n_nodes].copy(), keep[m][1]) for m in range(K)]
+
+    def bvh_build_batch_dev(self, items, n_items, d_packed=None, packed_cap=0, packed_first=0) -> int:
+        """items: (abi.BvhBatchItem * K) with device pointers; returns one past the last packed node."""
+        end = C.c_uint32(0)
+        self._chk(self.lib.vd_bvh_build_batch_dev(self.h, C.addressof(items), n_items, abi.ptr(d_packed) if d_packed is not None else None,
+                                                  packed_cap, packed_first, C.addressof(end)))
+        return end.value
+
     def bvh_last_build_stats(self) -> dict:
         st = abi.BvhBuildStats()
         self._chk(self.lib.vd_bvh_last_build_stats(self.h, C.byref(st)))
