@@ -837,6 +837,33 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
                                          "same_bytes_as_prepared": bool(indexed_bytes == (d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes()))},
                       "hit_fraction": round(float(hits["hit"].mean()), 3),
                       "occlusion_flags_equal_closest_hit": bool(np.array_equal(d_any.cpu().numpy().astype(np.uint32), hits["hit"]))}
+    # OPT-IN, not the reference's visit order (VD_OPT_TRACE_TIGHT_TLAS): the same scene prepared with a private top level over
+    # tight world boxes; acceptance = hit flags equal, distances within 1e-5 of the exact walk's (in practice the same bits)
+    ctx.set_option("trace.tight_tlas", 1)
+    t_prep = time.perf_counter()
+    acc_t = ctx.trace_prepare(ds)
+    t_prep = time.perf_counter() - t_prep
+    ctx.set_option("trace.tight_tlas", None)
+    d_hits_t = ctx.empty(len(rays) * 16)
+    d_any_t = torch.zeros(len(rays), dtype=torch.int32, device=dev)
+    ctx.set_timing(True)
+    t_clt, t_anyt = [], []
+    for _ in range(3):
+        ctx.trace_prepared_dev(acc_t, d_rays, len(rays), d_hits_t); t_clt.append(ctx.last_gpu_ms())
+        ctx.trace_any_prepared_dev(acc_t, d_rays, len(rays), d_any_t); t_anyt.append(ctx.last_gpu_ms())
+    ctx.set_timing(False)
+    ht = d_hits_t.cpu().numpy()[: len(rays) * 16].view(abi.HIT)
+    hm = hits["hit"] == 1
+    relerr = np.abs(ht["dist"][hm].astype(np.float64) - hits["dist"][hm]) / np.abs(hits["dist"][hm])
+    extra["trace"]["tight_tlas_option"] = {
+        "closest_hit_Mrays_per_s": round(len(rays) / min(t_clt) / 1e3, 1), "occlusion_Mrays_per_s": round(len(rays) / min(t_anyt) / 1e3, 1),
+        "prepare_ms": round(t_prep * 1e3, 2), "fallback_instances": acc_t.info()["tight_fallback_instances"],
+        "hit_flags_equal_exact_walk": bool(np.array_equal(ht["hit"], hits["hit"]) and np.array_equal(d_any_t.cpu().numpy().astype(np.uint32), hits["hit"])),
+        "max_rel_distance_error_vs_exact_walk": float(relerr.max()) if relerr.size else 0.0,
+        "distances_bit_equal": int((ht["dist"][hm].view(np.uint32) == hits["dist"][hm].view(np.uint32)).sum()), "hits": int(hm.sum()),
+        "note": "default off; the exact (reference visit order) numbers above are the parity path"}
+    acc_t.close()
+    del d_hits_t, d_any_t
     if not args.no_cpu_baseline:
         # vd_ref_trace on a bounded sample of the same rays: every 4th ray on all threads, every 64th on one thread
         threads = os.cpu_count() or 1

@@ -216,6 +216,18 @@ typedef enum VdOption {
                                      the walk: n_rays * 8 >= triangles <= 2 Mi, at most 65 535 meshes.  The 36 B per
                                      triangle live in the context's grow-only scratch (<= 72 MB, kept until
                                      vd_ctx_destroy); 2: up to 16 Mi triangles (576 MB); 0: never                */
+    VD_OPT_TRACE_TIGHT_TLAS = 28, /* 1: vd_trace_prepare_dev builds a PRIVATE top level for the prepared scene over tight
+                                     world boxes (the 8 transformed corners of each instance's BLAS root box, WITHOUT the
+                                     object-space seed of tlas.rs:39 that makes the reference's leaves overlap at the
+                                     origin; padded by 2e-5 of the largest coordinate) and starts rays at its true root.
+                                     Every BLAS and the walk inside an instance are unchanged, so hit flags are the
+                                     reference's and distances are within north_star's 1e-5 (bit-equal in practice; which
+                                     of two triangles at the SAME distance is reported may differ).  NOT the reference's
+                                     visit order: default 0, and off in every bit-exact parity run.  Needs
+                                     inv_transform = transform^-1 and finite boxes for EVERY instance (checked; one
+                                     that fails and the scene keeps its own top level - VdTraceAccelInfo says so) and
+                                     2 .. 32 768 instances (else ignored).  The private top level is a snapshot: after
+                                     instances move, prepare again.                                               */
     VD_OPT_COUNT_ = 32
 } VdOption;
 int         vd_ctx_set_option(VdCtx* ctx, int option /* VdOption */, int64_t value);
@@ -443,6 +455,16 @@ int vd_trace_dev(VdCtx* ctx, const VdTraceScene* d_scene /* struct on host, poin
 typedef struct VdTraceAccel VdTraceAccel;
 int vd_trace_prepare_dev(VdCtx* ctx, const VdTraceScene* d_scene, VdTraceAccel** out);
 int vd_trace_release(VdCtx* ctx, VdTraceAccel* accel);
+/* What a prepared scene holds: whether it walks a private top level (VD_OPT_TRACE_TIGHT_TLAS was set when it was
+ * prepared and every instance qualified), the nodes of the top level it walks (device pointer: the scene's own or
+ * the private one), how many instances did NOT qualify (inv_transform not the inverse of transform, or non-finite
+ * corners: any makes the option decline), and the bytes of de-indexed triangles it owns.                          */
+typedef struct VdTraceAccelInfo {
+    uint32_t tight_tlas, n_tlas_nodes, tight_fallback_instances, _pad;
+    uint64_t triangle_bytes;
+    const VdTlasNode* d_tlas_nodes;
+} VdTraceAccelInfo;
+int vd_trace_accel_info(const VdTraceAccel* accel, VdTraceAccelInfo* out);
 int vd_trace_prepared_dev(VdCtx* ctx, const VdTraceAccel* accel, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out);
 int vd_trace_any_prepared_dev(VdCtx* ctx, const VdTraceAccel* accel, const VdRay* d_rays, uint32_t n_rays,
                               uint32_t* d_out_hit);

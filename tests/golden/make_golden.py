@@ -219,7 +219,8 @@ def helmet_case():
     restatement's Python loops: this one fixture freezes the C oracle alone), the instance, its one-leaf TLAS and the
     oracle's hits for 160 x 160 primary rays from that camera.  No reference file is copied: geometry arrays only."""
     import zlib
-    from voidin_amd.gltf import GltfDocument
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from gltf_reader import GltfDocument
     src = "/root/reference/assets/glTF-Sample-Models/2.0/DamagedHelmet/glTF-Binary/DamagedHelmet.glb"
     if not os.path.exists(src):
         print("helmet_case: reference asset not present, fixture left as it is")

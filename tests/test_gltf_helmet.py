@@ -1,6 +1,6 @@
 """The reference's own mesh asset as a parity input (tests/golden/helmet.npz, made by tests/golden/make_golden.py from
 assets/glTF-Sample-Models/2.0/DamagedHelmet/glTF-Binary/DamagedHelmet.glb: the arrays GltfDocument::import hands to
-MeshPool::add) and the glTF reader that extracted it (voidin_amd/gltf.py)."""
+MeshPool::add) and the glTF reader that extracted it (tests/gltf_reader.py - test infrastructure: asset IO is out of the path's scope)."""
 import json
 import os
 import struct
@@ -11,7 +11,7 @@ import pytest
 
 from conftest import ROOT, fields_equal
 from voidin_amd import abi, synth
-from voidin_amd.gltf import GltfDocument
+from gltf_reader import GltfDocument
 
 GOLD = os.path.join(ROOT, "tests", "golden", "helmet.npz")
 

@@ -61,12 +61,12 @@ VD_DIST_ID_BYTES = 128
 # never by the library
 OPTIONS = {"cull.split_min": 1, "cull.variant": 2, "tlas.index": 10, "tlas.index_min": 11, "tlas.phase2": 12, "tlas.refresh": 13,
            "tlas.groups": 14, "tlas.spin_limit": 15, "tlas.spec": 16, "tlas.profile": 17,
-           "blas.wide_payload": 30, "trace.sort": 21, "trace.sort_min": 22, "trace.chunk": 23, "trace.yield": 24, "trace.waves": 25, "trace.auto_prepare": 27}
+           "blas.wide_payload": 30, "trace.sort": 21, "trace.sort_min": 22, "trace.chunk": 23, "trace.yield": 24, "trace.waves": 25, "trace.auto_prepare": 27, "trace.tight_tlas": 28}
 OPTION_ENV = {"VD_SPLIT_MIN": "cull.split_min", "VD_CULL_VARIANT": "cull.variant", "VD_TLAS_INDEX": "tlas.index",
               "VD_TLAS_INDEX_MIN": "tlas.index_min", "VD_TLAS_PHASE2": "tlas.phase2", "VD_TLAS_REFRESH": "tlas.refresh",
               "VD_TLAS_GROUPS": "tlas.groups", "VD_TLAS_SPIN_LIMIT": "tlas.spin_limit", "VD_TLAS_SPEC": "tlas.spec",
               "VD_TLAS_PROFILE": "tlas.profile", "VD_TRACE_SORT": "trace.sort",
-              "VD_TRACE_SORT_MIN": "trace.sort_min", "VD_TRACE_CHUNK": "trace.chunk", "VD_TRACE_YIELD": "trace.yield", "VD_TRACE_WAVES": "trace.waves", "VD_TRACE_AUTO_PREPARE": "trace.auto_prepare"}
+              "VD_TRACE_SORT_MIN": "trace.sort_min", "VD_TRACE_CHUNK": "trace.chunk", "VD_TRACE_YIELD": "trace.yield", "VD_TRACE_WAVES": "trace.waves", "VD_TRACE_AUTO_PREPARE": "trace.auto_prepare", "VD_TRACE_TIGHT_TLAS": "trace.tight_tlas"}
 
 STATUS_NAMES = {0: "VD_OK", -1: "VD_ERR_INVALID_ARG", -2: "VD_ERR_HIP", -3: "VD_ERR_DEGENERATE",
                 -4: "VD_ERR_TLAS_OVERFLOW", -5: "VD_ERR_NO_DEVICE", -6: "VD_ERR_STACK_OVERFLOW",
@@ -96,6 +96,12 @@ class DistInfo(C.Structure):
                 ("first_instance", C.c_uint32), ("n_local", C.c_uint32), ("mask_words_per_shard", C.c_uint32), ("id_bytes", C.c_uint32),
                 ("d_mask", C.c_void_p), ("d_mask_all", C.c_void_p), ("d_mesh_ids", C.c_void_p), ("rccl_version", C.c_int32),
                 ("_pad", C.c_int32), ("rccl_library", C.c_char * 128)]
+
+
+class TraceAccelInfo(C.Structure):
+    """VdTraceAccelInfo (include/voidin_abi.h)."""
+    _fields_ = [("tight_tlas", C.c_uint32), ("n_tlas_nodes", C.c_uint32), ("tight_fallback_instances", C.c_uint32), ("_pad", C.c_uint32),
+                ("triangle_bytes", C.c_uint64), ("d_tlas_nodes", C.c_void_p)]
 
 
 class BvhBatchItem(C.Structure):
@@ -155,6 +161,7 @@ PROTOTYPES = {
     "vd_trace_any_dev": (_I, [_P, C.POINTER(TraceScene), _P, _U, _P]),
     "vd_trace_prepare_dev": (_I, [_P, C.POINTER(TraceScene), C.POINTER(_P)]),
     "vd_trace_release": (_I, [_P, _P]),
+    "vd_trace_accel_info": (_I, [_P, _P]),
     "vd_trace_prepared_dev": (_I, [_P, _P, _P, _U, _P]),
     "vd_trace_any_prepared_dev": (_I, [_P, _P, _P, _U, _P]),
     "vd_shadow_rays_dev": (_I, [_P, _P, _P, _U, C.POINTER(C.c_float), _P]),

@@ -30,8 +30,17 @@ constexpr int kBuildThreads = 1024;
 struct Box { float mn[3], mx[3]; };
 
 // tlas.rs:35-44.  glam Mat4::transform_point3: ((X*p.x + Y*p.y) + Z*p.z) + W, no FMA.
+// n_mesh == 0 (internal, vd_tlas_build_from_boxes): `inst` is not an instance array but ready leaf boxes, six floats
+// {min xyz, max xyz} per leaf - the same builder then clusters boxes somebody else made (trace.hip's private top level).
 __device__ __forceinline__ Box leaf_box(const VdInstance* __restrict__ inst, const VdMeshInfo* __restrict__ meshes,
                                         unsigned n_mesh, unsigned i) {
+    if (n_mesh == 0u) {
+        const float* B = reinterpret_cast<const float*>(inst) + 6u * (size_t)i;
+        Box r;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r.mn[k] = B[k]; r.mx[k] = B[3 + k]; }
+        return r;
+    }
     const float4* t4 = reinterpret_cast<const float4*>(inst + i);
     const float4 X = t4[0], Y = t4[1], Z = t4[2], W = t4[3];
     const unsigned mesh_id = reinterpret_cast<const unsigned*>(inst + i)[32];
@@ -1344,6 +1353,12 @@ int tlas_host(VdCtx* ctx, const VdInstance* inst, uint32_t n, const VdMeshInfo* 
 }
 
 }  // namespace
+
+// internal (vd_common.hpp): the agglomerative build of tlas.rs:56-105 over leaf boxes given as six floats each
+int vd_tlas_build_from_boxes(VdCtx* ctx, const float* d_boxes, uint32_t n, VdTlasNode* d_nodes) {
+    if (!ctx || !d_boxes || !d_nodes || n == 0 || n > VD_TLAS_MAX_INSTANCES) return VD_ERR_INVALID_ARG;
+    return tlas_build_impl<VdTlasNode>(ctx, reinterpret_cast<const VdInstance*>(d_boxes), n, nullptr, 0u, d_nodes);
+}
 
 extern "C" {
 

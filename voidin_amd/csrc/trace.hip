@@ -14,7 +14,7 @@
 #include <new>
 
 // vd_trace_prepare_dev: per-scene data derived once from the six trace buffers
-struct VdTraceAccel { VdTraceScene scene; float* tris = nullptr; };
+struct VdTraceAccel { VdTraceScene scene; float* tris = nullptr; VdTlasNode* tight = nullptr; /* private top level (VD_OPT_TRACE_TIGHT_TLAS) */ unsigned tight_fallbacks = 0; };
 
 namespace {
 
@@ -130,6 +130,10 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
     uint2 cn = make_uint2(0u, 0u);         // payload of the current node
 #ifdef VD_TUNING
     unsigned dbg_outer = 0, dbg_iter = 0, dbg_lanes = 0, dbg_kind[3] = {0, 0, 0}, dbg_ray_steps = 0, dbg_ray_max = 0, dbg_drain = 0, dbg_lone = 0, dbg_few = 0;
+    // timeline (words 16..63 of the flag block): [16,17] = earliest wave start (100 MHz ticks), [18..40] = waves that ended in
+    // each 0.5 ms slot, [41..63] = stepping iterations done in each slot
+    if (lane == 0) atomicMin(reinterpret_cast<unsigned long long*>(overflow + 16), (unsigned long long)wall_clock64());
+    unsigned dbg_slot_iter = 0, dbg_slot = 0;
 #endif
 
     auto pop = [&]() {                     // leave the current node
@@ -232,6 +236,12 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             if (n_step == 0u || n_busy - n_step >= s.yield) break;
 #ifdef VD_TUNING
             ++dbg_iter; dbg_lanes += n_step; if (stepping) ++dbg_ray_steps; if (exhausted) ++dbg_drain;
+            if ((dbg_iter & 15u) == 0u) {       // every 16 iterations: which 0.5 ms slot are we in
+                const unsigned long long t0 = *reinterpret_cast<volatile unsigned long long*>(overflow + 16);
+                const unsigned slot = min(22u, (unsigned)((wall_clock64() - t0) / 50000ull));
+                if (slot != dbg_slot) { if (lane == 0 && dbg_slot_iter) atomicAdd(overflow + 41 + dbg_slot, dbg_slot_iter); dbg_slot = slot; dbg_slot_iter = 0; }
+                dbg_slot_iter += 16u;
+            }
             if (n_busy == 1u) ++dbg_lone; else if (n_busy <= 4u) ++dbg_few;
             dbg_kind[0] += (unsigned)__popcll(__ballot(stepping && leaf)); dbg_kind[1] += (unsigned)__popcll(__ballot(stepping && !leaf && !((st & kInBlas) != 0u) && cn.x == 0u));
             dbg_kind[2] += (unsigned)__popcll(__ballot(stepping && !leaf && !((st & kInBlas) != 0u) && cn.x != 0u));
@@ -361,6 +371,9 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
         atomicMax(overflow + 13, dbg_iter);                 // the wave that iterates longest ...
         atomicMax(overflow + 14, dbg_lone);                 // ... and the longest stretches with one / two to four ((st & kBusy) != 0u) lanes
         atomicMax(overflow + 15, dbg_few);
+        if (dbg_slot_iter) atomicAdd(overflow + 41 + dbg_slot, dbg_slot_iter);
+        const unsigned long long t0 = *reinterpret_cast<volatile unsigned long long*>(overflow + 16);
+        atomicAdd(overflow + 18 + min(22u, (unsigned)((wall_clock64() - t0) / 50000ull)), 1u);
     }
     atomicMax(overflow + 11, dbg_ray_max);
 #endif
@@ -764,6 +777,74 @@ __global__ __launch_bounds__(256) void prepare_tris_kernel(const VdMeshInfo* __r
     }
 }
 
+// ---- VD_OPT_TRACE_TIGHT_TLAS: a private top level over TIGHT world boxes ------------------------------------------
+// The reference seeds every TLAS leaf box with the OBJECT-space mesh box (tlas.rs:39: the fold starts from
+// [mesh.min, mesh.max]), so all leaves overlap around the origin and a ray enters most instances near it (145 of 2000 on
+// the stress scene).  Which instances a ray ENTERS does not change what it hits: inside an instance only the root's
+// children and below are tested (bvh.wgsl:35-76), all within the mesh's root box.  The private top level therefore
+// bounds each instance by the eight corners of its BLAS ROOT box under `transform` - no seed - padded by 2e-5 of the
+// box's largest coordinate (the rounding of transforming the ray in versus the corners out is ~1e-6 of that), and
+// clusters those boxes with the same agglomerative builder.  Used only where it is provably the same geometry: the
+// instance's inv_transform must invert its transform (|T * Tinv - I| <= 1e-3 per element) and every corner must be
+// finite.  ONE instance that fails either makes vd_trace_prepare_dev decline the option for the whole scene (it keeps
+// the scene's own top level; VdTraceAccelInfo.tight_fallback_instances says how many failed): the hits of an instance
+// whose inverse is stale lie outside its box, so whether the reference finds them depends on its visit order, and a
+// top level with non-finite boxes may have dropped clusters (tlas.rs:87-105 finds no partner for a NaN area) that only
+// the reference's own build reproduces.
+__global__ __launch_bounds__(256) void tight_boxes_kernel(const VdInstance* __restrict__ inst, unsigned n_inst, const VdMeshInfo* __restrict__ meshes,
+                                                          unsigned n_meshes, const VdBvhNode* __restrict__ bvh, unsigned n_bvh,
+                                                          const VdTlasNode* __restrict__ scene_tlas, unsigned n_scene_nodes,
+                                                          float* __restrict__ boxes, unsigned* __restrict__ n_fallback) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_inst) return;
+    const float* T = inst[i].transform;
+    const float* V = inst[i].inv_transform;
+    const VdMeshInfo m = meshes[min(inst[i].mesh, n_meshes - 1u)];
+    bool ok = m.bvh_index < n_bvh;
+    float worst = 0.0f;
+    for (int r = 0; r < 4 && ok; ++r)
+        for (int c = 0; c < 4; ++c) {
+            float a = 0.0f;
+            for (int k = 0; k < 4; ++k) a += T[4 * k + r] * V[4 * c + k];        // (T * Tinv)[r][c], column-major storage
+            worst = fmaxf(worst, fabsf(a - (r == c ? 1.0f : 0.0f)));
+        }
+    ok = ok && worst <= 1e-3f;                 // false for NaN too
+    float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
+    if (ok) {
+        const VdBvhNode root = bvh[m.bvh_index];
+        const float b[2][3] = {{root.min[0], root.min[1], root.min[2]}, {root.max[0], root.max[1], root.max[2]}};
+        for (int c = 0; c < 8; ++c) {
+            const float px = b[c & 1][0], py = b[(c >> 1) & 1][1], pz = b[(c >> 2) & 1][2];
+            for (int k = 0; k < 3; ++k) {
+                const float w = ((T[k] * px + T[4 + k] * py) + T[8 + k] * pz) + T[12 + k];
+                ok = ok && fabsf(w) < 1e30f;       // finite and inside the format's own range (MAX_DIST)
+                mn[k] = fminf(mn[k], w); mx[k] = fmaxf(mx[k], w);
+            }
+        }
+    }
+    if (ok) {
+        float big = 0.0f;
+        for (int k = 0; k < 3; ++k) big = fmaxf(big, fmaxf(fabsf(mn[k]), fabsf(mx[k])));
+        const float pad = 2e-5f * big + 1e-30f;
+        for (int k = 0; k < 3; ++k) { mn[k] -= pad; mx[k] += pad; }
+    } else {
+        atomicAdd(n_fallback, 1u);
+        const bool own_leaf = i + 1u < n_scene_nodes && scene_tlas[i + 1u].left_right == 0u && scene_tlas[i + 1u].instance_idx == i;
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = own_leaf ? scene_tlas[i + 1u].min[k] : -1e30f;
+            mx[k] = own_leaf ? scene_tlas[i + 1u].max[k] : 1e30f;
+        }
+    }
+    for (int k = 0; k < 3; ++k) { boxes[6u * i + k] = mn[k]; boxes[6u * i + 3 + k] = mx[k]; }
+}
+
+// The reference's build ends with one merge too many (tlas.rs:59 `while node_indices > 0`): node 2n has the true root
+// 2n - 1 as BOTH children and node 0 is its copy, so a ray that misses everything walks the tree twice.  The private
+// top level starts at the true root.
+__global__ void tight_root_kernel(VdTlasNode* nodes, unsigned n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && n >= 2u) nodes[0] = nodes[2u * n - 1u];
+}
+
 // order = the ray ids sorted by ray key (scratch of the context from byte `at`: past the flags and the entry records)
 int sort_rays(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n, const unsigned** out_order, size_t at) {
     const unsigned n_units = (n + kSortUnit - 1u) / kSortUnit;
@@ -819,7 +900,12 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     const unsigned* order = nullptr;
     if (sorted) { rc = sort_rays(ctx, sc, d_rays, n_rays, &order, sort_at); if (rc) return rc; }
     unsigned* d_flag = reinterpret_cast<unsigned*>(ctx->scratch);      // after sort_rays: the scratch may have grown
+#ifdef VD_TUNING
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 256, ctx->stream));
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag + 16, 0xff, 8, ctx->stream));
+#else
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 64, ctx->stream));
+#endif
     float4* d_pair = reinterpret_cast<float4*>(reinterpret_cast<char*>(ctx->scratch) + 256);
     float4* d_rec = reinterpret_cast<float4*>(reinterpret_cast<char*>(d_pair) + pair_bytes);
     unsigned* d_owner = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d_rec) + irec_bytes);
@@ -885,6 +971,15 @@ extern "C" {
 
 #ifdef VD_TUNING
 // tuning build only: {outer iterations, stepping-loop iterations, stepping lanes (64 bit), leaf / entry / TLAS-interior lane-steps} of the last trace call
+// tuning build only: the last trace call's timeline in 0.5 ms slots: out[0..22] waves that ended in the slot, out[23..45] stepping iterations done in it
+int vd_debug_trace_timeline(VdCtx* ctx, uint32_t* out /*[46]*/) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx || !out || !ctx->scratch) return VD_ERR_INVALID_ARG;
+    unsigned h[64];
+    if (hipMemcpy(h, ctx->scratch, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return VD_ERR_HIP;
+    for (int k = 0; k < 46; ++k) out[k] = h[18 + k];
+    return VD_OK;
+}
 int vd_debug_trace_counters(VdCtx* ctx, uint64_t* out /*[11]*/) {
     VdDeviceGuard vd_guard_(ctx);
     if (!ctx || !out || !ctx->scratch) return VD_ERR_INVALID_ARG;
@@ -938,7 +1033,46 @@ int vd_trace_prepare_dev(VdCtx* ctx, const VdTraceScene* d_scene, VdTraceAccel**
         if (e != hipSuccess) VD_FAIL(ctx, VD_ERR_HIP, hipGetErrorString(e));
         VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_prepare: a mesh's index range or a vertex index lies outside the scene's buffers");
     }
+    if (ctx->option(VD_OPT_TRACE_TIGHT_TLAS, 0) != 0 && d_scene->n_instances >= 2u && d_scene->n_instances <= VD_TLAS_MAX_INSTANCES) {
+        const unsigned n = d_scene->n_instances;
+        float* d_boxes = nullptr;           // not in the context's scratch: the builder lays that out for itself
+        unsigned h_fallback = 0;
+        bool good = hipMalloc(reinterpret_cast<void**>(&d_boxes), 24 * (size_t)n + 16) == hipSuccess &&
+                    hipMalloc(reinterpret_cast<void**>(&a->tight), sizeof(VdTlasNode) * (2 * (size_t)n + 1)) == hipSuccess;
+        if (good) {
+            unsigned* d_fb = reinterpret_cast<unsigned*>(d_boxes + 6 * (size_t)n);
+            (void)hipMemsetAsync(d_fb, 0, 4, ctx->stream);
+            hipLaunchKernelGGL(tight_boxes_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, d_scene->instances, n, d_scene->meshes, d_scene->n_meshes,
+                               d_scene->bvh_nodes, d_scene->n_bvh_nodes, d_scene->tlas_nodes, d_scene->n_tlas_nodes, d_boxes, d_fb);
+            good = vd_tlas_build_from_boxes(ctx, d_boxes, n, a->tight) == VD_OK;
+            if (good) {
+                hipLaunchKernelGGL(tight_root_kernel, dim3(1), dim3(64), 0, ctx->stream, a->tight, n);
+                good = hipMemcpyAsync(&h_fallback, d_fb, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+            }
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        if (d_boxes) (void)hipFree(d_boxes);
+        if (!good) {
+            if (a->tight) (void)hipFree(a->tight);
+            (void)hipFree(a->tris); delete a;
+            VD_FAIL(ctx, VD_ERR_OOM, "vd_trace_prepare: the private top level (VD_OPT_TRACE_TIGHT_TLAS) could not be built");
+        }
+        a->tight_fallbacks = h_fallback;
+        if (h_fallback) { (void)hipFree(a->tight); a->tight = nullptr; }      // declined: the reference's visit order is the only exact one here
+        else { a->scene.tlas_nodes = a->tight; a->scene.n_tlas_nodes = 2u * n + 1u; }
+    }
     *out = a;
+    return VD_OK;
+}
+
+int vd_trace_accel_info(const VdTraceAccel* accel, VdTraceAccelInfo* out) {
+    if (!accel || !out) return VD_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    out->tight_tlas = accel->tight ? 1u : 0u;
+    out->n_tlas_nodes = accel->scene.n_tlas_nodes;
+    out->tight_fallback_instances = accel->tight_fallbacks;
+    out->triangle_bytes = 36ull * (accel->scene.n_indices / 3u);
+    out->d_tlas_nodes = accel->scene.tlas_nodes;
     return VD_OK;
 }
 
@@ -947,6 +1081,7 @@ int vd_trace_release(VdCtx* ctx, VdTraceAccel* accel) {
     if (!ctx || !accel) return VD_ERR_INVALID_ARG;
     (void)hipStreamSynchronize(ctx->stream);
     if (accel->tris) (void)hipFree(accel->tris);
+    if (accel->tight) (void)hipFree(accel->tight);
     delete accel;
     return VD_OK;
 }

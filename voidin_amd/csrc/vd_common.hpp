@@ -83,6 +83,8 @@ struct VdDeviceGuard {
 // same buffer without a stream sync (callers sync before growing).
 int vd_ensure(VdCtx* ctx, void** buf, size_t* cur, size_t need);
 int vd_ensure_host(VdCtx* ctx, size_t need);   // ctx->host_stage: grow-only pinned host memory
+// tlas.hip: the agglomerative build of tlas.rs:56-105 over ready leaf boxes (six floats {min xyz, max xyz} per leaf; n <= 32 768)
+int vd_tlas_build_from_boxes(VdCtx* ctx, const float* d_boxes, uint32_t n, VdTlasNode* d_nodes);
 // Look-back scan state for n_tiles tiles: *ticket = 64-bit {epoch | ticket} word, *states = granules.
 // Zeroed once when (re)allocated; the epoch tags make per-launch clearing unnecessary.
 int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer);

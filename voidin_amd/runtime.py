@@ -297,6 +297,12 @@ class Context:
             ctx._chk(ctx.lib.vd_trace_prepare_dev(ctx.h, C.byref(scene.struct), C.byref(h)))
             self.h = h
 
+        def info(self) -> dict:
+            st = abi.TraceAccelInfo()
+            self.ctx._chk(self.ctx.lib.vd_trace_accel_info(self.h, C.byref(st)))
+            return {"tight_tlas": bool(st.tight_tlas), "n_tlas_nodes": int(st.n_tlas_nodes), "tight_fallback_instances": int(st.tight_fallback_instances),
+                    "triangle_bytes": int(st.triangle_bytes), "d_tlas_nodes": st.d_tlas_nodes}
+
         def close(self):
             if getattr(self, "h", None):
                 self.ctx.lib.vd_trace_release(self.ctx.h, self.h)
