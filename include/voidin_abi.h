@@ -216,6 +216,13 @@ typedef enum VdOption {
                                      the walk: n_rays * 8 >= triangles <= 2 Mi, at most 65 535 meshes.  The 36 B per
                                      triangle live in the context's grow-only scratch (<= 72 MB, kept until
                                      vd_ctx_destroy); 2: up to 16 Mi triangles (576 MB); 0: never                */
+    VD_OPT_TRACE_FAN = 29,        /* launches one vd_trace* call runs as (1..4; default 2).  Once the rays are handed out, a wave that
+                                     is down to a few live rays turns each into jobs - one per TLAS subtree on its stack - for
+                                     the next launch's waves: the rays that take thousands of steps stop being what the call
+                                     waits for.  Same bytes out (the minimum over (t, visit order) is kept through order keys;
+                                     DESIGN.md 3.5).  1 = one launch (A/B).  Calls with at least one ray per lane of the grid
+                                     and scenes of >= 64 instances only; 8 B per ray + up to 96 MB of job slots in the context's
+                                     grow-only scratch                                                             */
     VD_OPT_TRACE_TIGHT_TLAS = 28, /* 1: vd_trace_prepare_dev builds a PRIVATE top level for the prepared scene over tight
                                      world boxes (the 8 transformed corners of each instance's BLAS root box, WITHOUT the
                                      object-space seed of tlas.rs:39 that makes the reference's leaves overlap at the

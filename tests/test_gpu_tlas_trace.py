@@ -403,6 +403,68 @@ def test_trace_supply_binning_and_prepared_triangles_are_order_only(ctx, oracle,
     assert e.value.code == abi.VD_ERR_INVALID_ARG
 
 
+def _fan_scene(oracle, n_inst, extent, seed):
+    inst = synth.instances(n_inst, n_mesh=2, seed=seed, extent=extent, scale_range=(0.5, 2.0))
+    meshes_src = [synth.knot_mesh(64, 16), synth.uv_sphere(1.0, 6)]
+    V, I, B = [], [], []
+    infos = np.zeros(2, dtype=abi.MESH_INFO)
+    vo = bo = no = 0
+    for k, (v, i) in enumerate(meshes_src):
+        nodes, idx = oracle.bvh_build(v, i)
+        infos[k]["min"], infos[k]["max"] = synth.mesh_bounds(v)
+        infos[k]["index_count"], infos[k]["base_index"], infos[k]["vertex_offset"], infos[k]["bvh_index"] = len(idx), bo, vo, no
+        V.append(np.asarray(v, dtype=np.float32).reshape(-1, 3)); I.append(idx); B.append(nodes)
+        vo += len(V[-1]); bo += len(idx); no += len(nodes)
+    return (oracle.tlas_build(inst, infos), inst, infos, np.concatenate(B), np.concatenate(V), np.concatenate(I))
+
+
+@pytest.mark.parametrize("n_inst,extent", [(300, 100.0), (1500, 60.0)])
+def test_trace_fan_out_gives_the_same_bytes(ctx, oracle, ctx_options, n_inst, extent):
+    """VD_OPT_TRACE_FAN: a call with at least one ray per lane of the persistent grid runs as up to four launches; a draining
+    wave turns its last rays into one job per TLAS subtree on their stacks, and the ray's record is the minimum over its
+    jobs of (t, visit order).  The output must not change by a bit: closest-hit records (distance, instance AND triangle:
+    the tie-break by visit order) and occlusion flags of 1 (no fan-out), 2, 3 and 4 launches are the same bytes, through
+    the prepared, the plain and the indexed walk, and a sample of the rays equals the oracle.  The second scene is dense
+    (1500 overlapping instances: rays of thousands of steps, jobs that fan out again)."""
+    import torch
+    scene = _fan_scene(oracle, n_inst, extent, synth.SEED_BASE + 8)
+    side = 720                                         # 518 400 rays >= 256 CUs x 24 waves x 64 lanes
+    rays = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 0.75 * extent), pitch_deg=0), side, side)
+    n = len(rays)
+    ds = ctx.device_scene(scene)
+    acc = ctx.trace_prepare(ds)
+    d_rays, d_hits = ctx.upload(rays), ctx.empty(n * 16)
+    d_any = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ref_bytes = None
+    for mode in ("prepared", "plain", "indexed"):
+        ctx_options("trace.auto_prepare", 0 if mode == "indexed" else None)
+        for fan in (1, 2, 3, 4):
+            ctx_options("trace.fan", fan)
+            d_hits.fill_(0xEE); d_any.fill_(7)
+            if mode == "prepared":
+                ctx.trace_prepared_dev(acc, d_rays, n, d_hits); ctx.trace_any_prepared_dev(acc, d_rays, n, d_any)
+            else:
+                ctx.trace_dev(ds, d_rays, n, d_hits); ctx.trace_any_dev(ds, d_rays, n, d_any)
+            got = (d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes())
+            if ref_bytes is None:
+                ref_bytes = got
+                sub = np.ascontiguousarray(rays[::16])
+                want, _ = oracle.trace(scene, sub, threads=8)
+                h = np.frombuffer(got[0], dtype=abi.HIT)[::16]
+                hit = want["hit"] == 1
+                assert np.array_equal(h["hit"], want["hit"]) and hit.sum() > 3000
+                for f in ("dist", "instance", "triangle"):
+                    assert h[f][hit].tobytes() == want[f][hit].tobytes(), f
+                assert np.array_equal(np.frombuffer(got[1], dtype=np.uint32)[::16], want["hit"])
+            if got[0] != ref_bytes[0]:
+                a, b = np.frombuffer(got[0], dtype=abi.HIT), np.frombuffer(ref_bytes[0], dtype=abi.HIT)
+                bad = np.nonzero((a["hit"] != b["hit"]) | (a["dist"].view(np.uint32) != b["dist"].view(np.uint32)) |
+                                 (a["instance"] != b["instance"]) | (a["triangle"] != b["triangle"]))[0]
+                assert False, (mode, fan, len(bad), bad[:5].tolist(), a[bad[:3]].tolist(), b[bad[:3]].tolist())
+            assert got[1] == ref_bytes[1], (mode, fan, "occlusion", int((np.frombuffer(got[1], np.uint32) != np.frombuffer(ref_bytes[1], np.uint32)).sum()))
+    acc.close()
+
+
 def test_trace_records_survive_stale_slots_and_report_bad_leaves(ctx, oracle):
     """The per-call records of the walk (trace.hip, records_kernel): the two children of a TLAS node sit side by side at
     the LEFT child's index, tagged with the right child's.  An unreachable slot of the TLAS array may name the same left

@@ -174,7 +174,7 @@ def test_scenes_that_must_not_be_tightened(ctx, oracle, ctx_options):
         ctx.trace_prepared_dev(acc, d_rays, len(rays), d_hits)
         got = d_hits.cpu().numpy().view(abi.HIT)[: len(rays)]
         hit = want["hit"] == 1
-        assert np.array_equal(got["hit"], want["hit"]) and hit.sum() > 1000, case
+        assert np.array_equal(got["hit"], want["hit"]) and hit.sum() > (1000 if case == "stale" else 10), case
         for f in ("dist", "instance", "triangle"):
             assert got[f][hit].tobytes() == want[f][hit].tobytes(), (case, f)
         acc.close()

@@ -41,13 +41,16 @@ variants = [("single rays (default)", dict(sort=0, chunk=1), False), ("single ra
 if os.environ.get("AB_YIELD"):        # sweep of VD_OPT_TRACE_YIELD on the default supply
     variants = [("yield %2d%s" % (y, " prep" if pr else ""), dict(sort=0, chunk=1, **{"yield": y}), pr)
                 for y in [int(v) for v in os.environ["AB_YIELD"].split(",")] for pr in (False, True)]
+if os.environ.get("AB_FAN"):          # sweep of VD_OPT_TRACE_FAN (launches per call) on the default supply
+    variants = [("fan %d%s" % (r, " prep" if pr else ""), dict(sort=0, chunk=1, fan=r), pr)
+                for r in [int(v) for v in os.environ["AB_FAN"].split(",")] for pr in (False, True)]
 if os.environ.get("AB_WAVES"):        # sweep of VD_OPT_TRACE_WAVES on the default supply
     variants = [("waves/CU %2d%s" % (w, " prep" if pr else ""), dict(sort=0, chunk=1, waves=w), pr)
                 for w in [int(v) for v in os.environ["AB_WAVES"].split(",")] for pr in (False, True)]
 ref_bytes = ref_any = None
 ctx.set_timing(True)
 for name, opts, prep in variants:
-    for k in ("sort", "chunk", "yield", "waves"):
+    for k in ("sort", "chunk", "yield", "waves", "fan"):
         ctx.set_option("trace." + k, opts.get(k, -1))
     t_cl, t_any = [], []
     acc_v = acc_tight if prep == "tight" else acc
@@ -78,7 +81,7 @@ for name, opts, prep in variants:
                 ctx.lib.vd_debug_trace_timeline(ctx.h, tl_)
                 ended, iters = list(tl_)[:23], list(tl_)[23:]
                 last = max([k for k in range(23) if ended[k] or iters[k]] + [0])
-                print("    timeline, 0.5 ms slots: waves ended " + " ".join(str(v) for v in ended[: last + 1]))
+                print("    timeline, 2 ms slots: waves ended " + " ".join(str(v) for v in ended[: last + 1]))
                 print("                 k wave-iterations " + " ".join(str(v // 1000) for v in iters[: last + 1]))
     b, a = d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes()
     if ref_bytes is None:

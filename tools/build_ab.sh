@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 d=build/ab/$name; mkdir -p $d
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function"
-for f in ctx cull tlas trace blas hiz; do
+for f in ctx cull tlas trace blas hiz dist; do
   if [ "$f" = "${AB_FILE:-cull}" ] || [ ! -f voidin_amd/csrc/$f.o ]; then /opt/rocm/bin/hipcc $F "$@" -c voidin_amd/csrc/$f.hip -o $d/$f.o; else cp voidin_amd/csrc/$f.o $d/$f.o; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $d/libvoidin_hip.so $d/*.o

@@ -1205,45 +1205,6 @@ struct LevelCtl {                     // device-side counters
     unsigned active, active_next;             // triangles in the segments of this / the next level
 };
 
-// one thread per segment: items per segment, centroid keys / bins reset
-__global__ void a_seg_begin_kernel(Seg* segs, LevelCtl* ctl) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ctl->n_seg) return;
-    Seg& sg = segs[i];
-    sg.n_items = (sg.count + kItem - 1) / kItem;
-    sg.act[0] = sg.act[1] = sg.act[2] = 0u;
-    for (int k = 0; k < 24; ++k) sg.child_k[k] = (k % 6) < 3 ? kBig : -kBig - 1;
-    for (int k = 0; k < 72; ++k) { (&sg.bin_min[0][0][0])[k] = kBig; (&sg.bin_max[0][0][0])[k] = -kBig - 1; }
-}
-
-// single workgroup: exclusive scan of n_items over segments -> item_first, total items
-__global__ __launch_bounds__(1024) void a_items_scan_kernel(Seg* segs, LevelCtl* ctl) {
-    __shared__ unsigned s_part[1024];
-    const unsigned n = ctl->n_seg, tid = threadIdx.x;
-    const unsigned per = (n + 1023u) / 1024u;
-    const unsigned lo = min(n, tid * per), hi = min(n, lo + per);
-    unsigned sum = 0;
-    for (unsigned i = lo; i < hi; ++i) sum += segs[i].n_items;
-    s_part[tid] = sum;
-    __syncthreads();
-    for (unsigned off = 1; off < 1024u; off <<= 1) {
-        const unsigned v = tid >= off ? s_part[tid - off] : 0u;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    unsigned run = s_part[tid] - sum;
-    for (unsigned i = lo; i < hi; ++i) { segs[i].item_first = run; run += segs[i].n_items; }
-    if (tid == 1023u) ctl->n_items = s_part[1023];
-}
-
-__global__ void a_items_fill_kernel(const Seg* segs, const LevelCtl* ctl, unsigned* item_seg) {
-    const unsigned i = blockIdx.x;
-    if (i >= ctl->n_seg) return;
-    const Seg& sg = segs[i];
-    for (unsigned k = threadIdx.x; k < sg.n_items; k += blockDim.x) item_seg[sg.item_first + k] = i;
-}
-
 // Item geometry: item -> (segment, first relative position, valid count).  Lane order inside an
 // item is (wave, j, lane): position = rel0 + wave*256 + j*64 + lane.
 struct ItemCtx { unsigned seg, rel0, n_here; };
@@ -1288,15 +1249,6 @@ __global__ __launch_bounds__(256) void a_bits_kernel(const Seg* segs, const unsi
     if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = t0;
     __syncthreads();
     if (threadIdx.x == 0) item_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];   // what a_count would find in round 0
-}
-
-__global__ void a_planes_kernel(Seg* segs, const LevelCtl* ctl) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ctl->n_seg) return;
-    Seg& sg = segs[i];
-    float cbmin[3], cbmax[3];
-    for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(sg.cbk[k]); cbmax[k] = box_hi(sg.cbk[3 + k]); }
-    for (int c = 0; c < kCand; ++c) sg.pos[c] = cand_pos(cbmin, cbmax, c);
 }
 
 // predicate mask of this lane group: returns ballot per j (4 per wave)
@@ -1723,12 +1675,9 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
 }
 
 // one thread per segment: emit the two children, classify them, clear u flags
-__global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, TopNode* top, SmallRoot* small,
-                                  unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap, MidRoot* mid, unsigned mid_cap,
-                                  unsigned parity /* the set this level's a_child wrote */) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ctl->n_seg) return;
-    const Seg& sg = segs[i];
+__device__ __forceinline__ void finalize_segment(const Seg& sg, Seg* next, LevelCtl* ctl, TopNode* top, SmallRoot* small,
+                                                 unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap, MidRoot* mid, unsigned mid_cap,
+                                                 unsigned parity /* the set this level's a_child wrote */) {
     for (int c = 0; c < kCand; ++c) is_u_flag[sg.u_pay[c].x] = 0;
     const unsigned pair = atomicAdd(&ctl->n_top, 2u);
     if (pair + 2u > top_cap) { atomicOr(&ctl->err, 4u); return; }
@@ -1766,6 +1715,65 @@ __global__ void a_finalize_kernel(const Seg* segs, Seg* next, LevelCtl* ctl, Top
             for (int q = 0; q < 6; ++q) ns.cbk[q] = sg.child_k[12 + side * 6 + q];
         }
         top[pair + side] = t;
+    }
+}
+
+// The boundary between two levels as ONE single-workgroup launch (it was six: a_finalize, a_level_swap, a_seg_begin,
+// a_items_scan, a_items_fill, a_planes - each ~5.5 us in a dependent chain, on 15 levels): the level that ended emits its
+// children (segments of the next level, mid / small roots, leaves), the control words swap, and the next level's
+// segments get their items (count, first item, item -> segment map), reset child / bin keys and the 21 split planes.
+// `finalize` = 0 at the first level (its segments come from c_root_kernel).  Thousands of segments at most (each holds
+// more than kMidMax triangles), so one workgroup's loop is short next to the launches it replaces.
+__global__ __launch_bounds__(1024) void a_boundary_kernel(const Seg* ended, Seg* segs, LevelCtl* ctl, TopNode* top, SmallRoot* small,
+                                                          unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap, MidRoot* mid,
+                                                          unsigned mid_cap, unsigned parity, unsigned* item_seg, int finalize) {
+    __shared__ unsigned s_part[1024];
+    const unsigned tid = threadIdx.x;
+    if (finalize) {
+        const unsigned n_ended = ctl->n_seg;
+        for (unsigned i = tid; i < n_ended; i += 1024u) finalize_segment(ended[i], segs, ctl, top, small, is_u_flag, top_cap, small_cap, mid, mid_cap, parity);
+        __syncthreads();                                   // (workgroup-scope fence: the counters the threads added to are complete)
+        if (tid == 0) {
+            ctl->n_seg = ctl->n_seg_next; ctl->n_seg_next = 0; ctl->n_items = 0;
+            ctl->max_count = ctl->max_count_next; ctl->max_count_next = 0;
+            ctl->active = ctl->active_next; ctl->active_next = 0;
+        }
+        __syncthreads();
+    }
+    const unsigned n = ctl->n_seg;
+    const unsigned per = (n + 1023u) / 1024u;
+    const unsigned lo = min(n, tid * per), hi = min(n, lo + per);
+    unsigned sum = 0;
+    for (unsigned i = lo; i < hi; ++i) {
+        Seg& sg = segs[i];
+        sg.n_items = (sg.count + kItem - 1) / kItem;
+        sum += sg.n_items;
+        sg.act[0] = sg.act[1] = sg.act[2] = 0u;
+        for (int k = 0; k < 24; ++k) sg.child_k[k] = (k % 6) < 3 ? kBig : -kBig - 1;
+        for (int k = 0; k < 72; ++k) { (&sg.bin_min[0][0][0])[k] = kBig; (&sg.bin_max[0][0][0])[k] = -kBig - 1; }
+        float cbmin[3], cbmax[3];
+        for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(sg.cbk[k]); cbmax[k] = box_hi(sg.cbk[3 + k]); }
+        for (int c = 0; c < kCand; ++c) sg.pos[c] = cand_pos(cbmin, cbmax, c);
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    for (unsigned off = 1; off < 1024u; off <<= 1) {
+        const unsigned v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = s_part[tid] - sum;
+    for (unsigned i = lo; i < hi; ++i) { segs[i].item_first = run; run += segs[i].n_items; }
+    const unsigned n_items = s_part[1023];
+    if (tid == 1023u) ctl->n_items = n_items;
+    __syncthreads();
+    // item -> segment: every thread takes items tid, tid + 1024, ... and finds the last segment that starts at or before it
+    // (one segment of thousands of items at the first levels, thousands of small ones later: either way a few steps)
+    for (unsigned j = tid; j < n_items; j += 1024u) {
+        unsigned a = 0, b = n;
+        while (b - a > 1u) { const unsigned m = (a + b) >> 1; if (segs[m].item_first <= j) a = m; else b = m; }
+        item_seg[j] = a;
     }
 }
 
@@ -1977,7 +1985,7 @@ __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot*
             }
         }
         __syncthreads();
-        // emit the two children (as a_finalize_kernel does)
+        // emit the two children (as finalize_segment does)
         if (tid == 0) {
             const unsigned pair = atomicAdd(&ctl->n_top, 2u);
             if (pair + 2u > top_cap) { atomicOr(&ctl->err, 4u); L.n_stack = 0; }
@@ -2122,14 +2130,6 @@ __global__ void c_root_kernel(TopNode* top, const int* root_keys, const MeshDesc
     top[2u * m + 1u] = z;
 }
 
-__global__ void a_level_swap_kernel(LevelCtl* ctl) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        ctl->n_seg = ctl->n_seg_next; ctl->n_seg_next = 0; ctl->n_items = 0;
-        ctl->max_count = ctl->max_count_next; ctl->max_count_next = 0;
-        ctl->active = ctl->active_next; ctl->active_next = 0;
-    }
-}
-
 struct Arena {
     char* base; size_t off;
     template <typename T> T* take(size_t n) {
@@ -2225,6 +2225,8 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
     hipLaunchKernelGGL(blas_precompute_kernel, dim3(n_chunks), dim3(256), 0, st, P.meshes, K, P.idx_copy, P.cent, P.boxes, P.root_keys, &P.ctl->err, P.bad_mesh);
     const ArrSet sets[2] = {ArrSet{P.cent, P.boxes}, ArrSet{P.cent1, P.boxes1}};
     hipLaunchKernelGGL(c_root_kernel, dim3((K + 63u) / 64u), dim3(64), 0, st, P.top, P.root_keys, P.meshes, K, P.small, P.ctl, P.seg0, P.mid);
+    hipLaunchKernelGGL(a_boundary_kernel, dim3(1), dim3(1024), 0, st, (const Seg*)nullptr, P.seg0, P.ctl, P.top, P.small, P.is_u, top_cap, small_cap, P.mid, mid_cap, 0u,
+                       P.item_seg, 0);      // the first level's set-up
 
     // ---- phase A: level loop ----
     Seg* seg_cur = P.seg0; Seg* seg_next = P.seg1;
@@ -2240,7 +2242,7 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
     }
     unsigned n_seg = h_ctl.n_seg;
     int levels = 0;
-    stats.kernel_launches = 2;
+    stats.kernel_launches = 3;
     lap(stats.ms_precompute);
     // one level of phase A; PayT = Pay4 / Pay8 (see there)
     unsigned n_launch = 0;
@@ -2248,13 +2250,8 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
         using PayT = decltype(pay_tag);
         typedef typename PayT::T PT;
         const ArrSet cur = sets[level & 1], nxt = sets[(level + 1) & 1];
-        const unsigned seg_blocks = (n_seg_now + 63) / 64;
         // upper bound of items this level: sum ceil(count/kItem) <= T/kItem + n_seg
         const unsigned items_ub = (unsigned)(T / kItem) + n_seg_now + 1;
-        hipLaunchKernelGGL(a_seg_begin_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, P.ctl);
-        hipLaunchKernelGGL(a_items_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl);
-        hipLaunchKernelGGL(a_items_fill_kernel, dim3(n_seg_now), dim3(64), 0, st, seg_cur, P.ctl, P.item_seg);
-        hipLaunchKernelGGL(a_planes_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, P.ctl);
         PT* src = reinterpret_cast<PT*>(P.pay0); PT* dst = reinterpret_cast<PT*>(P.pay1);
         unsigned* const cnt[2] = {P.item_cnt, P.item_cnt1};      // round c counts in cnt[c & 1]
         hipLaunchKernelGGL((a_bits_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.cent, P.bits21, cnt[0]);
@@ -2286,9 +2283,9 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
         // 22 swaps: the arrangement is back in pay0
         hipLaunchKernelGGL((a_child_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, reinterpret_cast<const PT*>(P.pay0), cur.boxes,
                            cur.cent, nxt.boxes, nxt.cent);
-        hipLaunchKernelGGL(a_finalize_kernel, dim3(seg_blocks), dim3(64), 0, st, seg_cur, seg_next, P.ctl, P.top, P.small, P.is_u,
-                           top_cap, small_cap, P.mid, mid_cap, (unsigned)((level + 1) & 1));
-        hipLaunchKernelGGL(a_level_swap_kernel, dim3(1), dim3(64), 0, st, P.ctl);
+        // this level's children + the next level's set-up: one launch (a_boundary_kernel)
+        hipLaunchKernelGGL(a_boundary_kernel, dim3(1), dim3(1024), 0, st, seg_cur, seg_next, P.ctl, P.top, P.small, P.is_u, top_cap, small_cap, P.mid, mid_cap,
+                           (unsigned)((level + 1) & 1), P.item_seg, 1);
     };
     // The mid tier does not wait for the last levels: segments <= kMidMax go to the mid list as they appear, and after
     // every level the roots listed since the last launch start on the second stream, beside the levels that remain
@@ -2319,7 +2316,7 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
         if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
         n_seg = h_ctl.n_seg;
         Seg* t = seg_cur; seg_cur = seg_next; seg_next = t;
-        stats.kernel_launches += 10 + n_launch; n_launch = 0;
+        stats.kernel_launches += 5 + n_launch; n_launch = 0;
         if (++levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
         if (n_seg > 0 && h_ctl.n_mid >= mid_early + kMidEarlyMin) {     // enough new roots to be worth a launch beside the next level
             if (!ctx->aux_stream) VD_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));

@@ -80,7 +80,49 @@ struct Scene {
 // waves = one CU's L1) working one chunk off before it takes the next, so that the lanes of a wave and the waves of a CU
 // sit in a small window of the order.  Both were built to test whether locality pays on this part; it does not
 // (launch_trace), and the defaults are the round-2 supply.
-struct RaySource { const unsigned* order; unsigned n_rays, chunk, n_chunks; unsigned* next_chunk; };
+// Fan-out (single-ray supply, see kFan*): one job = one TLAS subtree of one ray.  48 bytes: as a pending job {ray, the distance
+// found so far, ray id, order key, the subtree as a stack-entry word}; when finished the same slot holds the job's result.
+struct FanJob { float ex, ey, ez, dx, dy, dz; float lim; unsigned ray_id, key, node, state, tri; };
+static_assert(sizeof(FanJob) == 48, "FanJob is three uint4");
+enum : unsigned { FAN_PENDING = 0u, FAN_MISS = 1u, FAN_HIT = 2u, FAN_NULL = 3u };
+struct Fan {                       // one launch's place in the fan-out (all nullptr / 0: a plain call)
+    FanJob* jobs; const unsigned* begin; const unsigned* end;      // this launch's supply = jobs[*begin, *end) instead of fresh rays (end == nullptr: fresh rays)
+    unsigned* append; unsigned cap;                                // where new jobs go: jobs[atomicAdd(append, n)], n <= cap
+    unsigned long long* best;                                      // per ray: min over finished jobs of {distance bits, key}
+    unsigned below, level;                                         // fan out when fewer than `below` rays are alive in a draining wave (0: never); key digit position
+};
+struct RaySource { const unsigned* order; unsigned n_rays, chunk, n_chunks; unsigned* next_chunk; Fan fan = {}; };
+
+// Fan-out.  The stress scene's call is as long as its longest rays - 8 500 dependent steps of ~1.4 us against a mean of 517 -
+// and for most of it a few waves each nurse a handful of such rays while the rest of the machine is idle (the "relay" that
+// only repacked whole rays into full waves made it slower: profiles/r04_trace_relay_experiment.log).  A ray's remaining work
+// IS its stack: every entry is a TLAS subtree still to be visited, and visits of different subtrees do not depend on each
+// other except through the distance found so far.  So a call runs as a few launches: once the rays are handed out, a wave
+// that is down to fewer than kFanBelow live rays turns each of them (when it is between instances: the stack then holds TLAS
+// entries only) into jobs - one for the node it is at, one per stack entry - that start from the distance the ray has
+// found so far, and ends; the next launch's waves draw jobs like rays, 64 per wave, and may fan out again.
+// Same result, bit for bit: the walk's answer is the minimum of (t, visit order) over the triangles the ray truly
+// intersects - pruning by the current distance only ever skips candidates that cannot beat it, and a later candidate at an
+// equal t loses (intersections.wgsl:40 `t < hit`).  Visit order over the tree is fixed by the ray alone (near child first,
+// by slab distance), so it is carried as a key: the ray's own result so far is digit 0, the node it is at digit 1, its stack
+// entries top to bottom digits 2, 3, ... - one digit per launch that fanned the job out - and a job accepts only t strictly
+// below the distance it started from, so an equal t never beats anything found before the fan-out.  Each finished job
+// records {distance bits, key} with an atomic min per ray; vd_fan_resolve_kernel lets the job that holds the minimum write the
+// ray's record.  (The reference's root is visited twice - tlas.rs:59 merges the true root with itself - and the second
+// visit can only tie: its job is not created.)
+#ifndef VD_FAN_PHASES
+#define VD_FAN_PHASES 2
+#endif
+#ifndef VD_FAN_BELOW
+#define VD_FAN_BELOW 32
+#endif
+#ifndef VD_FAN_GRACE
+#define VD_FAN_GRACE 128
+#endif
+constexpr unsigned kFanPhases = VD_FAN_PHASES;   // launches per call (VD_OPT_TRACE_FAN; 1 = one launch, no fan-out)
+constexpr unsigned kFanBelow = VD_FAN_BELOW;     // live rays below which a draining wave fans its rays out at once
+constexpr unsigned kFanGrace = VD_FAN_GRACE;     // stepping iterations after the last draw before a wave fans out whatever is still alive
+constexpr unsigned kFanAgain = 8;             // ... and between two looks at the rays that were inside an instance at the time
 
 // A fixed grid of waves; a lane whose ray is finished draws the next ray from a counter, so a wave stays full while
 // rays of very different cost (a few node visits to thousands) pass through it.  To let a lane restart at any point the
@@ -100,11 +142,15 @@ constexpr int kWgWaves = 6;             // waves per workgroup of the chunked fo
 // CHUNKS = false (default): idle lanes draw single rays from one global counter, one wave per workgroup - the round-2
 // form, kept apart so that it carries none of the chunk machinery (inside multi-wave workgroups with the chunk state live
 // the closest-hit walk spilled registers and lost 10 %: 38.5 -> 34.5 Mrays/s, same-session A/B against the round-2 library).
-template <bool ANY, bool PREP, bool CHUNKS>
+template <bool ANY, bool PREP, bool CHUNKS, bool FAN = false>
 __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restrict__ rays, const RaySource& src, VdHit* __restrict__ out,
                                            unsigned* __restrict__ out_any, unsigned* __restrict__ overflow) {
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned n_rays = src.n_rays;
+    const bool from_jobs = FAN && src.fan.end != nullptr;                       // this launch hands out jobs, not fresh rays
+    const unsigned job_begin = from_jobs ? *src.fan.begin : 0u;
+    const unsigned n_rays = from_jobs ? *src.fan.end - job_begin : src.n_rays;     // what this launch hands out
+    bool fan_off = false;                  // wave-uniform: the job list was full when this wave wanted to fan out
+    unsigned drain_iters = 0;              // wave-uniform: stepping iterations since this wave found the supply empty
     __shared__ vd_u64 s_word;              // chunked supply: {next, end} positions of the workgroup's current chunk
     unsigned p_next = 0, p_end = 0;        // a chunk this wave could not publish (another wave's was installed first)
     if (CHUNKS) {
@@ -150,6 +196,18 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
 #ifdef VD_TUNING
             dbg_ray_max = max(dbg_ray_max, dbg_ray_steps); dbg_ray_steps = 0;
 #endif
+            if (FAN && (ray_id & 0x80000000u)) {          // a job: its slot takes the result, the ray's minimum is updated
+                FanJob* J = src.fan.jobs + (ray_id & 0x7fffffffu);
+                if (res.hit) {
+                    const unsigned rid = J->ray_id;
+                    if (ANY) out_any[rid] = 1u;
+                    else {
+                        J->lim = res.dist; J->node = s.tlas[res.instance].instance_idx; J->tri = res.triangle;
+                        atomicMin(src.fan.best + rid, ((unsigned long long)__float_as_uint(res.dist) << 32) | J->key);
+                    }
+                }
+                J->state = (res.hit && !ANY) ? FAN_HIT : FAN_MISS;
+            } else
             if (ANY) out_any[ray_id] = res.hit;
             else { if (res.hit) res.instance = s.tlas[res.instance].instance_idx; out[ray_id] = res; }   // hits carry the leaf node until here
             st &= ~kBusy;
@@ -196,6 +254,29 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             const unsigned limit = CHUNKS ? base + got : n_rays;
             if (!((st & kBusy) != 0u)) {
                 const unsigned pos = base + vd_mbcnt(idle);
+                if (from_jobs && pos < limit && pos >= base) {
+                    const uint4* Jp = reinterpret_cast<const uint4*>(src.fan.jobs + (job_begin + pos));
+                    const uint4 j0 = Jp[0], j1 = Jp[1], j2 = Jp[2];
+                    const bool skip = j2.z != FAN_PENDING || (ANY && out_any[j1.w] != 0u);      // a filler slot, or the ray is known to be occluded
+                    if (skip) { if (j2.z == FAN_PENDING) src.fan.jobs[job_begin + pos].state = FAN_MISS; }
+                    else {
+                        world.ex = __uint_as_float(j0.x); world.ey = __uint_as_float(j0.y); world.ez = __uint_as_float(j0.z);
+                        world.dx = __uint_as_float(j0.w); world.dy = __uint_as_float(j1.x); world.dz = __uint_as_float(j1.y);
+                        world.ix = 1.0f / world.dx; world.iy = 1.0f / world.dy; world.iz = 1.0f / world.dz;   // ray_new: inv_dir = 1. / dir
+                        ray = world;
+                        // only t below the distance found before the fan-out counts - or, when another job of this ray has finished
+                        // with a hit meanwhile, t up to and including that distance (an equal t is decided by the keys)
+                        float lim = __uint_as_float(j1.z);
+                        if (!ANY) {
+                            const unsigned bd = (unsigned)(src.fan.best[j1.w] >> 32);
+                            if (bd < 0x7f800000u && __uint_as_float(bd + 1u) < lim) lim = __uint_as_float(bd + 1u);      // next float above a positive distance
+                        }
+                        res.dist = lim; res.hit = 0u; res.instance = 0xffffffffu; res.triangle = 0xffffffffu;
+                        const unsigned w = j2.y;                       // the subtree, as the stack held it (pop)
+                        cn = (w & 0xffffu) ? make_uint2(w, 0xffffffffu) : make_uint2(0u, w >> 16);
+                        ray_id = 0x80000000u | (job_begin + pos); st |= kBusy; st &= ~kDone; st &= ~kInBlas; head = 0; blas_base = 0;
+                    }
+                } else
                 if (pos < limit && pos >= base) {
                     const unsigned id = src.order ? src.order[pos] : pos;
                     const float4 a = reinterpret_cast<const float4*>(rays + id)[0], b = reinterpret_cast<const float4*>(rays + id)[1];
@@ -211,6 +292,70 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             if (done) exhausted = true;     // wave-uniform
         }
         if (!__ballot(((st & kBusy) != 0u))) break;
+        if (FAN && exhausted && src.fan.below != 0u && !fan_off) {
+            // nothing left to draw and few rays alive here: every ray that is between instances (its stack holds TLAS entries
+            // only) becomes jobs and leaves; rays inside an instance go on and are looked at again when the wave next gets here
+            const bool live = (st & kBusy) != 0u;
+            if ((unsigned)__popcll(__ballot(live)) < src.fan.below || drain_iters >= kFanGrace) {
+                if (drain_iters >= kFanGrace) drain_iters = kFanGrace - kFanAgain;
+                const bool can = live && (st & kInBlas) == 0u;
+                // the bottom entry of a ray that came through the reference's root: the true root's second visit (see above)
+                unsigned dup_word = 0u;
+                {
+                    const unsigned lr = s.tlas[0].left_right, l = lr & 0xffffu;
+                    if (lr != 0u && l == (lr >> 16)) { const unsigned w2 = s.tlas[l].left_right; dup_word = w2 != 0u ? w2 : (l << 16); }
+                }
+                const bool dup = can && head != 0u && dup_word != 0u && (ray_id & 0x80000000u) == 0u && s_stack[wv][0][lane] == dup_word;
+                const unsigned n_ent = can ? head - (dup ? 1u : 0u) : 0u;
+                const unsigned m = can ? n_ent + 2u : 0u;           // the result so far, the node it is at, the stack entries
+                unsigned incl = m;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const unsigned v = __shfl_up(incl, off); if (lane >= (unsigned)off) incl += v; }
+                const unsigned total = __shfl(incl, 63);
+                if (total != 0u) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(src.fan.append, total);
+                    base = __shfl(base, 0);
+                    if (base + total > src.fan.cap) {
+                        // list full: nobody of this wave fans out (now or later); the part of the reservation that lies inside
+                        // the list is filled with slots that say "nothing here"
+                        for (unsigned k = lane; k < total && base + k < src.fan.cap; k += 64u) src.fan.jobs[base + k].state = FAN_NULL;
+                        fan_off = true;
+                    } else if (can) {
+                        unsigned rid = ray_id, pkey = 0u;
+                        if (ray_id & 0x80000000u) {                 // a job fans out again: one more digit behind its own key
+                            FanJob* P = src.fan.jobs + (ray_id & 0x7fffffffu);
+                            rid = P->ray_id; pkey = P->key;
+                            P->state = FAN_MISS;                    // its result so far moves to the new slot below
+                        }
+                        const unsigned shift = 8u * (3u - src.fan.level);
+                        uint4* O = reinterpret_cast<uint4*>(src.fan.jobs + (base + incl - m));
+                        const uint4 r0 = make_uint4(__float_as_uint(world.ex), __float_as_uint(world.ey), __float_as_uint(world.ez), __float_as_uint(world.dx));
+                        const unsigned dyb = __float_as_uint(world.dy), dzb = __float_as_uint(world.dz), limb = __float_as_uint(res.dist);
+                        // digit 0: what the ray has found so far, as a finished job
+                        const unsigned inst0 = res.hit ? s.tlas[res.instance].instance_idx : 0xffffffffu;
+                        O[0] = r0; O[1] = make_uint4(dyb, dzb, limb, rid);
+                        O[2] = make_uint4(pkey, inst0, (res.hit && !ANY) ? FAN_HIT : FAN_MISS, res.triangle);
+                        if (res.hit && !ANY) atomicMin(src.fan.best + rid, ((unsigned long long)limb << 32) | pkey);
+                        if ((ray_id & 0x80000000u) == 0u) {         // a ray's first fan-out: its record so far (a miss unless a job says otherwise)
+                            if (ANY) out_any[rid] = res.hit;
+                            else { VdHit h = res; h.instance = inst0; out[rid] = h; }
+                        }
+                        // digit 1: the node the ray is at; digits 2..: the stack, top first
+                        O[3] = r0; O[4] = make_uint4(dyb, dzb, limb, rid);
+                        O[5] = make_uint4(pkey | (1u << shift), cn.x != 0u ? cn.x : (cn.y << 16), FAN_PENDING, 0u);
+                        for (unsigned e = 0; e < n_ent; ++e) {
+                            const unsigned at = head - 1u - e;
+                            const unsigned w = at < (unsigned)kLdsStack ? s_stack[wv][at][lane] : stack[at - (unsigned)kLdsStack];
+                            O[6u + 3u * e] = r0; O[7u + 3u * e] = make_uint4(dyb, dzb, limb, rid);
+                            O[8u + 3u * e] = make_uint4(pkey | ((2u + e) << shift), w, FAN_PENDING, 0u);
+                        }
+                        st &= ~kBusy;
+                    }
+                    if (!__ballot(((st & kBusy) != 0u))) break;
+                }
+            }
+        }
         // ---- interior steps (bvh.wgsl:56-74 and 104-121) and instance entries (bvh.wgsl:78-87) ----
         // A TLAS leaf is an instance to enter: instance -> inv_transform + mesh -> MeshInfo -> the mesh's root node -> its two
         // children is a chain of four dependent fetches, taken 140 times per ray on the stress scene (2000 overlapping
@@ -234,11 +379,15 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             const bool stepping = ((st & kBusy) != 0u) && !((st & kDone) != 0u) && (PREP || !leaf);
             const unsigned n_step = (unsigned)__popcll(__ballot(stepping));
             if (n_step == 0u || n_busy - n_step >= s.yield) break;
+            if (FAN && exhausted && src.fan.below != 0u && !fan_off) {      // time to fan out what is still alive?
+                drain_iters = (unsigned)__builtin_amdgcn_readfirstlane((int)(drain_iters + 1u));      // (kept in a scalar register: it was a spilled VGPR otherwise)
+                if (drain_iters >= kFanGrace) break;
+            }
 #ifdef VD_TUNING
             ++dbg_iter; dbg_lanes += n_step; if (stepping) ++dbg_ray_steps; if (exhausted) ++dbg_drain;
             if ((dbg_iter & 15u) == 0u) {       // every 16 iterations: which 0.5 ms slot are we in
                 const unsigned long long t0 = *reinterpret_cast<volatile unsigned long long*>(overflow + 16);
-                const unsigned slot = min(22u, (unsigned)((wall_clock64() - t0) / 50000ull));
+                const unsigned slot = min(22u, (unsigned)((wall_clock64() - t0) / 200000ull));
                 if (slot != dbg_slot) { if (lane == 0 && dbg_slot_iter) atomicAdd(overflow + 41 + dbg_slot, dbg_slot_iter); dbg_slot = slot; dbg_slot_iter = 0; }
                 dbg_slot_iter += 16u;
             }
@@ -373,7 +522,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
         atomicMax(overflow + 15, dbg_few);
         if (dbg_slot_iter) atomicAdd(overflow + 41 + dbg_slot, dbg_slot_iter);
         const unsigned long long t0 = *reinterpret_cast<volatile unsigned long long*>(overflow + 16);
-        atomicAdd(overflow + 18 + min(22u, (unsigned)((wall_clock64() - t0) / 50000ull)), 1u);
+        atomicAdd(overflow + 18 + min(22u, (unsigned)((wall_clock64() - t0) / 200000ull)), 1u);
     }
     atomicMax(overflow + 11, dbg_ray_max);
 #endif
@@ -386,30 +535,47 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
 // persistent grid = 24 waves per CU); the chunked form takes the scene / supply structs.
 struct SceneArgs { const VdTlasNode* tlas; const VdInstance* inst; const VdMeshInfo* meshes; const VdBvhNode* bvh;
                    const float* verts; const unsigned* indices; unsigned n_meshes, yield; const float4* irec; const float4* tpair; const float4* mrec; };
-template <bool ANY>
+template <bool ANY, bool FAN>      // FAN: the fan-out's code is compiled in (calls that run as one launch use the kernel without it)
 __global__ __launch_bounds__(64, 6)   // second argument (HIP): waves per SIMD = 24 per CU
 void trace_single_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
-                         unsigned* __restrict__ overflow, unsigned* next_ray, const unsigned* __restrict__ gate) {
+                         unsigned* __restrict__ overflow, unsigned* next_ray, const unsigned* __restrict__ gate, Fan fan) {
     if (gate && *gate == 0u) return;          // the call de-indexed the leaves itself and that went well: the other kernel runs
     const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, nullptr, a.irec, a.tpair, a.mrec, a.yield};
-    const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray};
-    trace_body<ANY, false, false>(s, rays, src, out, out_any, overflow);
+    const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray, fan};
+    trace_body<ANY, false, false, FAN>(s, rays, src, out, out_any, overflow);
 }
-template <bool ANY>
+template <bool ANY, bool FAN>
 __global__ __launch_bounds__(64, 6)
 void trace_single_prep_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                               unsigned* __restrict__ overflow, unsigned* next_ray, const float* __restrict__ tris,
-                              const unsigned* __restrict__ gate) {
+                              const unsigned* __restrict__ gate, Fan fan) {
     if (gate && *gate != 0u) return;          // the call's own de-indexing met an index range it cannot use: the indexed kernel runs
     const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, tris, a.irec, a.tpair, a.mrec, a.yield};
-    const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray};
-    trace_body<ANY, true, false>(s, rays, src, out, out_any, overflow);
+    const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray, fan};
+    trace_body<ANY, true, false, FAN>(s, rays, src, out, out_any, overflow);
 }
 template <bool ANY, bool PREP>
 __global__ __launch_bounds__(64 * kWgWaves, 6)
 void trace_chunk_kernel(Scene s, const VdRay* __restrict__ rays, RaySource src, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                         unsigned* __restrict__ overflow) {
     trace_body<ANY, PREP, true>(s, rays, src, out, out_any, overflow);
+}
+
+// fan-out, between two launches: the jobs appended so far are the next launch's supply
+__global__ void fan_snapshot_kernel(const unsigned* append, unsigned cap, unsigned* end) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *end = min(*append, cap);
+}
+// fan-out, after the last launch: of a ray's finished jobs the one holding the minimum {distance, key} writes the ray's record
+__global__ __launch_bounds__(256) void fan_resolve_kernel(const FanJob* __restrict__ jobs, const unsigned* __restrict__ append, unsigned cap,
+                                                          const unsigned long long* __restrict__ best, VdHit* __restrict__ out) {
+    const unsigned n = min(*append, cap);
+    for (unsigned j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
+        const FanJob J = jobs[j];
+        if (J.state != FAN_HIT) continue;
+        if (best[J.ray_id] != (((unsigned long long)__float_as_uint(J.lim) << 32) | J.key)) continue;
+        VdHit h; h.dist = J.lim; h.hit = 1u; h.instance = J.node; h.triangle = J.tri;
+        out[J.ray_id] = h;
+    }
 }
 
 // Shadow rays of the reference's deferred pass (src/bin/raytraced_shadows.wgsl:97): origin = pos + nor * 0.0001,
@@ -890,7 +1056,15 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
                            n_tri <= ((size_t)1 << (auto_opt >= 2 ? 24 : 21)) && (size_t)n_rays * 8u >= n_tri;
     const size_t tris_bytes = auto_prep ? (((size_t)36 * n_tri + 64 + 255) & ~(size_t)255) : 0;
     const size_t sort_at = tris_at + tris_bytes;
-    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, sort_at);
+    // fan-out (kFan*): single-ray supply, calls with at least one ray per lane of the grid, scenes with enough instances for
+    // a ray to be long.  [256 B control words][best: 8 B per ray][jobs: 48 B x cap]
+    const unsigned waves = (unsigned)ctx->num_cus * (unsigned)std::min<long long>(kWavesPerCu, std::max<long long>(1, ctx->option(VD_OPT_TRACE_WAVES, kWavesPerCu)));
+    unsigned phases = (unsigned)std::min<long long>(4, std::max<long long>(1, ctx->option(VD_OPT_TRACE_FAN, kFanPhases)));
+    if (!single || (size_t)n_rays < (size_t)waves * 64u || sc->n_instances < 64u) phases = 1u;
+    const unsigned fan_cap = (unsigned)std::min<size_t>((size_t)1 << 21, (size_t)n_rays * 2u);
+    const size_t best_bytes = ((size_t)n_rays * 8u + 255) & ~(size_t)255;
+    const size_t fan_bytes = phases > 1u ? 256 + best_bytes + (size_t)fan_cap * sizeof(FanJob) : 0;
+    int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, sort_at + fan_bytes);
     if (rc) return rc;
     // Binning is OFF by default: measured on the stress scene (tools/ab_trace.py, profiles/r03_ab_trace.log) rays handed
     // out in sorted order are SLOWER (32.0 against 35.7 Mrays/s): the walk is bound by the slowest of a wave's 64 fetches,
@@ -906,6 +1080,13 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
 #else
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 64, ctx->stream));
 #endif
+    unsigned* fan_ctl = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->scratch) + sort_at);      // [0] append, [1 + p] supply counter of launch p, [8 + p] end of launch p's supply
+    unsigned long long* fan_best = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(fan_ctl) + 256);
+    FanJob* fan_jobs = reinterpret_cast<FanJob*>(reinterpret_cast<char*>(fan_best) + best_bytes);
+    if (phases > 1u) {
+        VD_HIP_CHECK(ctx, hipMemsetAsync(fan_ctl, 0, 256, ctx->stream));
+        if (!d_any) VD_HIP_CHECK(ctx, hipMemsetAsync(fan_best, 0xff, best_bytes, ctx->stream));
+    }
     float4* d_pair = reinterpret_cast<float4*>(reinterpret_cast<char*>(ctx->scratch) + 256);
     float4* d_rec = reinterpret_cast<float4*>(reinterpret_cast<char*>(d_pair) + pair_bytes);
     unsigned* d_owner = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(d_rec) + irec_bytes);
@@ -931,15 +1112,25 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
         unsigned chunk = (unsigned)ctx->option(VD_OPT_TRACE_CHUNK, 1);
         if (chunk <= 1u && !order) {
             const SceneArgs a{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, yield, d_rec, d_pair, d_mrec};
-            const unsigned waves = (unsigned)ctx->num_cus * (unsigned)std::min<long long>(kWavesPerCu, std::max<long long>(1, ctx->option(VD_OPT_TRACE_WAVES, kWavesPerCu)));
-            if (d_tris) {
-                if (d_any) hipLaunchKernelGGL(trace_single_prep_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, d_tris, gate);
-                else hipLaunchKernelGGL(trace_single_prep_kernel<false>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, d_tris, gate);
+            // fan-out: launch 0 hands out the rays; launch p >= 1 the jobs appended before it started (fan_snapshot_kernel);
+            // every launch but the last may append; fan_resolve_kernel writes the records of the rays that were fanned out
+            for (unsigned ph = 0; ph < phases; ++ph) {
+                Fan fan = {};
+                if (phases > 1u) {
+                    fan.jobs = fan_jobs; fan.append = fan_ctl; fan.cap = fan_cap; fan.best = fan_best; fan.level = ph;
+                    fan.below = ph + 1u < phases ? kFanBelow : 0u;
+                    if (ph) { fan.begin = fan_ctl + 8 + (ph - 1); fan.end = fan_ctl + 8 + ph; }
+                }
+                if (ph) hipLaunchKernelGGL(fan_snapshot_kernel, dim3(1), dim3(64), 0, ctx->stream, fan_ctl, fan_cap, fan_ctl + 8 + ph);
+                unsigned* next = ph == 0 ? d_flag + 1 : fan_ctl + ph;
+#define VD_TRACE_S(K, ...) do { if (phases > 1u) { if (d_any) hipLaunchKernelGGL((K<true, true>), dim3(waves), dim3(64), 0, ctx->stream, __VA_ARGS__); else hipLaunchKernelGGL((K<false, true>), dim3(waves), dim3(64), 0, ctx->stream, __VA_ARGS__); } \
+                                else { if (d_any) hipLaunchKernelGGL((K<true, false>), dim3(waves), dim3(64), 0, ctx->stream, __VA_ARGS__); else hipLaunchKernelGGL((K<false, false>), dim3(waves), dim3(64), 0, ctx->stream, __VA_ARGS__); } } while (0)
+                if (d_tris) VD_TRACE_S(trace_single_prep_kernel, a, d_rays, n_rays, d_out, d_any, d_flag, next, d_tris, gate, fan);
+                if (!d_tris || gate) VD_TRACE_S(trace_single_kernel, a, d_rays, n_rays, d_out, d_any, d_flag, next, gate, fan);
+#undef VD_TRACE_S
             }
-            if (!d_tris || gate) {
-                if (d_any) hipLaunchKernelGGL(trace_single_kernel<true>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, gate);
-                else hipLaunchKernelGGL(trace_single_kernel<false>, dim3(waves), dim3(64), 0, ctx->stream, a, d_rays, n_rays, d_out, d_any, d_flag, d_flag + 1, gate);
-            }
+            if (phases > 1u && !d_any)
+                hipLaunchKernelGGL(fan_resolve_kernel, dim3((unsigned)ctx->num_cus * 4u), dim3(256), 0, ctx->stream, fan_jobs, fan_ctl, fan_cap, fan_best, d_out);
         } else {
             const unsigned groups = (unsigned)ctx->num_cus * (kWavesPerCu / kWgWaves);
             chunk = chunk <= 1u ? 64u : ((chunk + 63u) & ~63u);      // binned rays are handed out in chunks (of 64 at least)
@@ -971,7 +1162,7 @@ extern "C" {
 
 #ifdef VD_TUNING
 // tuning build only: {outer iterations, stepping-loop iterations, stepping lanes (64 bit), leaf / entry / TLAS-interior lane-steps} of the last trace call
-// tuning build only: the last trace call's timeline in 0.5 ms slots: out[0..22] waves that ended in the slot, out[23..45] stepping iterations done in it
+// tuning build only: the last trace call's timeline in 2 ms slots: out[0..22] waves that ended in the slot, out[23..45] stepping iterations done in it
 int vd_debug_trace_timeline(VdCtx* ctx, uint32_t* out /*[46]*/) {
     VdDeviceGuard vd_guard_(ctx);
     if (!ctx || !out || !ctx->scratch) return VD_ERR_INVALID_ARG;
