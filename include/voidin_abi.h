@@ -216,7 +216,7 @@ typedef enum VdOption {
                                      the walk: n_rays * 8 >= triangles <= 2 Mi, at most 65 535 meshes.  The 36 B per
                                      triangle live in the context's grow-only scratch (<= 72 MB, kept until
                                      vd_ctx_destroy); 2: up to 16 Mi triangles (576 MB); 0: never                */
-    VD_OPT_TRACE_FAN = 29,        /* launches one vd_trace* call runs as (1..4; default 2).  Once the rays are handed out, a wave that
+    VD_OPT_TRACE_FAN = 29,        /* launches one vd_trace* call runs as (1..4; default 3, and 1 for 15 calls after a call whose rays were all too short to fan out).  Once the rays are handed out, a wave that
                                      is down to a few live rays turns each into jobs - one per TLAS subtree on its stack - for
                                      the next launch's waves: the rays that take thousands of steps stop being what the call
                                      waits for.  Same bytes out (the minimum over (t, visit order) is kept through order keys;

@@ -111,7 +111,7 @@ struct RaySource { const unsigned* order; unsigned n_rays, chunk, n_chunks; unsi
 // ray's record.  (The reference's root is visited twice - tlas.rs:59 merges the true root with itself - and the second
 // visit can only tie: its job is not created.)
 #ifndef VD_FAN_PHASES
-#define VD_FAN_PHASES 2
+#define VD_FAN_PHASES 3
 #endif
 #ifndef VD_FAN_BELOW
 #define VD_FAN_BELOW 32
@@ -119,10 +119,14 @@ struct RaySource { const unsigned* order; unsigned n_rays, chunk, n_chunks; unsi
 #ifndef VD_FAN_GRACE
 #define VD_FAN_GRACE 128
 #endif
+#ifndef VD_FAN_AGE
+#define VD_FAN_AGE 512
+#endif
 constexpr unsigned kFanPhases = VD_FAN_PHASES;   // launches per call (VD_OPT_TRACE_FAN; 1 = one launch, no fan-out)
 constexpr unsigned kFanBelow = VD_FAN_BELOW;     // live rays below which a draining wave fans its rays out at once
 constexpr unsigned kFanGrace = VD_FAN_GRACE;     // stepping iterations after the last draw before a wave fans out whatever is still alive
 constexpr unsigned kFanAgain = 8;             // ... and between two looks at the rays that were inside an instance at the time
+constexpr unsigned kFanAge = VD_FAN_AGE;      // only rays that have been stepping for at least this many of the wave's iterations fan out (0: all)
 
 // A fixed grid of waves; a lane whose ray is finished draws the next ray from a counter, so a wave stays full while
 // rays of very different cost (a few node visits to thousands) pass through it.  To let a lane restart at any point the
@@ -151,6 +155,8 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
     const unsigned n_rays = from_jobs ? *src.fan.end - job_begin : src.n_rays;     // what this launch hands out
     bool fan_off = false;                  // wave-uniform: the job list was full when this wave wanted to fan out
     unsigned drain_iters = 0;              // wave-uniform: stepping iterations since this wave found the supply empty
+    unsigned wave_iters = 0;               // wave-uniform: stepping iterations of this wave (FAN: a ray's age = now - s_born[lane])
+    __shared__ unsigned s_born[(FAN && kFanAge) ? 64 : 1];
     __shared__ vd_u64 s_word;              // chunked supply: {next, end} positions of the workgroup's current chunk
     unsigned p_next = 0, p_end = 0;        // a chunk this wave could not publish (another wave's was installed first)
     if (CHUNKS) {
@@ -275,6 +281,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                         const unsigned w = j2.y;                       // the subtree, as the stack held it (pop)
                         cn = (w & 0xffffu) ? make_uint2(w, 0xffffffffu) : make_uint2(0u, w >> 16);
                         ray_id = 0x80000000u | (job_begin + pos); st |= kBusy; st &= ~kDone; st &= ~kInBlas; head = 0; blas_base = 0;
+                        if (FAN && kFanAge) s_born[lane] = wave_iters;
                     }
                 } else
                 if (pos < limit && pos >= base) {
@@ -287,6 +294,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
                     const VdTlasNode root = s.tlas[0];
                     cn = make_uint2(root.left_right, 0u);          // .y of a TLAS leaf = its node index
                     ray_id = id; st |= kBusy; st &= ~kDone; st &= ~kInBlas; head = 0; blas_base = 0;
+                    if (FAN && kFanAge) s_born[lane] = wave_iters;
                 }
             }
             if (done) exhausted = true;     // wave-uniform
@@ -298,7 +306,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             const bool live = (st & kBusy) != 0u;
             if ((unsigned)__popcll(__ballot(live)) < src.fan.below || drain_iters >= kFanGrace) {
                 if (drain_iters >= kFanGrace) drain_iters = kFanGrace - kFanAgain;
-                const bool can = live && (st & kInBlas) == 0u;
+                const bool can = live && (st & kInBlas) == 0u && (!kFanAge || wave_iters - s_born[kFanAge ? lane : 0u] >= kFanAge);
                 // the bottom entry of a ray that came through the reference's root: the true root's second visit (see above)
                 unsigned dup_word = 0u;
                 {
@@ -379,6 +387,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             const bool stepping = ((st & kBusy) != 0u) && !((st & kDone) != 0u) && (PREP || !leaf);
             const unsigned n_step = (unsigned)__popcll(__ballot(stepping));
             if (n_step == 0u || n_busy - n_step >= s.yield) break;
+            if (FAN && kFanAge) wave_iters = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_iters + 1u));
             if (FAN && exhausted && src.fan.below != 0u && !fan_off) {      // time to fan out what is still alive?
                 drain_iters = (unsigned)__builtin_amdgcn_readfirstlane((int)(drain_iters + 1u));      // (kept in a scalar register: it was a spilled VGPR otherwise)
                 if (drain_iters >= kFanGrace) break;
@@ -1061,6 +1070,11 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     const unsigned waves = (unsigned)ctx->num_cus * (unsigned)std::min<long long>(kWavesPerCu, std::max<long long>(1, ctx->option(VD_OPT_TRACE_WAVES, kWavesPerCu)));
     unsigned phases = (unsigned)std::min<long long>(4, std::max<long long>(1, ctx->option(VD_OPT_TRACE_FAN, kFanPhases)));
     if (!single || (size_t)n_rays < (size_t)waves * 64u || sc->n_instances < 64u) phases = 1u;
+    // The fan-out's kernels cost ~15 % where no ray lives long enough to fan out (more code, spilled registers, launches that find
+    // nothing to do): a call remembers how many jobs it made, and while the last call over the same top level made fewer than one
+    // per 64 rays the next 15 calls over it run as one launch with the plain kernels; then the fan-out is tried again.
+    const bool fan_default = ctx->option(VD_OPT_TRACE_FAN, -1) < 0;
+    if (phases > 1u && fan_default && ctx->fan_tlas == sc->tlas_nodes && ctx->fan_idle_calls != 0u) { phases = 1u; --ctx->fan_idle_calls; }
     const unsigned fan_cap = (unsigned)std::min<size_t>((size_t)1 << 21, (size_t)n_rays * 2u);
     const size_t best_bytes = ((size_t)n_rays * 8u + 255) & ~(size_t)255;
     const size_t fan_bytes = phases > 1u ? 256 + best_bytes + (size_t)fan_cap * sizeof(FanJob) : 0;
@@ -1144,7 +1158,9 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (phases > 1u) VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned + 1, fan_ctl, 4, hipMemcpyDeviceToHost, ctx->stream));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (phases > 1u) { ctx->fan_tlas = sc->tlas_nodes; ctx->fan_idle_calls = ctx->host_pinned[1] < n_rays / 64u ? 15u : 0u; }
     if (ctx->host_pinned[0] & 4u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: a TLAS leaf's instance, its mesh's root or the root's children lie outside the scene's buffers");
     if (ctx->host_pinned[0] & 2u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: BVH leaf with more than 3 triangles (BvhBuilder never makes one: blas.rs:108)");
     if (ctx->host_pinned[0]) VD_FAIL(ctx, VD_ERR_STACK_OVERFLOW, "vd_trace: traversal stack (128 entries per ray) exceeded");

@@ -35,6 +35,7 @@ struct VdCtx {
     void* expand_state = nullptr; size_t expand_state_bytes = 0;  // mask_scan_kernel: done counter + chunk offsets
     void* refit_state = nullptr; size_t refit_state_bytes = 0;    // TLAS refit: epoch-tagged {parent, sibling} links + arrival words
     unsigned refit_epoch = 0;                                     // tag of the last refit launch (0 = the arena is freshly zeroed)
+    const void* fan_tlas = nullptr; unsigned fan_idle_calls = 0;  // traversal fan-out: top level of the last call that tried it, calls left to run without it
     unsigned refit_n = 0;                                         // instance count the arena's layout was last used with
     unsigned long long scan_launches = 0;
     void* dbg_ptr = nullptr; unsigned dbg_count = 0;   // tuning hooks
