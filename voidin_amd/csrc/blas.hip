@@ -47,6 +47,13 @@ namespace {
 #ifndef VD_LANE_MAX
 #define VD_LANE_MAX 8
 #endif
+// -DVD_ISA_MARKS: comment lines + scheduling barriers at the section boundaries of the small-node path, so that the instructions of
+// a section can be counted in the assembly (tools/blas_small_isa.py -> profiles/r04_blas_small_isa.txt); never in a product build
+#ifdef VD_ISA_MARKS
+#define VD_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; VDMARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define VD_MARK(name) do { } while (0)
+#endif
 constexpr int kSmallMax = VD_SMALL_MAX;  // largest segment built by one wave out of LDS
 constexpr int kChunks = kSmallMax / 64;
 constexpr int kCand = 21;               // 3 axes x 7 planes (blas.rs:144-145; `bins` hard-coded to 8)
@@ -676,6 +683,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
         const unsigned first = W.g_first, count = W.g_count & 255u, cls = W.g_count >> 8;
         vd_wave_lds_sync();
         if (count == 0u) return false;
+        VD_MARK("setup_begin");
 #ifdef VD_PROF_SEL
         if (lane == 0) { atomicAdd(&Q.prof[4], 1u); atomicAdd(&Q.prof[5], count); }
 #endif
@@ -715,8 +723,10 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                     pb |= (ce < cand_pos(cbmin, cbmax, c) ? 1u : 0u) << c;
                 }
             }
+            VD_MARK("setup_end");
             // one trial (blas.rs:168-182 in closed form, as the wave-wide register path): moves el / pb
             auto trial = [&](int c, bool record) {
+                VD_MARK("trial_begin");
                 const bool p = valid && ((pb >> c) & 1u);
                 const unsigned gm = (unsigned)(__ballot(p) >> gb) & gmask;
                 const unsigned ttot = (unsigned)__popc(gm), ftot = n - ttot, tl = (unsigned)__popc(gm & ((1u << gl) - 1u)), x = gl;
@@ -744,9 +754,11 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 const int da = (int)((gb + dest) << 2);
                 const unsigned ep = (unsigned)__builtin_amdgcn_ds_permute(da, (int)(el | (pb << 10)));   // el < 1024, 21 predicate bits
                 el = ep & 1023u; pb = ep >> 10;
+                VD_MARK("trial_end");
             };
             for (int c = 0; c < kCand; ++c) trial(c, true);                        // blas.rs:144-147
             vd_wave_lds_sync();
+            VD_MARK("eval_begin");
             // evaluate (blas.rs:149-161): left = examined trues = {e : p_c(e) and e != u_c}, right = the rest (incl. u_c)
             if (valid) {
                 { const BoxKeys bb = box_keys(L, boxes, el);
@@ -775,6 +787,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 const unsigned ue = W.g_ue[g][c], tu = W.g_tt[g][c];
                 int lk[6] = {kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1}, rk[6] = {kBig, kBig, kBig, -kBig - 1, -kBig - 1, -kBig - 1};
                 for (unsigned i = 0; i < gw; ++i) {                                  // every lane takes part in the moves
+                    VD_MARK("eval_elem_begin");
                     const int from = (int)((src0 + i) << 2);
                     const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)word);
                     int k[6];
@@ -787,13 +800,16 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                         lk[q] = min(lk[q], inl ? k[q] : kBig); lk[3 + q] = max(lk[3 + q], inl ? k[3 + q] : -kBig - 1);
                         rk[q] = min(rk[q], inr ? k[q] : kBig); rk[3 + q] = max(rk[3 + q], inr ? k[3 + q] : -kBig - 1);
                     }
+                    VD_MARK("eval_elem_end");
                 }
+                VD_MARK("cost_begin");
                 const unsigned n1 = (tu & 127u) - (tu >> 7);
                 const float a1 = vd_area(box_hi(lk[3]) - box_lo(lk[0]), box_hi(lk[4]) - box_lo(lk[1]), box_hi(lk[5]) - box_lo(lk[2]));
                 const float a2 = vd_area(box_hi(rk[3]) - box_lo(rk[0]), box_hi(rk[4]) - box_lo(rk[1]), box_hi(rk[5]) - box_lo(rk[2]));
                 const vd_u64 kc = pv ? cost_key(a1 * (float)n1 + a2 * (float)(n_g - n1), c) : ~0ull;
                 hi3[pass] = (unsigned)(kc >> 32); lo3[pass] = (unsigned)kc; g3[pass] = g;
                 if (pv) atomicMin(&g_hi[g], hi3[pass]);
+                VD_MARK("cost_end");
             }
             vd_wave_lds_sync();
 #pragma unroll
@@ -806,7 +822,9 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             const int best = rejected || !have ? 0 : (int)(unsigned)key;
             const unsigned tb = W.g_tt[grp][best];
             const unsigned Lst = (tb & 127u) - (tb >> 7);                            // stale optimal_pivot (blas.rs:159,165)
+            VD_MARK("eval_end");
             trial(best, false);                                                     // blas.rs:164
+            VD_MARK("finish_begin");
             if (valid) { L.perm[0][s + gl] = (unsigned short)el; L.perm[1][s + gl] = (unsigned short)el; }
             if (valid) {
                 { const BoxKeys bb = box_keys(L, boxes, el);
@@ -845,6 +863,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                     atomicSub(&Q.s_pending, 1);                                     // after the children were counted
                 }
             }
+        VD_MARK("finish_end");
         return true;
     };
 
