@@ -145,7 +145,13 @@ NOTES = {
     "expand_pipe_experiment.log": "measured and NOT kept: persistent register-prefetch form of the 80 M-instance expansion",
     "blas_item_sweep.log": "phase A item size sweep (`-DVD_ITEM`), 8.4 M triangles",
     "blas_big_tier_experiment.log": "measured and NOT kept: an LDS tier for 2049..8192-prim segments (in-kernel cycles per phase)",
-    "ab_trace.log": "`tools/ab_trace.py`: ray supply (single rays / chunks), ray binning, de-indexed leaves on the stress scene (before the loop was restructured)",
+    "ab_trace.log": "`tools/ab_trace.py` on the stress scene: the walk as shipped that round (r01-r03: ray supply, binning, de-indexed leaves, before the loop was restructured; "
+                    "r04: exact walk with the fan-out, launches per call 1..4, the opt-in tight top level; tuning-build counters and the 2 ms timeline: lanes per iteration, "
+                    "lane-steps / instance entries / TLAS visits per ray, longest chain of dependent steps)",
+    "ab_trace_fan_sweep.log": "fan-out parameters before the age gate: grace (iterations after the last draw) 32..512, live-ray threshold 16..64, launches 1..3",
+    "ab_trace_fan_age_sweep.log": "fan-out with the age gate (only rays older than 256 / 512 / 1024 wave iterations fan out), 2 and 3 launches, and what the fan-out's kernels cost the tight-top-level walk",
+    "trace_relay_experiment.log": "measured and NOT kept: whole rays repacked into full waves over several launches (lanes per iteration 35 -> 50, every launch slower: the call waits for its longest rays)",
+    "blas_small_isa.txt": "`tools/blas_small_isa.py`: instructions per section of phase B's small-node path from the ISA (-DVD_ISA_MARKS), priced per batch",
     "ab_trace_loop.log": "`tools/ab_trace.py` after the stepping loop was restructured: VD_OPT_TRACE_YIELD and VD_OPT_TRACE_WAVES sweeps; tuning-build counters "
                          "(lanes per iteration, lane-steps per ray, longest ray, iterations after the last ray was handed out) at 1 M rays and at 64 / 1024 / 16 384 rays alone",
     "probe_gather.log": "`tools/probe_gather.hip`: what a CU pays for 64 divergent 64-byte fetches per wave-step (own 4 x 16 B / quad-cooperative / two lines), 28 waves per CU, "
