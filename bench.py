@@ -863,6 +863,27 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
         "distances_bit_equal": int((ht["dist"][hm].view(np.uint32) == hits["dist"][hm].view(np.uint32)).sum()), "hits": int(hm.sum()),
         "note": "default off; the exact (reference visit order) numbers above are the parity path"}
     acc_t.close()
+    # the same boxes under an LBVH built on all CUs (VD_OPT_TRACE_TIGHT_TLAS = 2): the form for scenes that move - the top level is
+    # rebuilt from the instance buffer per frame (vd_trace_accel_update_dev)
+    ctx.set_option("trace.tight_tlas", 2)
+    acc_l = ctx.trace_prepare(ds)
+    ctx.set_option("trace.tight_tlas", None)
+    t_upd = []
+    for _ in range(5):
+        t = time.perf_counter(); acc_l.update(); t_upd.append(time.perf_counter() - t)
+    ctx.set_timing(True)
+    t_cll, t_anyl = [], []
+    for _ in range(3):
+        ctx.trace_prepared_dev(acc_l, d_rays, len(rays), d_hits_t); t_cll.append(ctx.last_gpu_ms())
+        ctx.trace_any_prepared_dev(acc_l, d_rays, len(rays), d_any_t); t_anyl.append(ctx.last_gpu_ms())
+    ctx.set_timing(False)
+    hl = d_hits_t.cpu().numpy()[: len(rays) * 16].view(abi.HIT)
+    extra["trace"]["tight_tlas_option"]["lbvh"] = {
+        "closest_hit_Mrays_per_s": round(len(rays) / min(t_cll) / 1e3, 1), "occlusion_Mrays_per_s": round(len(rays) / min(t_anyl) / 1e3, 1),
+        "rebuild_ms_blocking": round(min(t_upd) * 1e3, 3),
+        "hit_flags_equal_exact_walk": bool(np.array_equal(hl["hit"], hits["hit"]) and np.array_equal(d_any_t.cpu().numpy().astype(np.uint32), hits["hit"])),
+        "distances_bit_equal": int((hl["dist"][hm].view(np.uint32) == hits["dist"][hm].view(np.uint32)).sum())}
+    acc_l.close()
     del d_hits_t, d_any_t
     if not args.no_cpu_baseline:
         # vd_ref_trace on a bounded sample of the same rays: every 4th ray on all threads, every 64th on one thread

@@ -233,8 +233,11 @@ typedef enum VdOption {
                                      visit order: default 0, and off in every bit-exact parity run.  Needs
                                      inv_transform = transform^-1 and finite boxes for EVERY instance (checked; one
                                      that fails and the scene keeps its own top level - VdTraceAccelInfo says so) and
-                                     2 .. 32 768 instances (else ignored).  The private top level is a snapshot: after
-                                     instances move, prepare again.                                               */
+                                     2 .. 32 768 instances (else ignored).  1: the top level is clustered by the
+                                     agglomerative builder of tlas.rs:56-105 (best tree; the sequential chain: 35 ms for
+                                     2 000 instances); 2: an LBVH built on all CUs (~0.1 ms, <= 32 767 instances) - the form
+                                     for scenes that move.  The private top level is a snapshot of the instances:
+                                     vd_trace_accel_update_dev rebuilds it after they moved.                       */
     VD_OPT_COUNT_ = 32
 } VdOption;
 int         vd_ctx_set_option(VdCtx* ctx, int option /* VdOption */, int64_t value);
@@ -467,11 +470,16 @@ int vd_trace_release(VdCtx* ctx, VdTraceAccel* accel);
  * the private one), how many instances did NOT qualify (inv_transform not the inverse of transform, or non-finite
  * corners: any makes the option decline), and the bytes of de-indexed triangles it owns.                          */
 typedef struct VdTraceAccelInfo {
-    uint32_t tight_tlas, n_tlas_nodes, tight_fallback_instances, _pad;
+    uint32_t tight_tlas /* 0: the scene's own top level is walked; 1 / 2: the private one, by builder */, n_tlas_nodes, tight_fallback_instances, _pad;
     uint64_t triangle_bytes;
     const VdTlasNode* d_tlas_nodes;
 } VdTraceAccelInfo;
 int vd_trace_accel_info(const VdTraceAccel* accel, VdTraceAccelInfo* out);
+/* Rebuilds the private top level of a prepared scene from the scene's instance buffer as it is NOW (the instances moved:
+ * shaders/compute_update.wgsl:10-28).  The triangles are not touched.  Blocks (it reads back whether every instance still
+ * qualifies; if one does not, the walk goes back to the scene's own top level until an update finds all qualifying again).
+ * A no-op for a scene prepared without VD_OPT_TRACE_TIGHT_TLAS: that one walks the host's top level, which the host refits.  */
+int vd_trace_accel_update_dev(VdCtx* ctx, VdTraceAccel* accel);
 int vd_trace_prepared_dev(VdCtx* ctx, const VdTraceAccel* accel, const VdRay* d_rays, uint32_t n_rays, VdHit* d_out);
 int vd_trace_any_prepared_dev(VdCtx* ctx, const VdTraceAccel* accel, const VdRay* d_rays, uint32_t n_rays,
                               uint32_t* d_out_hit);

@@ -32,16 +32,26 @@ def make_scene(oracle, meshes_src, inst):
     return (tl, inst, infos, B, V, I)
 
 
+MODE = 1          # VD_OPT_TRACE_TIGHT_TLAS value the helpers use: 1 = agglomerative top level, 2 = LBVH (set by the fixture below)
+
+
+@pytest.fixture(params=[1, 2], ids=["agglomerative", "lbvh"], autouse=True)
+def tight_mode(request):
+    global MODE
+    MODE = request.param
+    yield request.param
+
+
 def check_against_oracle(ctx, oracle, ctx_options, scene, rays, expect_tight=True, min_hits=1):
     """hit flags equal, distances within 1e-5, occlusion flags equal; returns (hits, bit-equal distances, accel info)."""
     import torch
     want, _ = oracle.trace(scene, rays, threads=8)
     ds = ctx.device_scene(scene)
-    ctx_options("trace.tight_tlas", 1)
+    ctx_options("trace.tight_tlas", MODE)
     acc = ctx.trace_prepare(ds)
     ctx_options("trace.tight_tlas", 0)              # the option acts when the scene is prepared, not when it is traced
     info = acc.info()
-    assert info["tight_tlas"] == expect_tight
+    assert info["tight_tlas"] == (MODE if expect_tight else 0)
     n = len(rays)
     d_rays, d_hits = ctx.upload(rays), ctx.empty(n * 16)
     d_any = torch.full((n,), 7, dtype=torch.int32, device="cuda")
@@ -68,7 +78,7 @@ def test_stress_shape_and_harness_shape(ctx, oracle, ctx_options):
     scene = make_scene(oracle, [synth.knot_mesh(128, 32)], inst)
     rays = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 90), pitch_deg=0), 192, 192)
     hits, same, info = check_against_oracle(ctx, oracle, ctx_options, scene, rays, min_hits=2000)
-    assert same == hits and info["tight_fallback_instances"] == 0 and info["n_tlas_nodes"] == 801
+    assert same == hits and info["tight_fallback_instances"] == 0 and info["n_tlas_nodes"] == (801 if MODE == 1 else 800)
     # bvh_gpu.rs shape: a few meshes, many instances
     inst = synth.instances(500, n_mesh=3, seed=synth.SEED_BASE + 8, extent=60.0, scale_range=(0.5, 3.0))
     scene = make_scene(oracle, [synth.uv_sphere(1.0, 4), synth.knot_mesh(96, 24), synth.triangle_soup(64)], inst)
@@ -165,7 +175,7 @@ def test_scenes_that_must_not_be_tightened(ctx, oracle, ctx_options):
         rays = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 35), pitch_deg=0), 200, 200)
         want, _ = oracle.trace(scene, rays, threads=8)
         ds = ctx.device_scene(scene)
-        ctx_options("trace.tight_tlas", 1)
+        ctx_options("trace.tight_tlas", MODE)
         acc = ctx.trace_prepare(ds)
         ctx_options("trace.tight_tlas", 0)
         info = acc.info()
@@ -187,4 +197,59 @@ def test_option_off_keeps_the_scene_top_level(ctx, oracle, ctx_options):
     acc = ctx.trace_prepare(ds)
     info = acc.info()
     assert not info["tight_tlas"] and info["n_tlas_nodes"] == 101 and info["tight_fallback_instances"] == 0
+    acc.close()
+
+
+def test_update_follows_moving_instances(ctx, oracle, ctx_options):
+    """vd_trace_accel_update_dev: the instances move (compute_update with the inverse kept in step), the private top level is
+    rebuilt from the instance buffer in place, the triangles are not touched; the walk equals the oracle's on the moved scene.
+    Then one instance's inverse goes stale: the update declines (the walk goes back to the scene's own top level, which the
+    host refits) - and takes the private one again once the inverse is repaired."""
+    import torch
+    inst = synth.instances(300, n_mesh=2, seed=synth.SEED_BASE + 47, extent=40.0, scale_range=(0.6, 2.0))
+    scene = make_scene(oracle, [synth.uv_sphere(1.0, 6), synth.knot_mesh(48, 12)], inst)
+    rays = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 60), pitch_deg=0), 160, 160)
+    n = len(rays)
+    ds = ctx.device_scene(scene)
+    ctx_options("trace.tight_tlas", MODE)
+    acc = ctx.trace_prepare(ds)
+    ctx_options("trace.tight_tlas", 0)
+    d_rays, d_hits = ctx.upload(rays), ctx.empty(n * 16)
+
+    def put(m):                                                  # the host animates the scene's instance buffer in place and refits ITS top level
+        ds.tensors[1].copy_(torch.from_numpy(np.ascontiguousarray(m).view(np.uint8).reshape(-1)))
+        ctx.tlas_refit_dev(ds.tensors[1], len(m), ds.tensors[2], len(scene[2]), ds.tensors[0])
+
+    def moved(step):
+        m = inst.copy()
+        T = m["transform"].reshape(-1, 4, 4).astype(np.float64)
+        T[:, 3, 0] += 1.5 * step * np.cos(np.arange(len(m)))
+        T[:, 3, 2] += 1.0 * step * np.sin(np.arange(len(m)))
+        m["transform"] = T.reshape(-1, 16).astype(np.float32)
+        m["inv_transform"] = np.linalg.inv(T.transpose(0, 2, 1)).transpose(0, 2, 1).reshape(-1, 16).astype(np.float32)
+        return m
+
+    for step in (1, 2):
+        m = moved(step)
+        put(m)
+        acc.update()
+        assert acc.info()["tight_tlas"] == MODE
+        want, _ = oracle.trace((oracle.tlas_build(m, scene[2]), m) + scene[2:], rays, threads=8)
+        ctx.trace_prepared_dev(acc, d_rays, n, d_hits)
+        got = d_hits.cpu().numpy().view(abi.HIT)[:n]
+        hit = want["hit"] == 1
+        assert np.array_equal(got["hit"], want["hit"]) and hit.sum() > 500
+        assert np.all(np.abs(got["dist"][hit].astype(np.float64) - want["dist"][hit]) <= REL_TOL * np.abs(want["dist"][hit]))
+    stale = moved(2)
+    stale["transform"][5, 12] += np.float32(4.0)                  # moved without its inverse
+    put(stale)
+    acc.update()
+    assert acc.info()["tight_tlas"] == 0 and acc.info()["tight_fallback_instances"] == 1
+    want, _ = oracle.trace((oracle.tlas_refit(stale, scene[2], scene[0]), stale) + scene[2:], rays, threads=8)
+    ctx.trace_prepared_dev(acc, d_rays, n, d_hits)
+    got = d_hits.cpu().numpy().view(abi.HIT)[:n]
+    assert got.tobytes() == np.ascontiguousarray(want).tobytes() or (np.array_equal(got["hit"], want["hit"]) and got["dist"][want["hit"] == 1].tobytes() == want["dist"][want["hit"] == 1].tobytes())
+    put(moved(2))
+    acc.update()
+    assert acc.info()["tight_tlas"] == MODE
     acc.close()

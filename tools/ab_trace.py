@@ -29,11 +29,19 @@ ds = ctx.device_scene((tl, inst_t, infos, nodes_b, tv, idx_b))
 acc = ctx.trace_prepare(ds)
 ctx.set_option("trace.tight_tlas", 1)          # opt-in: private top level over tight world boxes (not the reference's visit order)
 acc_tight = ctx.trace_prepare(ds)
+ctx.set_option("trace.tight_tlas", 2)          # ... the same boxes under an LBVH (built on all CUs)
+acc_lbvh = ctx.trace_prepare(ds)
 ctx.set_option("trace.tight_tlas", None)
+ctx.synchronize()
+for _acc, _nm in ((acc_tight, "agglomerative"), (acc_lbvh, "LBVH")):
+    _t = []
+    for _ in range(5):
+        t0 = time.perf_counter(); _acc.update(); _t.append(time.perf_counter() - t0)
+    print(f"private top level, {_nm}: vd_trace_accel_update_dev (rebuild from the instance buffer, blocking) {min(_t) * 1e3:.3f} ms")
 d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
 d_any = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
 variants = [("single rays (default)", dict(sort=0, chunk=1), False), ("single rays prep", dict(sort=0, chunk=1), True),
-            ("single rays prep TIGHT TLAS", dict(sort=0, chunk=1), "tight"),
+            ("single rays prep TIGHT TLAS", dict(sort=0, chunk=1), "tight"), ("single rays prep TIGHT TLAS (LBVH)", dict(sort=0, chunk=1), "lbvh"),
             ("chunk64 nosort", dict(sort=0, chunk=64), False), ("chunk64 nosort prep", dict(sort=0, chunk=64), True),
              ("chunk64 sort", dict(sort=1, chunk=64), False),
             ("chunk64 sort prep", dict(sort=1, chunk=64), True), ("chunk256 sort prep", dict(sort=1, chunk=256), True),
@@ -53,7 +61,7 @@ for name, opts, prep in variants:
     for k in ("sort", "chunk", "yield", "waves", "fan"):
         ctx.set_option("trace." + k, opts.get(k, -1))
     t_cl, t_any = [], []
-    acc_v = acc_tight if prep == "tight" else acc
+    acc_v = acc_tight if prep == "tight" else (acc_lbvh if prep == "lbvh" else acc)
     for _ in range(args.reps):
         if prep:
             ctx.trace_prepared_dev(acc_v, d_rays, len(rays), d_hits); t_cl.append(ctx.last_gpu_ms())
@@ -86,7 +94,7 @@ for name, opts, prep in variants:
     b, a = d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes()
     if ref_bytes is None:
         ref_bytes, ref_any = b, a
-    if prep == "tight":       # same hits and distances; the instance / triangle reported for two hits at one distance may differ
+    if prep in ("tight", "lbvh"):       # same hits and distances; the instance / triangle reported for two hits at one distance may differ
         h, r = np.frombuffer(b, dtype=abi.HIT), np.frombuffer(ref_bytes, dtype=abi.HIT)
         m = r["hit"] == 1
         print(f"    tight: hit flags equal {np.array_equal(h['hit'], r['hit'])}, distances bit-equal {int((h['dist'][m].view(np.uint32) == r['dist'][m].view(np.uint32)).sum())} of {int(m.sum())}")

@@ -162,6 +162,7 @@ PROTOTYPES = {
     "vd_trace_prepare_dev": (_I, [_P, C.POINTER(TraceScene), C.POINTER(_P)]),
     "vd_trace_release": (_I, [_P, _P]),
     "vd_trace_accel_info": (_I, [_P, _P]),
+    "vd_trace_accel_update_dev": (_I, [_P, _P]),
     "vd_trace_prepared_dev": (_I, [_P, _P, _P, _U, _P]),
     "vd_trace_any_prepared_dev": (_I, [_P, _P, _P, _U, _P]),
     "vd_shadow_rays_dev": (_I, [_P, _P, _P, _U, C.POINTER(C.c_float), _P]),

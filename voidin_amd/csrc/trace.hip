@@ -14,7 +14,14 @@
 #include <new>
 
 // vd_trace_prepare_dev: per-scene data derived once from the six trace buffers
-struct VdTraceAccel { VdTraceScene scene; float* tris = nullptr; VdTlasNode* tight = nullptr; /* private top level (VD_OPT_TRACE_TIGHT_TLAS) */ unsigned tight_fallbacks = 0; };
+struct VdTraceAccel {
+    VdTraceScene scene; float* tris = nullptr;
+    // private top level (VD_OPT_TRACE_TIGHT_TLAS): its nodes, which builder made it (1 agglomerative, 2 LBVH), the scene's own top
+    // level (what the walk goes back to when an update finds an instance that does not qualify), work memory of the builders
+    VdTlasNode* tight = nullptr; unsigned tight_mode = 0, tight_fallbacks = 0;
+    const VdTlasNode* user_tlas = nullptr; unsigned user_n_nodes = 0;
+    float* boxes = nullptr; unsigned* lbvh = nullptr;
+};
 
 namespace {
 
@@ -1020,6 +1027,108 @@ __global__ void tight_root_kernel(VdTlasNode* nodes, unsigned n) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && n >= 2u) nodes[0] = nodes[2u * n - 1u];
 }
 
+// ---- the private top level as an LBVH (VD_OPT_TRACE_TIGHT_TLAS = 2): built on all CUs in ~0.1 ms, so it can follow moving
+// instances every frame (vd_trace_accel_update_dev); the agglomerative builder (= 1) makes the better tree and takes the
+// reference's sequential chain to do it.  Morton codes of the box centres (10 bits per axis of the scene's extent), the
+// radix sort the ray binning uses, Karras' binary radix tree (one thread per interior node; equal codes are told apart by
+// their position), boxes bottom-up (the second child to arrive at a node goes on).  Nodes: 0 = the root, 1 + j = the
+// leaf of the j-th code in sorted order, n + i = interior node i (i >= 1): indices stay below 2n <= 65 536.
+__device__ __forceinline__ unsigned ord_of(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float of_ord(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+__global__ __launch_bounds__(256) void lbvh_extent_kernel(const float* __restrict__ boxes, unsigned n, unsigned* __restrict__ ext /*[6]: min xyz, max xyz of the centres*/) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 3; ++k) {
+        const float c = 0.5f * (boxes[6u * i + k] + boxes[6u * i + 3 + k]);
+        atomicMin(ext + k, ord_of(c)); atomicMax(ext + 3 + k, ord_of(c));
+    }
+}
+__device__ __forceinline__ unsigned spread10(unsigned v) {
+    v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu; v = (v | (v << 4)) & 0x030c30c3u; v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ __launch_bounds__(256) void lbvh_keys_kernel(const float* __restrict__ boxes, unsigned n, const unsigned* __restrict__ ext,
+                                                        unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    unsigned q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float lo = of_ord(ext[k]), hi = of_ord(ext[3 + k]);
+        const float c = 0.5f * (boxes[6u * i + k] + boxes[6u * i + 3 + k]);
+        const float t = hi > lo ? (c - lo) / (hi - lo) : 0.0f;
+        q[k] = (unsigned)fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
+    }
+    keys[i] = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+    vals[i] = i;
+}
+// length of the common prefix of the codes at sorted positions i and j (-1 outside the array); equal codes: their positions decide
+__device__ __forceinline__ int lbvh_delta(const unsigned* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned a = keys[i], b = keys[j];
+    return a != b ? __clz((int)(a ^ b)) : 32 + __clz((int)((unsigned)i ^ (unsigned)j));
+}
+__global__ __launch_bounds__(256) void lbvh_tree_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, const float* __restrict__ boxes,
+                                                        unsigned n, VdTlasNode* __restrict__ nodes, unsigned* __restrict__ parent, unsigned* __restrict__ arrived) {
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x), N = (int)n;
+    if (i >= N) return;
+    {   // the leaf of sorted position i
+        const unsigned inst = vals[i];
+        VdTlasNode lf;
+        for (int k = 0; k < 3; ++k) { lf.min[k] = boxes[6u * inst + k]; lf.max[k] = boxes[6u * inst + 3 + k]; }
+        lf.left_right = 0u; lf.instance_idx = inst;
+        nodes[1 + i] = lf;
+    }
+    if (i >= N - 1) return;
+    // Karras 2012: direction of the node's range, its other end, the split
+    const int d = lbvh_delta(keys, N, i, i + 1) - lbvh_delta(keys, N, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(keys, N, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(keys, N, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1) if (lbvh_delta(keys, N, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = lbvh_delta(keys, N, i, j);
+    int sp = 0;
+    for (int t = (l + 1) >> 1; ; t = (t + 1) >> 1) {
+        if (lbvh_delta(keys, N, i, i + (sp + t) * d) > dnode) sp += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + sp * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    const unsigned self = i == 0 ? 0u : n + (unsigned)i;
+    const unsigned left = lo == gamma ? 1u + (unsigned)gamma : n + (unsigned)gamma;            // gamma >= 1 when interior: the root is nobody's child
+    const unsigned right = hi == gamma + 1 ? 2u + (unsigned)gamma : n + (unsigned)gamma + 1u;
+    VdTlasNode nd;
+    for (int k = 0; k < 3; ++k) { nd.min[k] = 0.0f; nd.max[k] = 0.0f; }
+    nd.left_right = left | (right << 16); nd.instance_idx = 0xffffffffu;
+    nodes[self] = nd;
+    parent[left] = self; parent[right] = self;
+    arrived[self] = 0u;
+}
+__global__ __launch_bounds__(256) void lbvh_fit_kernel(unsigned n, VdTlasNode* nodes, const unsigned* __restrict__ parent, unsigned* arrived) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    unsigned k = 1u + i;                                   // climb from leaf i
+    for (;;) {
+        const unsigned p = parent[k];
+        __threadfence();                                   // my node's box is written before I announce myself
+        if (atomicAdd(arrived + p, 1u) == 0u) return;      // the first child to arrive leaves; the second finds both boxes written
+        __threadfence();
+        const unsigned lr = nodes[p].left_right, l = lr & 0xffffu, r = lr >> 16;
+        float mn[3], mx[3];
+        for (int q = 0; q < 3; ++q) {
+            mn[q] = fminf(__hip_atomic_load(&nodes[l].min[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&nodes[r].min[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            mx[q] = fmaxf(__hip_atomic_load(&nodes[l].max[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&nodes[r].max[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        for (int q = 0; q < 3; ++q) {
+            __hip_atomic_store(&nodes[p].min[q], mn[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&nodes[p].max[q], mx[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (p == 0u) return;
+        k = p;
+    }
+}
+
 // order = the ray ids sorted by ray key (scratch of the context from byte `at`: past the flags and the entry records)
 int sort_rays(VdCtx* ctx, const VdTraceScene* sc, const VdRay* d_rays, uint32_t n, const unsigned** out_order, size_t at) {
     const unsigned n_units = (n + kSortUnit - 1u) / kSortUnit;
@@ -1167,6 +1276,53 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     return VD_OK;
 }
 
+// The private top level of a prepared scene (VD_OPT_TRACE_TIGHT_TLAS: 1 = agglomerative, 2 = LBVH), from the scene's instances as
+// they are now.  Blocks (it reads back how many instances did not qualify); with any, the scene's own top level is walked.
+int build_tight_tlas(VdCtx* ctx, VdTraceAccel* a) {
+    const unsigned n = a->scene.n_instances;
+    hipStream_t st = ctx->stream;
+    unsigned* d_fb = reinterpret_cast<unsigned*>(a->boxes + 6 * (size_t)n);
+    VD_HIP_CHECK(ctx, hipMemsetAsync(d_fb, 0, 4, st));
+    hipLaunchKernelGGL(tight_boxes_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, a->scene.instances, n, a->scene.meshes, a->scene.n_meshes,
+                       a->scene.bvh_nodes, a->scene.n_bvh_nodes, a->user_tlas, a->user_n_nodes, a->boxes, d_fb);
+    if (a->tight_mode == 2u) {
+        const unsigned n_units = (n + kSortUnit - 1u) / kSortUnit;
+        const size_t arr = ((size_t)n * 4 + 255) & ~(size_t)255;
+        char* base = reinterpret_cast<char*>(a->lbvh);
+        unsigned* k[2] = {reinterpret_cast<unsigned*>(base), reinterpret_cast<unsigned*>(base + arr)};
+        unsigned* v[2] = {reinterpret_cast<unsigned*>(base + 2 * arr), reinterpret_cast<unsigned*>(base + 3 * arr)};
+        unsigned* parent = reinterpret_cast<unsigned*>(base + 4 * arr);                 // 2n + 2 words
+        unsigned* arrived = parent + 2 * (size_t)n + 2;                                 // 2n + 2 words
+        unsigned* ext = arrived + 2 * (size_t)n + 2;                                    // 8 words
+        unsigned* table = ext + 8;                                                      // 256 * n_units words
+        VD_HIP_CHECK(ctx, hipMemsetAsync(ext, 0xff, 12, st));
+        VD_HIP_CHECK(ctx, hipMemsetAsync(ext + 3, 0, 12, st));
+        hipLaunchKernelGGL(lbvh_extent_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, a->boxes, n, ext);
+        hipLaunchKernelGGL(lbvh_keys_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, a->boxes, n, ext, k[0], v[0]);
+        const unsigned blocks = (n_units + kSortWaves - 1u) / kSortWaves;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int x = pass & 1, y = x ^ 1;
+            hipLaunchKernelGGL(rs_count_kernel, dim3(blocks), dim3(64 * kSortWaves), 0, st, k[x], n, 8u * pass, n_units, table);
+            hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, st, table, 256u * n_units);
+            hipLaunchKernelGGL(rs_scatter_kernel, dim3(blocks), dim3(64 * kSortWaves), 0, st, k[x], v[x], n, 8u * pass, n_units, table, k[y], v[y]);
+        }
+        hipLaunchKernelGGL(lbvh_tree_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, k[0], v[0], a->boxes, n, a->tight, parent, arrived);
+        hipLaunchKernelGGL(lbvh_fit_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, n, a->tight, parent, arrived);
+    } else {
+        const int rc = vd_tlas_build_from_boxes(ctx, a->boxes, n, a->tight);
+        if (rc) return rc;
+        hipLaunchKernelGGL(tight_root_kernel, dim3(1), dim3(64), 0, st, a->tight, n);
+    }
+    VD_HIP_CHECK(ctx, hipGetLastError());
+    unsigned h_fallback = 0;
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_fallback, d_fb, 4, hipMemcpyDeviceToHost, st));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    a->tight_fallbacks = h_fallback;
+    if (h_fallback) { a->scene.tlas_nodes = a->user_tlas; a->scene.n_tlas_nodes = a->user_n_nodes; }      // declined: the reference's visit order is the only exact one here
+    else { a->scene.tlas_nodes = a->tight; a->scene.n_tlas_nodes = a->tight_mode == 2u ? 2u * n : 2u * n + 1u; }
+    return VD_OK;
+}
+
 bool scene_ok(const VdTraceScene* s) {
     return s && s->tlas_nodes && s->instances && s->meshes && s->bvh_nodes && s->vertices && s->indices && s->n_meshes &&
            s->n_tlas_nodes && s->n_instances;
@@ -1240,33 +1396,27 @@ int vd_trace_prepare_dev(VdCtx* ctx, const VdTraceScene* d_scene, VdTraceAccel**
         if (e != hipSuccess) VD_FAIL(ctx, VD_ERR_HIP, hipGetErrorString(e));
         VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace_prepare: a mesh's index range or a vertex index lies outside the scene's buffers");
     }
-    if (ctx->option(VD_OPT_TRACE_TIGHT_TLAS, 0) != 0 && d_scene->n_instances >= 2u && d_scene->n_instances <= VD_TLAS_MAX_INSTANCES) {
+    a->user_tlas = d_scene->tlas_nodes; a->user_n_nodes = d_scene->n_tlas_nodes;
+    const long long tight = ctx->option(VD_OPT_TRACE_TIGHT_TLAS, 0);
+    if (tight != 0 && d_scene->n_instances >= 2u && d_scene->n_instances <= (tight == 2 ? VD_TLAS_MAX_INSTANCES - 1u : VD_TLAS_MAX_INSTANCES)) {
         const unsigned n = d_scene->n_instances;
-        float* d_boxes = nullptr;           // not in the context's scratch: the builder lays that out for itself
-        unsigned h_fallback = 0;
-        bool good = hipMalloc(reinterpret_cast<void**>(&d_boxes), 24 * (size_t)n + 16) == hipSuccess &&
-                    hipMalloc(reinterpret_cast<void**>(&a->tight), sizeof(VdTlasNode) * (2 * (size_t)n + 1)) == hipSuccess;
-        if (good) {
-            unsigned* d_fb = reinterpret_cast<unsigned*>(d_boxes + 6 * (size_t)n);
-            (void)hipMemsetAsync(d_fb, 0, 4, ctx->stream);
-            hipLaunchKernelGGL(tight_boxes_kernel, dim3((n + 255u) / 256u), dim3(256), 0, ctx->stream, d_scene->instances, n, d_scene->meshes, d_scene->n_meshes,
-                               d_scene->bvh_nodes, d_scene->n_bvh_nodes, d_scene->tlas_nodes, d_scene->n_tlas_nodes, d_boxes, d_fb);
-            good = vd_tlas_build_from_boxes(ctx, d_boxes, n, a->tight) == VD_OK;
-            if (good) {
-                hipLaunchKernelGGL(tight_root_kernel, dim3(1), dim3(64), 0, ctx->stream, a->tight, n);
-                good = hipMemcpyAsync(&h_fallback, d_fb, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
-            }
-        }
-        (void)hipStreamSynchronize(ctx->stream);
-        if (d_boxes) (void)hipFree(d_boxes);
-        if (!good) {
+        a->tight_mode = tight == 2 ? 2u : 1u;
+        const size_t arr = ((size_t)n * 4 + 255) & ~(size_t)255;
+        const size_t lbvh_bytes = 4 * arr + 4 * (4 * (size_t)n + 4 + 8 + 256 * (size_t)((n + kSortUnit - 1u) / kSortUnit)) + 256;
+        bool good = hipMalloc(reinterpret_cast<void**>(&a->boxes), 24 * (size_t)n + 16) == hipSuccess &&       // (not in the context's scratch: the agglomerative builder lays that out for itself)
+                    hipMalloc(reinterpret_cast<void**>(&a->tight), sizeof(VdTlasNode) * (2 * (size_t)n + 1)) == hipSuccess &&
+                    (a->tight_mode != 2u || hipMalloc(reinterpret_cast<void**>(&a->lbvh), lbvh_bytes) == hipSuccess);
+        if (good) good = hipMemsetAsync(a->tight, 0, sizeof(VdTlasNode) * (2 * (size_t)n + 1), ctx->stream) == hipSuccess;      // slots a builder leaves unused read as leaves nobody reaches
+        int rc_t = good ? build_tight_tlas(ctx, a) : VD_ERR_OOM;
+        if (rc_t) {
+            (void)hipStreamSynchronize(ctx->stream);
+            if (a->boxes) (void)hipFree(a->boxes);
+            if (a->lbvh) (void)hipFree(a->lbvh);
             if (a->tight) (void)hipFree(a->tight);
             (void)hipFree(a->tris); delete a;
-            VD_FAIL(ctx, VD_ERR_OOM, "vd_trace_prepare: the private top level (VD_OPT_TRACE_TIGHT_TLAS) could not be built");
+            if (rc_t == VD_ERR_OOM) VD_FAIL(ctx, VD_ERR_OOM, "vd_trace_prepare: the private top level (VD_OPT_TRACE_TIGHT_TLAS) could not be allocated");
+            return rc_t;
         }
-        a->tight_fallbacks = h_fallback;
-        if (h_fallback) { (void)hipFree(a->tight); a->tight = nullptr; }      // declined: the reference's visit order is the only exact one here
-        else { a->scene.tlas_nodes = a->tight; a->scene.n_tlas_nodes = 2u * n + 1u; }
     }
     *out = a;
     return VD_OK;
@@ -1275,12 +1425,19 @@ int vd_trace_prepare_dev(VdCtx* ctx, const VdTraceScene* d_scene, VdTraceAccel**
 int vd_trace_accel_info(const VdTraceAccel* accel, VdTraceAccelInfo* out) {
     if (!accel || !out) return VD_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
-    out->tight_tlas = accel->tight ? 1u : 0u;
+    out->tight_tlas = (accel->tight && accel->scene.tlas_nodes == accel->tight) ? accel->tight_mode : 0u;
     out->n_tlas_nodes = accel->scene.n_tlas_nodes;
     out->tight_fallback_instances = accel->tight_fallbacks;
     out->triangle_bytes = 36ull * (accel->scene.n_indices / 3u);
     out->d_tlas_nodes = accel->scene.tlas_nodes;
     return VD_OK;
+}
+
+int vd_trace_accel_update_dev(VdCtx* ctx, VdTraceAccel* accel) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx || !accel) return VD_ERR_INVALID_ARG;
+    if (!accel->tight) return VD_OK;          // the scene's own top level is walked: the host refits that one (vd_tlas_refit_dev)
+    return build_tight_tlas(ctx, accel);
 }
 
 int vd_trace_release(VdCtx* ctx, VdTraceAccel* accel) {
@@ -1289,6 +1446,8 @@ int vd_trace_release(VdCtx* ctx, VdTraceAccel* accel) {
     (void)hipStreamSynchronize(ctx->stream);
     if (accel->tris) (void)hipFree(accel->tris);
     if (accel->tight) (void)hipFree(accel->tight);
+    if (accel->boxes) (void)hipFree(accel->boxes);
+    if (accel->lbvh) (void)hipFree(accel->lbvh);
     delete accel;
     return VD_OK;
 }

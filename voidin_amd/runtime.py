@@ -300,8 +300,12 @@ class Context:
         def info(self) -> dict:
             st = abi.TraceAccelInfo()
             self.ctx._chk(self.ctx.lib.vd_trace_accel_info(self.h, C.byref(st)))
-            return {"tight_tlas": bool(st.tight_tlas), "n_tlas_nodes": int(st.n_tlas_nodes), "tight_fallback_instances": int(st.tight_fallback_instances),
+            return {"tight_tlas": int(st.tight_tlas), "n_tlas_nodes": int(st.n_tlas_nodes), "tight_fallback_instances": int(st.tight_fallback_instances),
                     "triangle_bytes": int(st.triangle_bytes), "d_tlas_nodes": st.d_tlas_nodes}
+
+        def update(self):
+            """vd_trace_accel_update_dev: rebuild the private top level from the instance buffer as it is now."""
+            self.ctx._chk(self.ctx.lib.vd_trace_accel_update_dev(self.ctx.h, self.h))
 
         def close(self):
             if getattr(self, "h", None):
