@@ -223,6 +223,8 @@ typedef enum VdOption {
                                      DESIGN.md 3.5).  1 = one launch (A/B).  Calls with at least one ray per lane of the grid
                                      and scenes of >= 64 instances only; 8 B per ray + up to 96 MB of job slots in the context's
                                      grow-only scratch                                                             */
+    VD_OPT_TRACE_FAN_SLOTS = 26,  /* upper limit of the fan-out's job slots (default: 2 per ray, at most 2 Mi).  A wave that finds the
+                                     list full keeps its rays and runs them to the end; the tests use a small value to get there */
     VD_OPT_TRACE_TIGHT_TLAS = 28, /* 1: vd_trace_prepare_dev builds a PRIVATE top level for the prepared scene over tight
                                      world boxes (the 8 transformed corners of each instance's BLAS root box, WITHOUT the
                                      object-space seed of tlas.rs:39 that makes the reference's leaves overlap at the

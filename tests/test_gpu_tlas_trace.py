@@ -465,6 +465,29 @@ def test_trace_fan_out_gives_the_same_bytes(ctx, oracle, ctx_options, n_inst, ex
     acc.close()
 
 
+@pytest.mark.parametrize("slots", [0, 1000, 100_000])
+def test_trace_fan_out_with_a_job_list_that_fills_up(ctx, oracle, ctx_options, slots):
+    """The job list is full (VD_OPT_TRACE_FAN_SLOTS: 0, a few, some of what the call wants): waves that cannot reserve keep
+    their rays and run them to the end, the reserved-but-unusable slots read as empty - same bytes as the call without fan-out."""
+    import torch
+    scene = _fan_scene(oracle, 1500, 60.0, synth.SEED_BASE + 9)
+    rays = synth.primary_rays(synth.camera_uniform(eye=(0, 2.5, 45.0), pitch_deg=0), 720, 720)
+    n = len(rays)
+    ds = ctx.device_scene(scene)
+    acc = ctx.trace_prepare(ds)
+    d_rays, d_hits = ctx.upload(rays), ctx.empty(n * 16)
+    d_any = torch.zeros(n, dtype=torch.int32, device="cuda")
+    out = {}
+    for fan, cap in ((1, None), (3, slots), (4, slots)):
+        ctx_options("trace.fan", fan)
+        ctx_options("trace.fan_slots", cap)
+        d_hits.fill_(0xEE); d_any.fill_(7)
+        ctx.trace_prepared_dev(acc, d_rays, n, d_hits); ctx.trace_any_prepared_dev(acc, d_rays, n, d_any)
+        out[fan] = (d_hits.cpu().numpy().tobytes(), d_any.cpu().numpy().tobytes())
+    assert out[3] == out[1] and out[4] == out[1]
+    acc.close()
+
+
 def test_trace_records_survive_stale_slots_and_report_bad_leaves(ctx, oracle):
     """The per-call records of the walk (trace.hip, records_kernel): the two children of a TLAS node sit side by side at
     the LEFT child's index, tagged with the right child's.  An unreachable slot of the TLAS array may name the same left

@@ -1184,7 +1184,8 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     // per 64 rays the next 15 calls over it run as one launch with the plain kernels; then the fan-out is tried again.
     const bool fan_default = ctx->option(VD_OPT_TRACE_FAN, -1) < 0;
     if (phases > 1u && fan_default && ctx->fan_tlas == sc->tlas_nodes && ctx->fan_idle_calls != 0u) { phases = 1u; --ctx->fan_idle_calls; }
-    const unsigned fan_cap = (unsigned)std::min<size_t>((size_t)1 << 21, (size_t)n_rays * 2u);
+    unsigned fan_cap = (unsigned)std::min<size_t>((size_t)1 << 21, (size_t)n_rays * 2u);
+    if (ctx->option(VD_OPT_TRACE_FAN_SLOTS, -1) >= 0) fan_cap = (unsigned)std::min<long long>(fan_cap, ctx->option(VD_OPT_TRACE_FAN_SLOTS, -1));      // tests: a list that fills up
     const size_t best_bytes = ((size_t)n_rays * 8u + 255) & ~(size_t)255;
     const size_t fan_bytes = phases > 1u ? 256 + best_bytes + (size_t)fan_cap * sizeof(FanJob) : 0;
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, sort_at + fan_bytes);
