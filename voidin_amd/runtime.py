@@ -46,9 +46,9 @@ class Context:
             raise VoidinError(rc, "vd_ctx_create failed (need a gfx950 GPU; there is no CPU fallback)")
         self.h = h
         self.device = device
+        import torch
+        self.torch_device = torch.device("cuda", device)
         if use_torch_stream:
-            import torch
-            self.torch_device = torch.device("cuda", device)
             self.set_stream(torch.cuda.current_stream(self.torch_device).cuda_stream)
         self.apply_env_options()
 
