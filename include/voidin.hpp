@@ -451,6 +451,12 @@ class TraceScene {
     void trace_any(const VdRay* d_rays, uint32_t n_rays, uint32_t* d_hit) const {
         gpu_.check(vd_trace_any_prepared_dev(gpu_.ctx(), accel_, d_rays, n_rays, d_hit));
     }
+    // Opt-in (Gpu::set_option(VD_OPT_TRACE_TIGHT_TLAS, 1 or 2) before construction): the scene walks a private top level over
+    // tight world boxes - same hits, distances within 1e-5 (bit-equal in every test), not the reference's visit order.
+    // `info().tight_tlas` says whether it does (every instance must have inv_transform = transform^-1); `update()` rebuilds it
+    // from the instance buffer after the instances moved (compute_update.wgsl:10-28) - 2 = LBVH is the builder for that.
+    VdTraceAccelInfo info() const { VdTraceAccelInfo i{}; gpu_.check(vd_trace_accel_info(accel_, &i)); return i; }
+    void update() { gpu_.check(vd_trace_accel_update_dev(gpu_.ctx(), accel_)); }
 
    private:
     const Gpu& gpu_;

@@ -229,6 +229,26 @@ int main() {
             }
             gpu.set_option(VD_OPT_TRACE_YIELD, -1);
         }
+        // round 4: the opt-in private top level (agglomerative, then LBVH + an update): the instances here are translate + uniform scale
+        // with exact inverses, so every instance qualifies; hit flags and distances must be the exact walk's
+        for (int mode = 1; mode <= 2; ++mode) {
+            gpu.set_option(VD_OPT_TRACE_TIGHT_TLAS, mode);
+            voidin::TraceScene ts(gpu, ds);
+            gpu.set_option(VD_OPT_TRACE_TIGHT_TLAS, -1);
+            REQUIRE(ts.info().tight_tlas == (uint32_t)mode && ts.info().tight_fallback_instances == 0);
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) ts.update();                                         // same instances: the same top level again
+                ts.trace(d_rays, (uint32_t)rays.size(), d_hits);
+                ts.trace_any(d_rays, (uint32_t)rays.size(), d_any);
+                gpu.synchronize();
+                REQUIRE(hipMemcpy(got.data(), d_hits, sizeof(VdHit) * rays.size(), hipMemcpyDeviceToHost) == hipSuccess);
+                REQUIRE(hipMemcpy(any.data(), d_any, 4 * rays.size(), hipMemcpyDeviceToHost) == hipSuccess);
+                for (size_t i = 0; i < rays.size(); ++i) {
+                    REQUIRE(got[i].hit == hits[i].hit && any[i] == hits[i].hit);
+                    if (got[i].hit) REQUIRE(std::fabs(got[i].dist - hits[i].dist) <= 1e-5f * std::fabs(hits[i].dist));
+                }
+            }
+        }
         // one-rank DistEmitDraws == EmitDraws' compacted list (the RCCL library is bound at run time; skipped when it is not there)
         bool have_rccl = true;
         voidin::DistEmitDraws::Id id{};
