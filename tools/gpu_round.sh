@@ -55,8 +55,8 @@ ls -la $O
 echo "== traversal A/B with the tuning build's counters (lane-steps, entries per ray, timeline): exact walk, fan-out, tight top level"
 make -C voidin_amd/csrc tuning > /dev/null 2>&1
 { echo "# stress scene (2000 instances of a 131 k-triangle knot, 1 M primary rays), python tools/ab_trace.py; Mrays/s by HIP events";
-  python3 tools/ab_trace.py --reps 4 2>&1 | grep -v amdgpu.ids | head -4;
-  echo "## launches per call (VD_OPT_TRACE_FAN): 1 = the round-3 kernel"; AB_FAN=1,2,3,4 python3 tools/ab_trace.py --reps 3 2>&1 | grep -v amdgpu.ids | head -8;
+  python3 tools/ab_trace.py --reps 4 2>&1 | grep -v amdgpu.ids | head -10;
+  echo "## launches per call (VD_OPT_TRACE_FAN): 1 = the round-3 kernel"; AB_FAN=1,2,3,4 python3 tools/ab_trace.py --reps 3 2>&1 | grep -v amdgpu.ids | grep '^fan' | head -8;
   echo "## what the waves do (tuning build, ~2x slower; vd_debug_trace_counters / vd_debug_trace_timeline)";
   AB_COUNTERS=1 VOIDIN_HIP_LIB=$PWD/voidin_amd/csrc/libvoidin_hip_tuning.so python3 tools/ab_trace.py --reps 2 2>&1 | grep -v amdgpu.ids | head -14 | cut -c1-700;
   AB_FAN=1,3 AB_COUNTERS=1 VOIDIN_HIP_LIB=$PWD/voidin_amd/csrc/libvoidin_hip_tuning.so python3 tools/ab_trace.py --reps 2 2>&1 | grep -v amdgpu.ids | head -20 | cut -c1-700; } > $O/${R}_ab_trace.log 2>&1
