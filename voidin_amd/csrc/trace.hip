@@ -551,8 +551,12 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
 // persistent grid = 24 waves per CU); the chunked form takes the scene / supply structs.
 struct SceneArgs { const VdTlasNode* tlas; const VdInstance* inst; const VdMeshInfo* meshes; const VdBvhNode* bvh;
                    const float* verts; const unsigned* indices; unsigned n_meshes, yield; const float4* irec; const float4* tpair; const float4* mrec; };
+#ifndef VD_FAN_WPS
+#define VD_FAN_WPS 5
+#endif
 template <bool ANY, bool FAN>      // FAN: the fan-out's code is compiled in (calls that run as one launch use the kernel without it)
-__global__ __launch_bounds__(64, 6)   // second argument (HIP): waves per SIMD = 24 per CU
+__global__ __launch_bounds__(64, FAN ? VD_FAN_WPS : 6)   // second argument (HIP): waves per SIMD = 24 per CU; the fan-out's kernels take 96 registers at 5 per SIMD
+                                                         // instead of spilling 9-12 at 6 (124 -> 129 / 192 -> 202 Mrays/s, profiles/r04_ab_trace_fan_wps.log)
 void trace_single_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                          unsigned* __restrict__ overflow, unsigned* next_ray, const unsigned* __restrict__ gate, Fan fan) {
     if (gate && *gate == 0u) return;          // the call de-indexed the leaves itself and that went well: the other kernel runs
@@ -561,7 +565,7 @@ void trace_single_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n
     trace_body<ANY, false, false, FAN>(s, rays, src, out, out_any, overflow);
 }
 template <bool ANY, bool FAN>
-__global__ __launch_bounds__(64, 6)
+__global__ __launch_bounds__(64, FAN ? VD_FAN_WPS : 6)
 void trace_single_prep_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                               unsigned* __restrict__ overflow, unsigned* next_ray, const float* __restrict__ tris,
                               const unsigned* __restrict__ gate, Fan fan) {
