@@ -1296,9 +1296,13 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
                            d_out_count, states, ticket, n_tiles, first_instance);                                \
     } while (0)
     // fused form: tile size grows with n so that ticket + two barriers + look-back amortise while
-    // small inputs still spread over the chip.  variant > 0 forces a tile size (tools/ab_cull.py).
-    const int rounds = variant > 0 ? variant : (n_inst >= (4u << 20) ? 32 : (n_inst >= (5u << 18) ? 16 : (n_inst >= (1u << 18) ? 8 : 4)));
+    // small inputs still spread over the chip (a 100 k-instance scene in 1024-instance tiles is 98
+    // workgroups on 256 CUs; thresholds from profiles/r04_ab_cull_small.log).  variant > 0 forces a
+    // tile size (tools/ab_cull.py).
+    const int rounds = variant > 0 ? variant : (n_inst >= (4u << 20) ? 32 : (n_inst >= (5u << 18) ? 16 : (n_inst >= 600000u ? 8 : (n_inst >= 192000u ? 4 : (n_inst >= 48000u ? 2 : 1)))));
     switch (rounds) {
+        case 1: VD_LAUNCH_COMPACT(1); break;
+        case 2: VD_LAUNCH_COMPACT(2); break;
         case 4: VD_LAUNCH_COMPACT(4); break;
         case 8: VD_LAUNCH_COMPACT(8); break;
         case 16: VD_LAUNCH_COMPACT(16); break;
