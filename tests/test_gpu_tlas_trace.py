@@ -683,7 +683,7 @@ def _boxes_as_scene(boxes):
     return inst, meshes
 
 
-@pytest.mark.parametrize("helpers", ["1", "0"])
+@pytest.mark.parametrize("helpers", ["1", "0", "2"])
 def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, ctx_options, helpers):
     """The indexed build (tlas.hip, "build, indexed": pruned queries, two at a time - the one the chain needs and the one a
     merge would need) forced onto small inputs made of what can break it: identical and nested boxes (every union area
@@ -692,7 +692,7 @@ def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, ctx_options,
     ctx_options("tlas.index_min", 65)
     ctx_options("tlas.phase2", 64)
     ctx_options("tlas.refresh", 37)
-    ctx_options("tlas.spec", int(helpers))                                      # with / without the four helper waves
+    ctx_options("tlas.spec", int(helpers))                                      # with / without the four helper waves; 2: a helper WORKGROUP
 
     def cloud(n, seed, extent=60.0, size=4.0):
         u = synth.uniform01(seed, 0, 6 * n).reshape(n, 6).astype(np.float32)
@@ -741,11 +741,34 @@ def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, ctx_options,
         assert got["min"].view(np.uint32).tobytes() == want["min"].view(np.uint32).tobytes() and got["max"].view(np.uint32).tobytes() == want["max"].view(np.uint32).tobytes()
 
 
-def test_indexed_build_declines_when_every_area_ties(ctx, oracle):
+@pytest.mark.parametrize("spin_limit", [None, 0, 1, 40])
+def test_indexed_build_with_a_helper_workgroup_that_is_late_or_absent(ctx, oracle, ctx_options, spin_limit):
+    """VD_OPT_TLAS_SPEC = 2 (tlas.hip, "the two-workgroup form"): the speculative query runs on a second workgroup of the
+    same XCC and comes back through a mailbox.  Bounded waits decide what happens when the partner is not there: with a
+    spin limit of 0 the chain's workgroup closes the role at once (nobody can claim it: the launch leaves everything
+    untouched and the one-workgroup form queued behind it builds the tree); with 1 or 40 polls the first answers are
+    late, the chain stops asking and finishes on its own.  The same nodes every time."""
+    ctx_options("tlas.index_min", 65)
+    ctx_options("tlas.phase2", 64)
+    ctx_options("tlas.refresh", 200)
+    ctx_options("tlas.spec", 2)
+    if spin_limit is not None:
+        ctx_options("tlas.spin_limit", spin_limit)
+    for n, seed in ((3000, 21), (9000, 22)):
+        inst = synth.instances(n, seed=synth.SEED_BASE + seed, extent=150.0)
+        meshes = synth.mesh_infos()
+        want = oracle.tlas_build(inst, meshes)
+        for _ in range(2):                                                      # the mailbox is cleared per build
+            assert fields_equal(ctx.tlas_build(inst, meshes), want), (n, spin_limit)
+
+
+@pytest.mark.parametrize("spec", [1, 2])
+def test_indexed_build_declines_when_every_area_ties(ctx, oracle, ctx_options, spec):
     """Boxes that defeat the pruning (thousands of identical instances; a nest of boxes that all contain the origin cube):
     every union area ties, a query through the index would look into most slices, so the indexed build declines on the
     device and the plain chain queued behind it (16 workgroups at this size) starts over.  Same nodes as the oracle."""
     import time
+    ctx_options("tlas.spec", spec)                                              # 2: the chain's workgroup also tells its helper workgroup to leave
     n = 13000
     same = np.tile(np.array([[-1, -2, -3, 1, 2, 3]], np.float32), (n, 1))
     rng = np.random.default_rng(3)

@@ -541,7 +541,17 @@ constexpr unsigned kIxMaxInstances = 65536u;         // slice corners of 65536 e
 constexpr int kSortThreads = 512;
 
 struct __attribute__((aligned(16))) IxEntry { float mn[3]; unsigned slot; float mx[3]; unsigned node; };   // two 16-byte loads
-struct IxCtl { unsigned ok, fallback, pad[2]; };
+struct IxCtl { unsigned ok, fallback, done, pad; };      // done: the two-workgroup form finished the build (the one-workgroup form queued behind it returns)
+// Mailbox of the two-workgroup form (VD_OPT_TLAS_SPEC = 2): every 8-byte word is {payload : 32, tag : 32} and a message
+// is complete when all its words carry the same tag - the data is the flag, no fence, one store instruction per message.
+struct IxMail {
+    vd_u64 req[16];          // main -> helper: box[6], bound, ea, eb, last, b, epoch, flags
+    vd_u64 ans[16];          // helper -> main: key lo, key hi, e, node, box[6]
+    unsigned main_xcc;       // XCC id of the main workgroup + 1
+    unsigned claimed;        // 0 open, 1 a helper on the same XCC took the role, 2 closed by the main workgroup (nobody came)
+};
+constexpr unsigned kIxMailQuery = 1u, kIxMailExit = 2u;
+constexpr unsigned kIxClaimPolls = 40000u;               // ~20 ms: candidates that are not co-resident by then never will be
 
 __device__ __forceinline__ unsigned ix_spread6(unsigned x) {   // 5 bits -> every sixth bit
     return (x & 1u) | ((x & 2u) << 5) | ((x & 4u) << 10) | ((x & 8u) << 15) | ((x & 16u) << 20);
@@ -576,10 +586,10 @@ __global__ __launch_bounds__(kSortThreads) void tlas_index_kernel(const float* _
         if (lane == 0) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
     }
     if (__syncthreads_or(bad)) {                          // the fast arithmetic cannot order this input: plain chain
-        if (t == 0) { ctl->ok = 0u; ctl->fallback = 1u; }
+        if (t == 0) { ctl->ok = 0u; ctl->fallback = 1u; ctl->done = 0u; }
         return;
     }
-    if (t == 0) { ctl->ok = 1u; ctl->fallback = 0u; }
+    if (t == 0) { ctl->ok = 1u; ctl->fallback = 0u; ctl->done = 0u; }
     float scale[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -652,6 +662,8 @@ struct IxShared {
     IxRec res[2][8];                                     // by query parity: a wave may start the next query before the others
                                                          // have read this one's result; [4..7]: the helper waves' records
     unsigned work;                                       // slices looked into since the last check (the build declines when pruning fails)
+    unsigned role;                                       // two-workgroup form: 1 = this workgroup is the helper
+    unsigned msg[2][16];                                 // two-workgroup form: the message wave 0 received (main: the answer; helper: the request), by parity
     vd_u64 red[32];                                      // s_red of the plain chain (phase 2)
 };
 struct IxHit { vd_u64 key; unsigned e, node, slices; float box[6]; };   // slices: of the CALLING wave (the only field that differs between waves)
@@ -727,13 +739,14 @@ __device__ __forceinline__ unsigned ix_supers(const IxLds& L, const float (&tb)[
 // merge would give, and the chain takes it without asking.  About a third of all queries follow a merge.
 struct IxSpec { float box[6]; float bound; unsigned ea, eb, last, b; bool valid; };
 struct IxPair { IxHit main, spec; };
-template <int G, bool SPEC>
+template <int G, bool SPEC, int ROLE = 0>
 __device__ __forceinline__ IxPair ix_query(const IxEntry* entries, const IxLds& L, unsigned q, unsigned t_slot, const float (&tb)[6],
                                            unsigned e_t, float bound, IxProf* prof, const IxSpec& spec) {
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool helper = SPEC && wave >= (unsigned)G;
-    const unsigned w4 = helper ? wave - (unsigned)G : wave, ri = helper ? 4u + w4 : w4;
+    // ROLE 1: the workgroup is the remote helper (tlas_build_indexed_kernel<..., REMOTE>): its G waves answer `spec`
+    const bool helper = ROLE == 1 || (SPEC && wave >= (unsigned)G);
+    const unsigned w4 = ROLE == 1 ? wave : (helper ? wave - (unsigned)G : wave), ri = ROLE == 1 ? wave : (helper ? 4u + w4 : w4);
     IxShared* sh = L.sh;
     const unsigned p = q & 1u;
     long long t0 = 0;
@@ -905,13 +918,99 @@ static size_t ix_lds_bytes(unsigned n_slices, unsigned n_super, unsigned g, unsi
            (size_t)ix_cap2(n_slices, g) * 2 * waves + 16;            // lists: 2 bytes x waves
 }
 
-template <typename Node, int G, bool SPEC>
+// ---- the two-workgroup form (VD_OPT_TLAS_SPEC = 2) ----
+// The helper waves of the one-workgroup form share the SIMDs of the waves that answer the chain's own question (a query is
+// half VALU issue: 2884 -> 3350 cycles, plus ~400 of waiting for the helpers).  Here the speculative question goes to a
+// SECOND workgroup on another CU of the same XCC: the main workgroup posts {a U b, bound, ea, eb, last, b} before it
+// starts its own query, the helper answers through its own copy of the corner tables (same entries in global memory), and
+// the answer is picked up while thread 0 applies the merge.  Same XCC (checked with HW_REG_XCC_ID) = same L2, so the
+// entries need no agent-scope traffic: the main workgroup's stores are complete (vmcnt(0) + barrier) before the message
+// that follows them is posted, and the helper drops its L1 when it takes a message.  A merge that runs WHILE the helper
+// still reads is harmless: the answer is defined on the state the merge leaves, and entry ea / eb are excluded by entry
+// index, the relabelled last slot by value - the same result from either side of the merge; the corners only loosen.
+__device__ __forceinline__ unsigned ix_xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)); }   // HW_REG_XCC_ID[3:0]
+template <int N> __device__ __forceinline__ unsigned ix_lane_pick(const unsigned (&v)[N], unsigned lane) {
+    unsigned r = 0u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r = lane == (unsigned)i ? v[i] : r;
+    return r;
+}
+// The mailbox lives in the XCC's L2 (both workgroups sit behind it): plain stores (the L1 writes through) and reads that
+// are executed BY the L2 - a returning atomic OR with 0 (a load with sc0 may still hit the L1 when a workgroup is not
+// split over CUs: tried, the poll never saw the message).  An agent-scope store goes through to memory and, stores
+// being counted in vmcnt on gfx950, the first load wait of the query that follows pays for it; an agent-scope load
+// fetches from memory (~250 ns per hop: 2900 cycles of waiting per answer, profiles/r04_tlas_two_workgroups.log).
+__device__ __forceinline__ void ix_post(vd_u64* words, unsigned lane, unsigned n_words, unsigned payload, unsigned tag) {
+    if (lane < n_words) __hip_atomic_store(words + lane, ((vd_u64)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ vd_u64 ix_load_l2(const vd_u64* p) {
+    vd_u64 r;
+    const vd_u64 zero = 0ull;
+    asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p), "v"(zero) : "memory");
+    return r;
+}
+// one wave: wait for a complete message with tag `want` (or, want == 0, any tag newer than `after`); false on a timeout
+__device__ __forceinline__ bool ix_poll(const vd_u64* words, unsigned lane, unsigned n_words, unsigned want, unsigned after, unsigned limit,
+                                        unsigned& payload, unsigned& tag_out) {
+    unsigned spins = 0;
+    for (;;) {
+        vd_u64 w = 0ull;
+        if (lane < n_words) w = ix_load_l2(words + lane);            // one L2 atomic per word of the message, no more
+        const unsigned tag = (unsigned)(w >> 32);
+        const unsigned t0 = (unsigned)__builtin_amdgcn_readfirstlane((int)tag);
+        const bool same = __all(lane >= n_words || tag == t0);
+        if (same && (want ? t0 == want : (t0 != 0u && (int)(t0 - after) > 0))) { payload = (unsigned)w; tag_out = t0; return true; }
+        if (++spins > limit) return false;
+    }
+}
+
+// The helper workgroup: take the newest request, answer it, until told to leave (or nothing arrives for ~a second).
+template <int G>
+__device__ __forceinline__ void ix_helper_loop(const IxEntry* entries, const IxLds& L, IxMail* mail) {
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    IxShared* sh = L.sh;
+    ix_refresh(entries, L);
+    unsigned last = 0u, epoch = 0u, q = 0u;
+    for (unsigned it = 0;; ++it) {
+        unsigned* m = sh->msg[it & 1u];
+        if (wave == 0u) {
+            unsigned payload = 0u, tg = 0u;
+            const bool ok = ix_poll(mail->req, lane, 13u, 0u, last, kSpinLimit, payload, tg);
+            if (lane < 13u) m[lane] = payload;
+            if (lane == 0u) { m[14] = tg; m[15] = ok ? 1u : 0u; }
+            asm volatile("buffer_inv sc1" ::: "memory");           // what was stored before the message: not from this CU's L1
+        }
+        __syncthreads();
+        if (m[15] == 0u || (m[12] & kIxMailExit)) return;
+        last = m[14];
+        if (m[11] != epoch) { ix_refresh(entries, L); epoch = m[11]; }
+        if (m[12] & kIxMailQuery) {
+            IxSpec spec;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) spec.box[k] = __uint_as_float(m[k]);
+            spec.bound = __uint_as_float(m[6]); spec.ea = m[7]; spec.eb = m[8]; spec.last = m[9]; spec.b = m[10]; spec.valid = true;
+            const float none[6] = {0, 0, 0, 0, 0, 0};
+            const IxHit h = ix_query<G, false, 1>(entries, L, q++, 0u, none, 0u, 0.0f, nullptr, spec).main;
+            if (wave == 0u) {
+                const unsigned v[10] = {(unsigned)h.key, (unsigned)(h.key >> 32), h.e, h.node, __float_as_uint(h.box[0]), __float_as_uint(h.box[1]),
+                                        __float_as_uint(h.box[2]), __float_as_uint(h.box[3]), __float_as_uint(h.box[4]), __float_as_uint(h.box[5])};
+                ix_post(mail->ans, lane, 10u, ix_lane_pick(v, lane), last);
+            }
+        }
+    }
+}
+
+template <typename Node, int G, bool SPEC, bool REMOTE = false>
 __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_kernel(Node* __restrict__ nodes, unsigned n, IxEntry* entries, unsigned* slot_ent,
                                                                         unsigned E, float* sb, unsigned* slot_node, unsigned cap,
-                                                                        IxCtl* ctl, unsigned phase2_cnt, unsigned refresh_every, int profile) {
+                                                                        IxCtl* ctl, unsigned phase2_cnt, unsigned refresh_every, int profile,
+                                                                        IxMail* mail, unsigned spin_limit) {
     constexpr int kThreads = 64 * G * (SPEC ? 2 : 1), kWaves = kThreads / 64;
     constexpr bool spec_on = SPEC;
+    static_assert(!(SPEC && REMOTE), "the speculation runs either on this workgroup's helper waves or on the other workgroup");
     if (ctl->ok == 0u) return;                            // precondition failed: the plain chain is queued behind
+    if (!REMOTE && ctl->done != 0u) return;               // the two-workgroup form in front of this launch built the tree
     extern __shared__ __attribute__((aligned(16))) char smem[];
     IxLds L;
     L.n_slices = E / kIxSlice;
@@ -924,10 +1023,39 @@ __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_ke
     L.list1 = reinterpret_cast<unsigned short*>(p); p += (size_t)L.cap1 * 2 * kWaves;
     L.list2 = reinterpret_cast<unsigned short*>(p);
     const unsigned tid = threadIdx.x;
+    const unsigned wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < 32u) L.sh->red[tid] = ~0ull;
     if (tid < 16u) L.sh->res[tid >> 3][tid & 7u].key = ~0ull;   // records of waves that do not exist stay empty
+    if constexpr (REMOTE) {
+        // roles: workgroup 0 runs the chain; of the others, the first one that sits on the SAME XCC (= behind the same L2)
+        // becomes the helper, the rest leave.  Nobody in time: this launch leaves everything untouched and the
+        // one-workgroup form queued behind it runs.
+        if (blockIdx.x != 0u) {
+            if (tid == 0u) {
+                const unsigned me = ix_xcc_id() + 1u;
+                unsigned spins = 0u, m;
+                while ((m = __hip_atomic_load(&mail->main_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins <= kIxClaimPolls) {}
+                L.sh->role = (m == me && atomicCAS(&mail->claimed, 0u, 1u) == 0u) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (L.sh->role == 1u) ix_helper_loop<G>(entries, L, mail);
+            return;
+        }
+        if (tid == 0u) {
+            __hip_atomic_store(&mail->main_xcc, ix_xcc_id() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0u, c = 0u;
+            if (spin_limit != 0u)
+                while ((c = __hip_atomic_load(&mail->claimed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins <= kIxClaimPolls) {}
+            if (c == 0u) c = atomicCAS(&mail->claimed, 0u, 2u) == 0u ? 2u : 1u;      // closed - unless a helper got in first
+            L.sh->role = c;
+        }
+        __syncthreads();
+        if (L.sh->role != 1u) return;
+    }
     IxProf prof_data{0, 0, 0, 0, 0, 0, 0, 0, 0};
     IxProf* prof = profile ? &prof_data : nullptr;
+    unsigned long long t_wait = 0ull;                     // REMOTE: cycles wave 0 waited for answers; answers used / timed out
+    unsigned n_remote = 0u;
     ix_refresh(entries, L);                               // ends with a barrier
 
     // chain state: the same values in every thread
@@ -948,6 +1076,13 @@ __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_ke
     // every node this kernel wrote; the slot arrays were not touched).
     unsigned work = 0;                                    // per wave; the four are added up at a check
     unsigned next_check = 256u, last_check = 0u;
+    unsigned seq = 0u, epoch = 0u;                        // REMOTE: requests posted; refreshes done (the helper follows)
+    bool remote_ok = REMOTE;                              // false after a timeout: the chain asks its own questions from then on
+    auto post_exit = [&]() {
+        if constexpr (REMOTE) {
+            if (wave_id == 0u) ix_post(mail->req, tid, 13u, tid == 12u ? kIxMailExit : 0u, seq + 1u);
+        }
+    };
     if (tid == 0u) L.sh->work = 0u;
     auto take = [&](const IxHit& h, unsigned t_slot, unsigned e_t, unsigned node_t, const float (&tb)[6], unsigned& o_slot, unsigned& o_e,
                     unsigned& o_node, float (&o_box)[6]) {
@@ -972,6 +1107,7 @@ __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_ke
             __syncthreads();
             if ((unsigned long long)total > (unsigned long long)(L.n_slices / 8u + 1u) * (q - last_check)) {
                 if (tid == 0u) { ctl->fallback = 1u; ctl->ok = 0u; }
+                post_exit();
                 return;
             }
             if (tid == 0u) L.sh->work = 0u;                 // the next add is 256 queries (and as many barriers) away
@@ -984,11 +1120,22 @@ __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_ke
         float box_c[6];
         // if c comes back as a, the next question is best(a ∪ b) bounded by the previous chain element: prepare it meanwhile
         IxSpec spec;
-        spec.valid = spec_on && !a_stale && cnt - 1u != a && have_prev && e_prev != eb && e_prev != ea;
+        spec.valid = (spec_on || remote_ok) && !a_stale && cnt - 1u != a && have_prev && e_prev != eb && e_prev != ea;
         spec.ea = ea; spec.eb = eb; spec.last = cnt - 1u; spec.b = b;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { spec.box[k] = ix_min(box_a[k], box_b[k]); spec.box[3 + k] = ix_max(box_a[3 + k], box_b[3 + k]); }
         spec.bound = ix_union_area(spec.box, box_prev);
+        if constexpr (REMOTE) {
+            if (spec.valid) {                             // out before this workgroup's own query starts
+                seq += 1u;
+                if (wave_id == 0u) {
+                    const unsigned v[13] = {__float_as_uint(spec.box[0]), __float_as_uint(spec.box[1]), __float_as_uint(spec.box[2]),
+                                            __float_as_uint(spec.box[3]), __float_as_uint(spec.box[4]), __float_as_uint(spec.box[5]),
+                                            __float_as_uint(spec.bound), spec.ea, spec.eb, spec.last, spec.b, epoch, kIxMailQuery};
+                    ix_post(mail->req, tid, 13u, ix_lane_pick(v, tid), seq);
+                }
+            }
+        }
         const IxPair hit = ix_query<G, SPEC>(entries, L, q++, b, box_b, eb, bound, prof, spec);
         take(hit.main, b, eb, node_b, box_b, c, ec, node_c, box_c);
         if (a == c) {
@@ -1016,6 +1163,18 @@ __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_ke
                 else if (last != b) { entries[el_last].slot = b; slot_ent[b] = el_last; }
                 if (last >= 1u) el_last = slot_ent[last - 1u];                    // the next merge's last slot; after my own stores (same-thread order)
             }
+            if constexpr (REMOTE) {
+                if (spec.valid && wave_id == 0u) {        // the helper's answer, awaited while the merge's stores drain
+                    unsigned payload = 0u, tg = 0u;
+                    long long tw = 0;
+                    if (prof) tw = clock64();
+                    const bool ok = ix_poll(mail->ans, tid, 10u, seq, 0u, spin_limit, payload, tg);
+                    if (prof) t_wait += (unsigned long long)(clock64() - tw);
+                    unsigned* m = L.sh->msg[seq & 1u];
+                    if (tid < 10u) m[tid] = payload;
+                    if (tid == 0u) m[15] = ok ? 1u : 0u;
+                }
+            }
             if (have_prev && (e_prev == eb || e_prev == ea)) have_prev = false;   // prev is consumed (or names the merged entry)
             a_stale = last == a;
             node_a = used;
@@ -1027,12 +1186,28 @@ __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_ke
             if (refresh_every && ++since_refresh >= refresh_every) {
                 if (prof) tm = clock64();
                 ix_refresh(entries, L);
-                since_refresh = 0u;
+                since_refresh = 0u; epoch += 1u;
                 if (prof && tid == 0u) prof->t_refresh += (unsigned long long)(clock64() - tm);
             }
-            if (spec.valid) {                             // answered while best(b) was being worked out
+            bool answered = spec.valid;
+            if constexpr (REMOTE) {
+                if (spec.valid) {
+                    const unsigned* m = L.sh->msg[seq & 1u];
+                    if (m[15] != 0u) {
+                        IxHit h;
+                        h.key = ((vd_u64)m[1] << 32) | m[0]; h.e = m[2]; h.node = m[3]; h.slices = 0u;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) h.box[k] = __uint_as_float(m[4 + k]);
+                        take(h, a, ea, node_a, box_a, b, eb, node_b, box_b);
+                        n_remote += 1u;
+                    } else {                              // the helper did not answer in time: on our own from here on
+                        remote_ok = false; answered = false;
+                    }
+                }
+            } else if (spec.valid) {                      // answered while best(b) was being worked out
                 take(hit.spec, a, ea, node_a, box_a, b, eb, node_b, box_b);
-            } else {
+            }
+            if (!answered) {
                 const float bnd = have_prev ? ix_union_area(box_a, box_prev) : kNone;
                 take(ix_query<G, SPEC>(entries, L, q++, a, box_a, ea, bnd, prof, no_spec).main, a, ea, node_a, box_a, b, eb, node_b, box_b);
             }
@@ -1049,6 +1224,10 @@ __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_ke
                "cycles per query: bounds %.0f, entries %.0f, reduce+barrier %.0f; per merge %.0f; refresh total %llu\n",
                n, prof->queries, prof->own, (double)prof->n1 / prof->queries, (double)G * prof->n2 / prof->queries, (double)prof->t_bounds / prof->queries,
                (double)prof->t_entries / prof->queries, (double)prof->t_reduce / prof->queries, (double)prof->t_merge / (n - cnt), prof->t_refresh);
+    post_exit();
+    if (REMOTE && prof && tid == 0u)
+        printf("tlas indexed build, two workgroups: %u requests, %u answers used, helper %s; cycles wave 0 waited for an answer: %.0f per answer used\n",
+               seq, n_remote, remote_ok ? "alive" : "timed out", n_remote ? (double)t_wait / n_remote : 0.0);
     // ---- hand over to the plain scan: slot arrays from the live entries (+ the stale slot a the chain may still name) ----
     __syncthreads();
     for (unsigned e = tid; e < E; e += kThreads) {
@@ -1068,6 +1247,7 @@ __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_ke
     }
     __syncthreads();
     tlas_build_chain<Node, true, kThreads>(nodes, sb, slot_node, cap, L.sh->red, ChainState{cnt, used, a, b, true});
+    if (REMOTE && tid == 0u) ctl->done = 1u;
 }
 
 // ---- refit -------------------------------------------------------------------------------
@@ -1206,7 +1386,7 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     const size_t off_sort = off_map + (((size_t)n * 4 + 255) & ~(size_t)255);
     const size_t sort_stride = ((size_t)n * 4 + 255) & ~(size_t)255;
     const size_t off_ctl = off_sort + 4 * sort_stride;
-    const size_t need = indexed ? off_ctl + 256 : off_ent;
+    const size_t need = indexed ? off_ctl + 256 + ((sizeof(IxMail) + 255) & ~(size_t)255) : off_ent;
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
     if (rc) return rc;
     char* base = reinterpret_cast<char*>(ctx->scratch);
@@ -1232,29 +1412,39 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
         for (int k = 0; k < 4; ++k) keys[k] = reinterpret_cast<unsigned*>(base + off_sort + k * sort_stride);
         IxCtl* ctl = reinterpret_cast<IxCtl*>(base + off_ctl);
         const unsigned n_slices = E / kIxSlice, n_super = (n_slices + kIxSuper - 1u) / kIxSuper;
-        const bool spec = ctx->option(VD_OPT_TLAS_SPEC, 1) != 0;
+        IxMail* mail = reinterpret_cast<IxMail*>(base + off_ctl + 256);
+        const int spec_mode = (int)ctx->option(VD_OPT_TLAS_SPEC, 1);      // 0 none, 1 helper waves, 2 helper workgroup (then 1 if nobody shows up)
+        const bool spec = spec_mode != 0;
         hipLaunchKernelGGL(tlas_index_kernel, dim3(1), dim3(kSortThreads), 0, ctx->stream, sb, (unsigned)cap, n, E, keys[0], keys[1], keys[2], keys[3],
                            entries, slot_ent, ctl);
-        auto launch = [&](auto gc, auto sc) -> int {
+        auto launch = [&](auto gc, auto sc, auto rc_) -> int {
             constexpr int G = decltype(gc)::value;
-            constexpr bool S = decltype(sc)::value;
+            constexpr bool S = decltype(sc)::value, R = decltype(rc_)::value;
             constexpr unsigned waves = G * (S ? 2 : 1);
             const size_t lds = ix_lds_bytes(n_slices, n_super, G, waves);
-            constexpr int which = (std::is_same<Node, VdTlasNode>::value ? 0 : 1) + (S ? 2 : 0);
+            constexpr int which = (std::is_same<Node, VdTlasNode>::value ? 0 : 1) + (S ? 2 : 0) + (R ? 4 : 0);
             if (!ctx->tlas_ix_lds_opt_in[which]) {        // per context (= per device): up to 160 KB of dynamic LDS
                 constexpr unsigned max_slices = kIxMaxInstances / kIxSlice;
-                VD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tlas_build_indexed_kernel<Node, G, S>),
+                VD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tlas_build_indexed_kernel<Node, G, S, R>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       (int)ix_lds_bytes(max_slices, max_slices / kIxSuper, G, waves)));
                 ctx->tlas_ix_lds_opt_in[which] = true;
             }
-            hipLaunchKernelGGL((tlas_build_indexed_kernel<Node, G, S>), dim3(1), dim3(64 * waves), lds, ctx->stream, d_nodes, n, entries, slot_ent, E, sb,
-                               slot_node, (unsigned)cap, ctl, phase2, refresh, ctx->option(VD_OPT_TLAS_PROFILE, 0) ? 1 : 0);
+            // two-workgroup form: 32 workgroups, four per XCC - the chain runs on workgroup 0, one of the three others that
+            // land on its XCC becomes the helper, everybody else leaves at once
+            hipLaunchKernelGGL((tlas_build_indexed_kernel<Node, G, S, R>), dim3(R ? 32 : 1), dim3(64 * waves), lds, ctx->stream, d_nodes, n, entries, slot_ent, E, sb,
+                               slot_node, (unsigned)cap, ctl, phase2, refresh, ctx->option(VD_OPT_TLAS_PROFILE, 0) ? 1 : 0, mail, spin_limit);
             return 0;
         };
         using std::integral_constant;
-        // VD_TLAS_SPEC=0: without the helper waves (A/B)
-        const int lrc = spec ? launch(integral_constant<int, kIxGroup>{}, std::true_type{}) : launch(integral_constant<int, kIxGroup>{}, std::false_type{});
+        if (spec_mode == 2) {
+            VD_HIP_CHECK(ctx, hipMemsetAsync(mail, 0, sizeof(IxMail), ctx->stream));
+            const int rrc = launch(integral_constant<int, kIxGroup>{}, std::false_type{}, std::true_type{});
+            if (rrc) return rrc;
+        }
+        // VD_TLAS_SPEC=0: without the helper waves (A/B); behind the two-workgroup form: only if that one found no partner
+        const int lrc = spec ? launch(integral_constant<int, kIxGroup>{}, std::true_type{}, std::false_type{})
+                             : launch(integral_constant<int, kIxGroup>{}, std::false_type{}, std::false_type{});
         if (lrc) return lrc;
         // Decided on the device: leaf coordinates the fast arithmetic cannot order (NaN, inf, |x| >= 1e18), or boxes that
         // defeat the pruning (all union areas tie).  The indexed kernel then returned early and left the slot arrays as the

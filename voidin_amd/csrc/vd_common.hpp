@@ -47,7 +47,7 @@ struct VdCtx {
     hipStream_t aux_stream = nullptr;                          // copies that overlap a kernel on `stream`
     VdBvhBuildStats bvh_stats = {};                            // vd_bvh_last_build_stats
     bool mid_lds_opt_in = false;                               // blas_mid_kernel's dynamic-LDS attribute set on this device
-    bool tlas_ix_lds_opt_in[4] = {false, false, false, false};  // tlas_build_indexed_kernel<VdTlasNode / VdTlasNodeWide> x {plain, with helper waves}, likewise
+    bool tlas_ix_lds_opt_in[8] = {false, false, false, false, false, false, false, false};  // tlas_build_indexed_kernel<VdTlasNode / VdTlasNodeWide> x {plain, with helper waves}, likewise
 };
 
 // Every extern "C" entry point runs on the context's device: allocations, event records and launches otherwise go to
