@@ -371,7 +371,7 @@ def run_rank(args):
     step = step_fn(mode)
     ms_per_step = timed(step, args.steps, args.warmup)
 
-    breakdown, gather_modes, weak_line = None, None, None
+    breakdown, gather_modes, weak_line, bvh_replicas = None, None, None, None
     if distributed:
         # where a step goes at this N (every rank runs every leg; max over ranks, like the headline): the local cull to a
         # bitmask, the RCCL all-gather of the masks alone, and the expansion of ALL shards to the full draw list
@@ -413,6 +413,30 @@ def run_rank(args):
             if via_c:
                 sv_w.close()
             del sv_w, d_all_w, d_iw
+        if not args.no_extra:
+            # BASELINE's second metric at N GPUs.  The BLAS build of one mesh does not shard (every split is a
+            # global reduction over the node's segment, and the arrangement is order-dependent): REPLICAS ONLY - every rank
+            # builds a mesh of its own, no collective; aggregate = all ranks' triangles / the slowest rank's time.
+            import zlib
+            bu, bv_ = min(args.bvh_u, 1024), min(args.bvh_v, 1024)           # 2.1 M triangles per rank: bounded host time per rank
+            mv, mi = synth.knot_mesh(bu, bv_)
+            nt = len(mi) // 3
+            d_v, d_n = ctx.upload(mv), ctx.empty(2 * nt * 32)
+            t_b = []
+            for r_ in range(3):
+                d_ix = ctx.upload(mi)                                      # the build permutes the index buffer in place
+                barrier()
+                t0 = time.perf_counter()
+                nn = ctx.bvh_build_dev(d_v, len(mv), d_ix, nt, d_n, 2 * nt)
+                torch.cuda.synchronize()
+                t_b.append(max_over_ranks(time.perf_counter() - t0))
+            my_crc = zlib.crc32(d_n[: nn * 32].cpu().numpy().tobytes())
+            same = max_over_ranks(float(my_crc)) == float(my_crc) and max_over_ranks(-float(my_crc)) == -float(my_crc)   # max == min == mine
+            bvh_replicas = {"metric": "SAH BVH build Mprims/s, aggregate over ranks", "value": round(world * nt / min(t_b) / 1e6, 1),
+                            "tris_per_rank": nt, "ms_slowest_rank": round(min(t_b) * 1e3, 2), "ranks": world,
+                            "same_nodes_on_every_rank": bool(same), "nodes_crc32": my_crc,
+                            "note": "replicas only (SURVEY 8e): one mesh per rank, no collective; best of 3, max over ranks per build"}
+            del d_v, d_n, d_ix
         # leave d_all / d_cnt_all as a step of the headline mode on d_i leaves them
         step_no[0] = 0
         step()
@@ -505,6 +529,8 @@ def run_rank(args):
                              f"1-thread cull: {m / t1 / 1e6:.2f} M inst/s"}
 
     extra = {"cold_first_step_ms": round(cold_first_step_ms, 3)}
+    if bvh_replicas:
+        extra["bvh_build_replicas"] = bvh_replicas
     if gather_modes:
         extra["gather_modes"] = gather_modes
     if weak_line:

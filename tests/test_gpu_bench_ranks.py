@@ -46,3 +46,14 @@ def test_weak_scaling_mode_two_ranks():
                  "--no-cpu-baseline", env={"VOIDIN_DIST_BACKEND": "gloo"})
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["config"]["instances_total"] == 2000000
     assert two["config"]["verified_bit_exact_vs_oracle"] is True
+
+
+def test_two_ranks_report_the_second_metric_and_the_weak_run():
+    """Without --no-extra an N > 1 line also carries BASELINE's second metric at N GPUs - one BLAS build per rank, replicas
+    only, the same nodes on every rank - and the weak-scaled run next to the strong headline."""
+    two = _bench("--gpus", "2", "--instances", "400000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--bvh-u", "128", "--bvh-v", "64",
+                 env={"VOIDIN_DIST_BACKEND": "gloo"})
+    rep = two["extra"]["bvh_build_replicas"]
+    assert rep["ranks"] == 2 and rep["tris_per_rank"] == 2 * 128 * 64 and rep["same_nodes_on_every_rank"] is True and rep["value"] > 0
+    assert two["extra"]["weak_scaling"]["instances_total"] == 800000
+    assert two["value_full"] > 0 and two["value_shard"] > 0
