@@ -65,6 +65,7 @@ constexpr int kItem = VD_ITEM;          // phase A: positions per workgroup item
 constexpr int kPer = kItem / 256;       // positions per lane: position = rel0 + wave * (kItem / 4) + j * 64 + lane
 constexpr unsigned kMidEarlyMin = 256;  // mid-tier roots that make an early launch worth it (one per CU)
 constexpr int kBinItems = 8;            // a_bin_kernel: consecutive items per workgroup
+constexpr unsigned kFinalChunk = 128u;  // a_boundary_kernel: segments of the level that ended per workgroup
 #ifndef VD_MID_MAX
 #define VD_MID_MAX 2048
 #endif
@@ -262,9 +263,30 @@ constexpr unsigned kPay4Max = 1u << 25;
 
 // Cost of one candidate from binned statistics + the held-out `u` elements (blas.rs:149-155).
 // bins: [8][3] keys of the candidate's axis (non-u elements only); u list: payload + box.
+// The held-out elements of a node, staged once per node by lanes 0..20 of the evaluating wave: ids, predicate bits, box keys
+// and "this id came up before" (a trial's never-examined element can be the same triangle as an earlier trial's).  The 21
+// candidates used to walk the list themselves - 21 dependent box fetches from memory per lane, ~15 us per node with one
+// wave working (a_eval_kernel: 22 us a level; the mid tier: a tenth of a node's time, the other 15 waves at the barrier).
+struct EvalU { int key[kCand][6]; unsigned id[kCand], bits[kCand], dup; };
+__device__ __forceinline__ void eval_stage(EvalU& U, const u32x2* u_pay, const TriBox* __restrict__ boxes, unsigned lane) {
+    u32x2 v = {0u, 0u};
+    if (lane < (unsigned)kCand) {
+        v = u_pay[lane];
+        const TriBox bx = boxes[v.x];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { U.key[lane][q] = vd_key(bx.mn[q]); U.key[lane][3 + q] = vd_key(bx.mx[q]); }
+        U.id[lane] = v.x; U.bits[lane] = v.y;
+    }
+    bool dup = false;
+#pragma unroll
+    for (int i = 0; i < kCand - 1; ++i) { const unsigned o = (unsigned)__shfl((int)v.x, i); dup |= (unsigned)i < lane && lane < (unsigned)kCand && o == v.x; }
+    const unsigned long long m = __ballot(dup);
+    if (lane == 0u) U.dup = (unsigned)m;
+    vd_wave_lds_sync();
+}
 struct EvalIn {
     const int* bin_min; const int* bin_max;      // [8][3] for this axis
-    const u32x2* u_pay; const TriBox* boxes; int n_u; unsigned own_u;   // own_u = id of this candidate's u
+    const EvalU* u; unsigned own_u;              // own_u = id of this candidate's u
 };
 __device__ __forceinline__ float eval_candidate(const EvalIn& in, int axis, int k, float pos, unsigned n1, unsigned n) {
     int tmn[3] = {kBig, kBig, kBig}, tmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
@@ -277,16 +299,14 @@ __device__ __forceinline__ float eval_candidate(const EvalIn& in, int axis, int 
             else { fmn[q] = min(fmn[q], lo); fmx[q] = max(fmx[q], hi); }
         }
     }
-    for (int j = 0; j < in.n_u; ++j) {
-        const u32x2 v = in.u_pay[j];
-        bool dup = false;
-        for (int i = 0; i < j; ++i) dup |= in.u_pay[i].x == v.x;
-        if (dup) continue;
-        const TriBox bx = in.boxes[v.x];
-        const bool to_left = v.x != in.own_u && ((v.y >> (axis * 7 + k - 1)) & 1u);   // left = examined trues; u itself goes right
+    const unsigned dup = in.u->dup;
+    for (int j = 0; j < kCand; ++j) {
+        if ((dup >> j) & 1u) continue;
+        const unsigned id = in.u->id[j], bits = in.u->bits[j];
+        const bool to_left = id != in.own_u && ((bits >> (axis * 7 + k - 1)) & 1u);   // left = examined trues; u itself goes right
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const int lo = vd_key(bx.mn[q]), hi = vd_key(bx.mx[q]);
+            const int lo = in.u->key[j][q], hi = in.u->key[j][3 + q];
             if (to_left) { tmn[q] = min(tmn[q], lo); tmx[q] = max(tmx[q], hi); }
             else { fmn[q] = min(fmn[q], lo); fmx[q] = max(fmx[q], hi); }
         }
@@ -1219,7 +1239,7 @@ struct TopNode {                      // temporary top-tree node
 struct MidRoot { unsigned start, count, node, pad; int cbk[6]; int pad2[2]; };   // a segment the mid tier takes over
 
 struct LevelCtl {                     // device-side counters
-    unsigned n_seg, n_seg_next, n_items, n_top, n_small, err, n_mid, pad1;
+    unsigned n_seg, n_seg_next, n_items, n_top, n_small, err, n_mid, arrived;   // arrived: workgroups of a_boundary_kernel that have emitted their children
     unsigned max_count, max_count_next;       // largest segment of this / the next level (the host picks the round kernels by it)
     unsigned active, active_next;             // triangles in the segments of this / the next level
 };
@@ -1240,14 +1260,31 @@ __device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_s
 // level is evaluated once: bit c of bits21[x] = centroid[axis(c)] < pos[c].  At the start of a level an element's pos0 IS
 // its position, so this pass streams: centroid in, bits and the first payload (axis 0) out.
 template <typename P>
-__global__ __launch_bounds__(256) void a_bits_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
+__global__ __launch_bounds__(256) void a_bits_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                      typename P::T* __restrict__ pay, const f32x4* __restrict__ cent,
                                                      unsigned* __restrict__ bits21, unsigned* __restrict__ item_cnt) {
     __shared__ float s_pos[kCand + 3];
     __shared__ unsigned s_w[4];
     ItemCtx ic; const Seg* sg;
     if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
-    if (threadIdx.x < (unsigned)kCand) s_pos[threadIdx.x] = sg->pos[threadIdx.x];
+    // the 21 planes of the segment (blas.rs:142-146) from its centroid bounds; the segment's FIRST item also resets what the
+    // level accumulates in the record - child keys, bin keys, the rounds' windows - and leaves the planes there.  (All of
+    // that used to be a loop of the single-workgroup boundary kernel: 190 words x 1 859 segments through one CU, 100 us at
+    // the widest levels; here it is one store per lane.)
+    if (threadIdx.x < (unsigned)kCand) {
+        const int c = (int)threadIdx.x, axis = c / 7;
+        float cbmin[3] = {0.0f, 0.0f, 0.0f}, cbmax[3] = {0.0f, 0.0f, 0.0f};
+        cbmin[axis] = box_lo(sg->cbk[axis]); cbmax[axis] = box_hi(sg->cbk[3 + axis]);      // cand_pos reads this axis only
+        s_pos[c] = cand_pos(cbmin, cbmax, c);
+    }
+    if (blockIdx.x == sg->item_first) {
+        Seg& w = segs[ic.seg];
+        const unsigned t = threadIdx.x;
+        if (t < (unsigned)kCand) w.pos[t] = s_pos[t];
+        if (t < 24u) w.child_k[t] = (t % 6u) < 3u ? kBig : -kBig - 1;
+        if (t < 144u) { if (t < 72u) (&w.bin_min[0][0][0])[t] = kBig; else (&w.bin_max[0][0][0])[t - 72u] = -kBig - 1; }
+        if (t >= 252u && t < 255u) w.act[t - 252u] = 0u;
+    }
     if (threadIdx.x < 4u) s_w[threadIdx.x] = 0u;
     __syncthreads();
     unsigned t0 = 0;        // trues of round 0 in this wave (lane 0 runs every iteration of its wave)
@@ -1630,10 +1667,12 @@ __global__ __launch_bounds__(64) void a_eval_kernel(Seg* segs, LevelCtl* ctl, co
     if (blockIdx.x >= ctl->n_seg) return;
     Seg& sg = segs[blockIdx.x];
     const unsigned lane = threadIdx.x;
+    __shared__ EvalU s_u;
+    eval_stage(s_u, sg.u_pay, boxes, lane);
     vd_u64 key = ~0ull;
     if (lane < (unsigned)kCand) {
         const int c = (int)lane, a = c / 7, k = c % 7 + 1;
-        EvalIn in{&sg.bin_min[a][0][0], &sg.bin_max[a][0][0], sg.u_pay, boxes, kCand, sg.u_pay[c].x};
+        EvalIn in{&sg.bin_min[a][0][0], &sg.bin_max[a][0][0], &s_u, s_u.id[c]};
         const unsigned n1 = sg.ttot[c] - sg.u_p[c];
         key = cost_key(eval_candidate(in, a, k, sg.pos[c], n1, sg.count), (unsigned)c);
     }
@@ -1658,10 +1697,13 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
     __syncthreads();
     // [0,12): vertex boxes of the left / right child (blas.rs:115-123); [12,24): their centroid boxes, which are
     // the next level's `cb` (blas.rs:142) and save that level a pass
+    const unsigned Lst = sg->Lst;
+    // (A 12-key path for the items that lie wholly on one side of the pivot - all but one per segment - was measured: 3.64 ms
+    //  per build against 3.02, profiles/r04_blas_boundary.log; the per-element select between the halves is not what this
+    //  kernel waits for.)
     int k24[24];
 #pragma unroll
     for (int i = 0; i < 24; ++i) k24[i] = (i % 6) < 3 ? kBig : -kBig - 1;
-    const unsigned Lst = sg->Lst;
     for (unsigned xr = threadIdx.x; xr < ic.n_here; xr += 256u) {
         const unsigned x = ic.rel0 + xr;
         const unsigned id = P::pos(pay[sg->start + x]);
@@ -1693,89 +1735,144 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
     }
 }
 
-// one thread per segment: emit the two children, classify them, clear u flags
-__device__ __forceinline__ void finalize_segment(const Seg& sg, Seg* next, LevelCtl* ctl, TopNode* top, SmallRoot* small,
-                                                 unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap, MidRoot* mid, unsigned mid_cap,
-                                                 unsigned parity /* the set this level's a_child wrote */) {
-    for (int c = 0; c < kCand; ++c) is_u_flag[sg.u_pay[c].x] = 0;
-    const unsigned pair = atomicAdd(&ctl->n_top, 2u);
+// The level that ended emits its children, kFinalChunk segments per workgroup: one thread per segment reads its record,
+// clears the u flags and classifies the two children; the slots they need in the top-node array, the small / mid root lists
+// and the next level's segment list are counted in LDS and reserved by ONE global atomic per list and workgroup (the mid
+// tier of earlier levels runs on its own stream meanwhile and appends to the same lists), and then everything is written.
+// Before: one thread per segment with five returning global atomics each, all on the control words' cache line and in
+// divergent code (no wave aggregation) - 90 us at the widest levels - and 21 byte stores to the u flags, each followed by a
+// re-read of the record (a byte store may alias anything): 10 us for ONE segment (profiles/r04_blas_boundary.log).
+__device__ __forceinline__ void finalize_segments(const Seg* ended, unsigned n_ended, Seg* next, LevelCtl* ctl, unsigned* s_need,
+                                                  unsigned* s_base, TopNode* top, SmallRoot* small, unsigned char* is_u_flag, unsigned top_cap,
+                                                  unsigned small_cap, MidRoot* mid, unsigned mid_cap, unsigned parity /* the set this level's a_child wrote */) {
+    const unsigned tid = threadIdx.x;
+    const unsigned i = blockIdx.x * kFinalChunk + tid;
+    const bool act = tid < kFinalChunk && i < n_ended;
+    if (tid < 6u) s_need[tid] = 0u;                        // top, small, mid, next segments; largest count, triangles of the next level
+    __syncthreads();
+    int ck[24];
+    unsigned sg_start = 0, sg_count = 0, sg_Lst = 0, sg_node = 0, r_top = 0, r_slot[2] = {0u, 0u}, kind[2] = {0u, 0u}, cnt[2] = {0u, 0u};
+    if (act) {
+        const Seg& sg = ended[i];
+        unsigned uid[kCand];
+#pragma unroll
+        for (int c = 0; c < kCand; ++c) uid[c] = sg.u_pay[c].x;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) ck[k] = sg.child_k[k];
+        sg_start = sg.start; sg_count = sg.count; sg_Lst = sg.Lst; sg_node = sg.node;
+#pragma unroll
+        for (int c = 0; c < kCand; ++c) is_u_flag[uid[c]] = 0;
+        r_top = atomicAdd(&s_need[0], 2u);
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            cnt[side] = side == 0 ? sg_Lst : sg_count - sg_Lst;
+            if (cnt[side] <= 3u) kind[side] = 0u;                                   // leaf
+            else if (cnt[side] <= (unsigned)kSmallMax) { kind[side] = 2u; r_slot[side] = atomicAdd(&s_need[1], 1u); }
+            else if (cnt[side] <= (unsigned)kMidMax) { kind[side] = 3u; r_slot[side] = atomicAdd(&s_need[2], 1u); }
+            else { kind[side] = 4u; r_slot[side] = atomicAdd(&s_need[3], 1u); atomicMax(&s_need[4], cnt[side]); atomicAdd(&s_need[5], cnt[side]); }
+        }
+    }
+    __syncthreads();
+    if (tid < 4u) {
+        unsigned* g = tid == 0u ? &ctl->n_top : (tid == 1u ? &ctl->n_small : (tid == 2u ? &ctl->n_mid : &ctl->n_seg_next));
+        s_base[tid] = s_need[tid] ? atomicAdd(g, s_need[tid]) : 0u;
+    } else if (tid == 4u) { if (s_need[4]) atomicMax(&ctl->max_count_next, s_need[4]); }
+    else if (tid == 5u) { if (s_need[5]) atomicAdd(&ctl->active_next, s_need[5]); }
+    __syncthreads();
+    if (!act) return;
+    const unsigned pair = s_base[0] + r_top;
     if (pair + 2u > top_cap) { atomicOr(&ctl->err, 4u); return; }
-    top[sg.node].kind = 1u;
-    top[sg.node].left = pair;
+    top[sg_node].kind = 1u;
+    top[sg_node].left = pair;
+#pragma unroll
     for (int side = 0; side < 2; ++side) {
         TopNode t;
-        for (int q = 0; q < 3; ++q) { t.mn[q] = box_lo(sg.child_k[side * 6 + q]); t.mx[q] = box_hi(sg.child_k[side * 6 + 3 + q]); }
-        t.start = side == 0 ? sg.start : sg.start + sg.Lst;
-        t.count = side == 0 ? sg.Lst : sg.count - sg.Lst;
+        for (int q = 0; q < 3; ++q) { t.mn[q] = box_lo(ck[side * 6 + q]); t.mx[q] = box_hi(ck[side * 6 + 3 + q]); }
+        t.start = side == 0 ? sg_start : sg_start + sg_Lst;
+        t.count = cnt[side];
         t.left = 0; t.small = 0; t.pad = parity;
-        if (t.count <= 3u) {
+        if (kind[side] == 0u) {
             t.kind = 0u;
-        } else if (t.count <= (unsigned)kSmallMax) {
+        } else if (kind[side] == 2u) {
             t.kind = 2u;
-            const unsigned si = atomicAdd(&ctl->n_small, 1u);
+            const unsigned si = s_base[1] + r_slot[side];
             if (si < small_cap) small[si] = SmallRoot{t.start, t.count, pair + side, parity};
             else atomicOr(&ctl->err, 4u);
             t.small = si;
-        } else if (t.count <= (unsigned)kMidMax) {
+        } else if (kind[side] == 3u) {
             t.kind = 1u;
-            const unsigned mi = atomicAdd(&ctl->n_mid, 1u);
+            const unsigned mi = s_base[2] + r_slot[side];
             if (mi < mid_cap) {
                 MidRoot& m = mid[mi];
                 m.start = t.start; m.count = t.count; m.node = pair + side; m.pad = parity;
-                for (int q = 0; q < 6; ++q) m.cbk[q] = sg.child_k[12 + side * 6 + q];
+                for (int q = 0; q < 6; ++q) m.cbk[q] = ck[12 + side * 6 + q];
             } else atomicOr(&ctl->err, 4u);
         } else {
             t.kind = 1u;
-            const unsigned ni = atomicAdd(&ctl->n_seg_next, 1u);
-            atomicMax(&ctl->max_count_next, t.count);
-            atomicAdd(&ctl->active_next, t.count);
-            Seg& ns = next[ni];
+            Seg& ns = next[s_base[3] + r_slot[side]];
             ns.start = t.start; ns.count = t.count; ns.node = pair + side;
-            for (int q = 0; q < 6; ++q) ns.cbk[q] = sg.child_k[12 + side * 6 + q];
+            for (int q = 0; q < 6; ++q) ns.cbk[q] = ck[12 + side * 6 + q];
         }
         top[pair + side] = t;
     }
 }
 
-// The boundary between two levels as ONE single-workgroup launch (it was six: a_finalize, a_level_swap, a_seg_begin,
-// a_items_scan, a_items_fill, a_planes - each ~5.5 us in a dependent chain, on 15 levels): the level that ended emits its
-// children (segments of the next level, mid / small roots, leaves), the control words swap, and the next level's
-// segments get their items (count, first item, item -> segment map), reset child / bin keys and the 21 split planes.
-// `finalize` = 0 at the first level (its segments come from c_root_kernel).  Thousands of segments at most (each holds
-// more than kMidMax triangles), so one workgroup's loop is short next to the launches it replaces.
+// The boundary between two levels as ONE launch (it was six single-workgroup launches in a dependent chain on 15 levels,
+// then one single-workgroup launch that took 160 us at the widest levels: profiles/r04_blas_boundary.log): every workgroup
+// emits the children of kFinalChunk segments of the level that ended (finalize_segments); the LAST workgroup to arrive
+// then swaps the control words and sets the next level up - items per segment, first item, item -> segment map (the
+// records' child / bin keys and planes are reset by a_bits_kernel, on all CUs).  `finalize` = 0 at the first level (its
+// segments come from c_root_kernel; one workgroup).
 __global__ __launch_bounds__(1024) void a_boundary_kernel(const Seg* ended, Seg* segs, LevelCtl* ctl, TopNode* top, SmallRoot* small,
                                                           unsigned char* is_u_flag, unsigned top_cap, unsigned small_cap, MidRoot* mid,
                                                           unsigned mid_cap, unsigned parity, unsigned* item_seg, int finalize) {
-    __shared__ unsigned s_part[1024];
+    constexpr unsigned kFirstLds = 8192u;
+    __shared__ unsigned s_part[1024], s_first[kFirstLds], s_need[6], s_base[4], s_last;
     const unsigned tid = threadIdx.x;
+#ifdef VD_BOUNDARY_PROF
+    long long tp0 = clock64(), tp1 = tp0, tp2, tp3, tp4;
+    unsigned prof_ended = 0;
+#endif
     if (finalize) {
         const unsigned n_ended = ctl->n_seg;
-        for (unsigned i = tid; i < n_ended; i += 1024u) finalize_segment(ended[i], segs, ctl, top, small, is_u_flag, top_cap, small_cap, mid, mid_cap, parity);
-        __syncthreads();                                   // (workgroup-scope fence: the counters the threads added to are complete)
+#ifdef VD_BOUNDARY_PROF
+        prof_ended = n_ended;
+#endif
+        finalize_segments(ended, n_ended, segs, ctl, s_need, s_base, top, small, is_u_flag, top_cap, small_cap, mid, mid_cap, parity);
+        // the last workgroup to arrive goes on (its own and everybody else's records and counters are complete: release
+        // before the ticket, acquire after it)
+        if (gridDim.x > 1u) {                              // (a level of <= kFinalChunk segments is one workgroup: nothing to wait for, no fences)
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned ticket = __hip_atomic_fetch_add(&ctl->arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = ticket == gridDim.x - 1u ? 1u : 0u;
+            }
+            __syncthreads();
+            if (!s_last) return;
+            __threadfence();
+        } else __syncthreads();
         if (tid == 0) {
-            ctl->n_seg = ctl->n_seg_next; ctl->n_seg_next = 0; ctl->n_items = 0;
-            ctl->max_count = ctl->max_count_next; ctl->max_count_next = 0;
-            ctl->active = ctl->active_next; ctl->active_next = 0;
+            ctl->arrived = 0u;
+            ctl->n_seg = __hip_atomic_load(&ctl->n_seg_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ctl->n_seg_next = 0; ctl->n_items = 0;
+            ctl->max_count = __hip_atomic_load(&ctl->max_count_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ctl->max_count_next = 0;
+            ctl->active = __hip_atomic_load(&ctl->active_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ctl->active_next = 0;
         }
         __syncthreads();
     }
+#ifdef VD_BOUNDARY_PROF
+    tp1 = clock64();
+#endif
     const unsigned n = ctl->n_seg;
     const unsigned per = (n + 1023u) / 1024u;
     const unsigned lo = min(n, tid * per), hi = min(n, lo + per);
     unsigned sum = 0;
-    for (unsigned i = lo; i < hi; ++i) {
-        Seg& sg = segs[i];
-        sg.n_items = (sg.count + kItem - 1) / kItem;
-        sum += sg.n_items;
-        sg.act[0] = sg.act[1] = sg.act[2] = 0u;
-        for (int k = 0; k < 24; ++k) sg.child_k[k] = (k % 6) < 3 ? kBig : -kBig - 1;
-        for (int k = 0; k < 72; ++k) { (&sg.bin_min[0][0][0])[k] = kBig; (&sg.bin_max[0][0][0])[k] = -kBig - 1; }
-        float cbmin[3], cbmax[3];
-        for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(sg.cbk[k]); cbmax[k] = box_hi(sg.cbk[3 + k]); }
-        for (int c = 0; c < kCand; ++c) sg.pos[c] = cand_pos(cbmin, cbmax, c);
-    }
+    for (unsigned i = lo; i < hi; ++i) sum += (segs[i].count + kItem - 1) / kItem;      // loads only; n_items is stored with item_first below
     s_part[tid] = sum;
     __syncthreads();
+#ifdef VD_BOUNDARY_PROF
+    tp2 = clock64();
+#endif
     for (unsigned off = 1; off < 1024u; off <<= 1) {
         const unsigned v = tid >= off ? s_part[tid - off] : 0u;
         __syncthreads();
@@ -1783,17 +1880,40 @@ __global__ __launch_bounds__(1024) void a_boundary_kernel(const Seg* ended, Seg*
         __syncthreads();
     }
     unsigned run = s_part[tid] - sum;
-    for (unsigned i = lo; i < hi; ++i) { segs[i].item_first = run; run += segs[i].n_items; }
+    for (unsigned i = lo; i < hi; ++i) {
+        const unsigned ni = (segs[i].count + kItem - 1) / kItem;
+        segs[i].item_first = run; segs[i].n_items = ni;
+        if (i < kFirstLds) s_first[i] = run;
+        run += ni;
+    }
     const unsigned n_items = s_part[1023];
     if (tid == 1023u) ctl->n_items = n_items;
     __syncthreads();
+#ifdef VD_BOUNDARY_PROF
+    tp3 = clock64();
+#endif
     // item -> segment: every thread takes items tid, tid + 1024, ... and finds the last segment that starts at or before it
     // (one segment of thousands of items at the first levels, thousands of small ones later: either way a few steps)
-    for (unsigned j = tid; j < n_items; j += 1024u) {
-        unsigned a = 0, b = n;
-        while (b - a > 1u) { const unsigned m = (a + b) >> 1; if (segs[m].item_first <= j) a = m; else b = m; }
-        item_seg[j] = a;
+    // (the search runs on a copy of the first items in LDS: through the records in memory it was 12 dependent misses per item)
+    if (n <= kFirstLds) {
+        for (unsigned j = tid; j < n_items; j += 1024u) {
+            unsigned a = 0, b = n;
+            while (b - a > 1u) { const unsigned m = (a + b) >> 1; if (s_first[m] <= j) a = m; else b = m; }
+            item_seg[j] = a;
+        }
+    } else {
+        for (unsigned j = tid; j < n_items; j += 1024u) {
+            unsigned a = 0, b = n;
+            while (b - a > 1u) { const unsigned m = (a + b) >> 1; if (segs[m].item_first <= j) a = m; else b = m; }
+            item_seg[j] = a;
+        }
     }
+#ifdef VD_BOUNDARY_PROF
+    __syncthreads();
+    tp4 = clock64();
+    if (tid == 0) printf("a_boundary: ended %u, next %u segments, %u items; cycles: finalize %lld, set-up %lld, scan %lld, items %lld\n", prof_ended, n, n_items,
+                         tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
+#endif
 }
 
 // =============================================================================================
@@ -1816,6 +1936,7 @@ struct MidLds {
     unsigned wave_cnt[kMidThreads / 64];
     unsigned best, Lst, n_stack, pair;
     MidNode stack[16];
+    EvalU eval_u;
 };
 
 // one partition_shuffle of the node [s0, s0+n) on predicate bit `cc` (blas.rs:168-182 in closed form);
@@ -1961,10 +2082,11 @@ __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot*
         }
         __syncthreads();
         if (wave == 0u) {
+            eval_stage(L.eval_u, L.u_pay, boxes, lane);
             vd_u64 key = ~0ull;
             if (lane < (unsigned)kCand) {
                 const int c = (int)lane, a = c / 7, k = c % 7 + 1;
-                EvalIn in{&L.bin_min[a][0][0], &L.bin_max[a][0][0], L.u_pay, boxes, kCand, L.u_pay[c].x};
+                EvalIn in{&L.bin_min[a][0][0], &L.bin_max[a][0][0], &L.eval_u, L.eval_u.id[c]};
                 const unsigned n1 = L.ttot[c] - L.u_p[c];
                 key = cost_key(eval_candidate(in, a, k, L.pos[c], n1, n), (unsigned)c);
             }
@@ -2303,8 +2425,8 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
         hipLaunchKernelGGL((a_child_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, reinterpret_cast<const PT*>(P.pay0), cur.boxes,
                            cur.cent, nxt.boxes, nxt.cent);
         // this level's children + the next level's set-up: one launch (a_boundary_kernel)
-        hipLaunchKernelGGL(a_boundary_kernel, dim3(1), dim3(1024), 0, st, seg_cur, seg_next, P.ctl, P.top, P.small, P.is_u, top_cap, small_cap, P.mid, mid_cap,
-                           (unsigned)((level + 1) & 1), P.item_seg, 1);
+        hipLaunchKernelGGL(a_boundary_kernel, dim3((n_seg_now + kFinalChunk - 1u) / kFinalChunk), dim3(1024), 0, st, seg_cur, seg_next, P.ctl, P.top, P.small, P.is_u,
+                           top_cap, small_cap, P.mid, mid_cap, (unsigned)((level + 1) & 1), P.item_seg, 1);
     };
     // The mid tier does not wait for the last levels: segments <= kMidMax go to the mid list as they appear, and after
     // every level the roots listed since the last launch start on the second stream, beside the levels that remain
