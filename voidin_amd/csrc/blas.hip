@@ -1247,12 +1247,26 @@ struct LevelCtl {                     // device-side counters
 // Item geometry: item -> (segment, first relative position, valid count).  Lane order inside an
 // item is (wave, j, lane): position = rel0 + wave*256 + j*64 + lane.
 struct ItemCtx { unsigned seg, rel0, n_here; };
-__device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl, ItemCtx& ic, Seg const*& sg) {
-    if (blockIdx.x >= ctl->n_items) return false;
-    ic.seg = item_seg[blockIdx.x];
-    sg = segs + ic.seg;
-    ic.rel0 = (blockIdx.x - sg->item_first) * kItem;
-    ic.n_here = min((unsigned)kItem, sg->count - ic.rel0);
+// The head of a segment record, COPIED into registers once per workgroup (two scalar loads).  Through a `const Seg*` the
+// compiler re-read every field after every store that might alias it - the ISA of a_ranks_kernel was a chain of ~15
+// dependent loads, each followed by s_waitcnt 0, for a kernel that moves 4 bytes per lane (profiles/r04_blas_item_isa.txt).
+struct SegHead { unsigned start, count, node, item_first, n_items, best, Lst, ttot_cur, act[3], pad_act; };
+// The kernels read the head THROUGH the record (scalar loads, served by the scalar cache the segment's items share); a
+// copy of the 48 bytes into registers came out as three 16-byte VECTOR loads per lane and cost 8 ms per build
+// (-DVD_HEAD_COPY, profiles/r04_blas_item_isa.txt; with a readfirstlane'd index the copy is still vector loads).
+#ifdef VD_HEAD_COPY
+#define VD_HEAD_VIEW(sg, segs, ic) (void)0
+#else
+#define VD_HEAD_VIEW(sg, segs, ic) sg = reinterpret_cast<const SegHead*>((segs) + (ic).seg)
+#endif
+static_assert(offsetof(Seg, act) == offsetof(SegHead, act) && offsetof(Seg, ttot_cur) == offsetof(SegHead, ttot_cur), "SegHead mirrors the first words of Seg");
+__device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl, ItemCtx& ic, SegHead& h) {
+    const unsigned n_items = ctl->n_items, seg = item_seg[blockIdx.x];      // item_seg holds an entry for every workgroup of the grid
+    if (blockIdx.x >= n_items) return false;
+    ic.seg = seg;
+    h = *reinterpret_cast<const SegHead*>(segs + ic.seg);
+    ic.rel0 = (blockIdx.x - h.item_first) * kItem;
+    ic.n_here = min((unsigned)kItem, h.count - ic.rel0);
     return true;
 }
 
@@ -1265,8 +1279,9 @@ __global__ __launch_bounds__(256) void a_bits_kernel(Seg* segs, const unsigned* 
                                                      unsigned* __restrict__ bits21, unsigned* __restrict__ item_cnt) {
     __shared__ float s_pos[kCand + 3];
     __shared__ unsigned s_w[4];
-    ItemCtx ic; const Seg* sg;
-    if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
+    ItemCtx ic; SegHead hv; const SegHead* sg = &hv;
+    if (!item_ctx(segs, item_seg, ctl, ic, hv)) return;
+    VD_HEAD_VIEW(sg, segs, ic);
     // the 21 planes of the segment (blas.rs:142-146) from its centroid bounds; the segment's FIRST item also resets what the
     // level accumulates in the record - child keys, bin keys, the rounds' windows - and leaves the planes there.  (All of
     // that used to be a loop of the single-workgroup boundary kernel: 190 words x 1 859 segments through one CU, 100 us at
@@ -1274,7 +1289,7 @@ __global__ __launch_bounds__(256) void a_bits_kernel(Seg* segs, const unsigned* 
     if (threadIdx.x < (unsigned)kCand) {
         const int c = (int)threadIdx.x, axis = c / 7;
         float cbmin[3] = {0.0f, 0.0f, 0.0f}, cbmax[3] = {0.0f, 0.0f, 0.0f};
-        cbmin[axis] = box_lo(sg->cbk[axis]); cbmax[axis] = box_hi(sg->cbk[3 + axis]);      // cand_pos reads this axis only
+        cbmin[axis] = box_lo(segs[ic.seg].cbk[axis]); cbmax[axis] = box_hi(segs[ic.seg].cbk[3 + axis]);      // cand_pos reads this axis only
         s_pos[c] = cand_pos(cbmin, cbmax, c);
     }
     if (blockIdx.x == sg->item_first) {
@@ -1287,10 +1302,16 @@ __global__ __launch_bounds__(256) void a_bits_kernel(Seg* segs, const unsigned* 
     }
     if (threadIdx.x < 4u) s_w[threadIdx.x] = 0u;
     __syncthreads();
-    unsigned t0 = 0;        // trues of round 0 in this wave (lane 0 runs every iteration of its wave)
-    for (unsigned x = threadIdx.x; x < ic.n_here; x += 256u) {
-        const unsigned a = sg->start + ic.rel0 + x;
-        const f32x4 c = cent[a];
+    unsigned t0 = 0;        // trues of round 0 in this wave
+    const unsigned a0 = sg->start + ic.rel0;
+    f32x4 cv[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) { const unsigned x = threadIdx.x + 256u * (unsigned)j; cv[j] = cent[a0 + (x < ic.n_here ? x : 0u)]; }   // all loads first (see item_load)
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned x = threadIdx.x + 256u * (unsigned)j;
+        const bool in = x < ic.n_here;
+        const f32x4 c = cv[j];
         unsigned bits = 0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -1298,9 +1319,8 @@ __global__ __launch_bounds__(256) void a_bits_kernel(Seg* segs, const unsigned* 
             bits |= (c.y < s_pos[7 + k] ? 1u : 0u) << (7 + k);
             bits |= (c.z < s_pos[14 + k] ? 1u : 0u) << (14 + k);
         }
-        bits21[a] = bits;
-        pay[a] = P::make(a, bits, 0u);
-        t0 += (unsigned)__popcll(__ballot((bits & 1u) != 0u));
+        if (in) { bits21[a0 + x] = bits; pay[a0 + x] = P::make(a0 + x, bits, 0u); }
+        t0 += (unsigned)__popcll(__ballot(in && (bits & 1u) != 0u));
     }
     if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = t0;
     __syncthreads();
@@ -1315,29 +1335,42 @@ __global__ __launch_bounds__(256) void a_bits_kernel(Seg* segs, const unsigned* 
 // an axis and for the final shuffle), and copies the band [band, act) that the previous round froze, so that the
 // buffer it writes holds the whole arrangement again.  `r` is the round index 0..21.
 struct Window { unsigned band, act; };
-__device__ __forceinline__ Window round_window(const Seg* sg, int r) {
+__device__ __forceinline__ Window round_window(const SegHead* sg, int r) {
     Window w;
     if (r % 7 == 0) { w.band = w.act = 0u; }
     else { w.act = sg->act[r % 3]; w.band = (r % 7 == 1) ? 0u : sg->act[(r + 2) % 3]; }
     return w;
 }
 
-// predicates of the item's positions that lie in the shuffled window (positions below `act` stay out of the ballots)
+// the item's payloads: all loads first, unconditional (a lane past the item's end re-reads the item's first position) - inside
+// `if (in window)` every load was its own basic block with its own s_waitcnt 0: four serial round trips per lane
 template <typename P>
-__device__ __forceinline__ void item_masks(const Seg* sg, const ItemCtx& ic, const typename P::T* __restrict__ pay, int c,
+__device__ __forceinline__ void item_load(const SegHead* sg, const ItemCtx& ic, const typename P::T* __restrict__ pay, typename P::T (&vals)[kPer]) {
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const typename P::T* __restrict__ base = pay + sg->start + ic.rel0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned x = wave * (unsigned)(kItem / 4) + j * 64u + lane;
+#ifdef VD_OLD_LOAD
+        if (x < ic.n_here) vals[j] = base[x];
+#else
+        vals[j] = base[x < ic.n_here ? x : 0u];
+#endif
+    }
+}
+// predicates of the item's positions that lie in the shuffled window (positions below `act` stay out of the ballots)
+template <typename P, bool LOAD = true>
+__device__ __forceinline__ void item_masks(const SegHead* sg, const ItemCtx& ic, const typename P::T* __restrict__ pay, int c,
                                            unsigned act, unsigned long long (&masks)[kPer], typename P::T (&vals)[kPer]) {
     const unsigned cc = c >= 0 ? (unsigned)c : sg->best;
     const unsigned sh = P::shift(cc);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (LOAD) item_load<P>(sg, ic, pay, vals);
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const unsigned x = wave * (unsigned)(kItem / 4) + j * 64u + lane;
-        bool p = false;
-        if (x < ic.n_here && ic.rel0 + x >= act) {
-            vals[j] = pay[sg->start + ic.rel0 + x];
-            p = (P::word(vals[j]) >> sh) & 1u;
-        }
-        masks[j] = __ballot(p);
+        const bool in = x < ic.n_here && ic.rel0 + x >= act;
+        masks[j] = __ballot(in && ((P::word(vals[j]) >> sh) & 1u));
     }
 }
 
@@ -1348,17 +1381,21 @@ __global__ __launch_bounds__(256) void a_count_kernel(const Seg* segs, const uns
                                                       typename P::T* __restrict__ pay, int c, unsigned* item_cnt,
                                                       const unsigned* __restrict__ bits21, int refresh) {
     __shared__ unsigned s_w[4];
-    ItemCtx ic; const Seg* sg;
-    if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
+    ItemCtx ic; SegHead hv; const SegHead* sg = &hv;
+    if (!item_ctx(segs, item_seg, ctl, ic, hv)) return;
+    VD_HEAD_VIEW(sg, segs, ic);
     const Window win = round_window(sg, c >= 0 ? c : kCand);
     if (ic.rel0 + ic.n_here <= win.act) { if (threadIdx.x == 0) item_cnt[blockIdx.x] = 0u; return; }   // wholly frozen
     if (P::kRefresh && refresh) {
         const unsigned axis = (c >= 0 ? (unsigned)c : sg->best) / 7u;
-        for (unsigned x = threadIdx.x; x < ic.n_here; x += 256u) {
-            const unsigned a = sg->start + ic.rel0 + x;
-            const unsigned pos = P::pos(pay[a]);
-            pay[a] = P::make(pos, bits21[pos], axis);
-        }
+        const unsigned a0 = sg->start + ic.rel0;
+        unsigned ps[kPer], nb[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) { const unsigned x = threadIdx.x + 256u * (unsigned)j; ps[j] = P::pos(pay[a0 + (x < ic.n_here ? x : 0u)]); }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) nb[j] = bits21[ps[j]];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) { const unsigned x = threadIdx.x + 256u * (unsigned)j; if (x < ic.n_here) pay[a0 + x] = P::make(ps[j], nb[j], axis); }
         __syncthreads();       // item_masks re-reads them in another lane order (same workgroup: its own stores are visible)
     }
     unsigned long long masks[kPer]; typename P::T vals[kPer];
@@ -1415,22 +1452,38 @@ __global__ __launch_bounds__(1024) void a_scan_kernel(Seg* segs, const LevelCtl*
 // levels whose segments have <= 1024 items - all but the first few): every thread adds up to four of the segment's item
 // counts itself, two wave sums, and the result comes out of the barrier the kernel has anyway - the single-workgroup
 // scan between count and ranks (5.9 us, moves nothing) is not launched at those levels.
+// (the loads are a step of their own so that a kernel can issue them together with its payload loads: both need only the
+// segment's head)
 template <bool SF>
-__device__ __forceinline__ void prefix_begin(const Seg* sg, const unsigned* __restrict__ item_pre, unsigned* s_red) {
+__device__ __forceinline__ void prefix_load(const SegHead* sg, const unsigned* __restrict__ item_pre, unsigned (&v)[4]) {
+    if (!SF) return;
+    const unsigned ni = sg->n_items;
+    const unsigned* __restrict__ cn = item_pre + sg->item_first;       // SF: `item_pre` is the count array of the round
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned i = threadIdx.x + (unsigned)k * 256u;
+#ifdef VD_OLD_PREFIX
+        v[k] = 0u; if (i < ni) v[k] = cn[i];
+#else
+        v[k] = cn[i < ni ? i : 0u];                          // unconditional: in flight together
+#endif
+    }
+}
+template <bool SF>
+__device__ __forceinline__ void prefix_begin(const SegHead* sg, const unsigned (&v)[4], unsigned* s_red) {
     if (!SF) return;
     const unsigned mine = blockIdx.x - sg->item_first, ni = sg->n_items;
-    const unsigned* __restrict__ cn = item_pre + sg->item_first;       // SF: `item_pre` is the count array of the round
     unsigned pa = 0, pb = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const unsigned i = threadIdx.x + (unsigned)k * 256u;
-        if (i < ni) { const unsigned v = cn[i]; pb += v; pa += i < mine ? v : 0u; }
+        pb += i < ni ? v[k] : 0u; pa += i < mine ? v[k] : 0u;      // mine <= ni
     }
     pa = wave_sum_u(pa); pb = wave_sum_u(pb);
     if ((threadIdx.x & 63u) == 0u) { s_red[threadIdx.x >> 6] = pa; s_red[4u + (threadIdx.x >> 6)] = pb; }
 }
 template <bool SF>
-__device__ __forceinline__ void prefix_end(const Seg* sg, const unsigned* __restrict__ item_pre, const unsigned* s_red, unsigned& run, unsigned& ttot) {
+__device__ __forceinline__ void prefix_end(const SegHead* sg, const unsigned* __restrict__ item_pre, const unsigned* s_red, unsigned& run, unsigned& ttot) {
     if (SF) { run = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]); ttot = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]); }
     else { run = item_pre[blockIdx.x] - item_pre[sg->item_first]; ttot = sg->ttot_cur; }
 }
@@ -1442,19 +1495,23 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
                                                       unsigned* __restrict__ falsepos, unsigned* __restrict__ truepos,
                                                       unsigned* __restrict__ cnt_next) {
     __shared__ unsigned s_w[4], s_red[8];
-    ItemCtx ic; const Seg* sg;
-    if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
+    ItemCtx ic; SegHead hv; const SegHead* sg = &hv;
+    if (!item_ctx(segs, item_seg, ctl, ic, hv)) return;
+    VD_HEAD_VIEW(sg, segs, ic);
     if (cnt_next && threadIdx.x == 0) cnt_next[blockIdx.x] = 0u;      // a_apply of this round adds the next round's trues up in it
     const Window win = round_window(sg, c >= 0 ? c : kCand);
     if (ic.rel0 + ic.n_here <= win.act) return;             // wholly frozen
     unsigned long long masks[kPer]; typename P::T vals[kPer];
-    item_masks<P>(sg, ic, pay, c, win.act, masks, vals);
+    unsigned pv[4];
+    item_load<P>(sg, ic, pay, vals);
+    prefix_load<SF>(sg, item_pre, pv);
+    item_masks<P, false>(sg, ic, pay, c, win.act, masks, vals);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned t = 0;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
     if (lane == 0u) s_w[wave] = t;
-    prefix_begin<SF>(sg, item_pre, s_red);
+    prefix_begin<SF>(sg, pv, s_red);
     __syncthreads();
     unsigned run, ttot;
     prefix_end<SF>(sg, item_pre, s_red, run, ttot);
@@ -1508,8 +1565,9 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
                                                       const unsigned* __restrict__ truepos, unsigned char* __restrict__ is_u_flag,
                                                       const unsigned* __restrict__ bits21, unsigned* __restrict__ cnt_next) {
     __shared__ unsigned s_w[4], s_red[8];
-    ItemCtx ic; const Seg* sg;
-    if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
+    ItemCtx ic; SegHead hv; const SegHead* sg = &hv;
+    if (!item_ctx(segs, item_seg, ctl, ic, hv)) return;
+    VD_HEAD_VIEW(sg, segs, ic);
     const int r = c >= 0 ? c : kCand;
     const Window win = round_window(sg, r);
     const unsigned copy_from = mode == 2 ? 0u : win.band;
@@ -1517,52 +1575,80 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned own_cnt = 0;                                  // elements counted into this very item (wave-uniform)
     const unsigned sh_next = P::shift((unsigned)(r + 1)), axis_next = (unsigned)(r + 1) / 7u;
-    // the band the previous round froze: straight copy, so that `dst` holds the whole arrangement
+    // Loads first, stores last, nothing conditional in between (see item_load): the item's payloads, in mode 2 the 21 bits
+    // of each (every position of the segment is rewritten with the next axis' bits), then the rank tables, then the stores.
+    unsigned long long masks[kPer]; typename P::T vals[kPer];
+    unsigned pv[4];
+    item_load<P>(sg, ic, src, vals);
+    prefix_load<SF>(sg, item_pre, pv);
+    unsigned nb[kPer];
+    if (mode == 2 && P::kRefresh) {
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane, xa = ic.rel0 + xr;
-        bool pn = false;
-        if (xr < ic.n_here && xa >= copy_from && xa < win.act) {
-            typename P::T v = src[sg->start + xa];
-            if (mode == 2) {
-                if (P::kRefresh) v = P::make(P::pos(v), bits21[P::pos(v)], axis_next);
-                pn = (P::word(v) >> sh_next) & 1u;
+        for (int j = 0; j < kPer; ++j) nb[j] = bits21[P::pos(vals[j])];
+    }
+    // the band the previous round froze: straight copy, so that `dst` holds the whole arrangement
+    if (ic.rel0 < win.act && copy_from < win.act) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane, xa = ic.rel0 + xr;
+            bool pn = false;
+            if (xr < ic.n_here && xa >= copy_from && xa < win.act) {
+                typename P::T v = vals[j];
+                if (mode == 2) {
+                    if (P::kRefresh) v = P::make(P::pos(v), nb[j], axis_next);
+                    pn = (P::word(v) >> sh_next) & 1u;
+                }
+                dst[sg->start + xa] = v;
             }
-            dst[sg->start + xa] = v;
+            if (mode == 2) own_cnt += (unsigned)__popcll(__ballot(pn));
         }
-        if (mode == 2) own_cnt += (unsigned)__popcll(__ballot(pn));
     }
     if (ic.rel0 + ic.n_here <= win.act) {
         if (mode == 2 && own_cnt && lane == 0u) __hip_atomic_fetch_add(cnt_next + blockIdx.x, own_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     // predicates and TL are recomputed from the payload (cheaper than a per-position word through HBM)
-    unsigned long long masks[kPer]; typename P::T vals[kPer];
-    item_masks<P>(sg, ic, src, c, win.act, masks, vals);
+    item_masks<P, false>(sg, ic, src, c, win.act, masks, vals);
     unsigned t = 0;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
     if (lane == 0u) s_w[wave] = t;
-    prefix_begin<SF>(sg, item_pre, s_red);
+    prefix_begin<SF>(sg, pv, s_red);
     __syncthreads();
     unsigned run, ttot;
     prefix_end<SF>(sg, item_pre, s_red, run, ttot);
     for (unsigned w = 0; w < wave; ++w) run += s_w[w];
     // everything below is partition_shuffle on the window [act, n): positions relative to act
     const unsigned n = sg->count - win.act, s = sg->start + win.act, ftot = n - ttot;
-    bool counts[kPer]; unsigned land[kPer];      // counted after the loop: the four gathers stay in flight together
+    bool counts[kPer]; unsigned land[kPer];
+    bool in[kPer], pp[kPer], need_t[kPer], need_f[kPer];
+    unsigned xx[kPer], FF[kPer], TT[kPer], tp[kPer], fp[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
+        in[j] = xr < ic.n_here && ic.rel0 + xr >= win.act;
+        xx[j] = ic.rel0 + xr - win.act;
+        pp[j] = (masks[j] >> lane) & 1ull;
+        const unsigned tl = run + vd_mbcnt(masks[j]);
+        FF[j] = xx[j] - tl; TT[j] = ttot - tl - (pp[j] ? 1u : 0u);
+        need_t[j] = in[j] && FF[j] != 0u && FF[j] <= ttot;
+        need_f[j] = in[j] && TT[j] + 1u <= ftot;
+        run += (unsigned)__popcll(masks[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {                       // the eight gathers of a lane in flight together (index 0 of the window's tables exists)
+        tp[j] = truepos[s + (need_t[j] ? FF[j] - 1u : 0u)];
+        fp[j] = falsepos[s + (need_f[j] ? TT[j] : 0u)];
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
         counts[j] = false; land[j] = 0u;
-        if (xr < ic.n_here && ic.rel0 + xr >= win.act) {
-            const unsigned x = ic.rel0 + xr - win.act;
-            const bool p = (masks[j] >> lane) & 1ull;
-            const unsigned tl = run + vd_mbcnt(masks[j]);
-            const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
-            const long long tF = F == 0u ? (long long)n : (F <= ttot ? (long long)truepos[s + F - 1u] : -1ll);
+        if (in[j]) {
+            const unsigned x = xx[j];
+            const bool p = pp[j];
+            const long long tF = FF[j] == 0u ? (long long)n : (need_t[j] ? (long long)tp[j] : -1ll);
             const bool left = (long long)x < tF;
-            const unsigned fj = (T + 1u <= ftot) ? falsepos[s + T] : n;
+            const unsigned fj = need_f[j] ? fp[j] : n;
             const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
             const bool is_u = fetch == n - 1u;
             unsigned dest;
@@ -1572,7 +1658,7 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
             typename P::T v = vals[j];
             const unsigned upos = P::pos(v);
             if (mode == 2) {
-                if (P::kRefresh) v = P::make(upos, bits21[upos], axis_next);
+                if (P::kRefresh) v = P::make(upos, nb[j], axis_next);
                 counts[j] = (P::word(v) >> sh_next) & 1u;
             } else if (mode == 1) {
                 counts[j] = ((P::word(v) >> sh_next) & 1u) && (is_u || dest >= ttot);   // left of the pivot = frozen for the next round
@@ -1588,7 +1674,6 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
                 is_u_flag[upos] = 1;
             }
         }
-        run += (unsigned)__popcll(masks[j]);
     }
     if (mode != 0) {
 #pragma unroll
@@ -1638,14 +1723,24 @@ __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* i
             if (cur_seg != kNone) { __syncthreads(); flush(cur_seg); __syncthreads(); reset(); __syncthreads(); }
             cur_seg = seg;
         }
-        const Seg* sg = segs + seg;
-        const unsigned rel0 = (item - sg->item_first) * kItem;
-        const unsigned n_here = min((unsigned)kItem, sg->count - rel0);
-        for (unsigned xr = threadIdx.x; xr < n_here; xr += 256u) {
-            const unsigned pos = P::pos(pay[sg->start + rel0 + xr]);
-            if (is_u_flag[pos]) continue;
-            const TriBox bx = boxes[pos];
-            const unsigned b21 = bits21[pos];
+        const SegHead hv = *reinterpret_cast<const SegHead*>(segs + seg);
+        const unsigned rel0 = (item - hv.item_first) * kItem;
+        const unsigned n_here = min((unsigned)kItem, hv.count - rel0);
+        // positions first, then everything gathered by position, then the LDS atomics (see item_load)
+        const unsigned a0 = hv.start + rel0;
+        unsigned ps[kPer], b21s[kPer];
+        unsigned char us[kPer];
+        TriBox bxs[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) { const unsigned xr = threadIdx.x + 256u * (unsigned)j; ps[j] = P::pos(pay[a0 + (xr < n_here ? xr : 0u)]); }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) { us[j] = is_u_flag[ps[j]]; bxs[j] = boxes[ps[j]]; b21s[j] = bits21[ps[j]]; }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned xr = threadIdx.x + 256u * (unsigned)j;
+            if (xr >= n_here || us[j]) continue;
+            const TriBox bx = bxs[j];
+            const unsigned b21 = b21s[j];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const int b = 7 - __popc((b21 >> (7 * a)) & 0x7fu);   // bin = number of planes the centroid is not below
@@ -1691,8 +1786,9 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
                                                       const f32x4* __restrict__ cent, TriBox* __restrict__ boxes_next,
                                                       f32x4* __restrict__ cent_next) {
     __shared__ int s_k[24];
-    ItemCtx ic; const Seg* sg;
-    if (!item_ctx(segs, item_seg, ctl, ic, sg)) return;
+    ItemCtx ic; SegHead hv; const SegHead* sg = &hv;
+    if (!item_ctx(segs, item_seg, ctl, ic, hv)) return;
+    VD_HEAD_VIEW(sg, segs, ic);
     if (threadIdx.x < 24) s_k[threadIdx.x] = (threadIdx.x % 6) < 3 ? kBig : -kBig - 1;
     __syncthreads();
     // [0,12): vertex boxes of the left / right child (blas.rs:115-123); [12,24): their centroid boxes, which are
@@ -1704,11 +1800,22 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
     int k24[24];
 #pragma unroll
     for (int i = 0; i < 24; ++i) k24[i] = (i % 6) < 3 ? kBig : -kBig - 1;
-    for (unsigned xr = threadIdx.x; xr < ic.n_here; xr += 256u) {
+    // ids first, then the 48 bytes of each (all gathers of a lane in flight together: see item_load), then stores and keys
+    const unsigned a0 = sg->start + ic.rel0;
+    unsigned ids[kPer];
+    TriBox bxs[kPer];
+    f32x4 cs[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) { const unsigned xr = threadIdx.x + 256u * (unsigned)j; ids[j] = P::pos(pay[a0 + (xr < ic.n_here ? xr : 0u)]); }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) { bxs[j] = boxes[ids[j]]; cs[j] = cent[ids[j]]; }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned xr = threadIdx.x + 256u * (unsigned)j;
+        if (xr >= ic.n_here) continue;
         const unsigned x = ic.rel0 + xr;
-        const unsigned id = P::pos(pay[sg->start + x]);
-        const TriBox bx = boxes[id];
-        const f32x4 c = cent[id];
+        const TriBox bx = bxs[j];
+        const f32x4 c = cs[j];
         boxes_next[sg->start + x] = bx;
         cent_next[sg->start + x] = c;
         const float ce[3] = {c.x, c.y, c.z};
