@@ -92,25 +92,29 @@ __device__ __forceinline__ float pay_c(const u32x4& v, int axis) {
 __device__ __forceinline__ float box_lo(int key) { return vd_unkey(min(key, vd_key(1e30f))); }
 __device__ __forceinline__ float box_hi(int key) { return vd_unkey(max(key, vd_key(-1e30f))); }
 
-// Wave-wide min / max: inside a 16-lane row on the VALU (DPP), across the four rows through the LDS crossbar - two
-// crossbar moves instead of six (the crossbar is what phase B's shuffles saturate).
+// Wave-wide min / max / sum entirely on the VALU: inside a 16-lane row by DPP (quad_perm, row_half_mirror, row_mirror),
+// across the rows by row_bcast:15 (row r's last lane into row r + 1; rows 1 and 3 take it) and row_bcast:31 (lane 31
+// into rows 2 and 3), which leaves the result in lane 63; one v_readlane hands it to everybody.  (The two cross-row steps
+// were ds_bpermute round trips through the LDS crossbar, each with its s_waitcnt: 24 reductions per workgroup in
+// a_child_kernel = 48 dependent crossbar trips.)
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template <int CTRL, int ROWS> __device__ __forceinline__ int dpp_rows_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWS, 0xf, false); }
 __device__ __forceinline__ int wave_min_i(int v) {
     v = min(v, dpp_i<0xB1>(v)); v = min(v, dpp_i<0x4E>(v)); v = min(v, dpp_i<0x141>(v)); v = min(v, dpp_i<0x140>(v));
-    v = min(v, __shfl_xor(v, 16)); v = min(v, __shfl_xor(v, 32));
-    return v;
+    v = min(v, dpp_rows_i<0x142, 0xA>(v, v)); v = min(v, dpp_rows_i<0x143, 0xC>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_max_i(int v) {
     v = max(v, dpp_i<0xB1>(v)); v = max(v, dpp_i<0x4E>(v)); v = max(v, dpp_i<0x141>(v)); v = max(v, dpp_i<0x140>(v));
-    v = max(v, __shfl_xor(v, 16)); v = max(v, __shfl_xor(v, 32));
-    return v;
+    v = max(v, dpp_rows_i<0x142, 0xA>(v, v)); v = max(v, dpp_rows_i<0x143, 0xC>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
-__device__ __forceinline__ unsigned wave_sum_u(unsigned u) {      // every stage leaves a group's sum in all of its lanes
+__device__ __forceinline__ unsigned wave_sum_u(unsigned u) {
     int v = (int)u;
     v += dpp_i<0xB1>(v); v += dpp_i<0x4E>(v); v += dpp_i<0x141>(v); v += dpp_i<0x140>(v);
-    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-    return (unsigned)v;
+    v += dpp_rows_i<0x142, 0xA>(0, v); v += dpp_rows_i<0x143, 0xC>(0, v);
+    return (unsigned)__builtin_amdgcn_readlane(v, 63);
 }
 
 // min / max over the aligned group of 8 lanes a lane belongs to, on the VALU (DPP) - the LDS crossbar is what the
@@ -1252,8 +1256,9 @@ struct ItemCtx { unsigned seg, rel0, n_here; };
 // dependent loads, each followed by s_waitcnt 0, for a kernel that moves 4 bytes per lane (profiles/r04_blas_item_isa.txt).
 struct SegHead { unsigned start, count, node, item_first, n_items, best, Lst, ttot_cur, act[3], pad_act; };
 // The kernels read the head THROUGH the record (scalar loads, served by the scalar cache the segment's items share); a
-// copy of the 48 bytes into registers came out as three 16-byte VECTOR loads per lane and cost 8 ms per build
-// (-DVD_HEAD_COPY, profiles/r04_blas_item_isa.txt; with a readfirstlane'd index the copy is still vector loads).
+// copy of the 48 bytes into registers cost 8 ms per build as a struct assignment (three 16-byte VECTOR loads per lane, also
+// with a readfirstlane'd index) and 16 ms field by field (one s_load_dwordx8 + x2 + x1 batch): -DVD_HEAD_COPY,
+// profiles/r04_blas_item_isa.txt.
 #ifdef VD_HEAD_COPY
 #define VD_HEAD_VIEW(sg, segs, ic) (void)0
 #else
@@ -1264,7 +1269,12 @@ __device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_s
     const unsigned n_items = ctl->n_items, seg = item_seg[blockIdx.x];      // item_seg holds an entry for every workgroup of the grid
     if (blockIdx.x >= n_items) return false;
     ic.seg = seg;
-    h = *reinterpret_cast<const SegHead*>(segs + ic.seg);
+    {   // field by field: a struct assignment is lowered to a memcpy and comes out as vector loads
+        const SegHead* g = reinterpret_cast<const SegHead*>(segs + seg);
+        h.start = g->start; h.count = g->count; h.node = g->node; h.item_first = g->item_first;
+        h.n_items = g->n_items; h.best = g->best; h.Lst = g->Lst; h.ttot_cur = g->ttot_cur;
+        h.act[0] = g->act[0]; h.act[1] = g->act[1]; h.act[2] = g->act[2]; h.pad_act = 0u;
+    }
     ic.rel0 = (blockIdx.x - h.item_first) * kItem;
     ic.n_here = min((unsigned)kItem, h.count - ic.rel0);
     return true;
