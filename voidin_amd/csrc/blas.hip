@@ -2064,11 +2064,14 @@ __device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, 
     unsigned long long masks[kMidPer];
     unsigned t = 0;
 #pragma unroll
+    for (int j = 0; j < kMidPer; ++j) {                  // all reads first, unconditional (a lane past the end re-reads position 0): see item_load
+        const unsigned x = wave * 512u + j * 64u + lane;
+        v[j] = L.pay[s0 + (x < n ? x : 0u)];
+    }
+#pragma unroll
     for (int j = 0; j < kMidPer; ++j) {
         const unsigned x = wave * 512u + j * 64u + lane;
-        bool p = false;
-        if (x < n) { v[j] = L.pay[s0 + x]; p = (v[j].y >> cc) & 1u; }
-        masks[j] = __ballot(p);
+        masks[j] = __ballot(x < n && ((v[j].y >> cc) & 1u));
         t += (unsigned)__popcll(masks[j]);
     }
     if (lane == 0u) L.wave_cnt[wave] = t;
@@ -2091,6 +2094,18 @@ __device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, 
     __syncthreads();
     const unsigned ftot = n - ttot;
     unsigned dest[kMidPer];
+    unsigned short tps[kMidPer], fps[kMidPer];
+    run = before;
+#pragma unroll
+    for (int j = 0; j < kMidPer; ++j) {                  // the sixteen table reads of a lane in flight together
+        const unsigned x = wave * 512u + j * 64u + lane;
+        const bool p = (masks[j] >> lane) & 1ull;
+        const unsigned tl = run + vd_mbcnt(masks[j]);
+        const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
+        tps[j] = L.tpos[s0 + ((x < n && F != 0u && F <= ttot) ? F - 1u : 0u)];
+        fps[j] = L.fpos[s0 + ((x < n && T + 1u <= ftot) ? T : 0u)];
+        run += (unsigned)__popcll(masks[j]);
+    }
     run = before;
 #pragma unroll
     for (int j = 0; j < kMidPer; ++j) {
@@ -2100,9 +2115,9 @@ __device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, 
             const bool p = (masks[j] >> lane) & 1ull;
             const unsigned tl = run + vd_mbcnt(masks[j]);
             const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
-            const int tF = F == 0u ? (int)n : (F <= ttot ? (int)L.tpos[s0 + F - 1u] : -1);
+            const int tF = F == 0u ? (int)n : (F <= ttot ? (int)tps[j] : -1);
             const bool left = (int)x < tF;
-            const unsigned fj = (T + 1u <= ftot) ? (unsigned)L.fpos[s0 + T] : n;
+            const unsigned fj = (T + 1u <= ftot) ? (unsigned)fps[j] : n;
             const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
             const bool is_u = fetch == n - 1u;
             unsigned d;
@@ -2153,7 +2168,9 @@ __global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot*
         for (unsigned i2 = tid; i2 < 144u * 16u; i2 += kMidThreads) (&L.bins16[0][0])[i2] = ((i2 >> 4) % 6u) < 3u ? kBig : -kBig - 1;
         if (tid >= 192u && tid < 192u + 24u) L.child_k[tid - 192u] = ((tid - 192u) % 6u) < 3u ? kBig : -kBig - 1;
         __syncthreads();
-        // predicate bits of the 21 planes
+        // predicate bits of the 21 planes.  (Measured and not kept: 2 / 4 / 8 elements per lane and step with their gathers in
+        // flight together, here and in the bin and child loops - the 128-register budget of four workgroups per CU spills
+        // 143 registers instead of 36: 28.6 ms per build against 27.9; three or two workgroups per CU: 28.6 / 28.7.)
         for (unsigned x = tid; x < n; x += kMidThreads) {
             u32x2 v = L.pay[s0 + x];
             const f32x4 c = cent[v.x];
