@@ -30,7 +30,7 @@ echo "== rocprof kernel stats (BVH side)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kb -o bvh -- python3 tools/bench_bvh.py --u 2048 --v 2048 --reps 2 > $O/kb_stdout.log 2>&1
 find $O/kb -name "*kernel_trace.csv" -delete
 cp $(find $O/kb -name "bvh_kernel_stats.csv" | head -1) $O/${R}_bvh_kernel_stats.csv
-grep -v amdgpu.ids $O/kb_stdout.log | tail -12 > $O/${R}_bench_bvh.log
+grep -v amdgpu.ids $O/kb_stdout.log | tail -22 > $O/${R}_bench_bvh.log
 echo "== rocprof pmc"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o cull -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-extra > $O/pmc_fetch_stdout.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o cull -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-extra > $O/pmc_write_stdout.log 2>&1
