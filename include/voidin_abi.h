@@ -202,6 +202,8 @@ typedef enum VdOption {
                                      2: the speculative query runs on a second workgroup of the same XCC
                                      (measured slower: 205 vs 188 ms at 32 768)    */
     VD_OPT_TLAS_PROFILE = 17,     /* 1: the indexed build prints its in-kernel cycle counters             */
+    VD_OPT_TLAS_CHAIN_LDS = 18,   /* 0: the single-workgroup chain reads its slot arrays from memory even when
+                                     they would fit LDS (<= 4096 instances); default 1 (A/B)               */
     VD_OPT_BLAS_WIDE_PAYLOAD = 30,/* 1: vd_bvh_build moves the 8-byte payload (what meshes above 2^25 triangles use) at
                                      any size (tests); default 0                                                  */
     VD_OPT_TRACE_SORT = 21,       /* 1: vd_trace* bin the rays first (sorted by origin cell + direction) and hand them

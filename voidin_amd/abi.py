@@ -60,12 +60,12 @@ VD_DIST_ID_BYTES = 128
 # VdOption (include/voidin_abi.h); the environment names are read by the PYTHON harness only (Context.apply_env_options),
 # never by the library
 OPTIONS = {"cull.split_min": 1, "cull.variant": 2, "tlas.index": 10, "tlas.index_min": 11, "tlas.phase2": 12, "tlas.refresh": 13,
-           "tlas.groups": 14, "tlas.spin_limit": 15, "tlas.spec": 16, "tlas.profile": 17,
+           "tlas.groups": 14, "tlas.spin_limit": 15, "tlas.spec": 16, "tlas.profile": 17, "tlas.chain_lds": 18,
            "blas.wide_payload": 30, "trace.sort": 21, "trace.sort_min": 22, "trace.chunk": 23, "trace.yield": 24, "trace.waves": 25, "trace.auto_prepare": 27, "trace.tight_tlas": 28, "trace.fan": 29, "trace.fan_slots": 26}
 OPTION_ENV = {"VD_SPLIT_MIN": "cull.split_min", "VD_CULL_VARIANT": "cull.variant", "VD_TLAS_INDEX": "tlas.index",
               "VD_TLAS_INDEX_MIN": "tlas.index_min", "VD_TLAS_PHASE2": "tlas.phase2", "VD_TLAS_REFRESH": "tlas.refresh",
               "VD_TLAS_GROUPS": "tlas.groups", "VD_TLAS_SPIN_LIMIT": "tlas.spin_limit", "VD_TLAS_SPEC": "tlas.spec",
-              "VD_TLAS_PROFILE": "tlas.profile", "VD_TRACE_SORT": "trace.sort",
+              "VD_TLAS_PROFILE": "tlas.profile", "VD_TLAS_CHAIN_LDS": "tlas.chain_lds", "VD_TRACE_SORT": "trace.sort",
               "VD_TRACE_SORT_MIN": "trace.sort_min", "VD_TRACE_CHUNK": "trace.chunk", "VD_TRACE_YIELD": "trace.yield", "VD_TRACE_WAVES": "trace.waves", "VD_TRACE_AUTO_PREPARE": "trace.auto_prepare", "VD_TRACE_TIGHT_TLAS": "trace.tight_tlas", "VD_TRACE_FAN": "trace.fan"}
 
 STATUS_NAMES = {0: "VD_OK", -1: "VD_ERR_INVALID_ARG", -2: "VD_ERR_HIP", -3: "VD_ERR_DEGENERATE",

@@ -287,22 +287,37 @@ __device__ __forceinline__ void tlas_build_chain(Node* __restrict__ nodes, float
     if (threadIdx.x == 0) nodes[0] = nodes[slot_node[a]];   // tlas.rs:84
 }
 
-template <typename Node>
-__global__ __launch_bounds__(kBuildThreads) void tlas_build_kernel(Node* __restrict__ nodes, unsigned n,
+// `in_lds` (scenes of up to kChainLdsMax instances - the sizes the reference's demos have): the slot arrays move into LDS
+// before the chain starts, so a scan reads 24 B per slot at LDS latency instead of from the L2 (1 000 instances: 2 500
+// dependent scans of ~1.3 us, most of it the round trip of the loads).
+constexpr unsigned kChainLdsMax = 4096u;
+template <typename Node, int THREADS = kBuildThreads>
+__global__ __launch_bounds__(THREADS) void tlas_build_kernel(Node* __restrict__ nodes, unsigned n,
                                                                    float* sb, unsigned* slot_node,
-                                                                   unsigned cap, const unsigned* __restrict__ only_if) {
+                                                                   unsigned cap, const unsigned* __restrict__ only_if, int in_lds) {
     if (only_if && *only_if == 0u) return;                  // see tlas_build_impl
+    extern __shared__ __attribute__((aligned(16))) char chain_lds[];
     __shared__ vd_u64 s_red[32];   // [2][16] per-wave keys by scan parity
     if (threadIdx.x < 32) s_red[threadIdx.x] = ~0ull;
     int nan = 0;
-    for (unsigned i = threadIdx.x; i < n; i += kBuildThreads) {
+    for (unsigned i = threadIdx.x; i < n; i += THREADS) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) { const float v = sb[q * cap + i]; nan |= v != v; }
     }
     const bool any_nan = __syncthreads_or(nan) != 0;         // also orders the s_red initialisation
     const ChainState fresh{n, n + 1u, 0u, 0u, false};
-    if (any_nan) tlas_build_chain<Node, false>(nodes, sb, slot_node, cap, s_red, fresh);
-    else tlas_build_chain<Node, true>(nodes, sb, slot_node, cap, s_red, fresh);
+    if (in_lds) {
+        float* ls = reinterpret_cast<float*>(chain_lds);
+        unsigned* ln = reinterpret_cast<unsigned*>(ls + 6u * cap);
+        for (unsigned i = threadIdx.x; i < 6u * cap; i += THREADS) ls[i] = sb[i];      // (the slack past n is read 16 B at a time: copied too)
+        for (unsigned i = threadIdx.x; i < n; i += THREADS) ln[i] = slot_node[i];
+        __syncthreads();
+        if (any_nan) tlas_build_chain<Node, false, THREADS>(nodes, ls, ln, cap, s_red, fresh);
+        else tlas_build_chain<Node, true, THREADS>(nodes, ls, ln, cap, s_red, fresh);
+        return;
+    }
+    if (any_nan) tlas_build_chain<Node, false, THREADS>(nodes, sb, slot_node, cap, s_red, fresh);
+    else tlas_build_chain<Node, true, THREADS>(nodes, sb, slot_node, cap, s_red, fresh);
 }
 
 // ---- build, several workgroups ---------------------------------------------------------------
@@ -1401,6 +1416,22 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     if (groups > kMwMaxGroups) groups = kMwMaxGroups;
     if (groups > (unsigned)ctx->num_cus) groups = (unsigned)ctx->num_cus;
     if (n >= (1u << 20)) groups = 1u;
+    // the single-workgroup chain over LDS-resident slot arrays (28 B per slot) for small scenes
+    const int chain_in_lds = n <= kChainLdsMax && ctx->option(VD_OPT_TLAS_CHAIN_LDS, 1) != 0 ? 1 : 0;
+    const size_t chain_lds = chain_in_lds ? cap * 28 : 0;
+    if (chain_in_lds) {
+        constexpr int which = std::is_same<Node, VdTlasNode>::value ? 0 : 1;
+        if (!ctx->tlas_chain_lds_opt_in[which]) {
+            const int max_lds = (int)((((size_t)kChainLdsMax + 7) & ~(size_t)3) * 28);
+            VD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tlas_build_kernel<Node>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+            ctx->tlas_chain_lds_opt_in[which] = true;
+        }
+    }
+    // (fewer waves for small scenes - 256 lanes up to 1024 instances, 512 up to 2048 - were measured: no change; a scan is
+    //  ~1 us of dependent instructions whatever the size: target, loads, arithmetic, two reductions around one barrier)
+    auto launch_chain = [&](const unsigned* only_if) {
+        hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), chain_lds, ctx->stream, d_nodes, n, sb, slot_node, (unsigned)cap, only_if, chain_in_lds);
+    };
     vd_time_begin(ctx);
     VD_HIP_CHECK(ctx, hipMemsetAsync(d_nodes, 0, sizeof(Node) * (2 * (size_t)n + 1), ctx->stream));   // TlasNode::default()
     hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
@@ -1450,20 +1481,17 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
         // defeat the pruning (all union areas tie).  The indexed kernel then returned early and left the slot arrays as the
         // leaves kernel wrote them; the plain chain runs instead - on 16 workgroups where that pays, with ITS redo behind it.
         if (groups <= 1u) {
-            hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
-                               (unsigned)cap, (const unsigned*)&ctl->fallback);
+            launch_chain((const unsigned*)&ctl->fallback);
         } else {
             VD_HIP_CHECK(ctx, hipMemsetAsync(sh, 0, sizeof(MwShared), ctx->stream));
             hipLaunchKernelGGL((tlas_build_mw_kernel<Node>), dim3(groups * 8u), dim3(kMwThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
                                (unsigned)cap, sh, spin_limit, (const unsigned*)&ctl->fallback);
             hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
                                n_mesh, d_nodes, sb, slot_node, (unsigned)cap, 0, (const unsigned*)&sh->fail);
-            hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
-                               (unsigned)cap, (const unsigned*)&sh->fail);
+            launch_chain((const unsigned*)&sh->fail);
         }
     } else if (groups <= 1u) {
-        hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
-                           (unsigned)cap, (const unsigned*)nullptr);
+        launch_chain((const unsigned*)nullptr);
     } else {
         VD_HIP_CHECK(ctx, hipMemsetAsync(sh, 0, sizeof(MwShared), ctx->stream));
         hipLaunchKernelGGL((tlas_build_mw_kernel<Node>), dim3(groups * 8u), dim3(kMwThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
@@ -1473,8 +1501,7 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
         // on the device, so the call stays asynchronous.  Every node a build writes is written again by the redo.
         hipLaunchKernelGGL((tlas_leaves_kernel<Node>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_inst, n, d_meshes,
                            n_mesh, d_nodes, sb, slot_node, (unsigned)cap, 0, (const unsigned*)&sh->fail);
-        hipLaunchKernelGGL((tlas_build_kernel<Node>), dim3(1), dim3(kBuildThreads), 0, ctx->stream, d_nodes, n, sb, slot_node,
-                           (unsigned)cap, (const unsigned*)&sh->fail);
+        launch_chain((const unsigned*)&sh->fail);
     }
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());

@@ -46,6 +46,7 @@ struct VdCtx {
     void* host_stage = nullptr;  size_t host_stage_bytes = 0;  // grow-only pinned staging (BLAS top tree)
     hipStream_t aux_stream = nullptr;                          // copies that overlap a kernel on `stream`
     VdBvhBuildStats bvh_stats = {};                            // vd_bvh_last_build_stats
+    bool tlas_chain_lds_opt_in[2] = {false, false};              // tlas_build_kernel<VdTlasNode / VdTlasNodeWide>: dynamic LDS for the slot arrays
     bool mid_lds_opt_in = false;                               // blas_mid_kernel's dynamic-LDS attribute set on this device
     bool tlas_ix_lds_opt_in[8] = {false, false, false, false, false, false, false, false};  // tlas_build_indexed_kernel<VdTlasNode / VdTlasNodeWide> x {plain, with helper waves}, likewise
 };
