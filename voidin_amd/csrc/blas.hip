@@ -1804,9 +1804,6 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
     // [0,12): vertex boxes of the left / right child (blas.rs:115-123); [12,24): their centroid boxes, which are
     // the next level's `cb` (blas.rs:142) and save that level a pass
     const unsigned Lst = sg->Lst;
-    // (A 12-key path for the items that lie wholly on one side of the pivot - all but one per segment - was measured: 3.64 ms
-    //  per build against 3.02, profiles/r04_blas_boundary.log; the per-element select between the halves is not what this
-    //  kernel waits for.)
     int k24[24];
 #pragma unroll
     for (int i = 0; i < 24; ++i) k24[i] = (i % 6) < 3 ? kBig : -kBig - 1;
@@ -1822,12 +1819,49 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const unsigned xr = threadIdx.x + 256u * (unsigned)j;
+        if (xr < ic.n_here) { boxes_next[a0 + xr] = bxs[j]; cent_next[a0 + xr] = cs[j]; }
+    }
+#ifndef VD_CHILD24
+    // all but ONE item of a segment lie wholly on one side of the pivot: 12 running keys and 12 reductions instead of 24
+    // (27.6 ms per build against 27.85 with the 24-key form for every item, -DVD_CHILD24; before the loads of this kernel
+    // were issued together the same idea was SLOWER, 3.64 ms of a_child per build against 3.02)
+    const bool all_left = ic.rel0 + ic.n_here <= Lst, all_right = ic.rel0 >= Lst;
+    if (all_left || all_right) {
+        int k12[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) k12[i] = (i % 6) < 3 ? kBig : -kBig - 1;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned xr = threadIdx.x + 256u * (unsigned)j;
+            if (xr >= ic.n_here) continue;
+            const TriBox bx = bxs[j];
+            const float ce[3] = {cs[j].x, cs[j].y, cs[j].z};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                k12[q] = min(k12[q], vd_key(bx.mn[q]));
+                k12[3 + q] = max(k12[3 + q], vd_key(bx.mx[q]));
+                k12[6 + q] = min(k12[6 + q], vd_key_lo(ce[q]));
+                k12[9 + q] = max(k12[9 + q], vd_key_hi(ce[q]));
+            }
+        }
+        const unsigned o = all_left ? 0u : 6u;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const bool is_min = (i % 6) < 3;
+            const int r = is_min ? wave_min_i(k12[i]) : wave_max_i(k12[i]);
+            const unsigned slot = (i < 6 ? 0u : 12u) + o + (unsigned)(i % 6);
+            if ((threadIdx.x & 63u) == 0u) { if (is_min) atomicMin(&s_k[slot], r); else atomicMax(&s_k[slot], r); }
+        }
+    } else
+#endif
+    {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned xr = threadIdx.x + 256u * (unsigned)j;
         if (xr >= ic.n_here) continue;
         const unsigned x = ic.rel0 + xr;
         const TriBox bx = bxs[j];
         const f32x4 c = cs[j];
-        boxes_next[sg->start + x] = bx;
-        cent_next[sg->start + x] = c;
         const float ce[3] = {c.x, c.y, c.z};
         const int o = x < Lst ? 0 : 6;
 #pragma unroll
@@ -1843,6 +1877,7 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
         const bool is_min = (i % 6) < 3;
         const int r = is_min ? wave_min_i(k24[i]) : wave_max_i(k24[i]);
         if ((threadIdx.x & 63u) == 0u) { if (is_min) atomicMin(&s_k[i], r); else atomicMax(&s_k[i], r); }
+    }
     }
     __syncthreads();
     if (threadIdx.x < 24) {
