@@ -159,6 +159,14 @@ NOTES = {
     "trace_l2.txt": "`tools/gpu_prof_trace_l2.sh`: L1 / L2 / fabric counters of the traversal kernels per launch and per ray (rocprofv3 --pmc, one group per pass)",
     "trace_guard_isa.txt": "the toolchain finding behind the explicit `pos < limit` in the ray refill (ISA excerpt)",
     "tlas_nn_table_sim.log": "`tools/tlas_nn_table_sim.py`: hit rates of a nearest-neighbour table in the literal TLAS chain, by refresh interval",
+    "blas_item_isa.txt": "the ISA of `a_ranks_kernel` before / after (every load, wait and barrier in program order) and the same-box A/B series of round 4's BLAS work "
+                         "(`tools/gpu_blas_ab_multi.sh`): loads of an item in flight together, the segment head through the scalar cache, kernarg preload, DPP reductions, mid tier, a_child",
+    "blas_boundary.log": "in-kernel cycle stamps of `a_boundary_kernel` (-DVD_BOUNDARY_PROF) before / after it was spread over all CUs; `a_eval` / mid-tier evaluation staging",
+    "blas_two_stream_experiment.log": "measured and NOT kept: a level's rounds as two halves on two streams; two halves of the build with their own level loops",
+    "tlas_two_workgroups.log": "VERDICT r3 item 7, measured and not made the default: the indexed TLAS build's speculative query on a second workgroup of the same XCC (205 vs 188 ms) with the counters that say why; mailbox variants",
+    "tlas_chain_lds.log": "`tools/tlas_chain_lds_ab.py`: TLAS builds of <= 4096 instances with the chain's slot arrays in LDS against reading them from memory",
+    "ab_cull_small.log": "`tools/ab_cull.py --variants 0,1,2,4,8` at 1 k .. 1 M instances: tile size of the fused single-launch cull (the automatic choice is variant 0)",
+    "ab_trace_fan_wps.log": "the fan-out's kernels compiled for 4 / 5 / 6 waves per SIMD (spills against occupancy) on the stress scene",
 }
 
 
