@@ -2616,27 +2616,55 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
         stats.kernel_launches += 1;
         return VD_OK;
     };
-    while (n_seg > 0) {
-        const bool scan_free = (h_ctl.max_count + kItem - 1) / kItem <= 1024u;
-        if (wide_pay) run_level(Pay8{}, n_seg, seg_cur, seg_next, levels, scan_free); else run_level(Pay4{}, n_seg, seg_cur, seg_next, levels, scan_free);
-        VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_ctl, P.ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
-        VD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        if (h_ctl.err & ERR_DEGENERATE)
-            VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
-        if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
-        n_seg = h_ctl.n_seg;
-        Seg* t = seg_cur; seg_cur = seg_next; seg_next = t;
-        stats.kernel_launches += 5 + n_launch; n_launch = 0;
-        if (++levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
-        if (n_seg > 0 && h_ctl.n_mid >= mid_early + kMidEarlyMin) {     // enough new roots to be worth a launch beside the next level
-            if (!ctx->aux_stream) VD_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-            if (!ctx->ev_aux) VD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
-            const int rc_m = launch_mid(ctx->aux_stream, mid_early, h_ctl.n_mid - mid_early);    // the stream was synchronised just above
-            if (rc_m) return rc_m;
-            VD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_aux, ctx->aux_stream));
-            mid_early = h_ctl.n_mid;
-            aux_join.s = ctx->aux_stream;
+    // The host stays ONE LEVEL AHEAD of the device: level L + 1 is queued - its grids sized by what level L's exact counts
+    // allow (at most twice as many segments, none larger than level L's largest) - before the host waits for the control
+    // words level L leaves behind, so the device never idles for the round trip (~60 us per level before).  The kernels
+    // read the true counts from the control words; the level queued after the last real one finds no items and falls
+    // through.  Control words travel into pinned memory (two slots) behind an event each.
+    if (n_seg > 0) {
+        if (!ctx->lvl_pinned) VD_HIP_CHECK(ctx, hipHostMalloc(&ctx->lvl_pinned, 2 * sizeof(LevelCtl)));
+        for (int e = 0; e < 2; ++e)
+            if (!ctx->ev_lvl[e]) VD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lvl[e], hipEventDisableTiming));
+        LevelCtl* h_pin = reinterpret_cast<LevelCtl*>(ctx->lvl_pinned);
+        struct MainJoin {        // an error return must not leave queued levels running over scratch the next call reuses
+            hipStream_t s = nullptr;
+            ~MainJoin() { if (s) (void)hipStreamSynchronize(s); }
+        } main_join;
+        main_join.s = st;
+        auto queue_level = [&](unsigned n_seg_bound, unsigned max_count_bound) {
+            const bool scan_free = (max_count_bound + kItem - 1) / kItem <= 1024u;
+            if (wide_pay) run_level(Pay8{}, n_seg_bound, seg_cur, seg_next, levels, scan_free); else run_level(Pay4{}, n_seg_bound, seg_cur, seg_next, levels, scan_free);
+            Seg* t = seg_cur; seg_cur = seg_next; seg_next = t;
+            stats.kernel_launches += 5 + n_launch; n_launch = 0;
+            levels += 1;
+        };
+        queue_level(n_seg, h_ctl.max_count);                 // level 0: exact
+        unsigned bound = (unsigned)std::min<size_t>(2 * (size_t)n_seg, seg_cap), max_bound = h_ctl.max_count;
+        for (;;) {
+            const int slot = (levels - 1) & 1;               // the control words the last queued level leaves
+            VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_pin[slot], P.ctl, sizeof(LevelCtl), hipMemcpyDeviceToHost, st));
+            VD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_lvl[slot], st));
+            if (levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
+            queue_level(bound, max_bound);                   // one level ahead
+            VD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_lvl[slot]));
+            h_ctl = h_pin[slot];
+            if (h_ctl.err & ERR_DEGENERATE)
+                VD_FAIL(ctx, VD_ERR_DEGENERATE, "vd_bvh_build: every split candidate rejected (the reference builder crashes on this input)");
+            if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
+            n_seg = h_ctl.n_seg;
+            if (n_seg == 0) { levels -= 1; break; }          // the level just queued is empty
+            bound = (unsigned)std::min<size_t>(2 * (size_t)n_seg, seg_cap); max_bound = h_ctl.max_count;
+            if (h_ctl.n_mid >= mid_early + kMidEarlyMin) {   // enough new roots to be worth a launch beside the levels in flight
+                if (!ctx->aux_stream) VD_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+                if (!ctx->ev_aux) VD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
+                const int rc_m = launch_mid(ctx->aux_stream, mid_early, h_ctl.n_mid - mid_early);    // these roots are complete: the event above is behind their level
+                if (rc_m) return rc_m;
+                VD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_aux, ctx->aux_stream));
+                mid_early = h_ctl.n_mid;
+                aux_join.s = ctx->aux_stream;
+            }
         }
+        main_join.s = nullptr;
     }
     stats.levels_phase_a = (uint32_t)levels;
     lap(stats.ms_phase_a);

@@ -102,6 +102,8 @@ int vd_ctx_destroy(VdCtx* ctx) {
     if (ctx->stage_aux) (void)hipFree(ctx->stage_aux);
     if (ctx->host_pinned) (void)hipHostFree(ctx->host_pinned);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+    if (ctx->lvl_pinned) (void)hipHostFree(ctx->lvl_pinned);
+    for (int e = 0; e < 2; ++e) if (ctx->ev_lvl[e]) (void)hipEventDestroy(ctx->ev_lvl[e]);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);

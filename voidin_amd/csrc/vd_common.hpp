@@ -44,6 +44,7 @@ struct VdCtx {
     void* stage_aux = nullptr;   size_t stage_aux_bytes = 0;
     uint32_t* host_pinned = nullptr;                           // 64 u32 of pinned host memory
     void* host_stage = nullptr;  size_t host_stage_bytes = 0;  // grow-only pinned staging (BLAS top tree)
+    void* lvl_pinned = nullptr; hipEvent_t ev_lvl[2] = {nullptr, nullptr};   // BLAS level loop: control words of the last two levels (pinned) + their events
     hipStream_t aux_stream = nullptr;                          // copies that overlap a kernel on `stream`
     VdBvhBuildStats bvh_stats = {};                            // vd_bvh_last_build_stats
     bool tlas_chain_lds_opt_in[2] = {false, false};              // tlas_build_kernel<VdTlasNode / VdTlasNodeWide>: dynamic LDS for the slot arrays
