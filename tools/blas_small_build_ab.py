@@ -15,4 +15,4 @@ for (u, v) in ((88, 88), (256, 256), (724, 724)):
         d_i = ctx.upload(mi); torch.cuda.synchronize()
         t = time.perf_counter(); ctx.bvh_build_dev(d_v, len(mv), d_i, nt, d_n, 2 * nt); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
     st = ctx.bvh_last_build_stats()
-    print(f"{nt} triangles alone: best {min(ts[2:]) * 1e3:.3f} ms, median {np.median(ts[2:]) * 1e3:.3f} ms; levels {st['levels_phase_a'] if isinstance(st, dict) else getattr(st, 'levels_phase_a', '?')}", flush=True)
+    print(f"{nt} triangles alone: best {min(ts[2:]) * 1e3:.3f} ms, median {np.median(ts[2:]) * 1e3:.3f} ms; last build: {st}", flush=True)
