@@ -2164,7 +2164,8 @@ __device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, 
         }
         run += (unsigned)__popcll(masks[j]);
     }
-    __syncthreads();
+    // (no barrier here: every read of L.pay happened before the first barrier of this shuffle, and the tables read above are
+    //  not written again before the barrier below)
 #pragma unroll
     for (int j = 0; j < kMidPer; ++j)
         if (dest[j] != kNone) L.pay[s0 + dest[j]] = v[j];
