@@ -191,7 +191,7 @@ typedef enum VdOption {
                                      (pass 1 -> scan -> pass 2); default 2 Mi                            */
     VD_OPT_CULL_VARIANT = 2,      /* cull kernel variant (A/B; a small SIGNED id taken as is); default 0  */
     VD_OPT_TLAS_INDEX = 10,       /* 0: never use the indexed TLAS build; default 1                       */
-    VD_OPT_TLAS_INDEX_MIN = 11,   /* smallest n the indexed build takes; default 4096                     */
+    VD_OPT_TLAS_INDEX_MIN = 11,   /* smallest n the indexed build takes; default 6800                     */
     VD_OPT_TLAS_PHASE2 = 12,      /* clusters left at which the indexed build hands over to plain scans;
                                      default 2048                                                        */
     VD_OPT_TLAS_REFRESH = 13,     /* merges between two re-tightenings of the index corners; default 1024 */
@@ -203,7 +203,7 @@ typedef enum VdOption {
                                      (measured slower: 205 vs 188 ms at 32 768)    */
     VD_OPT_TLAS_PROFILE = 17,     /* 1: the indexed build prints its in-kernel cycle counters             */
     VD_OPT_TLAS_CHAIN_LDS = 18,   /* 0: the single-workgroup chain reads its slot arrays from memory even when
-                                     they would fit LDS (<= 4096 instances); default 1 (A/B)               */
+                                     they would fit LDS (<= 5600 instances); default 1 (A/B)               */
     VD_OPT_BLAS_WIDE_PAYLOAD = 30,/* 1: vd_bvh_build moves the 8-byte payload (what meshes above 2^25 triangles use) at
                                      any size (tests); default 0                                                  */
     VD_OPT_TRACE_SORT = 21,       /* 1: vd_trace* bin the rays first (sorted by origin cell + direction) and hand them

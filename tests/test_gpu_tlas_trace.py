@@ -20,8 +20,10 @@ def test_tlas_build_matches_golden(ctx, n):
     assert ctx.tlas_refit(g["instances"], g["meshes"], nodes).tobytes() == nodes.tobytes()
 
 
-@pytest.mark.parametrize("n", [1000, 4097])
+@pytest.mark.parametrize("n", [1000, 4097, 5600, 6003, 6900])
 def test_tlas_build_seeded_vs_oracle(ctx, oracle, n):
+    """Sizes on every default path of the build: the single-workgroup chain over LDS-resident slot arrays (up to 5600
+    instances), the same chain reading them from memory (up to VD_OPT_TLAS_INDEX_MIN = 6800), the indexed build above."""
     meshes = synth.mesh_infos()
     inst = synth.instances(n, seed=synth.SEED_BASE + 6, extent=300.0)
     want = oracle.tlas_build(inst, meshes)

@@ -290,7 +290,7 @@ __device__ __forceinline__ void tlas_build_chain(Node* __restrict__ nodes, float
 // `in_lds` (scenes of up to kChainLdsMax instances - the sizes the reference's demos have): the slot arrays move into LDS
 // before the chain starts, so a scan reads 24 B per slot at LDS latency instead of from the L2 (1 000 instances: 2 500
 // dependent scans of ~1.3 us, most of it the round trip of the loads).
-constexpr unsigned kChainLdsMax = 4096u;
+constexpr unsigned kChainLdsMax = 5600u;                 // 28 B per slot: 157 KB of the 160 KB LDS
 template <typename Node, int THREADS = kBuildThreads>
 __global__ __launch_bounds__(THREADS) void tlas_build_kernel(Node* __restrict__ nodes, unsigned n,
                                                                    float* sb, unsigned* slot_node,
@@ -1386,7 +1386,7 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     // LDS; above that the scans are spread over several workgroups.  Per-context options (vd_ctx_set_option):
     // VD_OPT_TLAS_INDEX = 0 switches it off (A/B), VD_OPT_TLAS_INDEX_MIN / _PHASE2 / _REFRESH tune it.
     const int env_index = (int)ctx->option(VD_OPT_TLAS_INDEX, 1);
-    const unsigned ix_min = (unsigned)ctx->option(VD_OPT_TLAS_INDEX_MIN, 4096);
+    const unsigned ix_min = (unsigned)ctx->option(VD_OPT_TLAS_INDEX_MIN, 6800);    // below: the chain is faster (from LDS up to 5600 instances; tools/tlas_index_min_ab.py)
     unsigned phase2 = (unsigned)ctx->option(VD_OPT_TLAS_PHASE2, 2048);
     const unsigned refresh = (unsigned)ctx->option(VD_OPT_TLAS_REFRESH, 1024);
     if (phase2 < 64u) phase2 = 64u;
