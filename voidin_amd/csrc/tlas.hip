@@ -1020,7 +1020,7 @@ template <typename Node, int G, bool SPEC, bool REMOTE = false>
 __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_kernel(Node* __restrict__ nodes, unsigned n, IxEntry* entries, unsigned* slot_ent,
                                                                         unsigned E, float* sb, unsigned* slot_node, unsigned cap,
                                                                         IxCtl* ctl, unsigned phase2_cnt, unsigned refresh_every, int profile,
-                                                                        IxMail* mail, unsigned spin_limit) {
+                                                                        IxMail* mail, unsigned spin_limit, int chain_in_lds) {
     constexpr int kThreads = 64 * G * (SPEC ? 2 : 1), kWaves = kThreads / 64;
     constexpr bool spec_on = SPEC;
     static_assert(!(SPEC && REMOTE), "the speculation runs either on this workgroup's helper waves or on the other workgroup");
@@ -1244,24 +1244,35 @@ __global__ __launch_bounds__(64 * G * (SPEC ? 2 : 1)) void tlas_build_indexed_ke
         printf("tlas indexed build, two workgroups: %u requests, %u answers used, helper %s; cycles wave 0 waited for an answer: %.0f per answer used\n",
                seq, n_remote, remote_ok ? "alive" : "timed out", n_remote ? (double)t_wait / n_remote : 0.0);
     // ---- hand over to the plain scan: slot arrays from the live entries (+ the stale slot a the chain may still name) ----
+    // The corner tables are dead from here on: the slot arrays of the <= phase2_cnt clusters that are left go where they
+    // were, in LDS (the host sized the allocation for both), and the ~3 scans per remaining merge read them there.
     __syncthreads();
-    for (unsigned e = tid; e < E; e += kThreads) {
-        const float4 lo = reinterpret_cast<const float4*>(entries + e)[0], hi = reinterpret_cast<const float4*>(entries + e)[1];
-        const unsigned slot = __float_as_uint(lo.w);
-        if (slot != kIxDead) {
-            sb[slot] = lo.x; sb[cap + slot] = lo.y; sb[2 * cap + slot] = lo.z;
-            sb[3 * cap + slot] = hi.x; sb[4 * cap + slot] = hi.y; sb[5 * cap + slot] = hi.z;
-            slot_node[slot] = __float_as_uint(hi.w);
+    auto hand_over = [&](float* hb, unsigned* hn, unsigned hcap) {
+        for (unsigned e = tid; e < E; e += kThreads) {
+            const float4 lo = reinterpret_cast<const float4*>(entries + e)[0], hi = reinterpret_cast<const float4*>(entries + e)[1];
+            const unsigned slot = __float_as_uint(lo.w);
+            if (slot != kIxDead) {
+                hb[slot] = lo.x; hb[hcap + slot] = lo.y; hb[2 * hcap + slot] = lo.z;
+                hb[3 * hcap + slot] = hi.x; hb[4 * hcap + slot] = hi.y; hb[5 * hcap + slot] = hi.z;
+                hn[slot] = __float_as_uint(hi.w);
+            }
         }
-    }
-    __syncthreads();
-    if (a_stale && tid == 0u) {
+        __syncthreads();
+        if (a_stale && tid == 0u) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) sb[k * cap + a] = box_a[k];
-        slot_node[a] = node_a;
+            for (int k = 0; k < 6; ++k) hb[k * hcap + a] = box_a[k];
+            hn[a] = node_a;
+        }
+        __syncthreads();
+        tlas_build_chain<Node, true, kThreads>(nodes, hb, hn, hcap, L.sh->red, ChainState{cnt, used, a, b, true});
+    };
+    if (chain_in_lds) {
+        const unsigned lcap = (phase2_cnt + 8u + 3u) & ~3u;   // slot `cnt` itself can be named (the stale a)
+        float* ls = reinterpret_cast<float*>(L.slice);
+        hand_over(ls, reinterpret_cast<unsigned*>(ls + 6u * lcap), lcap);
+    } else {
+        hand_over(sb, slot_node, cap);
     }
-    __syncthreads();
-    tlas_build_chain<Node, true, kThreads>(nodes, sb, slot_node, cap, L.sh->red, ChainState{cnt, used, a, b, true});
     if (REMOTE && tid == 0u) ctl->done = 1u;
 }
 
@@ -1444,6 +1455,7 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
         IxCtl* ctl = reinterpret_cast<IxCtl*>(base + off_ctl);
         const unsigned n_slices = E / kIxSlice, n_super = (n_slices + kIxSuper - 1u) / kIxSuper;
         IxMail* mail = reinterpret_cast<IxMail*>(base + off_ctl + 256);
+        const int chain_in_lds_ix = ctx->option(VD_OPT_TLAS_CHAIN_LDS, 1) != 0 && (size_t)phase2 * 28 <= 120000 ? 1 : 0;
         const int spec_mode = (int)ctx->option(VD_OPT_TLAS_SPEC, 1);      // 0 none, 1 helper waves, 2 helper workgroup (then 1 if nobody shows up)
         const bool spec = spec_mode != 0;
         hipLaunchKernelGGL(tlas_index_kernel, dim3(1), dim3(kSortThreads), 0, ctx->stream, sb, (unsigned)cap, n, E, keys[0], keys[1], keys[2], keys[3],
@@ -1452,7 +1464,9 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
             constexpr int G = decltype(gc)::value;
             constexpr bool S = decltype(sc)::value, R = decltype(rc_)::value;
             constexpr unsigned waves = G * (S ? 2 : 1);
-            const size_t lds = ix_lds_bytes(n_slices, n_super, G, waves);
+            // (+ room for the slot arrays of the plain scans the build ends with: they take the corner tables' place)
+            const size_t lds_chain = chain_in_lds_ix ? ((sizeof(IxShared) + 15) & ~(size_t)15) + (size_t)((phase2 + 8u + 3u) & ~3u) * 28 : 0;
+            const size_t lds = std::max(ix_lds_bytes(n_slices, n_super, G, waves), lds_chain);
             constexpr int which = (std::is_same<Node, VdTlasNode>::value ? 0 : 1) + (S ? 2 : 0) + (R ? 4 : 0);
             if (!ctx->tlas_ix_lds_opt_in[which]) {        // per context (= per device): up to 160 KB of dynamic LDS
                 constexpr unsigned max_slices = kIxMaxInstances / kIxSlice;
@@ -1464,7 +1478,7 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
             // two-workgroup form: 32 workgroups, four per XCC - the chain runs on workgroup 0, one of the three others that
             // land on its XCC becomes the helper, everybody else leaves at once
             hipLaunchKernelGGL((tlas_build_indexed_kernel<Node, G, S, R>), dim3(R ? 32 : 1), dim3(64 * waves), lds, ctx->stream, d_nodes, n, entries, slot_ent, E, sb,
-                               slot_node, (unsigned)cap, ctl, phase2, refresh, ctx->option(VD_OPT_TLAS_PROFILE, 0) ? 1 : 0, mail, spin_limit);
+                               slot_node, (unsigned)cap, ctl, phase2, refresh, ctx->option(VD_OPT_TLAS_PROFILE, 0) ? 1 : 0, mail, spin_limit, chain_in_lds_ix);
             return 0;
         };
         using std::integral_constant;
