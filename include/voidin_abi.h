@@ -193,7 +193,7 @@ typedef enum VdOption {
     VD_OPT_TLAS_INDEX = 10,       /* 0: never use the indexed TLAS build; default 1                       */
     VD_OPT_TLAS_INDEX_MIN = 11,   /* smallest n the indexed build takes; default 6800                     */
     VD_OPT_TLAS_PHASE2 = 12,      /* clusters left at which the indexed build hands over to plain scans;
-                                     default 2048                                                        */
+                                     default 4096                                                        */
     VD_OPT_TLAS_REFRESH = 13,     /* merges between two re-tightenings of the index corners; default 1024 */
     VD_OPT_TLAS_GROUPS = 14,      /* workgroups of the plain chain (1 = single workgroup); default by n   */
     VD_OPT_TLAS_SPIN_LIMIT = 15,  /* polls before the several-workgroup chain gives up and the build is
