@@ -70,8 +70,17 @@ constexpr unsigned kFinalChunk = 128u;  // a_boundary_kernel: segments of the le
 #define VD_MID_MAX 2048
 #endif
 constexpr int kMidMax = VD_MID_MAX;      // largest segment split by ONE workgroup out of LDS (mid tier); 0 disables the tier
-constexpr int kMidThreads = kMidMax > 0 ? kMidMax / 8 : 64;   // 8 positions per lane
-constexpr int kMidPer = 8;              // positions per lane: position = wave*512 + j*64 + lane
+// Mid tier geometry (A/B, profiles/r04_blas_item_isa.txt): 4 positions per lane = 512 lanes per workgroup, four workgroups per
+// CU (a 64-register budget) - 27.0 ms per build against 27.7 with 8 positions per lane / 256 lanes: per-lane state halves, and so
+// do the serial gathers of the bits / bin / child loops; 2 positions per lane (1024 lanes): 27.9.
+#ifndef VD_MID_PER
+#define VD_MID_PER 4
+#endif
+#ifndef VD_MID_WGS
+#define VD_MID_WGS 4                    // workgroups per CU the mid kernel's register budget is set for
+#endif
+constexpr int kMidPer = VD_MID_PER;     // positions per lane: position = wave * 64 * kMidPer + j * 64 + lane
+constexpr int kMidThreads = kMidMax > 0 ? kMidMax / kMidPer : 64;
 constexpr unsigned kNone = 0xffffffffu;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -2100,12 +2109,12 @@ __device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, 
     unsigned t = 0;
 #pragma unroll
     for (int j = 0; j < kMidPer; ++j) {                  // all reads first, unconditional (a lane past the end re-reads position 0): see item_load
-        const unsigned x = wave * 512u + j * 64u + lane;
+        const unsigned x = wave * (64u * (unsigned)kMidPer) + j * 64u + lane;
         v[j] = L.pay[s0 + (x < n ? x : 0u)];
     }
 #pragma unroll
     for (int j = 0; j < kMidPer; ++j) {
-        const unsigned x = wave * 512u + j * 64u + lane;
+        const unsigned x = wave * (64u * (unsigned)kMidPer) + j * 64u + lane;
         masks[j] = __ballot(x < n && ((v[j].y >> cc) & 1u));
         t += (unsigned)__popcll(masks[j]);
     }
@@ -2117,7 +2126,7 @@ __device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, 
     unsigned run = before;
 #pragma unroll
     for (int j = 0; j < kMidPer; ++j) {
-        const unsigned x = wave * 512u + j * 64u + lane;
+        const unsigned x = wave * (64u * (unsigned)kMidPer) + j * 64u + lane;
         if (x < n) {
             const bool p = (masks[j] >> lane) & 1ull;
             const unsigned tl = run + vd_mbcnt(masks[j]);
@@ -2133,7 +2142,7 @@ __device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, 
     run = before;
 #pragma unroll
     for (int j = 0; j < kMidPer; ++j) {                  // the sixteen table reads of a lane in flight together
-        const unsigned x = wave * 512u + j * 64u + lane;
+        const unsigned x = wave * (64u * (unsigned)kMidPer) + j * 64u + lane;
         const bool p = (masks[j] >> lane) & 1ull;
         const unsigned tl = run + vd_mbcnt(masks[j]);
         const unsigned F = x - tl, T = ttot - tl - (p ? 1u : 0u);
@@ -2144,7 +2153,7 @@ __device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, 
     run = before;
 #pragma unroll
     for (int j = 0; j < kMidPer; ++j) {
-        const unsigned x = wave * 512u + j * 64u + lane;
+        const unsigned x = wave * (64u * (unsigned)kMidPer) + j * 64u + lane;
         dest[j] = kNone;
         if (x < n) {
             const bool p = (masks[j] >> lane) & 1ull;
@@ -2172,7 +2181,7 @@ __device__ __forceinline__ void mid_shuffle(MidLds& L, unsigned s0, unsigned n, 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kMidThreads, 4) void blas_mid_kernel(const MidRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
+__global__ __launch_bounds__(kMidThreads, (VD_MID_WGS * kMidThreads / 64 + 3) / 4) void blas_mid_kernel(const MidRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
                                                                unsigned* __restrict__ ids32, ArrSet set0, ArrSet set1, LevelCtl* ctl, TopNode* top,
                                                                SmallRoot* small, unsigned top_cap, unsigned small_cap, unsigned first) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
