@@ -64,7 +64,10 @@ constexpr int kBig = 0x7fffffff;
 constexpr int kItem = VD_ITEM;          // phase A: positions per workgroup item (256 lanes x kPer)
 constexpr int kPer = kItem / 256;       // positions per lane: position = rel0 + wave * (kItem / 4) + j * 64 + lane
 constexpr unsigned kMidEarlyMin = 256;  // mid-tier roots that make an early launch worth it (one per CU)
-constexpr int kBinItems = 8;            // a_bin_kernel: consecutive items per workgroup
+#ifndef VD_BIN_ITEMS
+#define VD_BIN_ITEMS 8
+#endif
+constexpr int kBinItems = VD_BIN_ITEMS;  // a_bin_kernel: consecutive items per workgroup
 constexpr unsigned kFinalChunk = 128u;  // a_boundary_kernel: segments of the level that ended per workgroup
 #ifndef VD_MID_MAX
 #define VD_MID_MAX 2048
@@ -360,7 +363,10 @@ __device__ __forceinline__ vd_u64 wave_min_u64(vd_u64 v) {
 // e in [0, N): centroids and box keys stay put, only the 2-byte permutation moves.
 struct SmallRoot { unsigned start, count, top_node, pad; };
 
-constexpr int kSubWaves = 4;                       // waves of the workgroup that shares one subtree image
+#ifndef VD_SUB_WAVES
+#define VD_SUB_WAVES 4
+#endif
+constexpr int kSubWaves = VD_SUB_WAVES;                       // waves of the workgroup that shares one subtree image
 struct WaveScratch {                              // per-wave: the node this wave is splitting
     float pos[kCand + 3];
     unsigned ttot[kCand + 3];
@@ -614,8 +620,11 @@ __global__ __launch_bounds__(1024) void b_order_kernel(const SmallRoot* __restri
     for (unsigned i = tid; i < n; i += 1024u) order[atomicAdd(&s_bin[min(roots[i].count, (unsigned)kSmallMax + 1u)], 1u)] = i;
 }
 
+// waves per SIMD the small kernel's register budget is set for: 4: 28.7 ms per build, 5: 27.9, 6: 27.2 (the default until the
+// end of round 4), 7: 26.5-27.0, 8: 26.8 (profiles/r04_blas_item_isa.txt, seventh A/B) - the kernel is VALU-issue-bound and
+// more resident waves keep the issue slots fuller than the spilled registers cost
 #ifndef VD_SMALL_OCC
-#define VD_SMALL_OCC 6
+#define VD_SMALL_OCC 8
 #endif
 __global__ __launch_bounds__(64 * kSubWaves, VD_SMALL_OCC)
 void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __restrict__ n_roots_p,
