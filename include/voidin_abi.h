@@ -194,7 +194,7 @@ typedef enum VdOption {
     VD_OPT_TLAS_INDEX_MIN = 11,   /* smallest n the indexed build takes; default 6800                     */
     VD_OPT_TLAS_PHASE2 = 12,      /* clusters left at which the indexed build hands over to plain scans;
                                      default 4096                                                        */
-    VD_OPT_TLAS_REFRESH = 13,     /* merges between two re-tightenings of the index corners; default 1024 */
+    VD_OPT_TLAS_REFRESH = 13,     /* merges between two re-tightenings of the index corners; default 512  */
     VD_OPT_TLAS_GROUPS = 14,      /* workgroups of the plain chain (1 = single workgroup); default by n   */
     VD_OPT_TLAS_SPIN_LIMIT = 15,  /* polls before the several-workgroup chain gives up and the build is
                                      redone on one workgroup (0 forces the redo: tests)                   */

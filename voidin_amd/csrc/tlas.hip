@@ -1399,7 +1399,7 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     const int env_index = (int)ctx->option(VD_OPT_TLAS_INDEX, 1);
     const unsigned ix_min = (unsigned)ctx->option(VD_OPT_TLAS_INDEX_MIN, 6800);    // below: the chain is faster (from LDS up to 5600 instances; tools/tlas_index_min_ab.py)
     unsigned phase2 = (unsigned)ctx->option(VD_OPT_TLAS_PHASE2, 4096);     // 2048 until the final scans moved into LDS (round 4): 184.6 -> 182.7 ms at 32 768, 41.1 -> 39.2 at 8192
-    const unsigned refresh = (unsigned)ctx->option(VD_OPT_TLAS_REFRESH, 1024);
+    const unsigned refresh = (unsigned)ctx->option(VD_OPT_TLAS_REFRESH, 512);      // re-swept in round 4: 256: 183.4 ms at 32 768, 512: 182.4, 1024: 183.1, 2048: 185.5
     if (phase2 < 64u) phase2 = 64u;
     const bool indexed = env_index != 0 && n >= ix_min && n > phase2 && n <= kIxMaxInstances;
     // scratch: 6 float slot arrays + slot node ids (capacity n), the several-workgroup exchange words, and - only when the
