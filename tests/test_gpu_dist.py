@@ -64,9 +64,9 @@ def test_sharded_visibility_two_ranks_one_gpu(oracle, world, n, n_mesh):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, n_mesh)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
+    res = [q.get(timeout=900) for _ in range(world)]
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=300)
     for rank, cnt, blob in res:
         assert cnt >= 0, blob
         assert cnt == wn and blob == want[:wn].tobytes(), f"rank {rank}"
@@ -103,9 +103,9 @@ def test_blas_batch_two_ranks_one_gpu(oracle):
     procs = [ctx.Process(target=_blas_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(2)]
+    res = [q.get(timeout=900) for _ in range(2)]
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=300)
     for rank, blobs in res:
         assert isinstance(blobs, list), blobs
         for (nb, ib), (wn, wi) in zip(blobs, want):

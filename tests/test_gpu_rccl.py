@@ -90,7 +90,7 @@ print("RCCL_GRAPH_OK")
 def test_rccl_world1_step_equals_single_gpu_compaction():
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    out = subprocess.run(["timeout", "420", sys.executable, "-c", CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=480, env=env)
+    out = subprocess.run(["timeout", "840", sys.executable, "-c", CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0 and "RCCL_WORLD1_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 
@@ -100,7 +100,7 @@ def test_rccl_step_replays_from_a_hip_graph():
     replayed result FAILS; only RCCL explicitly refusing the capture (the child's exit code 3, with its message) is a skip."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    out = subprocess.run(["timeout", "240", sys.executable, "-c", GRAPH_CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=300, env=env)
+    out = subprocess.run(["timeout", "700", sys.executable, "-c", GRAPH_CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=800, env=env)
     assert out.returncode != 124, "graph capture / replay of the RCCL step did not finish in 240 s:\n" + out.stdout[-1500:] + out.stderr[-1500:]
     if out.returncode == 3:
         pytest.skip("RCCL refused the graph capture of a collective: " + out.stdout[-300:])
