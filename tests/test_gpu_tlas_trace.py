@@ -743,6 +743,20 @@ def test_indexed_build_on_ties_nesting_and_stale_slots(ctx, oracle, ctx_options,
         assert got["min"].view(np.uint32).tobytes() == want["min"].view(np.uint32).tobytes() and got["max"].view(np.uint32).tobytes() == want["max"].view(np.uint32).tobytes()
 
 
+@pytest.mark.parametrize("chain_lds", [0, 1])
+def test_tlas_chain_slot_arrays_in_lds_or_in_memory(ctx, oracle, ctx_options, chain_lds):
+    """VD_OPT_TLAS_CHAIN_LDS: the plain scans - the whole build of a small scene, and the end of an indexed build - read their
+    slot arrays from LDS (default) or from memory.  Same nodes either way, on a small scene, on one that fills the LDS
+    allocation to the last slots, and on an indexed build forced onto 3000 instances with the hand-over at 700 clusters."""
+    ctx_options("tlas.chain_lds", chain_lds)
+    meshes = synth.mesh_infos()
+    for n, forced in ((1500, False), (5600, False), (3000, True)):
+        if forced:
+            ctx_options("tlas.index_min", 65); ctx_options("tlas.phase2", 700); ctx_options("tlas.refresh", 300)
+        inst = synth.instances(n, seed=synth.SEED_BASE + 40 + n % 5, extent=200.0)
+        assert fields_equal(ctx.tlas_build(inst, meshes), oracle.tlas_build(inst, meshes)), (n, forced, chain_lds)
+
+
 @pytest.mark.parametrize("spin_limit", [None, 0, 1, 40])
 def test_indexed_build_with_a_helper_workgroup_that_is_late_or_absent(ctx, oracle, ctx_options, spin_limit):
     """VD_OPT_TLAS_SPEC = 2 (tlas.hip, "the two-workgroup form"): the speculative query runs on a second workgroup of the
