@@ -90,7 +90,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct TriBox { float mn[3]; float pad0; float mx[3]; float pad1; };   // 32 B, by triangle id
+// 24 B, by triangle id.  (32 B with two pad words - two aligned 16-byte loads - until the kernels that move boxes turned out
+// HBM-bound: a_child at 5.2 TB/s with 14 % VALU; 24 B: 26.8 -> 26.05 ms per build, -DVD_BOX32 for the A/B.)
+#ifdef VD_BOX32
+struct TriBox { float mn[3]; float pad0; float mx[3]; float pad1; };
+#else
+struct TriBox { float mn[3]; float mx[3]; };
+#endif
 struct TmpNode { float mn[3]; unsigned left_first; float mx[3]; unsigned count; };   // == VdBvhNode layout
 
 enum : unsigned { ERR_DEGENERATE = 1u, ERR_BAD_INDEX = 2u, ERR_INTERNAL = 4u };
@@ -231,7 +237,9 @@ __global__ __launch_bounds__(256) void blas_precompute_kernel(const MeshDesc* __
             k12[9 + k] = max(k12[9 + k], vd_key_hi(ce[k]));
         }
         }
+#ifdef VD_BOX32
         bx.pad0 = bx.pad1 = 0.0f;
+#endif
         const f32x4 c4 = {ce[0], ce[1], ce[2], __uint_as_float(g)};   // .w: the triangle's id travels with its centroid
         cent[g] = c4;
         boxes[g] = bx;
@@ -402,10 +410,9 @@ __device__ __forceinline__ BoxKeys box_keys(const WaveLds& L, const TriBox* __re
 #pragma unroll
     for (int q = 0; q < 6; ++q) r.k[q] = L.box[q][e];
 #else
-    const f32x4* p = reinterpret_cast<const f32x4*>(boxes + L.gid[e]);
-    const f32x4 a = p[0], b = p[1];
-    r.k[0] = vd_key(a.x); r.k[1] = vd_key(a.y); r.k[2] = vd_key(a.z);
-    r.k[3] = vd_key(b.x); r.k[4] = vd_key(b.y); r.k[5] = vd_key(b.z);
+    const TriBox bx = boxes[L.gid[e]];
+    r.k[0] = vd_key(bx.mn[0]); r.k[1] = vd_key(bx.mn[1]); r.k[2] = vd_key(bx.mn[2]);
+    r.k[3] = vd_key(bx.mx[0]); r.k[4] = vd_key(bx.mx[1]); r.k[5] = vd_key(bx.mx[2]);
 #endif
     return r;
 }
@@ -1825,7 +1832,7 @@ __global__ __launch_bounds__(256) void a_child_kernel(Seg* segs, const unsigned*
     int k24[24];
 #pragma unroll
     for (int i = 0; i < 24; ++i) k24[i] = (i % 6) < 3 ? kBig : -kBig - 1;
-    // ids first, then the 48 bytes of each (all gathers of a lane in flight together: see item_load), then stores and keys
+    // ids first, then the 40 bytes of each (all gathers of a lane in flight together: see item_load), then stores and keys
     const unsigned a0 = sg->start + ic.rel0;
     unsigned ids[kPer];
     TriBox bxs[kPer];
