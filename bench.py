@@ -833,6 +833,8 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
     # per-scene preparation (vd_trace_prepare_dev: de-indexed leaf triangles); the timed calls are the prepared ones, the
     # plain entry points are timed beside them and must give the same bytes
     acc = ctx.trace_prepare(ds)
+    ctx.set_option("trace.fan", 3)                # the default's value, PINNED: left to itself the fan-out skips itself for 15 calls after a call
+                                                  # that found no long rays (per-context state), and timings would depend on the calls before
     ctx.set_timing(True)
     t_cl, t_any, t_cl0, t_any0 = [], [], [], []
     for _ in range(3):
@@ -880,12 +882,12 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
     ctx.set_timing(False)
     ht = d_hits_t.cpu().numpy()[: len(rays) * 16].view(abi.HIT)
     hm = hits["hit"] == 1
-    relerr = np.abs(ht["dist"][hm].astype(np.float64) - hits["dist"][hm]) / np.abs(hits["dist"][hm])
+    abserr = np.abs(ht["dist"][hm].astype(np.float64) - hits["dist"][hm])
     extra["trace"]["tight_tlas_option"] = {
         "closest_hit_Mrays_per_s": round(len(rays) / min(t_clt) / 1e3, 1), "occlusion_Mrays_per_s": round(len(rays) / min(t_anyt) / 1e3, 1),
         "prepare_ms": round(t_prep * 1e3, 2), "fallback_instances": acc_t.info()["tight_fallback_instances"],
         "hit_flags_equal_exact_walk": bool(np.array_equal(ht["hit"], hits["hit"]) and np.array_equal(d_any_t.cpu().numpy().astype(np.uint32), hits["hit"])),
-        "max_rel_distance_error_vs_exact_walk": float(relerr.max()) if relerr.size else 0.0,
+        "max_abs_distance_error": float(abserr.max()) if abserr.size else 0.0,       # vs the exact walk; north_star allows 1e-5
         "distances_bit_equal": int((ht["dist"][hm].view(np.uint32) == hits["dist"][hm].view(np.uint32)).sum()), "hits": int(hm.sum()),
         "note": "default off; the exact (reference visit order) numbers above are the parity path"}
     acc_t.close()
@@ -908,6 +910,7 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
         "closest_hit_Mrays_per_s": round(len(rays) / min(t_cll) / 1e3, 1), "occlusion_Mrays_per_s": round(len(rays) / min(t_anyl) / 1e3, 1),
         "rebuild_ms_blocking": round(min(t_upd) * 1e3, 3),
         "hit_flags_equal_exact_walk": bool(np.array_equal(hl["hit"], hits["hit"]) and np.array_equal(d_any_t.cpu().numpy().astype(np.uint32), hits["hit"])),
+        "max_abs_distance_error": float(np.abs(hl["dist"][hm].astype(np.float64) - hits["dist"][hm]).max()) if hm.any() else 0.0,
         "distances_bit_equal": int((hl["dist"][hm].view(np.uint32) == hits["dist"][hm].view(np.uint32)).sum())}
     acc_l.close()
     del d_hits_t, d_any_t
@@ -919,12 +922,14 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
         t = time.perf_counter(); hN, _ = ref.trace(scene_host, sN, threads=threads); tN = time.perf_counter() - t
         sub = hits[::4]
         hit = hN["hit"] == 1
-        ok = bool(np.array_equal(hN["hit"], sub["hit"]) and np.all(np.abs(hN["dist"][hit] - sub["dist"][hit]) <= 1e-5 * np.abs(hN["dist"][hit])))
+        ok = bool(np.array_equal(hN["hit"], sub["hit"]) and hN["dist"].tobytes() == sub["dist"].tobytes())
+        max_abs = float(np.abs(hN["dist"][hit].astype(np.float64) - sub["dist"][hit]).max()) if hit.any() else 0.0
         extra["trace"]["cpu_baseline"] = {"value": round(len(sN) / tN / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                                           "one_thread_Mrays_per_s": round(len(s1) / t1 / 1e6, 4),
                                           "sample": f"every 4th ray of the same batch on {threads} threads ({len(sN)} rays), every 64th on 1 thread "
                                                     f"({len(s1)} rays), oracle vd_ref_trace",
-                                          "gpu_equals_oracle_on_sample_hit_flags_and_dist_1e-5": ok}
+                                          "gpu_equals_oracle_on_sample_hit_flags_and_distance_bits": ok,
+                                          "max_abs_distance_error": max_abs}       # exact walk vs oracle: 0.0 (bit-equal); north_star allows 1e-5
     acc.close()
     del ds, d_rays, d_hits, d_any
     # the reference's own harness shape (src/bin/bvh_gpu.rs:107-131): one large mesh + four small ones, 4 M primary rays
@@ -944,6 +949,7 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
                                     "closest_hit_Mrays_per_s": round(len(rays2) / min(t2) / 1e3, 1),
                                     "hit_fraction": round(float(h2["hit"].mean()), 3)}
     acc2.close()
+    ctx.set_option("trace.fan", None)
     del ds2, d_r2, d_h2
     # the one real mesh the reference checkout carries, as its default demo places and views it (src/bin/model.rs:100-106, :235):
     # tests/golden/helmet.npz = the arrays GltfDocument::import hands to MeshPool::add + the oracle's tree checksums and hits

@@ -83,6 +83,25 @@ class ExternalBuffer {
     void* ptr_ = nullptr;
 };
 
+// A semaphore the renderer exported (VK_KHR_external_semaphore_fd) - what orders the frame's queue.submit
+// (crates/app/src/app.rs:334-348) against the HIP stream without a CPU wait: wait(frame) ... cull ... signal(frame), all
+// enqueued on the context's stream.  `value` is the timeline point; a binary semaphore ignores it.
+class ExternalSemaphore {
+   public:
+    ExternalSemaphore(const Gpu& gpu, int opaque_fd, bool timeline) : gpu_(gpu) {
+        gpu.check(vd_import_external_semaphore(gpu.ctx(), opaque_fd, timeline ? 1 : 0, &handle_));   // consumes the fd
+    }
+    ~ExternalSemaphore() { if (handle_) vd_release_external_semaphore(gpu_.ctx(), handle_); }
+    ExternalSemaphore(const ExternalSemaphore&) = delete;
+    ExternalSemaphore& operator=(const ExternalSemaphore&) = delete;
+    void wait_async(uint64_t value = 0) const { gpu_.check(vd_wait_external_semaphore_async(gpu_.ctx(), handle_, value)); }
+    void signal_async(uint64_t value = 0) const { gpu_.check(vd_signal_external_semaphore_async(gpu_.ctx(), handle_, value)); }
+
+   private:
+    const Gpu& gpu_;
+    VdExternalSemaphore* handle_ = nullptr;
+};
+
 // ---- crates/bvh ---------------------------------------------------------------------------
 enum class DistKind { Hit, Miss };   // enum Dist { Hit(f32), Miss } (crates/bvh/src/intersection.rs:22-26)
 struct Dist {
@@ -226,8 +245,9 @@ class MeshPool {
         const uint32_t first_node = (uint32_t)bvh_nodes.size();
         bvh_nodes.resize(first_node + node_room);
         uint32_t end = first_node;
-        gpu_.check(vd_bvh_build_batch(gpu_.ctx(), items.data(), (uint32_t)n_meshes, bvh_nodes.data(), bvh_nodes.size(), first_node, &end));
-        bvh_nodes.resize(end);                                  // nodes.truncate(pool) of every mesh (blas.rs:93)
+        const int rc = vd_bvh_build_batch(gpu_.ctx(), items.data(), (uint32_t)n_meshes, bvh_nodes.data(), bvh_nodes.size(), first_node, &end);
+        bvh_nodes.resize(rc == VD_OK ? end : first_node);       // nodes.truncate(pool) of every mesh (blas.rs:93); a failed batch leaves the pool as it was
+        gpu_.check(rc);
         for (size_t m = 0; m < n_meshes; ++m) {
             const MeshRef& mesh = meshes[m];
             MeshInfo info{};

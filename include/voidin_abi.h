@@ -254,11 +254,31 @@ int         vd_ctx_set_option(VdCtx* ctx, int option /* VdOption */, int64_t val
  * Vulkan allocation behind it is exported as an opaque fd (VK_KHR_external_memory_fd) and mapped
  * here; the returned device pointer is then passed as `d_out` of vd_cull_emit_dev /
  * vd_cull_compact_dev.  The fd is consumed on success (Vulkan/HIP convention).  Ordering
- * against the consumer is the caller's: vd_ctx_synchronize, or an exported semaphore.        */
+ * against the consumer: the external semaphores below (no CPU wait), or vd_ctx_synchronize.  */
 typedef struct VdExternalBuffer VdExternalBuffer;
 int vd_import_external_buffer(VdCtx* ctx, int opaque_fd, uint64_t size_bytes, VdExternalBuffer** out_handle,
                               void** out_device_ptr);
 int vd_release_external_buffer(VdCtx* ctx, VdExternalBuffer* handle);
+
+/* ... and its ordering.  The renderer's frame is ONE queue.submit followed by present
+ * (crates/app/src/app.rs:334-348); a CPU wait on each side of a 0.27 ms cull would be most of the frame.  A Vulkan
+ * semaphore exported as an opaque fd (VK_KHR_external_semaphore_fd; binary, or timeline with is_timeline != 0) is
+ * imported once, and then
+ *     vd_wait_external_semaphore_async(ctx, frame_ready, f)      the submit that wrote instances / camera has finished
+ *     vd_cull_compact_dev(ctx, ..., d_out = imported buffer, ...)
+ *     vd_signal_external_semaphore_async(ctx, draws_ready, f)    Geometry::record's submit waits for this one
+ * are three operations ENQUEUED on the context's stream: no host round trip.  `value` is the timeline point (ignored
+ * for a binary semaphore).  The fd is consumed on success.  vd_release_external_semaphore synchronises the stream
+ * first (queued waits / signals refer to the semaphore).
+ * What this image can test: argument validation and the error path of a descriptor that is not a semaphore
+ * (tests/test_gpu_tlas_trace.py).  A functional round trip needs a Vulkan device and loader on the box - the image
+ * has neither - so none is claimed; the calls are hipImportExternalSemaphore / hip{Wait,Signal}ExternalSemaphoresAsync /
+ * hipDestroyExternalSemaphore and nothing else.                                                                       */
+typedef struct VdExternalSemaphore VdExternalSemaphore;
+int vd_import_external_semaphore(VdCtx* ctx, int opaque_fd, int is_timeline, VdExternalSemaphore** out_handle);
+int vd_wait_external_semaphore_async(VdCtx* ctx, VdExternalSemaphore* handle, uint64_t value);
+int vd_signal_external_semaphore_async(VdCtx* ctx, VdExternalSemaphore* handle, uint64_t value);
+int vd_release_external_semaphore(VdCtx* ctx, VdExternalSemaphore* handle);
 
 /* ------------------------------------------------------------------------------------ */
 /* Cull + emit                                                      */
@@ -284,7 +304,12 @@ int vd_cull_emit_dev(VdCtx* ctx, const VdCameraUniform* camera /* host */,
  * (instance_count = 0) so that the unchanged
  * `multi_draw_indexed_indirect(buf, 0, N)` consumer (visibility.rs:188-192) stays valid;
  * with pad_tail == 0 only out[0..count) is written (for multi_draw_indexed_indirect_count).
- * `out` must hold n_inst commands either way.                                           */
+ * `out` must hold n_inst commands either way.
+ * Error value of the count: the ordered scans behind the compaction wait for each other across
+ * workgroups, and every such wait is bounded.  If one ever times out (a workgroup of the launch was lost)
+ * the list is not written and the count becomes 0xffffffff - larger than any n_inst: vd_cull_compact
+ * returns VD_ERR_HIP for it, callers of the *_dev forms see it in *d_out_count (pad_tail then pads
+ * nothing).  The next call on the context starts from clean scan state by itself.         */
 int vd_cull_compact(VdCtx* ctx, const VdCameraUniform* camera,
                     const VdMeshInfo* meshes, uint32_t n_mesh,
                     const VdInstance* instances, uint32_t n_inst,

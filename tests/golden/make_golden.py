@@ -248,9 +248,175 @@ def helmet_case():
     print("helmet: nodes", len(nodes), "hits", int(hits["hit"].sum()))
 
 
+
+# ---- the reference's own demo scene, for the cull (src/bin/model.rs) -----------------------------------------------
+def _f32(x):
+    return np.float32(x)
+
+
+def _mul(A, B):
+    """glam 0.24 Mat4 * Mat4 in f32: column j of the product = ((A.x*b.x + A.y*b.y) + A.z*b.z) + A.w*b.w (mul_vec4 per column).
+    Matrices here are (4, 4) arrays of COLUMNS: M[j] = column j."""
+    A, B = np.asarray(A, np.float32), np.asarray(B, np.float32)
+    out = np.zeros((4, 4), np.float32)
+    for j in range(4):
+        out[j] = ((A[0] * B[j][0] + A[1] * B[j][1]) + A[2] * B[j][2]) + A[3] * B[j][3]
+    return out
+
+
+def _translation(x, y, z):
+    M = np.eye(4, dtype=np.float32); M[3][:3] = (_f32(x), _f32(y), _f32(z)); return M
+
+
+def _scale(x, y, z):
+    return np.diag(np.array([x, y, z, 1.0], np.float32)).astype(np.float32)
+
+
+def _rot(axis, angle):
+    a = _f32(angle)
+    s, c = np.sin(a, dtype=np.float32), np.cos(a, dtype=np.float32)
+    M = np.eye(4, dtype=np.float32)
+    if axis == "x": M[1][:3] = (0, c, s); M[2][:3] = (0, -s, c)
+    if axis == "y": M[0][:3] = (c, 0, -s); M[2][:3] = (s, 0, c)
+    if axis == "z": M[0][:3] = (c, s, 0); M[1][:3] = (-s, c, 0)
+    return M
+
+
+def _node_matrix_f32(n):
+    """gltf Node::transform().matrix() of a decomposed node, in f32: T * R * S."""
+    if "matrix" in n:
+        return np.asarray(n["matrix"], np.float32).reshape(4, 4)
+    x, y, z, w = (np.float32(v) for v in n.get("rotation", (0, 0, 0, 1)))
+    one, two = np.float32(1), np.float32(2)
+    R = np.eye(4, dtype=np.float32)
+    R[0][:3] = (one - two * (y * y + z * z), two * (x * y + z * w), two * (x * z - y * w))
+    R[1][:3] = (two * (x * y - z * w), one - two * (x * x + z * z), two * (y * z + x * w))
+    R[2][:3] = (two * (x * z + y * w), two * (y * z - x * w), one - two * (x * x + y * y))
+    t, sc = n.get("translation", (0, 0, 0)), n.get("scale", (1, 1, 1))
+    return _mul(_mul(_translation(*t), R), _scale(*sc))
+
+
+def model_scene_cases():
+    """The ONE place the reference runs emit_draws on a real scene: src/bin/model.rs:62-147 under the camera of :235.
+    What the cull reads of a mesh is MeshInfo.{min, max, index_count, base_index, vertex_offset} (emit_draws.wgsl:13-63),
+    and MeshPool::add (crates/pools/src/mesh/mod.rs:309-351) fills those from the POSITION bounds, the index count and the
+    running sums - all of which a glTF document states in its JSON (accessor min / max are mandatory for POSITION, exact f32).
+    So the table is restated for every mesh the demo loads whose document is in the checkout:
+      ids 0..3    MeshPool::new's four built-in meshes (mesh/mod.rs:266-274)
+      ids 4..106  Sponza's 103 primitives (Sponza.gltf is there; Sponza.bin - the triangles - is a missing blob, and not needed)
+      id  107     DamagedHelmet.glb
+      id  108     make_uv_sphere(1, 10), added again by model.rs:119-120
+    assets/ferris3d_v1.0.glb is a missing blob (.MISSING_LARGE_BLOBS): its meshes and the instances model.rs makes of them
+    (:108-117, :137-141) are left out, so ids after 107 are one document short of the reference's.  bvh_index is 0 throughout:
+    emit_draws never reads it, and Sponza's node counts cannot be known without its triangles.
+    Instances, in the reference's order: the two area-light planes (app.rs:220-235), Sponza's node walk under
+    rot_y(pi/2) * T(7,-5,1) * S(3), the helmet under T(0,0,9) * S(3), the ten spheres of the moving ring (:122-134; their
+    materials are thread_rng there - irrelevant to the cull - and 1 here).  Matrix products follow glam's f32 evaluation order.
+    Three fixtures: the demo camera (everything passes: with the reference's object-space radius - SURVEY 8a C2 - Sponza's
+    primitives, hundreds of units large before the node's 0.008 scale, are never culled from there); a camera at the end of
+    the nave that leaves about half the scene behind it; and the scene three times over (327 meshes: past the 256 rows an
+    8-bit mesh id can name, 348 instances) from inside, half of it culled."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from gltf_reader import GltfDocument
+    base = "/root/reference/assets/glTF-Sample-Models/2.0/"
+    sponza_p, helmet_p = base + "Sponza/glTF/Sponza.gltf", base + "DamagedHelmet/glTF-Binary/DamagedHelmet.glb"
+    if not (os.path.exists(sponza_p) and os.path.exists(helmet_p)):
+        print("model_scene_cases: reference assets not present, fixtures left as they are")
+        return
+    rows = []                                            # (min, max, index_count, vertex_count)
+    for v, i in (synth.plane_mesh(), synth.plane_mesh_rot_x(), synth.uv_sphere(1.0, 1), synth.uv_sphere(1.0, 10)):
+        mn, mx = synth.mesh_bounds(v)
+        rows.append((mn, mx, len(i), len(v)))
+    sponza = json.load(open(sponza_p))
+    acc = sponza["accessors"]
+    sponza_prims = []
+    for mi, m in enumerate(sponza["meshes"]):
+        for pi, pr in enumerate(m["primitives"]):
+            at = pr["attributes"]
+            if "POSITION" not in at or "NORMAL" not in at:                      # gltf_model/mod.rs:118-123
+                continue
+            a = acc[at["POSITION"]]
+            n_idx = acc[pr["indices"]]["count"] if "indices" in pr else a["count"]
+            rows.append((np.asarray(a["min"], np.float32), np.asarray(a["max"], np.float32), n_idx, a["count"]))
+            sponza_prims.append((mi, pi))
+    assert len(sponza_prims) == 103
+    helmet = GltfDocument.load(helmet_p)
+    (hp,) = helmet.primitives()
+    mn, mx = synth.mesh_bounds(hp.positions)
+    rows.append((mn, mx, len(hp.indices), len(hp.positions)))
+    sv, si = synth.uv_sphere(1.0, 10)
+    mn, mx = synth.mesh_bounds(sv)
+    rows.append((mn, mx, len(si), len(sv)))
+    meshes = np.zeros(len(rows), dtype=abi.MESH_INFO)
+    base_index = vertex_offset = 0
+    for k, (mn, mx, n_idx, n_v) in enumerate(rows):                             # mesh/mod.rs:310-345
+        meshes[k]["min"], meshes[k]["max"] = mn, mx
+        meshes[k]["index_count"], meshes[k]["base_index"], meshes[k]["vertex_offset"] = n_idx, base_index, vertex_offset
+        base_index += n_idx; vertex_offset += n_v
+    SPONZA0, HELMET, SPHERE = 4, 4 + 103, 4 + 103 + 1
+
+    inst = []
+    PI = np.float32(np.pi)
+
+    def add(M, mesh):
+        inst.append(synth.instance_from_matrix(np.asarray(M, np.float32).reshape(16), mesh=mesh))
+
+    for T in (_mul(_translation(0, 10, 15), _rot("x", -PI / _f32(4))), _mul(_translation(0, 10, -25), _rot("x", _f32(-3) * PI / _f32(4)))):
+        add(_mul(T, _scale(2.5, 4.0, 1.0)), 1)                                   # app.rs:230-234: transform * scale((wh / 2).extend(1)), VERTICAL_PLANE_MESH
+
+    def walk(doc, ni, parent, mesh_of):
+        n = doc["nodes"][ni]
+        M = _mul(parent, _node_matrix_f32(n))
+        for c in n.get("children", []):                                         # gltf_model/mod.rs:189-191: children first
+            walk(doc, c, M, mesh_of)
+        if "mesh" in n:
+            for pi in range(len(doc["meshes"][n["mesh"]]["primitives"])):
+                if (n["mesh"], pi) in mesh_of:
+                    add(M, mesh_of[(n["mesh"], pi)])
+
+    root = _mul(_mul(_rot("y", PI / _f32(2)), _translation(7, -5, 1)), _scale(3, 3, 3))          # model.rs:94-98
+    for ni in sponza["scenes"][0]["nodes"]:
+        walk(sponza, ni, root, {k: SPONZA0 + j for j, k in enumerate(sponza_prims)})
+    root = _mul(_translation(0, 0, 9), _scale(3, 3, 3))                                              # model.rs:104-106
+    for ni in helmet.doc["scenes"][0]["nodes"]:
+        walk(helmet.doc, ni, root, {(hp.mesh, hp.primitive): HELMET})
+    for i in range(10):                                                                              # model.rs:122-134
+        angle = _f32(2) * PI * _f32(i) / _f32(10)
+        add(_translation(_f32(3.5) * np.cos(angle, dtype=np.float32), _f32(3.5) * np.sin(angle, dtype=np.float32), -17), SPHERE)
+    inst = np.array(inst, dtype=abi.INSTANCE)
+    assert len(inst) == 2 + 103 + 1 + 10 and len(meshes) == 109
+
+    # the scene three times over: mesh tables appended (running sums go on), copies moved aside
+    m3 = np.concatenate([meshes] * 3)
+    m3["base_index"] = np.concatenate([[0], np.cumsum(m3["index_count"].astype(np.uint64))[:-1]]).astype(np.uint32)
+    vcount = np.array([r[3] for r in rows] * 3, dtype=np.int64)
+    m3["vertex_offset"] = np.concatenate([[0], np.cumsum(vcount)[:-1]]).astype(np.int32)
+    i3 = []
+    for k, dx in enumerate((0.0, 55.0, -55.0)):
+        for r in inst:
+            M = _mul(_translation(dx, 0, 0), r["transform"].reshape(4, 4))
+            i3.append(synth.instance_from_matrix(M.reshape(16), mesh=int(r["mesh"]) + 109 * k))
+    i3 = np.array(i3, dtype=abi.INSTANCE)
+
+    cases = {"cull_model_scene": (synth.camera_uniform(), meshes, inst),                                      # model.rs:235
+             "cull_model_scene_nave": (synth.camera_uniform(eye=(-20.0, 3.0, 0.0), yaw_deg=90.0, pitch_deg=0.0), meshes, inst),
+             "cull_model_scene_x3": (synth.camera_uniform(eye=(0.0, 3.0, 0.0), yaw_deg=180.0, pitch_deg=0.0), m3, i3)}
+    for name, (cam, ms, ins) in cases.items():
+        d_np = npr.cull_emit(cam, ms, ins)
+        d_c = ref.cull_emit(cam, ms, ins)
+        assert d_np.tobytes() == d_c.tobytes(), name
+        comp, cnt = npr.compact(d_np)
+        c2, cnt2 = ref.compact(d_c)
+        assert cnt == cnt2 and comp.tobytes() == c2[:cnt2].tobytes()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), camera=cam, meshes=ms, instances=ins, draws=d_np, compact=comp, count=np.uint32(cnt))
+        print(name, "visible", cnt, "/", len(ins), "meshes", len(ms))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     helmet_case()
+    model_scene_cases()
     cull_cases()
     blas_cases()
     builtin_pool_case()

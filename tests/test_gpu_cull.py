@@ -10,7 +10,8 @@ from voidin_amd import abi, synth
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["cull_model_wide.npz", "cull_model_small.npz", "cull_jitter_wide.npz", "cull_jitter_small.npz"]
+CASES = ["cull_model_wide.npz", "cull_model_small.npz", "cull_jitter_wide.npz", "cull_jitter_small.npz",
+         "cull_model_scene.npz", "cull_model_scene_nave.npz", "cull_model_scene_x3.npz"]   # the last three: the reference's own demo scene (make_golden.model_scene_cases)
 
 
 def run_dev(ctx, cam, meshes, inst, pad_tail=False):
@@ -31,12 +32,19 @@ def run_dev(ctx, cam, meshes, inst, pad_tail=False):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_golden_fixtures(ctx, name):
+def test_golden_fixtures(ctx, ctx_options, name):
     g = golden(name)
     emit, comp, cnt = run_dev(ctx, g["camera"], g["meshes"], g["instances"])
     assert emit.tobytes() == g["draws"].tobytes()
     assert cnt == int(g["count"])
     assert comp[:cnt].tobytes() == g["compact"].tobytes()
+    # the split form (what inputs of >= 2 Mi instances run): bit mask + per-instance mesh id table - 1-byte ids up to 256
+    # meshes, 2-byte ids beyond (cull_model_scene_x3 has 327) - + scan + expansion
+    ctx_options("cull.split_min", 1)
+    emit, comp, cnt = run_dev(ctx, g["camera"], g["meshes"], g["instances"])
+    ctx_options("cull.split_min", None)
+    assert emit.tobytes() == g["draws"].tobytes()
+    assert cnt == int(g["count"]) and comp[:cnt].tobytes() == g["compact"].tobytes()
     # host-pointer entry points give the same bytes
     assert ctx.cull_emit(g["camera"], g["meshes"], g["instances"]).tobytes() == g["draws"].tobytes()
     c2, n2 = ctx.cull_compact(g["camera"], g["meshes"], g["instances"])

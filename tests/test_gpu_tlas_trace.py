@@ -1,5 +1,7 @@
 """Parity of the HIP TLAS build / refit and traversal against the CPU oracle, through the C ABI.
-Node layouts are bit-exact; hit distances within 1e-5 relative (north_star tolerance)."""
+Node layouts are bit-exact.  Hit distances: the default walk visits the nodes in the reference's order on the oracle's
+evaluation model, so its distances are asserted BIT-EQUAL to the oracle's (north_star allows 1e-5; the order-changing
+options are checked against that absolute tolerance in tests/test_gpu_trace_tight.py)."""
 import numpy as np
 import pytest
 
@@ -8,7 +10,6 @@ from voidin_amd import abi, synth
 from voidin_amd.runtime import VoidinError
 
 pytestmark = pytest.mark.gpu
-REL_TOL = 1e-5
 
 
 @pytest.mark.parametrize("n", [1, 2, 5, 40, 300, "nan_60"])
@@ -270,6 +271,27 @@ def test_tlas_overflow_and_bad_args(ctx):
     assert ctx.lib.vd_import_external_buffer(ctx.h, -1, 4096, C.byref(hnd), C.byref(ptr)) == abi.VD_ERR_INVALID_ARG
     assert ctx.lib.vd_import_external_buffer(ctx.h, 0, 0, C.byref(hnd), C.byref(ptr)) == abi.VD_ERR_INVALID_ARG
     assert ctx.lib.vd_release_external_buffer(ctx.h, None) == abi.VD_ERR_INVALID_ARG
+    # external semaphores: argument validation, and a descriptor that is not a semaphore is an error code,
+    # not a crash.  (A functional wait / signal round trip needs a Vulkan device on the box: not claimed, not faked.)
+    sem = C.c_void_p()
+    assert ctx.lib.vd_import_external_semaphore(ctx.h, -1, 0, C.byref(sem)) == abi.VD_ERR_INVALID_ARG
+    assert ctx.lib.vd_import_external_semaphore(ctx.h, 0, 1, None) == abi.VD_ERR_INVALID_ARG
+    assert ctx.lib.vd_wait_external_semaphore_async(ctx.h, None, 1) == abi.VD_ERR_INVALID_ARG
+    assert ctx.lib.vd_signal_external_semaphore_async(ctx.h, None, 1) == abi.VD_ERR_INVALID_ARG
+    assert ctx.lib.vd_release_external_semaphore(ctx.h, None) == abi.VD_ERR_INVALID_ARG
+    import os
+    for timeline in (0, 1):
+        r, w = os.pipe()                     # an open descriptor, but no semaphore behind it
+        sem = C.c_void_p()
+        rc = ctx.lib.vd_import_external_semaphore(ctx.h, r, timeline, C.byref(sem))
+        if rc == abi.VD_OK:                  # (a driver that accepts any fd at import must at least hand out a handle that can be released)
+            assert sem.value and ctx.lib.vd_release_external_semaphore(ctx.h, sem) in (abi.VD_OK, abi.VD_ERR_HIP)
+        else:
+            assert rc == abi.VD_ERR_HIP and not sem.value and b"hipImportExternalSemaphore" in ctx.lib.vd_last_error(ctx.h)
+            os.close(r)
+        os.close(w)
+    # the context still works afterwards
+    ctx.synchronize()
 
 
 def test_trace_matches_golden(ctx):
@@ -278,7 +300,7 @@ def test_trace_matches_golden(ctx):
     h = ctx.trace(scene, g["rays"])
     assert np.array_equal(h["hit"], g["hit"])
     hit = g["hit"] == 1
-    assert np.all(np.abs(h["dist"][hit] - g["dist"][hit]) <= REL_TOL * np.abs(g["dist"][hit]))
+    assert h["dist"].tobytes() == g["dist"].tobytes()                  # bit for bit, misses (1e30) included
     assert (h["dist"][~hit] == np.float32(1e30)).all()
 
 
@@ -306,7 +328,7 @@ def test_trace_seeded_scene_vs_oracle(ctx, oracle):
     got = ctx.trace(scene, rays)
     assert np.array_equal(got["hit"], want["hit"]) and want["hit"].sum() > 1000
     hit = want["hit"] == 1
-    assert np.all(np.abs(got["dist"][hit] - want["dist"][hit]) <= REL_TOL * np.abs(want["dist"][hit]))
+    assert got["dist"].tobytes() == want["dist"].tobytes()             # bit for bit, misses (1e30) included
     assert max_stack <= 64
     # device-pointer entry point + the occlusion query of the shadow pass (raytraced_shadows.wgsl:97-102): its flag
     # is the closest-hit traversal's `hit`
@@ -390,7 +412,7 @@ def test_trace_supply_binning_and_prepared_triangles_are_order_only(ctx, oracle,
                 first = got.tobytes()
                 assert np.array_equal(got["hit"], want["hit"]) and want["hit"].sum() > 300
                 hit = want["hit"] == 1
-                assert got["dist"][hit].tobytes() == want["dist"][hit].tobytes()          # bit-equal in fact (tolerance: 1e-5)
+                assert got["dist"][hit].tobytes() == want["dist"][hit].tobytes()          # bit for bit
                 # which instance and which triangle: the walk carries the TLAS leaf and resolves the instance when the ray retires
                 assert np.array_equal(got["instance"][hit], want["instance"][hit])
                 assert np.array_equal(got["triangle"][hit], want["triangle"][hit])
@@ -668,8 +690,7 @@ def test_trace_axis_aligned_and_degenerate_rays(ctx, oracle):
     got = ctx.trace(scene, rays)
     assert np.array_equal(got["hit"], want["hit"]) and want["hit"].sum() > 500
     hit = want["hit"] == 1
-    assert np.all(np.abs(got["dist"][hit] - want["dist"][hit]) <= REL_TOL * np.abs(want["dist"][hit]))
-    assert got["dist"].view(np.uint32).tobytes() == want["dist"].view(np.uint32).tobytes()      # in fact bit for bit, NaN-free or not
+    assert got["dist"].view(np.uint32).tobytes() == want["dist"].view(np.uint32).tobytes()      # bit for bit, NaN-free or not
 
 
 def _boxes_as_scene(boxes):

@@ -8,7 +8,8 @@ from conftest import golden
 from oracle import np_restate as npr
 from voidin_amd import abi, synth
 
-CASES = ["cull_model_wide.npz", "cull_model_small.npz", "cull_jitter_wide.npz", "cull_jitter_small.npz"]
+CASES = ["cull_model_wide.npz", "cull_model_small.npz", "cull_jitter_wide.npz", "cull_jitter_small.npz",
+         "cull_model_scene.npz", "cull_model_scene_nave.npz", "cull_model_scene_x3.npz"]   # the last three: the reference's own demo scene (make_golden.model_scene_cases)
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -158,6 +158,10 @@ PROTOTYPES = {
     "vd_trace_dev": (_I, [_P, C.POINTER(TraceScene), _P, _U, _P]),
     "vd_import_external_buffer": (_I, [_P, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "vd_release_external_buffer": (_I, [_P, _P]),
+    "vd_import_external_semaphore": (_I, [_P, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "vd_wait_external_semaphore_async": (_I, [_P, _P, C.c_uint64]),
+    "vd_signal_external_semaphore_async": (_I, [_P, _P, C.c_uint64]),
+    "vd_release_external_semaphore": (_I, [_P, _P]),
     "vd_trace_any_dev": (_I, [_P, C.POINTER(TraceScene), _P, _U, _P]),
     "vd_trace_prepare_dev": (_I, [_P, C.POINTER(TraceScene), C.POINTER(_P)]),
     "vd_trace_release": (_I, [_P, _P]),

@@ -2795,9 +2795,9 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
                     return VD_ERR_INVALID_ARG;
                 }
             } else {
-                if (packed_at + pool > packed_cap) {
+                if (packed_at + pool > packed_cap || packed_at + pool > 0xffffffffull) {     // out_first_node / bvh_index are 32-bit
                     if (out_failed_mesh) *out_failed_mesh = m;
-                    snprintf(ctx->err, sizeof(ctx->err), "vd_bvh_build_batch: the packed node buffer is full at mesh %u", m);
+                    snprintf(ctx->err, sizeof(ctx->err), "vd_bvh_build_batch: the packed node buffer is full at mesh %u (or its node indices pass 2^32)", m);
                     return VD_ERR_INVALID_ARG;
                 }
                 out = d_packed + packed_at;
@@ -2973,7 +2973,7 @@ int vd_bvh_build_batch(VdCtx* ctx, VdBvhBatchItem* items, uint32_t n_items, VdBv
     uint64_t at = packed_first;
     for (uint32_t m = 0; m < n_items && !rc; ++m) {        // room on the caller's side
         const uint32_t need = hm[m].out_n_nodes;
-        if (items[m].out_nodes ? need > items[m].node_cap : at + need > packed_cap) {
+        if (items[m].out_nodes ? need > items[m].node_cap : (at + need > packed_cap || at + need > 0xffffffffull)) {   // 32-bit node indices
             snprintf(ctx->err, sizeof(ctx->err), "vd_bvh_build_batch: item %u needs %u nodes: node_cap / packed_cap too small", m, need);
             rc = VD_ERR_INVALID_ARG; failed = m;
         }

@@ -46,7 +46,7 @@ int vd_ensure_host(VdCtx* ctx, size_t need) {
     return VD_OK;
 }
 
-int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer) {
+int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, unsigned* epoch, bool start_timer) {
     const size_t need = (16 + (size_t)n_tiles * 8 + 15) & ~(size_t)15;
     const bool periodic = (++ctx->scan_launches & ((1ull << 28) - 1)) == 0;   // epoch field is 30 bits: never let it lap
     if (need > ctx->scan_state_bytes || !ctx->scan_state || periodic) {
@@ -54,6 +54,7 @@ int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, u
         if (rc) return rc;
         VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->scan_state, 0, ctx->scan_state_bytes, ctx->stream));
     }
+    *epoch = (unsigned)(ctx->scan_launches & 0x3fffffffull);   // unique among the granules alive: the arena is zeroed every 2^28 launches
     *ticket = reinterpret_cast<unsigned long long*>(ctx->scan_state);
     *states = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->scan_state) + 16);
     if (start_timer) vd_time_begin(ctx);   // vd_last_gpu_ms brackets the scan kernel itself
@@ -177,6 +178,60 @@ int vd_release_external_buffer(VdCtx* ctx, VdExternalBuffer* handle) {
     hipError_t e = hipDestroyExternalMemory(handle->mem);
     delete handle;
     if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "hipDestroyExternalMemory -> %s", hipGetErrorString(e)); return VD_ERR_HIP; }
+    return VD_OK;
+}
+
+// The other half of the hand-off: the renderer's frame is one queue.submit (crates/app/src/app.rs:334-348); a Vulkan semaphore
+// exported as an opaque fd (VK_KHR_external_semaphore_fd; binary or timeline) orders that submit against the HIP stream
+// WITHOUT a CPU wait on either side: wait -> vd_cull_*_dev -> signal are all enqueued on the context's stream.
+struct VdExternalSemaphore { hipExternalSemaphore_t sem; int timeline; };
+
+int vd_import_external_semaphore(VdCtx* ctx, int opaque_fd, int is_timeline, VdExternalSemaphore** out_handle) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (opaque_fd < 0 || !out_handle) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_import_external_semaphore: bad fd / out pointer");
+    *out_handle = nullptr;
+    hipExternalSemaphoreHandleDesc hd;
+    memset(&hd, 0, sizeof(hd));
+    hd.type = is_timeline ? hipExternalSemaphoreHandleTypeTimelineSemaphoreFd : hipExternalSemaphoreHandleTypeOpaqueFd;
+    hd.handle.fd = opaque_fd;
+    hipExternalSemaphore_t sem = nullptr;
+    VD_HIP_CHECK(ctx, hipImportExternalSemaphore(&sem, &hd));
+    VdExternalSemaphore* h = new (std::nothrow) VdExternalSemaphore{sem, is_timeline ? 1 : 0};
+    if (!h) { (void)hipDestroyExternalSemaphore(sem); return VD_ERR_OOM; }
+    *out_handle = h;
+    return VD_OK;
+}
+
+int vd_wait_external_semaphore_async(VdCtx* ctx, VdExternalSemaphore* handle, uint64_t value) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!handle) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_wait_external_semaphore_async: null handle");
+    hipExternalSemaphoreWaitParams wp;
+    memset(&wp, 0, sizeof(wp));
+    wp.params.fence.value = handle->timeline ? value : 0ull;       // a binary semaphore carries no value
+    VD_HIP_CHECK(ctx, hipWaitExternalSemaphoresAsync(&handle->sem, &wp, 1, ctx->stream));
+    return VD_OK;
+}
+
+int vd_signal_external_semaphore_async(VdCtx* ctx, VdExternalSemaphore* handle, uint64_t value) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!handle) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_signal_external_semaphore_async: null handle");
+    hipExternalSemaphoreSignalParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.params.fence.value = handle->timeline ? value : 0ull;
+    VD_HIP_CHECK(ctx, hipSignalExternalSemaphoresAsync(&handle->sem, &sp, 1, ctx->stream));
+    return VD_OK;
+}
+
+int vd_release_external_semaphore(VdCtx* ctx, VdExternalSemaphore* handle) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx || !handle) return VD_ERR_INVALID_ARG;
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));          // waits / signals still queued on the stream refer to it
+    hipError_t e = hipDestroyExternalSemaphore(handle->sem);
+    delete handle;
+    if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "hipDestroyExternalSemaphore -> %s", hipGetErrorString(e)); return VD_ERR_HIP; }
     return VD_OK;
 }
 

@@ -194,18 +194,22 @@ __global__ __launch_bounds__(kBlock, 3)
 void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
                          const VdInstance* __restrict__ inst, unsigned n_inst, VdDrawIndexedIndirect* __restrict__ out,
                          unsigned* __restrict__ out_count, vd_u64* tile_state, vd_u64* ticket_counter,
-                         unsigned n_tiles, unsigned first_instance) {
+                         unsigned n_tiles, unsigned first_instance, unsigned epoch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // dynamic LDS: per-wave slabs, then per-round records (mesh id | visible << 31), then scalars
     unsigned* s_rec = reinterpret_cast<unsigned*>(smem + kWavesPerBlock * kSlabBytes);   // [ROUNDS][kBlock]
-    unsigned* s_misc = s_rec + ROUNDS * kBlock;   // [0] ticket, [1] epoch / tile_excl, [2..5] wave totals
+    unsigned* s_misc = s_rec + ROUNDS * kBlock;   // [0] ticket, [1] tile_excl, [2..5] wave totals
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     char* slab = smem + wave * kSlabBytes;
 
-    if (threadIdx.x == 0) s_misc[0] = vd_take_ticket(ticket_counter, n_tiles, &s_misc[1]);
+    if (threadIdx.x == 0) s_misc[0] = vd_take_ticket(ticket_counter, epoch);
     __syncthreads();
-    const unsigned tile = s_misc[0], epoch = s_misc[1];
+    const unsigned tile = s_misc[0];
     __syncthreads();
+    if (tile >= n_tiles) return;                  // (a launch draws exactly n_tiles tickets: never expected)
+#ifdef VD_TUNING
+    if (ticket_counter[1] == (vd_u64)tile + 1ull) return;   // tests/test_gpu_scan_fault.py: this workgroup "dies" before it publishes anything
+#endif
     const size_t tile_first = (size_t)tile * (kBlock * ROUNDS);
     // wave-contiguous ranges keep the output order (wave, round, lane) == instance order
     const size_t wave_first = tile_first + (size_t)wave * (kWave * ROUNDS);
@@ -239,11 +243,12 @@ void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, 
         const unsigned excl = vd_lookback(tile_state, epoch, tile, tile_total);
         if (lane == 0) {
             s_misc[1] = excl;
-            if (tile == n_tiles - 1u) *out_count = excl + tile_total;
+            if (tile == n_tiles - 1u) *out_count = excl == VD_SCAN_STUCK ? VD_SCAN_STUCK : excl + tile_total;
         }
     }
     __syncthreads();
     unsigned base = s_misc[1];
+    if (base == VD_SCAN_STUCK) return;            // a predecessor never published its total: no list (the count says so)
     for (unsigned w = 0; w < wave; ++w) base += s_misc[2 + w];
 
 #pragma unroll 1
@@ -1048,12 +1053,13 @@ constexpr int kCompactTile = kBlock * kCompactPerThread;
 __global__ __launch_bounds__(kBlock) void compact_draws_kernel(const VdDrawIndexedIndirect* __restrict__ in, unsigned n,
                                                                VdDrawIndexedIndirect* __restrict__ out,
                                                                unsigned* __restrict__ out_count, vd_u64* tile_state,
-                                                               vd_u64* ticket_counter, unsigned n_tiles) {
-    __shared__ unsigned s_ticket, s_epoch, s_wave_total[kWavesPerBlock], s_tile_excl;
+                                                               vd_u64* ticket_counter, unsigned n_tiles, unsigned epoch) {
+    __shared__ unsigned s_ticket, s_wave_total[kWavesPerBlock], s_tile_excl;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_ticket = vd_take_ticket(ticket_counter, n_tiles, &s_epoch);
+    if (threadIdx.x == 0) s_ticket = vd_take_ticket(ticket_counter, epoch);
     __syncthreads();
-    const unsigned tile = s_ticket, epoch = s_epoch;
+    const unsigned tile = s_ticket;
+    if (tile >= n_tiles) return;                  // (a launch draws exactly n_tiles tickets: never expected)
     const size_t wave_first = (size_t)tile * kCompactTile + (size_t)wave * (kWave * kCompactPerThread);
     unsigned long long masks[kCompactPerThread];
     unsigned wave_total = 0;
@@ -1074,11 +1080,12 @@ __global__ __launch_bounds__(kBlock) void compact_draws_kernel(const VdDrawIndex
         const unsigned excl = vd_lookback(tile_state, epoch, tile, tile_total);
         if (lane == 0) {
             s_tile_excl = excl;
-            if (tile == n_tiles - 1u) *out_count = excl + tile_total;
+            if (tile == n_tiles - 1u) *out_count = excl == VD_SCAN_STUCK ? VD_SCAN_STUCK : excl + tile_total;
         }
     }
     __syncthreads();
     unsigned base = s_tile_excl;
+    if (base == VD_SCAN_STUCK) return;
     for (unsigned w = 0; w < wave; ++w) base += s_wave_total[w];
     unsigned* out32 = reinterpret_cast<unsigned*>(out);
 #pragma unroll
@@ -1264,6 +1271,7 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
     if (!d_instances || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_compact: null instances/out");
     int variant = ctx->cull_variant;
     vd_u64* ticket; vd_u64* states;
+    unsigned scan_epoch = 0;
     int rc = VD_OK;
     if ((variant <= 0) && n_inst >= ctx->split_min) {
         // Split form (default for large inputs): pass 1 streams the instances and writes only one bit
@@ -1289,11 +1297,11 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
 #define VD_LAUNCH_COMPACT(R)                                                                                     \
     do {                                                                                                         \
         const unsigned n_tiles = (n_inst + kBlock * (R) - 1) / (kBlock * (R));                                   \
-        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);                                              \
+        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, &scan_epoch, true);                                 \
         if (rc) return rc;                                                                                       \
         hipLaunchKernelGGL((cull_compact_kernel<R>), dim3(n_tiles), dim3(kBlock), (compact_lds_bytes<R>()),      \
                            ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_out,          \
-                           d_out_count, states, ticket, n_tiles, first_instance);                                \
+                           d_out_count, states, ticket, n_tiles, first_instance, scan_epoch);                    \
     } while (0)
     // fused form: tile size grows with n so that ticket + two barriers + look-back amortise while
     // small inputs still spread over the chip (a 100 k-instance scene in 1024-instance tiles is 98
@@ -1446,10 +1454,11 @@ int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t
     if (!d_in || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_compact_draws: null in/out");
     const unsigned n_tiles = (n + kCompactTile - 1) / kCompactTile;
     vd_u64* ticket; vd_u64* states;
-    int rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);
+    unsigned scan_epoch = 0;
+    int rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, &scan_epoch, true);
     if (rc) return rc;
     hipLaunchKernelGGL(compact_draws_kernel, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, d_in, n, d_out, d_out_count,
-                       states, ticket, n_tiles);
+                       states, ticket, n_tiles, scan_epoch);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;
@@ -1527,6 +1536,10 @@ int vd_cull_compact(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo*
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *out_count = ctx->host_pinned[0];
+    if (*out_count > n_inst) {        // VD_SCAN_STUCK: a cross-workgroup wait of the scan timed out (vd_common.hpp) - no list was written
+        *out_count = 0;
+        VD_FAIL(ctx, VD_ERR_HIP, "vd_cull_compact: the compaction scan gave up waiting for a workgroup (count sentinel 0xffffffff)");
+    }
     const size_t n_copy = pad_tail ? n_inst : *out_count;
     if (n_copy) {
         VD_HIP_CHECK(ctx, hipMemcpyAsync(out, dout, n_copy * sizeof(VdDrawIndexedIndirect), hipMemcpyDeviceToHost, ctx->stream));
@@ -1534,5 +1547,22 @@ int vd_cull_compact(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo*
     }
     return VD_OK;
 }
+
+#ifdef VD_TUNING
+// Tuning / test hook (libvoidin_hip_tuning.so only): the workgroup that draws ticket `tile` of the next fused
+// cull + compaction launches leaves before it publishes anything - what a workgroup lost to a fault looks like to the
+// others.  tile < 0 clears it.  tests/test_gpu_scan_fault.py.
+int vd_debug_scan_fault(VdCtx* ctx, int tile) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    vd_u64* ticket; vd_u64* states; unsigned ep;
+    int rc = vd_scan_scratch(ctx, 1u << 16, &ticket, &states, &ep, false);   // makes sure the arena exists (and is large enough for the test's launches)
+    if (rc) return rc;
+    const vd_u64 v = tile < 0 ? 0ull : (vd_u64)tile + 1ull;
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(ticket + 1, &v, 8, hipMemcpyHostToDevice, ctx->stream));
+    VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VD_OK;
+}
+#endif
 
 }  // extern "C"

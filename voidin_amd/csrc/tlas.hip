@@ -1597,24 +1597,28 @@ int vd_tlas_build_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const Vd
                       VdTlasNode* d_nodes) {
     VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, false);
+    if (!rc) ctx->fan_forget(d_nodes);     // vd_trace*: what the last walk over this top level found no longer holds
     return rc ? rc : tlas_build_impl<VdTlasNode>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
 }
 int vd_tlas_build_wide_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                            VdTlasNodeWide* d_nodes) {
     VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, true);
+    if (!rc) ctx->fan_forget(d_nodes);     // vd_trace*: what the last walk over this top level found no longer holds
     return rc ? rc : tlas_build_impl<VdTlasNodeWide>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
 }
 int vd_tlas_refit_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                       VdTlasNode* d_nodes) {
     VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, false);
+    if (!rc) ctx->fan_forget(d_nodes);     // vd_trace*: what the last walk over this top level found no longer holds
     return rc ? rc : tlas_refit_impl<VdTlasNode>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
 }
 int vd_tlas_refit_wide_dev(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMeshInfo* d_meshes, uint32_t n_mesh,
                            VdTlasNodeWide* d_nodes) {
     VdDeviceGuard vd_guard_(ctx);   // run on ctx->device whatever the calling thread's current device is
     int rc = check_args(ctx, d_inst, n, d_meshes, n_mesh, d_nodes, true);
+    if (!rc) ctx->fan_forget(d_nodes);     // vd_trace*: what the last walk over this top level found no longer holds
     return rc ? rc : tlas_refit_impl<VdTlasNodeWide>(ctx, d_inst, n, d_meshes, n_mesh, d_nodes);
 }
 

@@ -969,8 +969,9 @@ __global__ __launch_bounds__(256) void prepare_tris_kernel(const VdMeshInfo* __r
 // the stress scene).  Which instances a ray ENTERS does not change what it hits: inside an instance only the root's
 // children and below are tested (bvh.wgsl:35-76), all within the mesh's root box.  The private top level therefore
 // bounds each instance by the eight corners of its BLAS ROOT box under `transform` - no seed - padded by 2e-5 of the
-// box's largest coordinate (the rounding of transforming the ray in versus the corners out is ~1e-6 of that), and
-// clusters those boxes with the same agglomerative builder.  Used only where it is provably the same geometry: the
+// box's largest coordinate (the rounding of transforming the ray in versus the corners out is ~1e-6 of that) PLUS how far
+// `inv_transform`, which is all the walk uses, puts the geometry from where `transform` puts the corners (per axis, from
+// T * Tinv - I: see the kernel), and clusters those boxes with the same agglomerative builder.  Used only where it is provably the same geometry: the
 // instance's inv_transform must invert its transform (|T * Tinv - I| <= 1e-3 per element) and every corner must be
 // finite.  ONE instance that fails either makes vd_trace_prepare_dev decline the option for the whole scene (it keeps
 // the scene's own top level; VdTraceAccelInfo.tight_fallback_instances says how many failed): the hits of an instance
@@ -988,31 +989,43 @@ __global__ __launch_bounds__(256) void tight_boxes_kernel(const VdInstance* __re
     const VdMeshInfo m = meshes[min(inst[i].mesh, n_meshes - 1u)];
     bool ok = m.bvh_index < n_bvh;
     float worst = 0.0f;
+    float E[3][4];                             // rows 0..2 of T * Tinv - I: where the walk's geometry sits relative to T's
     for (int r = 0; r < 4 && ok; ++r)
         for (int c = 0; c < 4; ++c) {
             float a = 0.0f;
             for (int k = 0; k < 4; ++k) a += T[4 * k + r] * V[4 * c + k];        // (T * Tinv)[r][c], column-major storage
-            worst = fmaxf(worst, fabsf(a - (r == c ? 1.0f : 0.0f)));
+            const float e = fabsf(a - (r == c ? 1.0f : 0.0f));
+            if (r < 3) E[r][c] = e;
+            worst = fmaxf(worst, e);
         }
     ok = ok && worst <= 1e-3f;                 // false for NaN too
     float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
+    float dev[3] = {0.0f, 0.0f, 0.0f};
     if (ok) {
         const VdBvhNode root = bvh[m.bvh_index];
         const float b[2][3] = {{root.min[0], root.min[1], root.min[2]}, {root.max[0], root.max[1], root.max[2]}};
         for (int c = 0; c < 8; ++c) {
             const float px = b[c & 1][0], py = b[(c >> 1) & 1][1], pz = b[(c >> 2) & 1][2];
+            float w[3];
             for (int k = 0; k < 3; ++k) {
-                const float w = ((T[k] * px + T[4 + k] * py) + T[8 + k] * pz) + T[12 + k];
-                ok = ok && fabsf(w) < 1e30f;       // finite and inside the format's own range (MAX_DIST)
-                mn[k] = fminf(mn[k], w); mx[k] = fmaxf(mx[k], w);
+                w[k] = ((T[k] * px + T[4 + k] * py) + T[8 + k] * pz) + T[12 + k];
+                ok = ok && fabsf(w[k]) < 1e30f;       // finite and inside the format's own range (MAX_DIST)
+                mn[k] = fminf(mn[k], w[k]); mx[k] = fmaxf(mx[k], w[k]);
             }
+            // The walk takes rays into the instance with inv_transform ALONE, so the geometry it sees is Tinv^-1 * p, not
+            // T * p: with T * Tinv = I + E that is (I + E)^-1 * (T p) = T p - E (T p) + O(E^2) - off by at most
+            // sum_c |E[k][c]| |(T p)_c| + |E[k][3]| along axis k (a float inverse of an instance 2 000 units out leaves
+            // E ~ 1e-4 in the translation column; one nudged by 5e-4 without its inverse passes the 1e-3 test too).
+            for (int k = 0; k < 3; ++k) dev[k] = fmaxf(dev[k], ((E[k][0] * fabsf(w[0]) + E[k][1] * fabsf(w[1])) + E[k][2] * fabsf(w[2])) + E[k][3]);
         }
     }
     if (ok) {
         float big = 0.0f;
         for (int k = 0; k < 3; ++k) big = fmaxf(big, fmaxf(fabsf(mn[k]), fabsf(mx[k])));
-        const float pad = 2e-5f * big + 1e-30f;
-        for (int k = 0; k < 3; ++k) { mn[k] -= pad; mx[k] += pad; }
+        for (int k = 0; k < 3; ++k) {
+            const float pad = (2e-5f * big + 1e-30f) + 1.01f * dev[k];        // rounding of ray-in versus corners-out + the inverse's own error
+            mn[k] -= pad; mx[k] += pad;
+        }
     } else {
         atomicAdd(n_fallback, 1u);
         const bool own_leaf = i + 1u < n_scene_nodes && scene_tlas[i + 1u].left_right == 0u && scene_tlas[i + 1u].instance_idx == i;
@@ -1187,7 +1200,8 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     // nothing to do): a call remembers how many jobs it made, and while the last call over the same top level made fewer than one
     // per 64 rays the next 15 calls over it run as one launch with the plain kernels; then the fan-out is tried again.
     const bool fan_default = ctx->option(VD_OPT_TRACE_FAN, -1) < 0;
-    if (phases > 1u && fan_default && ctx->fan_tlas == sc->tlas_nodes && ctx->fan_idle_calls != 0u) { phases = 1u; --ctx->fan_idle_calls; }
+    const bool fan_same_scene = ctx->fan_tlas == sc->tlas_nodes && ctx->fan_nodes == sc->n_tlas_nodes && ctx->fan_inst == sc->n_instances;
+    if (phases > 1u && fan_default && fan_same_scene && ctx->fan_idle_calls != 0u) { phases = 1u; --ctx->fan_idle_calls; }
     unsigned fan_cap = (unsigned)std::min<size_t>((size_t)1 << 21, (size_t)n_rays * 2u);
     if (ctx->option(VD_OPT_TRACE_FAN_SLOTS, -1) >= 0) fan_cap = (unsigned)std::min<long long>(fan_cap, ctx->option(VD_OPT_TRACE_FAN_SLOTS, -1));      // tests: a list that fills up
     const size_t best_bytes = ((size_t)n_rays * 8u + 255) & ~(size_t)255;
@@ -1274,7 +1288,10 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (phases > 1u) VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned + 1, fan_ctl, 4, hipMemcpyDeviceToHost, ctx->stream));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (phases > 1u) { ctx->fan_tlas = sc->tlas_nodes; ctx->fan_idle_calls = ctx->host_pinned[1] < n_rays / 64u ? 15u : 0u; }
+    if (phases > 1u) {
+        ctx->fan_tlas = sc->tlas_nodes; ctx->fan_nodes = sc->n_tlas_nodes; ctx->fan_inst = sc->n_instances;
+        ctx->fan_idle_calls = ctx->host_pinned[1] < n_rays / 64u ? 15u : 0u;
+    }
     if (ctx->host_pinned[0] & 4u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: a TLAS leaf's instance, its mesh's root or the root's children lie outside the scene's buffers");
     if (ctx->host_pinned[0] & 2u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: BVH leaf with more than 3 triangles (BvhBuilder never makes one: blas.rs:108)");
     if (ctx->host_pinned[0]) VD_FAIL(ctx, VD_ERR_STACK_OVERFLOW, "vd_trace: traversal stack (128 entries per ray) exceeded");
@@ -1442,6 +1459,7 @@ int vd_trace_accel_update_dev(VdCtx* ctx, VdTraceAccel* accel) {
     VdDeviceGuard vd_guard_(ctx);
     if (!ctx || !accel) return VD_ERR_INVALID_ARG;
     if (!accel->tight) return VD_OK;          // the scene's own top level is walked: the host refits that one (vd_tlas_refit_dev)
+    ctx->fan_forget(accel->tight);
     return build_tight_tlas(ctx, accel);
 }
 
@@ -1449,6 +1467,7 @@ int vd_trace_release(VdCtx* ctx, VdTraceAccel* accel) {
     VdDeviceGuard vd_guard_(ctx);
     if (!ctx || !accel) return VD_ERR_INVALID_ARG;
     (void)hipStreamSynchronize(ctx->stream);
+    if (accel->tight) ctx->fan_forget(accel->tight);
     if (accel->tris) (void)hipFree(accel->tris);
     if (accel->tight) (void)hipFree(accel->tight);
     if (accel->boxes) (void)hipFree(accel->boxes);

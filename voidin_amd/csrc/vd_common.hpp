@@ -36,6 +36,8 @@ struct VdCtx {
     void* refit_state = nullptr; size_t refit_state_bytes = 0;    // TLAS refit: epoch-tagged {parent, sibling} links + arrival words
     unsigned refit_epoch = 0;                                     // tag of the last refit launch (0 = the arena is freshly zeroed)
     const void* fan_tlas = nullptr; unsigned fan_idle_calls = 0;  // traversal fan-out: top level of the last call that tried it, calls left to run without it
+    unsigned fan_nodes = 0, fan_inst = 0;                         // ... and its node / instance counts: the verdict is about THAT scene
+    void fan_forget(const void* tlas) { if (tlas == fan_tlas) { fan_tlas = nullptr; fan_idle_calls = 0; } }   // the top level at this address was rebuilt / refitted / released
     unsigned refit_n = 0;                                         // instance count the arena's layout was last used with
     unsigned long long scan_launches = 0;
     void* dbg_ptr = nullptr; unsigned dbg_count = 0;   // tuning hooks
@@ -88,9 +90,9 @@ int vd_ensure(VdCtx* ctx, void** buf, size_t* cur, size_t need);
 int vd_ensure_host(VdCtx* ctx, size_t need);   // ctx->host_stage: grow-only pinned host memory
 // tlas.hip: the agglomerative build of tlas.rs:56-105 over ready leaf boxes (six floats {min xyz, max xyz} per leaf; n <= 32 768)
 int vd_tlas_build_from_boxes(VdCtx* ctx, const float* d_boxes, uint32_t n, VdTlasNode* d_nodes);
-// Look-back scan state for n_tiles tiles: *ticket = 64-bit {epoch | ticket} word, *states = granules.
-// Zeroed once when (re)allocated; the epoch tags make per-launch clearing unnecessary.
-int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer);
+// Look-back scan state for n_tiles tiles: *ticket = 64-bit {epoch | ticket} word, *states = granules, *epoch = this
+// launch's tag (pass it to the kernel).  Zeroed once when (re)allocated; the epoch tags make per-launch clearing unnecessary.
+int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, unsigned* epoch, bool start_timer);
 
 static inline void vd_time_begin(VdCtx* ctx) {
     ctx->timed_mid = false;
@@ -158,28 +160,41 @@ typedef unsigned long long vd_u64;
 // tile_state[t] is one naturally aligned 8-byte {epoch:30 | status:2 | value:32} granule written
 // by ONE agent-scope store and polled by agent-scope loads (write-through / L1-bypassing on
 // gfx950), so the data is its own flag and no fence is needed.  A granule whose epoch is not the
-// launch's epoch is INVALID, so nothing has to be zeroed between launches: the 64-bit ticket
-// word {epoch:32 | next ticket:32} hands out both, and the workgroup that draws the last ticket
-// re-arms it for the next launch ({epoch + 1, 0}).  Tickets come from an atomic counter, so every
-// predecessor of a running tile is itself running or finished: no residency assumption.
-enum : unsigned { VD_TILE_AGGREGATE = 1u, VD_TILE_INCLUSIVE = 2u };
+// launch's epoch is INVALID, so nothing has to be zeroed between launches.  The EPOCH COMES FROM THE
+// HOST (vd_scan_scratch: a per-context launch counter, passed as a kernel argument), and the 64-bit
+// ticket word {epoch:32 | next ticket:32} is re-armed by the first workgroup of a launch that finds
+// another launch's epoch in it: a launch never depends on what an earlier one left behind - one that
+// was aborted half-way, say - and exactly n_tiles tickets 0..n_tiles-1 are drawn per launch.  Tickets
+// come from an atomic counter, so every predecessor of a running tile is itself running or finished:
+// no residency assumption.
+// Every wait is BOUNDED: a tile whose predecessor does not show up within kScanSpinLimit polls (seconds; an
+// ordinary wait is microseconds) publishes VD_TILE_POISON and returns VD_SCAN_STUCK, every later tile runs
+// into the poison and does the same at once, and the last tile writes VD_SCAN_STUCK to the count - an error
+// code (VD_ERR_HIP on the host-pointer entry points), not a stream that never finishes.
+enum : unsigned { VD_TILE_AGGREGATE = 1u, VD_TILE_INCLUSIVE = 2u, VD_TILE_POISON = 3u };
+constexpr unsigned VD_SCAN_STUCK = 0xffffffffu;
+constexpr unsigned kScanSpinLimit = 1u << 20;
 
 __device__ __forceinline__ vd_u64 vd_tile_pack(unsigned epoch, unsigned status, unsigned value) {
     return ((vd_u64)(epoch & 0x3fffffffu) << 34) | ((vd_u64)status << 32) | value;
 }
 
-// ONE lane: draw a ticket.  Returns the ticket; *epoch = this launch's epoch.
-__device__ __forceinline__ unsigned vd_take_ticket(vd_u64* ticket_word, unsigned n_tiles, unsigned* epoch) {
-    const vd_u64 t = __hip_atomic_fetch_add(ticket_word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned ticket = (unsigned)t, ep = (unsigned)(t >> 32);
-    *epoch = ep;
-    if (ticket == n_tiles - 1u)   // every ticket of this launch is out: re-arm for the next one
-        __hip_atomic_store(ticket_word, (vd_u64)(ep + 1u) << 32, VD_RLX_AGENT);
-    return ticket;
+// ONE lane: draw a ticket of the launch `epoch`.
+__device__ __forceinline__ unsigned vd_take_ticket(vd_u64* ticket_word, unsigned epoch) {
+    vd_u64 t = __hip_atomic_fetch_add(ticket_word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(t >> 32) == epoch) return (unsigned)t;
+    for (;;) {    // the word still belongs to an earlier launch: whoever swaps this launch's epoch in holds ticket 0
+        vd_u64 cur = __hip_atomic_load(ticket_word, VD_RLX_AGENT);
+        if ((unsigned)(cur >> 32) == epoch)
+            return (unsigned)__hip_atomic_fetch_add(ticket_word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_compare_exchange_strong(ticket_word, &cur, ((vd_u64)epoch << 32) | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT))
+            return 0u;
+    }
 }
 
 // Called by ONE full wave of the workgroup. Returns the exclusive prefix of tile `t`
-// (sum of `total` over tiles < t) in every lane, after publishing this tile's state.
+// (sum of `total` over tiles < t) in every lane, after publishing this tile's state - or VD_SCAN_STUCK.
 // `first` marks the first tile of a segment (segmented scan): its prefix restarts at 0.
 __device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned epoch, unsigned t, unsigned total, bool first = false) {
     const unsigned lane = vd_lane();
@@ -191,38 +206,49 @@ __device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned epo
     if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_AGGREGATE, total), VD_RLX_AGENT);
     unsigned exclusive = 0u;
     int look = (int)t - 1;
+    bool stuck = false;
     {   // tiles finish roughly in ticket order: wait for the immediate predecessor with ONE lane
         // (one 8-byte poll per iteration instead of a 64-granule window), then sweep the window
-        vd_u64 s0 = 0;
         if (lane == 0) {
-            s0 = __hip_atomic_load(&tile_state[look], VD_RLX_AGENT);
+            vd_u64 s0 = __hip_atomic_load(&tile_state[look], VD_RLX_AGENT);
+            unsigned spins = 0;
             while ((unsigned)(s0 >> 34) != ep || ((unsigned)(s0 >> 32) & 3u) == 0u) {
+                if (++spins > kScanSpinLimit) { stuck = true; break; }
                 __builtin_amdgcn_s_sleep(8);
                 s0 = __hip_atomic_load(&tile_state[look], VD_RLX_AGENT);
             }
         }
+        stuck = __builtin_amdgcn_readfirstlane((int)stuck) != 0;
     }
-    for (;;) {
+    while (!stuck) {
         const int idx = look - (int)lane;
         vd_u64 s = vd_tile_pack(ep, VD_TILE_INCLUSIVE, 0u);   // virtual tiles before 0
+        bool mine_stuck = false;
         if (idx >= 0) {
             s = __hip_atomic_load(&tile_state[idx], VD_RLX_AGENT);
+            unsigned spins = 0;
             while ((unsigned)(s >> 34) != ep || ((unsigned)(s >> 32) & 3u) == 0u) {   // not written in this launch yet
+                if (++spins > kScanSpinLimit) { mine_stuck = true; break; }
                 __builtin_amdgcn_s_sleep(1);
                 s = __hip_atomic_load(&tile_state[idx], VD_RLX_AGENT);
             }
         }
         const unsigned status = (unsigned)(s >> 32) & 3u;
         const unsigned value = (unsigned)s;
-        const unsigned long long incl = __ballot(status == VD_TILE_INCLUSIVE);
+        const unsigned long long incl = __ballot(!mine_stuck && status == VD_TILE_INCLUSIVE);
         // lanes at or before the first INCLUSIVE one (closest predecessors first) contribute
-        const unsigned first = incl ? (unsigned)__builtin_ctzll(incl) : 63u;
-        unsigned v = lane <= first ? value : 0u;
+        const unsigned first_incl = incl ? (unsigned)__builtin_ctzll(incl) : 63u;
+        if (__ballot(lane <= first_incl && (mine_stuck || status == VD_TILE_POISON))) { stuck = true; break; }   // a predecessor gave up, or never came
+        unsigned v = lane <= first_incl ? value : 0u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         exclusive += v;
         if (incl) break;
         look -= 64;
+    }
+    if (stuck) {
+        if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_POISON, 0u), VD_RLX_AGENT);
+        return VD_SCAN_STUCK;
     }
     if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_INCLUSIVE, exclusive + total), VD_RLX_AGENT);
     return exclusive;
