@@ -46,7 +46,7 @@ int vd_ensure_host(VdCtx* ctx, size_t need) {
     return VD_OK;
 }
 
-int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, unsigned* epoch, bool start_timer) {
+int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer) {
     const size_t need = (16 + (size_t)n_tiles * 8 + 15) & ~(size_t)15;
     const bool periodic = (++ctx->scan_launches & ((1ull << 28) - 1)) == 0;   // epoch field is 30 bits: never let it lap
     if (need > ctx->scan_state_bytes || !ctx->scan_state || periodic) {
@@ -54,7 +54,6 @@ int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, u
         if (rc) return rc;
         VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->scan_state, 0, ctx->scan_state_bytes, ctx->stream));
     }
-    *epoch = (unsigned)(ctx->scan_launches & 0x3fffffffull);   // unique among the granules alive: the arena is zeroed every 2^28 launches
     *ticket = reinterpret_cast<unsigned long long*>(ctx->scan_state);
     *states = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->scan_state) + 16);
     if (start_timer) vd_time_begin(ctx);   // vd_last_gpu_ms brackets the scan kernel itself

@@ -194,22 +194,26 @@ __global__ __launch_bounds__(kBlock, 3)
 void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
                          const VdInstance* __restrict__ inst, unsigned n_inst, VdDrawIndexedIndirect* __restrict__ out,
                          unsigned* __restrict__ out_count, vd_u64* tile_state, vd_u64* ticket_counter,
-                         unsigned n_tiles, unsigned first_instance, unsigned epoch) {
+                         unsigned n_tiles, unsigned first_instance) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // dynamic LDS: per-wave slabs, then per-round records (mesh id | visible << 31), then scalars
     unsigned* s_rec = reinterpret_cast<unsigned*>(smem + kWavesPerBlock * kSlabBytes);   // [ROUNDS][kBlock]
-    unsigned* s_misc = s_rec + ROUNDS * kBlock;   // [0] ticket, [1] tile_excl, [2..5] wave totals
+    unsigned* s_misc = s_rec + ROUNDS * kBlock;   // [0] ticket, [1] epoch / tile_excl, [2..5] wave totals
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     char* slab = smem + wave * kSlabBytes;
 
-    if (threadIdx.x == 0) s_misc[0] = vd_take_ticket(ticket_counter, epoch);
+    if (threadIdx.x == 0) s_misc[0] = vd_take_ticket(ticket_counter, n_tiles, &s_misc[1]);
     __syncthreads();
-    const unsigned tile = s_misc[0];
+    const unsigned tile = s_misc[0], epoch = s_misc[1];
     __syncthreads();
-    if (tile >= n_tiles) return;                  // (a launch draws exactly n_tiles tickets: never expected)
+    if (tile >= n_tiles) return;                  // (the ticket word was not at {epoch, 0} when the launch began: never expected)
 #ifdef VD_TUNING
     if (ticket_counter[1] == (vd_u64)tile + 1ull) return;   // tests/test_gpu_scan_fault.py: this workgroup "dies" before it publishes anything
 #endif
+    // The count is written by the LAST tile; until then it holds the error value, stored by the FIRST tile before anything can
+    // depend on it (the fence completes the store before this tile's granule - which every other tile's prefix waits for - goes
+    // out): a launch that loses its last workgroup leaves the sentinel, not the previous call's count.
+    if (tile == 0u && threadIdx.x == 0) { __hip_atomic_store(out_count, VD_SCAN_STUCK, VD_RLX_AGENT); __threadfence(); }
     const size_t tile_first = (size_t)tile * (kBlock * ROUNDS);
     // wave-contiguous ranges keep the output order (wave, round, lane) == instance order
     const size_t wave_first = tile_first + (size_t)wave * (kWave * ROUNDS);
@@ -1053,13 +1057,14 @@ constexpr int kCompactTile = kBlock * kCompactPerThread;
 __global__ __launch_bounds__(kBlock) void compact_draws_kernel(const VdDrawIndexedIndirect* __restrict__ in, unsigned n,
                                                                VdDrawIndexedIndirect* __restrict__ out,
                                                                unsigned* __restrict__ out_count, vd_u64* tile_state,
-                                                               vd_u64* ticket_counter, unsigned n_tiles, unsigned epoch) {
-    __shared__ unsigned s_ticket, s_wave_total[kWavesPerBlock], s_tile_excl;
+                                                               vd_u64* ticket_counter, unsigned n_tiles) {
+    __shared__ unsigned s_ticket, s_epoch, s_wave_total[kWavesPerBlock], s_tile_excl;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_ticket = vd_take_ticket(ticket_counter, epoch);
+    if (threadIdx.x == 0) s_ticket = vd_take_ticket(ticket_counter, n_tiles, &s_epoch);
     __syncthreads();
-    const unsigned tile = s_ticket;
-    if (tile >= n_tiles) return;                  // (a launch draws exactly n_tiles tickets: never expected)
+    const unsigned tile = s_ticket, epoch = s_epoch;
+    if (tile >= n_tiles) return;                  // (the ticket word was not at {epoch, 0} when the launch began: never expected)
+    if (tile == 0u && threadIdx.x == 0) { __hip_atomic_store(out_count, VD_SCAN_STUCK, VD_RLX_AGENT); __threadfence(); }   // see cull_compact_kernel
     const size_t wave_first = (size_t)tile * kCompactTile + (size_t)wave * (kWave * kCompactPerThread);
     unsigned long long masks[kCompactPerThread];
     unsigned wave_total = 0;
@@ -1271,7 +1276,6 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
     if (!d_instances || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_compact: null instances/out");
     int variant = ctx->cull_variant;
     vd_u64* ticket; vd_u64* states;
-    unsigned scan_epoch = 0;
     int rc = VD_OK;
     if ((variant <= 0) && n_inst >= ctx->split_min) {
         // Split form (default for large inputs): pass 1 streams the instances and writes only one bit
@@ -1297,11 +1301,11 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
 #define VD_LAUNCH_COMPACT(R)                                                                                     \
     do {                                                                                                         \
         const unsigned n_tiles = (n_inst + kBlock * (R) - 1) / (kBlock * (R));                                   \
-        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, &scan_epoch, true);                                 \
+        rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);                                              \
         if (rc) return rc;                                                                                       \
         hipLaunchKernelGGL((cull_compact_kernel<R>), dim3(n_tiles), dim3(kBlock), (compact_lds_bytes<R>()),      \
                            ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_out,          \
-                           d_out_count, states, ticket, n_tiles, first_instance, scan_epoch);                    \
+                           d_out_count, states, ticket, n_tiles, first_instance);                                \
     } while (0)
     // fused form: tile size grows with n so that ticket + two barriers + look-back amortise while
     // small inputs still spread over the chip (a 100 k-instance scene in 1024-instance tiles is 98
@@ -1454,11 +1458,10 @@ int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t
     if (!d_in || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_compact_draws: null in/out");
     const unsigned n_tiles = (n + kCompactTile - 1) / kCompactTile;
     vd_u64* ticket; vd_u64* states;
-    unsigned scan_epoch = 0;
-    int rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, &scan_epoch, true);
+    int rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);
     if (rc) return rc;
     hipLaunchKernelGGL(compact_draws_kernel, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, d_in, n, d_out, d_out_count,
-                       states, ticket, n_tiles, scan_epoch);
+                       states, ticket, n_tiles);
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;
@@ -1538,6 +1541,7 @@ int vd_cull_compact(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo*
     *out_count = ctx->host_pinned[0];
     if (*out_count > n_inst) {        // VD_SCAN_STUCK: a cross-workgroup wait of the scan timed out (vd_common.hpp) - no list was written
         *out_count = 0;
+        if (ctx->scan_state) (void)hipMemsetAsync(ctx->scan_state, 0, ctx->scan_state_bytes, ctx->stream);   // whatever state the launch left: start over
         VD_FAIL(ctx, VD_ERR_HIP, "vd_cull_compact: the compaction scan gave up waiting for a workgroup (count sentinel 0xffffffff)");
     }
     const size_t n_copy = pad_tail ? n_inst : *out_count;
@@ -1555,8 +1559,8 @@ int vd_cull_compact(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo*
 int vd_debug_scan_fault(VdCtx* ctx, int tile) {
     VdDeviceGuard vd_guard_(ctx);
     if (!ctx) return VD_ERR_INVALID_ARG;
-    vd_u64* ticket; vd_u64* states; unsigned ep;
-    int rc = vd_scan_scratch(ctx, 1u << 16, &ticket, &states, &ep, false);   // makes sure the arena exists (and is large enough for the test's launches)
+    vd_u64* ticket; vd_u64* states;
+    int rc = vd_scan_scratch(ctx, 1u << 16, &ticket, &states, false);   // makes sure the arena exists (and is large enough for the test's launches)
     if (rc) return rc;
     const vd_u64 v = tile < 0 ? 0ull : (vd_u64)tile + 1ull;
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ticket + 1, &v, 8, hipMemcpyHostToDevice, ctx->stream));

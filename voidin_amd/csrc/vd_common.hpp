@@ -74,6 +74,7 @@ struct VdDeviceGuard {
         if (e_ != hipSuccess) {                                                              \
             snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__,   \
                      #call, hipGetErrorString(e_));                                          \
+            (void)hipGetLastError();   /* reported here: a later launch check must not find it again */ \
             return VD_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
@@ -90,9 +91,9 @@ int vd_ensure(VdCtx* ctx, void** buf, size_t* cur, size_t need);
 int vd_ensure_host(VdCtx* ctx, size_t need);   // ctx->host_stage: grow-only pinned host memory
 // tlas.hip: the agglomerative build of tlas.rs:56-105 over ready leaf boxes (six floats {min xyz, max xyz} per leaf; n <= 32 768)
 int vd_tlas_build_from_boxes(VdCtx* ctx, const float* d_boxes, uint32_t n, VdTlasNode* d_nodes);
-// Look-back scan state for n_tiles tiles: *ticket = 64-bit {epoch | ticket} word, *states = granules, *epoch = this
-// launch's tag (pass it to the kernel).  Zeroed once when (re)allocated; the epoch tags make per-launch clearing unnecessary.
-int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, unsigned* epoch, bool start_timer);
+// Look-back scan state for n_tiles tiles: *ticket = 64-bit {epoch | ticket} word, *states = granules.
+// Zeroed once when (re)allocated; the epoch tags make per-launch clearing unnecessary.
+int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer);
 
 static inline void vd_time_begin(VdCtx* ctx) {
     ctx->timed_mid = false;
@@ -160,17 +161,17 @@ typedef unsigned long long vd_u64;
 // tile_state[t] is one naturally aligned 8-byte {epoch:30 | status:2 | value:32} granule written
 // by ONE agent-scope store and polled by agent-scope loads (write-through / L1-bypassing on
 // gfx950), so the data is its own flag and no fence is needed.  A granule whose epoch is not the
-// launch's epoch is INVALID, so nothing has to be zeroed between launches.  The EPOCH COMES FROM THE
-// HOST (vd_scan_scratch: a per-context launch counter, passed as a kernel argument), and the 64-bit
-// ticket word {epoch:32 | next ticket:32} is re-armed by the first workgroup of a launch that finds
-// another launch's epoch in it: a launch never depends on what an earlier one left behind - one that
-// was aborted half-way, say - and exactly n_tiles tickets 0..n_tiles-1 are drawn per launch.  Tickets
-// come from an atomic counter, so every predecessor of a running tile is itself running or finished:
-// no residency assumption.
+// launch's epoch is INVALID, so nothing has to be zeroed between launches: the 64-bit ticket
+// word {epoch:32 | next ticket:32} hands out both, and the workgroup that draws the last ticket
+// re-arms it for the next launch ({epoch + 1, 0}) - the state advances ON THE DEVICE, so a launch
+// recorded in a HIP graph replays correctly (tests/test_gpu_frame_loop.py).  Tickets come from an
+// atomic counter, so every predecessor of a running tile is itself running or finished: no
+// residency assumption.
 // Every wait is BOUNDED: a tile whose predecessor does not show up within kScanSpinLimit polls (seconds; an
 // ordinary wait is microseconds) publishes VD_TILE_POISON and returns VD_SCAN_STUCK, every later tile runs
 // into the poison and does the same at once, and the last tile writes VD_SCAN_STUCK to the count - an error
-// code (VD_ERR_HIP on the host-pointer entry points), not a stream that never finishes.
+// code (VD_ERR_HIP on the host-pointer entry points, which also zero the scan state before they return), not a
+// stream that never finishes.  The launch after it draws its tickets under the next epoch and is clean.
 enum : unsigned { VD_TILE_AGGREGATE = 1u, VD_TILE_INCLUSIVE = 2u, VD_TILE_POISON = 3u };
 constexpr unsigned VD_SCAN_STUCK = 0xffffffffu;
 constexpr unsigned kScanSpinLimit = 1u << 20;
@@ -179,18 +180,14 @@ __device__ __forceinline__ vd_u64 vd_tile_pack(unsigned epoch, unsigned status, 
     return ((vd_u64)(epoch & 0x3fffffffu) << 34) | ((vd_u64)status << 32) | value;
 }
 
-// ONE lane: draw a ticket of the launch `epoch`.
-__device__ __forceinline__ unsigned vd_take_ticket(vd_u64* ticket_word, unsigned epoch) {
-    vd_u64 t = __hip_atomic_fetch_add(ticket_word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((unsigned)(t >> 32) == epoch) return (unsigned)t;
-    for (;;) {    // the word still belongs to an earlier launch: whoever swaps this launch's epoch in holds ticket 0
-        vd_u64 cur = __hip_atomic_load(ticket_word, VD_RLX_AGENT);
-        if ((unsigned)(cur >> 32) == epoch)
-            return (unsigned)__hip_atomic_fetch_add(ticket_word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_compare_exchange_strong(ticket_word, &cur, ((vd_u64)epoch << 32) | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT))
-            return 0u;
-    }
+// ONE lane: draw a ticket.  Returns the ticket; *epoch = this launch's epoch.
+__device__ __forceinline__ unsigned vd_take_ticket(vd_u64* ticket_word, unsigned n_tiles, unsigned* epoch) {
+    const vd_u64 t = __hip_atomic_fetch_add(ticket_word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned ticket = (unsigned)t, ep = (unsigned)(t >> 32);
+    *epoch = ep;
+    if (ticket == n_tiles - 1u)   // every ticket of this launch is out: re-arm for the next one
+        __hip_atomic_store(ticket_word, (vd_u64)(ep + 1u) << 32, VD_RLX_AGENT);
+    return ticket;
 }
 
 // Called by ONE full wave of the workgroup. Returns the exclusive prefix of tile `t`
