@@ -411,6 +411,13 @@ def model_scene_cases():
         assert cnt == cnt2 and comp.tobytes() == c2[:cnt2].tobytes()
         np.savez_compressed(os.path.join(OUT, name + ".npz"), camera=cam, meshes=ms, instances=ins, draws=d_np, compact=comp, count=np.uint32(cnt))
         print(name, "visible", cnt, "/", len(ins), "meshes", len(ms))
+    # ... and the top level App::setup_scene builds over exactly these instances (app.rs:252-253 -> MeshPool::generate_tlas ->
+    # Tlas::build, tlas.rs:31-105): 116 leaves, most of them Sponza primitives whose boxes nest and overlap
+    t_np = npr.tlas_nodes(inst, meshes)
+    t_c = ref.tlas_build(inst, meshes)
+    assert same(t_np, t_c)
+    np.savez_compressed(os.path.join(OUT, "tlas_model_scene.npz"), instances=inst, meshes=meshes, nodes=t_np)
+    print("tlas_model_scene", len(t_np), "nodes")
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ from voidin_amd.runtime import VoidinError
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 40, 300, "nan_60"])
+@pytest.mark.parametrize("n", [1, 2, 5, 40, 300, "nan_60", "model_scene"])     # model_scene: the reference's own demo scene (make_golden.model_scene_cases)
 def test_tlas_build_matches_golden(ctx, n):
     g = golden(f"tlas_{n}.npz")       # nan_60: NaN / inf - inf transforms; f32::min/max ignore the NaN corners (tlas.rs:39-44)
     nodes = ctx.tlas_build(g["instances"], g["meshes"])

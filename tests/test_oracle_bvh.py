@@ -89,11 +89,12 @@ def test_blas_degenerate_input_is_an_error(oracle):
     assert e.value.code == abi.VD_ERR_DEGENERATE
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 40, 300])
+@pytest.mark.parametrize("n", [1, 2, 5, 40, 300, "model_scene"])
 def test_tlas_c_oracle_matches_golden(oracle, n):
     g = golden(f"tlas_{n}.npz")
     nodes = oracle.tlas_build(g["instances"], g["meshes"])
     assert fields_equal(nodes, g["nodes"])
+    n = len(g["instances"])
     # T2: all 2N+1 slots used; node 2N (copied to 0) merges the true root 2N-1 with itself
     assert nodes[0]["left_right"] == (2 * n - 1) | ((2 * n - 1) << 16)
     assert fields_equal(nodes[0:1], nodes[2 * n:2 * n + 1])
@@ -104,7 +105,7 @@ def test_tlas_c_oracle_matches_golden(oracle, n):
     assert np.array_equal(wide["min"], nodes["min"]) and np.array_equal(wide["max"], nodes["max"])
 
 
-@pytest.mark.parametrize("name", ["tlas_40.npz", "tlas_nan_60.npz"])
+@pytest.mark.parametrize("name", ["tlas_40.npz", "tlas_nan_60.npz", "tlas_model_scene.npz"])
 def test_tlas_numpy_matches_golden(name):
     g = golden(name)
     with np.errstate(invalid="ignore", over="ignore"):
