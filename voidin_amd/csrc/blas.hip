@@ -1749,33 +1749,62 @@ __global__ __launch_bounds__(256) void a_bin_kernel(Seg* segs, const unsigned* i
         }
     };
     reset();
-    __syncthreads();
-    for (unsigned k = 0; k < (unsigned)kBinItems; ++k) {
-        const unsigned item = blockIdx.x * kBinItems + k;
-        if (item >= n_items) break;
-        const unsigned seg = item_seg[item];
+    if (n_items == 0u) return;
+    // A workgroup's life used to be kBinItems times {item -> segment, segment -> head, head -> element loads, LDS atomics}: four
+    // dependent round trips per item, 32 per workgroup, with the machine holding one workgroup per slot (98 us per level for a
+    // kernel that moves 29 B per element).  Now the descriptors of all its items are fetched together up front (wave-uniform:
+    // scalar registers), and the element loads of item k + 1 are in flight while item k's atomics run.
+    unsigned seg_k[kBinItems], a0_k[kBinItems], n_k[kBinItems];
+#pragma unroll
+    for (int k = 0; k < kBinItems; ++k) {
+        const unsigned item = blockIdx.x * kBinItems + (unsigned)k;
+        seg_k[k] = item_seg[item < n_items ? item : n_items - 1u];
+    }
+#pragma unroll
+    for (int k = 0; k < kBinItems; ++k) {
+        const unsigned item = blockIdx.x * kBinItems + (unsigned)k;
+        const SegHead* g = reinterpret_cast<const SegHead*>(segs + seg_k[k]);
+        const unsigned start = g->start, count = g->count, first = g->item_first;
+        const unsigned rel0 = (item - first) * kItem;
+        const bool ok = item < n_items && rel0 < count;
+        seg_k[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)(ok ? seg_k[k] : kNone));
+        a0_k[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)(ok ? start + rel0 : 0u));
+        n_k[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)(ok ? min((unsigned)kItem, count - rel0) : 0u));
+    }
+    struct Loaded { unsigned b21[kPer]; unsigned char u[kPer]; TriBox bx[kPer]; };
+    auto load_item = [&](int k, Loaded& d) {
+        const unsigned a0 = a0_k[k], n_here = n_k[k];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned xr = threadIdx.x + 256u * (unsigned)j;
+#ifdef VD_BIN_GATHER
+            const unsigned ps = P::pos(pay[a0 + (xr < n_here ? xr : 0u)]);
+#else
+            const unsigned ps = a0 + (xr < n_here ? xr : 0u);       // (n_here == 0: position 0 of the arrays, never used)
+#endif
+            d.u[j] = is_u_flag[ps]; d.bx[j] = boxes[ps]; d.b21[j] = bits21[ps];
+        }
+    };
+    Loaded buf[2];
+    load_item(0, buf[0]);
+    __syncthreads();                                   // the reset is done
+#pragma unroll
+    for (int k = 0; k < kBinItems; ++k) {
+        if (k + 1 < kBinItems) load_item(k + 1, buf[(k + 1) & 1]);      // in flight while this item's atomics run
+        const unsigned seg = seg_k[k];
+        if (seg == kNone) continue;
         if (seg != cur_seg) {
             if (cur_seg != kNone) { __syncthreads(); flush(cur_seg); __syncthreads(); reset(); __syncthreads(); }
             cur_seg = seg;
         }
-        const SegHead hv = *reinterpret_cast<const SegHead*>(segs + seg);
-        const unsigned rel0 = (item - hv.item_first) * kItem;
-        const unsigned n_here = min((unsigned)kItem, hv.count - rel0);
-        // positions first, then everything gathered by position, then the LDS atomics (see item_load)
-        const unsigned a0 = hv.start + rel0;
-        unsigned ps[kPer], b21s[kPer];
-        unsigned char us[kPer];
-        TriBox bxs[kPer];
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) { const unsigned xr = threadIdx.x + 256u * (unsigned)j; ps[j] = P::pos(pay[a0 + (xr < n_here ? xr : 0u)]); }
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) { us[j] = is_u_flag[ps[j]]; bxs[j] = boxes[ps[j]]; b21s[j] = bits21[ps[j]]; }
+        const Loaded& d = buf[k & 1];
+        const unsigned n_here = n_k[k];
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
             const unsigned xr = threadIdx.x + 256u * (unsigned)j;
-            if (xr >= n_here || us[j]) continue;
-            const TriBox bx = bxs[j];
-            const unsigned b21 = b21s[j];
+            if (xr >= n_here || d.u[j]) continue;
+            const TriBox bx = d.bx[j];
+            const unsigned b21 = d.b21[j];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const int b = 7 - __popc((b21 >> (7 * a)) & 0x7fu);   // bin = number of planes the centroid is not below
