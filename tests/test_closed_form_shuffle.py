@@ -61,3 +61,74 @@ def test_unexamined_element_lands_right_even_when_true(oracle):
         hits += bool(keys[ids[piv]] < 0.5)
         assert (keys[ids[:piv]] < 0.5).all()
     assert 100 < hits < 400
+
+
+def closed_form_sparse(p, rng):
+    """The form phase A runs (blas.hip a_ranks_kernel / a_apply_kernel): only the elements the shuffle swaps write the
+    rank -> position tables, and an entry is believed only where it must be this round's.  The front pointer examines the
+    originals at [0, pivot] in place and the back pointer the rest, pivot = Ttot - p(u): a position left of Ttot is consumed
+    from the left, one right of it from the right, AT Ttot the t_F entry decides, and `u` is within one position of Ttot.
+    The tables start as garbage (they are never cleared between rounds) and every position reads its entries, written or not."""
+    p = np.asarray(p, bool)
+    n = len(p)
+    TL = np.concatenate([[0], np.cumsum(p)[:-1]]).astype(np.int64)
+    ttot = int(p.sum())
+    ftot = n - ttot
+    truepos = rng.integers(0, n + 1, n + 2)
+    falsepos = rng.integers(0, n + 1, n + 2)
+    writes = 0
+    for x in range(n):
+        if p[x] and x + 1 >= ttot:
+            truepos[ttot - TL[x] - 1] = x; writes += 1
+        if not p[x] and x <= ttot + 1:
+            falsepos[x - TL[x]] = x; writes += 1
+    arr = np.full(n, -1, np.int64)
+    L = None
+    for x in range(n):
+        F = x - TL[x]
+        T = ttot - TL[x] - int(p[x])
+        need_t = F != 0 and F <= ttot
+        need_f = T + 1 <= ftot
+        tp = truepos[F - 1] if need_t else truepos[0]
+        fp = falsepos[T] if need_f else falsepos[0]
+        tF = n if F == 0 else (tp if need_t else -1)
+        fj = fp if need_f else n
+        left = x < ttot or (x == ttot and x < tF)
+        amb = ttot - 1 <= x <= ttot + 1
+        fetch = x + n - tF if left else (n - 1 - x) + fj + 1
+        if amb and fetch == n - 1:
+            assert L is None
+            dest = L = ttot - int(p[x])
+        elif left:
+            dest = x if p[x] else tF - 1
+        else:
+            dest = fj if p[x] else x - 1
+        assert 0 <= dest < n and arr[dest] < 0
+        arr[dest] = x
+    assert L is not None
+    return L, arr, writes
+
+
+def test_sparse_tables_equal_literal_loop(oracle):
+    rng = np.random.default_rng(23)
+    moved = total = 0
+    for it in range(2500):
+        n = int(rng.integers(1, 120))
+        keys = rng.random(n).astype(np.float32)
+        pos = np.float32([0.0, 1.0, 0.125, 0.5, rng.random()][it % 5])       # no trues, all trues, an eighth, half, anything
+        piv, ids = oracle.partition_shuffle(keys, np.arange(n), 0, n, pos)
+        L, arr, w = closed_form_sparse(keys < pos, rng)
+        assert piv == L and np.array_equal(ids, arr)
+        moved += w; total += n
+    assert moved < 0.6 * total                                # the dense form stores n entries
+
+
+def test_sparse_tables_every_predicate_up_to_12(oracle):
+    rng = np.random.default_rng(29)
+    for n in range(1, 13):
+        for bits in range(1 << n):
+            p = np.array([(bits >> k) & 1 for k in range(n)], bool)
+            keys = np.where(p, 0.25, 0.75).astype(np.float32)
+            piv, ids = oracle.partition_shuffle(keys, np.arange(n), 0, n, np.float32(0.5))
+            L, arr, _ = closed_form_sparse(p, rng)
+            assert piv == L and np.array_equal(ids, arr)

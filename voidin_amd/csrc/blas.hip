@@ -273,7 +273,7 @@ struct Pay4 {
     static __device__ __forceinline__ T make(unsigned pos, unsigned bits21, unsigned axis) { return pos | (((bits21 >> (7u * axis)) & 0x7fu) << 25); }
     static __device__ __forceinline__ unsigned pos(T v) { return v & 0x1ffffffu; }
     static __device__ __forceinline__ unsigned word(T v) { return v; }
-    static __device__ __forceinline__ unsigned shift(unsigned c) { return 25u + c % 7u; }
+    static __host__ __device__ __forceinline__ unsigned shift(unsigned c) { return 25u + c % 7u; }
 };
 struct Pay8 {
     typedef u32x2 T;
@@ -281,7 +281,7 @@ struct Pay8 {
     static __device__ __forceinline__ T make(unsigned pos, unsigned bits21, unsigned) { T v = {pos, bits21}; return v; }
     static __device__ __forceinline__ unsigned pos(T v) { return v.x; }
     static __device__ __forceinline__ unsigned word(T v) { return v.y; }
-    static __device__ __forceinline__ unsigned shift(unsigned c) { return c; }
+    static __host__ __device__ __forceinline__ unsigned shift(unsigned c) { return c; }
 };
 constexpr unsigned kPay4Max = 1u << 25;
 
@@ -1376,6 +1376,23 @@ __device__ __forceinline__ Window round_window(const SegHead* sg, int r) {
     else { w.act = sg->act[r % 3]; w.band = (r % 7 == 1) ? 0u : sg->act[(r + 2) % 3]; }
     return w;
 }
+// What the two kernels of a round derive from its index r = 0..21 (21: the final shuffle, c = -1), worked out once on the
+// host: the remainders by 7 and 3 were scalar arithmetic at the head of every workgroup of the 700 launches of a build.
+struct RoundK { int c; unsigned sh, sh_next, axis_next, i_act, i_band, i_next, whole, second; };
+template <typename P>
+inline RoundK make_round(int c) {
+    const unsigned r = c >= 0 ? (unsigned)c : (unsigned)kCand;
+    RoundK k;
+    k.c = c; k.sh = P::shift(r); k.sh_next = P::shift(r + 1u); k.axis_next = (r + 1u) / 7u;
+    k.i_act = r % 3u; k.i_band = (r + 2u) % 3u; k.i_next = (r + 1u) % 3u; k.whole = r % 7u == 0u ? 1u : 0u; k.second = r % 7u == 1u ? 1u : 0u;
+    return k;
+}
+__device__ __forceinline__ Window round_window(const SegHead* sg, const RoundK& k) {
+    Window w;
+    if (k.whole) { w.band = w.act = 0u; }
+    else { w.act = sg->act[k.i_act]; w.band = k.second ? 0u : sg->act[k.i_band]; }
+    return w;
+}
 
 // the item's payloads: all loads first, unconditional (a lane past the item's end re-reads the item's first position) - inside
 // `if (in window)` every load was its own basic block with its own s_waitcnt 0: four serial round trips per lane
@@ -1395,10 +1412,21 @@ __device__ __forceinline__ void item_load(const SegHead* sg, const ItemCtx& ic, 
 }
 // predicates of the item's positions that lie in the shuffled window (positions below `act` stay out of the ballots)
 template <typename P, bool LOAD = true>
+__device__ __forceinline__ void item_masks_sh(const SegHead* sg, const ItemCtx& ic, const typename P::T* __restrict__ pay, unsigned sh,
+                                              unsigned act, unsigned long long (&masks)[kPer], typename P::T (&vals)[kPer]);
+template <typename P, bool LOAD = true>
+__device__ __forceinline__ void item_masks(const SegHead* sg, const ItemCtx& ic, const typename P::T* __restrict__ pay, const RoundK& k,
+                                           unsigned act, unsigned long long (&masks)[kPer], typename P::T (&vals)[kPer]) {
+    item_masks_sh<P, LOAD>(sg, ic, pay, k.c >= 0 ? k.sh : P::shift(sg->best), act, masks, vals);
+}
+template <typename P, bool LOAD = true>
 __device__ __forceinline__ void item_masks(const SegHead* sg, const ItemCtx& ic, const typename P::T* __restrict__ pay, int c,
                                            unsigned act, unsigned long long (&masks)[kPer], typename P::T (&vals)[kPer]) {
-    const unsigned cc = c >= 0 ? (unsigned)c : sg->best;
-    const unsigned sh = P::shift(cc);
+    item_masks_sh<P, LOAD>(sg, ic, pay, P::shift(c >= 0 ? (unsigned)c : sg->best), act, masks, vals);
+}
+template <typename P, bool LOAD>
+__device__ __forceinline__ void item_masks_sh(const SegHead* sg, const ItemCtx& ic, const typename P::T* __restrict__ pay, unsigned sh,
+                                              unsigned act, unsigned long long (&masks)[kPer], typename P::T (&vals)[kPer]) {
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (LOAD) item_load<P>(sg, ic, pay, vals);
 #pragma unroll
@@ -1526,7 +1554,7 @@ __device__ __forceinline__ void prefix_end(const SegHead* sg, const unsigned* __
 // round step 3: TL per position + rank -> position tables
 template <typename P, bool SF>
 __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                      const typename P::T* __restrict__ pay, int c, const unsigned* item_pre,
+                                                      const typename P::T* __restrict__ pay, const RoundK rk, const unsigned* item_pre,
                                                       unsigned* __restrict__ falsepos, unsigned* __restrict__ truepos,
                                                       unsigned* __restrict__ cnt_next) {
     __shared__ unsigned s_w[4], s_red[8];
@@ -1534,13 +1562,13 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
     if (!item_ctx(segs, item_seg, ctl, ic, hv)) return;
     VD_HEAD_VIEW(sg, segs, ic);
     if (cnt_next && threadIdx.x == 0) cnt_next[blockIdx.x] = 0u;      // a_apply of this round adds the next round's trues up in it
-    const Window win = round_window(sg, c >= 0 ? c : kCand);
+    const Window win = round_window(sg, rk);
     if (ic.rel0 + ic.n_here <= win.act) return;             // wholly frozen
     unsigned long long masks[kPer]; typename P::T vals[kPer];
     unsigned pv[4];
     item_load<P>(sg, ic, pay, vals);
     prefix_load<SF>(sg, item_pre, pv);
-    item_masks<P, false>(sg, ic, pay, c, win.act, masks, vals);
+    item_masks<P, false>(sg, ic, pay, rk, win.act, masks, vals);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned t = 0;
 #pragma unroll
@@ -1560,8 +1588,19 @@ __global__ __launch_bounds__(256) void a_ranks_kernel(const Seg* segs, const uns
             const unsigned x = ic.rel0 + xr - win.act;
             const bool p = (masks[j] >> lane) & 1ull;
             const unsigned tl = run + vd_mbcnt(masks[j]);
-            if (p) truepos[s + (ttot - tl - 1u)] = x;     // index T: (T+1)-th true from the right
-            else falsepos[s + (x - tl)] = x;              // index F: (F+1)-th false from the left
+            // Only the elements the shuffle SWAPS are ever looked up and believed (a_apply): the front pointer examines the
+            // originals at [0, pivot] in place and the back pointer those right of it, pivot = ttot - p(u) - a true left of
+            // ttot - 1 and a false right of ttot + 1 is nobody's t_F / f_{T+1}, and two thirds of the table stores never happen
+            // (tests/test_closed_form_shuffle.py holds this form against the literal loop, stale entries included)
+#ifdef VD_DENSE_TABLES
+            const bool wr = true;
+#else
+            const bool wr = p ? x + 1u >= ttot : x <= ttot + 1u;
+#endif
+            if (wr) {
+                if (p) truepos[s + (ttot - tl - 1u)] = x;     // index T: (T+1)-th true from the right
+                else falsepos[s + (x - tl)] = x;              // index F: (F+1)-th false from the left
+            }
         }
         run += (unsigned)__popcll(masks[j]);
     }
@@ -1595,7 +1634,7 @@ __device__ __forceinline__ void count_runs(bool me, unsigned item, unsigned* __r
 //   mode 0: the next round's predicate is not known yet (the final shuffle follows the cost evaluation): a_count runs.
 template <typename P, int mode, bool SF>
 __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                      const typename P::T* __restrict__ src, typename P::T* __restrict__ dst, int c,
+                                                      const typename P::T* __restrict__ src, typename P::T* __restrict__ dst, const RoundK rk,
                                                       const unsigned* item_pre, const unsigned* __restrict__ falsepos,
                                                       const unsigned* __restrict__ truepos, unsigned char* __restrict__ is_u_flag,
                                                       const unsigned* __restrict__ bits21, unsigned* __restrict__ cnt_next) {
@@ -1603,13 +1642,13 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
     ItemCtx ic; SegHead hv; const SegHead* sg = &hv;
     if (!item_ctx(segs, item_seg, ctl, ic, hv)) return;
     VD_HEAD_VIEW(sg, segs, ic);
-    const int r = c >= 0 ? c : kCand;
-    const Window win = round_window(sg, r);
+    const int c = rk.c;
+    const Window win = round_window(sg, rk);
     const unsigned copy_from = mode == 2 ? 0u : win.band;
     if (ic.rel0 + ic.n_here <= copy_from) return;         // frozen before the previous round: both buffers agree
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned own_cnt = 0;                                  // elements counted into this very item (wave-uniform)
-    const unsigned sh_next = P::shift((unsigned)(r + 1)), axis_next = (unsigned)(r + 1) / 7u;
+    const unsigned sh_next = rk.sh_next, axis_next = rk.axis_next;
     // Loads first, stores last, nothing conditional in between (see item_load): the item's payloads, in mode 2 the 21 bits
     // of each (every position of the segment is rewritten with the next axis' bits), then the rank tables, then the stores.
     unsigned long long masks[kPer]; typename P::T vals[kPer];
@@ -1643,7 +1682,7 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
         return;
     }
     // predicates and TL are recomputed from the payload (cheaper than a per-position word through HBM)
-    item_masks<P, false>(sg, ic, src, c, win.act, masks, vals);
+    item_masks<P, false>(sg, ic, src, rk, win.act, masks, vals);
     unsigned t = 0;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
@@ -1682,10 +1721,20 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
             const unsigned x = xx[j];
             const bool p = pp[j];
             const long long tF = FF[j] == 0u ? (long long)n : (need_t[j] ? (long long)tp[j] : -1ll);
-            const bool left = (long long)x < tF;
             const unsigned fj = need_f[j] ? fp[j] : n;
+#ifdef VD_DENSE_TABLES
+            const bool left = (long long)x < tF;
+            const bool amb = true;
+#else
+            // a_ranks writes only the entries the shuffle's swaps look up, so an entry is trusted only where it must be this
+            // round's: the front pointer examines the originals at [0, pivot] in place and the back pointer the rest, pivot =
+            // ttot or ttot - 1 - everything left of ttot is consumed from the left, everything right of it from the right, and
+            // AT ttot the t_F entry decides (its writer sits right of ttot - 1); `u` is within one position of ttot
+            const bool left = x < ttot || (x == ttot && (long long)x < tF);
+            const bool amb = x + 1u - ttot <= 2u;
+#endif
             const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
-            const bool is_u = fetch == n - 1u;
+            const bool is_u = amb && fetch == n - 1u;
             unsigned dest;
             if (is_u) dest = ttot - (p ? 1u : 0u);
             else if (left) dest = p ? x : (unsigned)tF - 1u;
@@ -1705,7 +1754,7 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
                 // counts as the reference sees them: examined trues of the WHOLE segment = frozen prefix + this window's
                 const u32x2 urec = {upos, bits21[upos]};               // the record keeps all 21 bits: the cost evaluation needs them
                 w.u_pay[c] = urec; w.u_p[c] = p ? 1u : 0u; w.ttot[c] = win.act + ttot;
-                w.act[(r + 1) % 3] = win.act + ttot - (p ? 1u : 0u);   // this trial's pivot: where the next round starts
+                w.act[rk.i_next] = win.act + ttot - (p ? 1u : 0u);   // this trial's pivot: where the next round starts
                 is_u_flag[upos] = 1;
             }
         }
@@ -2637,10 +2686,11 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
             const unsigned* pre = scan_free ? cnt[c & 1] : P.item_pre;
             if (!scan_free) hipLaunchKernelGGL(a_scan_kernel, dim3(1), dim3(1024), 0, st, seg_cur, P.ctl, cnt[c & 1], P.item_pre);
             auto ranks = scan_free ? a_ranks_kernel<PayT, true> : a_ranks_kernel<PayT, false>;
-            hipLaunchKernelGGL(ranks, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, pre, P.falsepos, P.truepos, cnt_next);
+            const RoundK rk = make_round<PayT>(cc);
+            hipLaunchKernelGGL(ranks, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, rk, pre, P.falsepos, P.truepos, cnt_next);
             auto apply = scan_free ? (mode == 0 ? a_apply_kernel<PayT, 0, true> : mode == 1 ? a_apply_kernel<PayT, 1, true> : a_apply_kernel<PayT, 2, true>)
                                    : (mode == 0 ? a_apply_kernel<PayT, 0, false> : mode == 1 ? a_apply_kernel<PayT, 1, false> : a_apply_kernel<PayT, 2, false>);
-            hipLaunchKernelGGL(apply, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, cc, pre,
+            hipLaunchKernelGGL(apply, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, rk, pre,
                                P.falsepos, P.truepos, P.is_u, P.bits21, cnt_next);
             n_launch += scan_free ? 2u : 3u;
             PT* t = src; src = dst; dst = t;
