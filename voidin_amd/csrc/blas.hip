@@ -2660,12 +2660,14 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
     lap(stats.ms_precompute);
     // one level of phase A; PayT = Pay4 / Pay8 (see there)
     unsigned n_launch = 0;
-    auto run_level = [&](auto pay_tag, unsigned n_seg_now, Seg* seg_cur, Seg* seg_next, int level, bool scan_free) {
+    auto run_level = [&](auto pay_tag, unsigned n_seg_now, size_t active_bound, Seg* seg_cur, Seg* seg_next, int level, bool scan_free) {
         using PayT = decltype(pay_tag);
         typedef typename PayT::T PT;
         const ArrSet cur = sets[level & 1], nxt = sets[(level + 1) & 1];
-        // upper bound of items this level: sum ceil(count/kItem) <= T/kItem + n_seg
-        const unsigned items_ub = (unsigned)(T / kItem) + n_seg_now + 1;
+        // upper bound of items this level: sum ceil(count/kItem) <= active/kItem + n_seg, `active` = the triangles still in
+        // segments of phase A (it only falls from level to level; the last levels of an uneven tree hold a few segments, and a
+        // grid of 8 200 workgroups costs 4.9 us to start even if every one of them leaves at once: profiles/r05_blas_issue_cost.log)
+        const unsigned items_ub = (unsigned)(std::min<size_t>(T, active_bound) / kItem) + n_seg_now + 1;
         PT* src = reinterpret_cast<PT*>(P.pay0); PT* dst = reinterpret_cast<PT*>(P.pay1);
         unsigned* const cnt[2] = {P.item_cnt, P.item_cnt1};      // round c counts in cnt[c & 1]
         hipLaunchKernelGGL((a_bits_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.cent, P.bits21, cnt[0]);
@@ -2736,21 +2738,23 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
             ~MainJoin() { if (s) (void)hipStreamSynchronize(s); }
         } main_join;
         main_join.s = st;
-        auto queue_level = [&](unsigned n_seg_bound, unsigned max_count_bound) {
+        auto queue_level = [&](unsigned n_seg_bound, unsigned max_count_bound, size_t active_bound) {
             const bool scan_free = (max_count_bound + kItem - 1) / kItem <= 1024u;
-            if (wide_pay) run_level(Pay8{}, n_seg_bound, seg_cur, seg_next, levels, scan_free); else run_level(Pay4{}, n_seg_bound, seg_cur, seg_next, levels, scan_free);
+            if (wide_pay) run_level(Pay8{}, n_seg_bound, active_bound, seg_cur, seg_next, levels, scan_free);
+            else run_level(Pay4{}, n_seg_bound, active_bound, seg_cur, seg_next, levels, scan_free);
             Seg* t = seg_cur; seg_cur = seg_next; seg_next = t;
             stats.kernel_launches += 5 + n_launch; n_launch = 0;
             levels += 1;
         };
-        queue_level(n_seg, h_ctl.max_count);                 // level 0: exact
+        queue_level(n_seg, h_ctl.max_count, h_ctl.active);   // level 0: exact
         unsigned bound = (unsigned)std::min<size_t>(2 * (size_t)n_seg, seg_cap), max_bound = h_ctl.max_count;
+        size_t active_bound = h_ctl.active;
         for (;;) {
             const int slot = (levels - 1) & 1;               // the control words the last queued level leaves
             VD_HIP_CHECK(ctx, hipMemcpyAsync(&h_pin[slot], P.ctl, sizeof(LevelCtl), hipMemcpyDeviceToHost, st));
             VD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_lvl[slot], st));
             if (levels > 4096) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: level loop did not terminate");
-            queue_level(bound, max_bound);                   // one level ahead
+            queue_level(bound, max_bound, active_bound);     // one level ahead
             VD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_lvl[slot]));
             h_ctl = h_pin[slot];
             if (h_ctl.err & ERR_DEGENERATE)
@@ -2758,7 +2762,7 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
             if (h_ctl.err) VD_FAIL(ctx, VD_ERR_HIP, "vd_bvh_build: internal capacity exceeded");
             n_seg = h_ctl.n_seg;
             if (n_seg == 0) { levels -= 1; break; }          // the level just queued is empty
-            bound = (unsigned)std::min<size_t>(2 * (size_t)n_seg, seg_cap); max_bound = h_ctl.max_count;
+            bound = (unsigned)std::min<size_t>(2 * (size_t)n_seg, seg_cap); max_bound = h_ctl.max_count; active_bound = h_ctl.active;
             if (h_ctl.n_mid >= mid_early + kMidEarlyMin) {   // enough new roots to be worth a launch beside the levels in flight
                 if (!ctx->aux_stream) VD_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
                 if (!ctx->ev_aux) VD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
