@@ -168,7 +168,10 @@ NOTES = {
     "ab_cull_small.log": "`tools/ab_cull.py --variants 0,1,2,4,8` at 1 k .. 1 M instances: tile size of the fused single-launch cull (the automatic choice is variant 0)",
     "ab_trace_fan_wps.log": "the fan-out's kernels compiled for 4 / 5 / 6 waves per SIMD (spills against occupancy) on the stress scene",
     "ab_trace_sibling_pruning.log": "VERDICT r4 item 6, measured and NOT kept: sibling jobs of the fan-out publish hits early and read the shared bound at every instance entry (bit-identical, 126 vs 128 Mrays/s)",
-    "fuzz.log": "round 5 fuzz campaign: 7 200 random meshes, 900 random cull scenes (both forms), 600 random TLAS scenes, 750 random trace scenes x 6 walks against the oracle, byte for byte: 0 mismatches",
+    "fuzz.log": "round 5 fuzz campaign: 7 200 + 2 700 (after the sparse rank tables; up to 250 k triangles) random meshes, 900 random cull scenes (both forms), 600 random TLAS scenes, 750 random trace scenes x 6 walks against the oracle, byte for byte: 0 mismatches",
+    "stress.log": "the race / repeat stress tools at the round's final tree: every run of the cull, expansion, refit, BLAS build (incl. a 3 000-mesh batch), TLAS build and traversal compared with the first, bit for bit",
+    "blas_issue_cost.log": "what bounds the two kernels of a phase-A round: sparse rank tables (kept), pads of 200 scalar / vector instructions and of dependent loads, empty-grid probes (4.9 us to start a round's 32 768 waves), "
+                           "item sizes, wave-uniform short forms, per-item records, host-side round constants (kept), phase B beside the last levels - each with its same-box numbers",
     "blas_mid_ab.log": "VERDICT r4 item 2 (ii), measured and NOT kept: the BLAS mid tier at 4096 / 8192 triangles against 2048",
     "blas_bin_stream.log": "`a_bin_kernel` streaming in pos0 order instead of gathering through the final arrangement, then with its loads pipelined across items: same-box A/B, kernel stats, `a_boundary` cycle stamps",
 }
