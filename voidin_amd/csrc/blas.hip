@@ -420,10 +420,17 @@ __device__ __forceinline__ BoxKeys box_keys(const WaveLds& L, const TriBox* __re
 
 // One closed-form shuffle of segment [s, s+n) with predicate cent[axis] < pos: reads perm[src],
 // writes perm[src^1].  NCH = number of 64-position chunks compiled in (1 = the n <= 64 fast path).
+// The seven planes of an axis are nested (blas.rs:146): what trial k left of its pivot passes trial k + 1 as well and
+// partition_shuffle walks over it without a swap - trial k + 1 IS the shuffle of the suffix [act, n), act = the previous
+// trial's pivot (phase A's rounds rest on the same fact, round_window).  `node_s`, `node_n`: the node; [band, act): what
+// the previous trial froze, copied across so that the buffer written holds the whole arrangement; a wave walks over
+// ceil((n - act) / 64) chunks instead of all of them.  out_ttot counts the frozen prefix (all trues) as the reference does.
 template <int NCH>
-__device__ __forceinline__ void wave_shuffle(WaveLds& L, int src, unsigned s, unsigned n, int axis, float pos,
+__device__ __forceinline__ void wave_shuffle(WaveLds& L, int src, unsigned node_s, unsigned node_n, int axis, float pos, unsigned band, unsigned act,
                                              unsigned& out_ttot, unsigned& out_ue, unsigned& out_up) {
     const unsigned lane = vd_lane();
+    for (unsigned x = band + lane; x < act; x += 64u) L.perm[src ^ 1][node_s + x] = L.perm[src][node_s + x];
+    const unsigned s = node_s + act, n = node_n - act;
     const unsigned short* pin = L.perm[src] + s;
     unsigned short* pout = L.perm[src ^ 1] + s;
     const float* cen = L.cent[axis];
@@ -483,15 +490,16 @@ __device__ __forceinline__ void wave_shuffle(WaveLds& L, int src, unsigned s, un
         run += (unsigned)__popcll(masks[ch]);
     }
     vd_wave_lds_sync();
-    out_ttot = ttot; out_ue = ue; out_up = up;
+    out_ttot = act + ttot; out_ue = ue; out_up = up;
 }
 
-__device__ __forceinline__ void wave_shuffle_any(WaveLds& L, int src, unsigned s, unsigned n, int axis, float pos,
+__device__ __forceinline__ void wave_shuffle_any(WaveLds& L, int src, unsigned s, unsigned n, int axis, float pos, unsigned band, unsigned act,
                                                  unsigned& tt, unsigned& ue, unsigned& up) {
-    if (n <= 64u) wave_shuffle<1>(L, src, s, n, axis, pos, tt, ue, up);
-    else if (kChunks >= 2 && n <= 128u) wave_shuffle<(kChunks >= 2 ? 2 : 1)>(L, src, s, n, axis, pos, tt, ue, up);
-    else if (kChunks >= 4 && n <= 256u) wave_shuffle<(kChunks >= 4 ? 4 : 1)>(L, src, s, n, axis, pos, tt, ue, up);
-    else wave_shuffle<kChunks>(L, src, s, n, axis, pos, tt, ue, up);
+    const unsigned nw = n - act;                     // the chunks compiled in follow the window, not the node
+    if (nw <= 64u) wave_shuffle<1>(L, src, s, n, axis, pos, band, act, tt, ue, up);
+    else if (kChunks >= 2 && nw <= 128u) wave_shuffle<(kChunks >= 2 ? 2 : 1)>(L, src, s, n, axis, pos, band, act, tt, ue, up);
+    else if (kChunks >= 4 && nw <= 256u) wave_shuffle<(kChunks >= 4 ? 4 : 1)>(L, src, s, n, axis, pos, band, act, tt, ue, up);
+    else wave_shuffle<kChunks>(L, src, s, n, axis, pos, band, act, tt, ue, up);
 }
 
 constexpr int kLaneMax = VD_LANE_MAX;   // a subtree root of at most this many prims starts in the group path (8 lanes)
@@ -1004,10 +1012,17 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 cur ^= 1;                                                             // 21 flips
                 if (valid) L.perm[cur][s + lane] = (unsigned short)el;
             } else {
+                unsigned w_band = 0, w_act = 0;                                       // the window of the wave's own shuffles (wave_shuffle)
                 for (int c = 0; c < kCand; ++c) {                                     // blas.rs:144-147
                     unsigned tt, ue, up;
+#ifdef VD_NO_B_WINDOWS
+                    w_band = 0; w_act = 0;
+#else
+                    if (c % 7 == 0) { w_band = 0; w_act = 0; }
+#endif
                     if (is_root && root_by_block) block_shuffle_leader(L, Q, cur, n, c / 7, W.pos[c], tt, ue, up);
-                    else wave_shuffle_any(L, cur, s, n, c / 7, W.pos[c], tt, ue, up);
+                    else wave_shuffle_any(L, cur, s, n, c / 7, W.pos[c], w_band, w_act, tt, ue, up);
+                    w_band = w_act; w_act = tt - up;                                  // this trial's pivot: where the next one on the axis starts
                     cur ^= 1;
                     if (lane == 0) { W.u_e[c] = (unsigned short)ue; W.u_p[c] = (unsigned short)up; W.ttot[c] = tt; }
                 }
@@ -1121,7 +1136,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                     block_shuffle_leader(L, Q, cur, n, best / 7, W.pos[best], tt, ue, up);
                     if (lane == 0) Q.r_active = 0u;
                     __syncthreads();                                     // B0 with r_active = 0: the helpers leave
-                } else wave_shuffle_any(L, cur, s, n, best / 7, W.pos[best], tt, ue, up);
+                } else wave_shuffle_any(L, cur, s, n, best / 7, W.pos[best], 0u, 0u, tt, ue, up);
                 cur ^= 1;                                                // 22 flips: back in buffer 0
             }
             int k12[12];                                                 // children boxes (blas.rs:115-123)
