@@ -753,7 +753,7 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
                                        "binned_44B_per_prim_level": {"algorithmic_bytes": int(b44), "achieved": round(b44 / best / 1e9, 1),
                                                                      "frac": round(b44 / best / 1e9 / HBM_PEAK_GBS, 4),
                                                                      "floor_ms_at_peak": round(b44 / HBM_PEAK_GBS / 1e6, 3)},
-                                       "note": "the builder moves 44 B per prim per shuffle round in phase A (DESIGN 3.3), not 770 B per level: the "
+                                       "note": "the builder moves ~21 B per active prim per shuffle round in phase A (DESIGN 3.3), not 770 B per level: the "
                                                "770 B figure prices the reference's 21 bounds passes, which one binning pass replaces"}}
     del d_v, d_n, d_idx
 
