@@ -16,7 +16,7 @@ f = glob.glob(f"gpurun_out/r5_blas_kstats/prof_{v}/**/*kernel_stats.csv", recurs
 if f:
     for r in csv.DictReader(open(f[0])):
         n = re.sub(r'\(anonymous namespace\)::', '', r['Name']).split('(')[0].replace('void ', '')
-        if float(r['TotalDurationNs']) / 4e6 > 0.05:
+        if float(r['TotalDurationNs']) / 4e6 > 0.12:
             print(f"{n:44s} calls {int(r['Calls']):5d} ms/build {float(r['TotalDurationNs']) / 4e6:7.3f}  avg us {float(r['AverageNs']) / 1e3:8.1f}")
 PY
   rm -rf $P
