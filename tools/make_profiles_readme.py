@@ -168,7 +168,7 @@ NOTES = {
     "ab_cull_small.log": "`tools/ab_cull.py --variants 0,1,2,4,8` at 1 k .. 1 M instances: tile size of the fused single-launch cull (the automatic choice is variant 0)",
     "ab_trace_fan_wps.log": "the fan-out's kernels compiled for 4 / 5 / 6 waves per SIMD (spills against occupancy) on the stress scene",
     "ab_trace_sibling_pruning.log": "VERDICT r4 item 6, measured and NOT kept: sibling jobs of the fan-out publish hits early and read the shared bound at every instance entry (bit-identical, 126 vs 128 Mrays/s)",
-    "fuzz.log": "round 5 fuzz campaign: 7 200 + 2 700 (after the sparse rank tables; up to 250 k triangles) random meshes, 900 random cull scenes (both forms), 600 random TLAS scenes, 750 random trace scenes x 6 walks against the oracle, byte for byte: 0 mismatches",
+    "fuzz.log": "round 5 fuzz campaign: 7 200 + 2 700 (after the sparse rank tables; up to 250 k triangles) + 9 600 (final tree) random meshes, 900 + 800 random cull scenes (both forms), 600 + 600 random TLAS scenes, 750 + 600 random trace scenes x 6 walks against the oracle, byte for byte: 0 mismatches",
     "blas_sizes.log": "BLAS build time by mesh size, 131 k .. 32.8 M triangles, one mesh per build",
     "stress.log": "the race / repeat stress tools at the round's final tree: every run of the cull, expansion, refit, BLAS build (incl. a 3 000-mesh batch), TLAS build and traversal compared with the first, bit for bit",
     "blas_issue_cost.log": "what bounds the two kernels of a phase-A round: sparse rank tables (kept), pads of 200 scalar / vector instructions and of dependent loads, empty-grid probes (4.9 us to start a round's 32 768 waves), "
