@@ -105,3 +105,34 @@ def test_tree_shape_counts_every_partitioned_primitive(oracle):
     assert total == len(i) // 3
     assert got["sum_active_prims"] == active and got["depth"] == depth
     assert got["interior_nodes"] == int((nodes["count"] == 0).sum()) - 1
+
+
+def test_second_metric_is_promoted_into_the_keys_a_reader_keeps():
+    """BASELINE's metric names two numbers; the BVH build, the TLAS refit and the padded (consumer) form of the
+    headline are copied from `extra` into `roofline` / `cpu_baseline` (the objects the driver's record keeps)."""
+    import bench
+    line = {"roofline": {"bound": "hbm"}, "cpu_baseline": {"value": 1.0}}
+    extra = {
+        "bvh_build": {"n_tris": 8_388_608, "ms": 25.0, "value": 335.5, "bit_exact_vs_oracle": True,
+                      "phases_ms": {"ms_phase_a": 16.0, "ms_phase_b": 7.5, "kernel_launches": 900},
+                      "roofline": {"emulating_770B_per_prim_level": {"frac": 0.72}, "binned_44B_per_prim_level": {"frac": 0.046}},
+                      "cpu_baseline": {"value": 0.108, "cores": 1, "kind": "port", "sample": "the timed mesh"}},
+        "tlas": {"refit_queued_ms": 0.09, "build_ms": 185.0, "bit_exact_vs_oracle": True, "cpu_baseline": {"value": 29000.0}},
+        "tlas_wide_64k": {"refit_gpu_ms": 0.095, "refit_after_motion_bit_exact_vs_oracle": True},
+        "cull_compact_pad_tail": {k: {"ms": 0.28, "M_inst_per_s": 35000.0, "visible_fraction": 0.9, "tail_bytes": 1,
+                                      "whole_padded_buffer_bit_exact_vs_oracle": True} for k in ("baseline", "dist_small")},
+    }
+    bench.promote_second_metric(line, extra)
+    b = line["roofline"]["bvh_build"]
+    for k in ("n_tris", "ms", "Mprims_per_s", "traffic_bytes", "frac_real", "frac_770B", "frac_44B", "bit_exact_vs_oracle", "kernel_launches"):
+        assert k in b, k
+    pmc = json.load(open(bench.latest_pmc("bvh")))
+    assert b["traffic_bytes"] == int(pmc["total"]["sum_MB"] * 1e6)
+    assert abs(b["frac_real"] - b["traffic_bytes"] / 25.0e-3 / 8e12) < 1e-3
+    assert line["cpu_baseline"]["bvh_build"] == {"Mprims_per_s": 0.108, "cores": 1, "kind": "port", "sample": "the timed mesh"}
+    assert line["roofline"]["tlas_refit_ms"]["32768"] == 0.09 and line["roofline"]["tlas_refit_ms"]["65536_wide"] == 0.095
+    assert set(line["roofline"]["pad_tail"]) == {"baseline", "dist_small"}
+    # a line without the extras (--no-extra, N > 1) is left alone
+    bare = {"roofline": {}, "cpu_baseline": None}
+    bench.promote_second_metric(bare, {})
+    assert bare == {"roofline": {}, "cpu_baseline": None}

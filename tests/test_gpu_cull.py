@@ -65,6 +65,67 @@ def test_ragged_sizes_bit_exact(ctx, oracle, n, dist):
     assert cnt == wn and comp.tobytes() == wc.tobytes()
 
 
+CLOUDS = {"wide": dict(scale_range=(0.25, 4.0)), "small": dict(scale_range=(0.02, 0.6), extent=600.0),
+          "mid": dict(scale_range=(0.5, 1.2), extent=1500.0)}
+
+
+@pytest.mark.parametrize("znear", [0.001, 1.0, 100.0])
+@pytest.mark.parametrize("zfar", [50.0, 500.0, 5.0, -10.0])
+@pytest.mark.parametrize("cloud", ["wide", "small", "mid"])
+def test_finite_far_plane_takes_the_third_return_of_is_visible(ctx, ctx_options, oracle, cloud, zfar, znear):
+    """`is_visible`'s third test, `c.z + r > znear && c.z - r > zfar` (shaders/emit_draws.wgsl:28-30), never fires under the
+    reference's own camera (zfar = +inf, crates/components/src/camera.rs:22-23,38) - but the 320-byte uniform is an INPUT and a
+    caller can hand over a finite far plane.  Emit + compact, fused and split form, memcmp against the oracle; on the clouds
+    whose scales let an instance behind the camera pass the two side-plane tests (max scale in ~[0.78, 1)) the far test must
+    change the survivor set, i.e. the branch is TAKEN under test."""
+    cam_inf, meshes = synth.camera_uniform(), synth.mesh_infos()
+    cam = cam_inf.copy()
+    cam["zfar"], cam["znear"] = np.float32(zfar), np.float32(znear)
+    n = 300_000
+    inst = synth.instances(n, seed=synth.SEED_BASE + 2, with_inverse=False, **CLOUDS[cloud])
+    want = oracle.cull_emit(cam, meshes, inst, threads=8)
+    want_inf = oracle.cull_emit(cam_inf, meshes, inst, threads=8)
+    culled_by_far = int(want_inf["instance_count"].sum()) - int(want["instance_count"].sum())
+    assert culled_by_far >= 0
+    if cloud in ("wide", "mid") and zfar <= 50.0:
+        assert culled_by_far > 0, "the far-plane return is not exercised by this case"
+    wc, wn = oracle.compact(want, pad_tail=True)
+    for split in (False, True):
+        if split:
+            ctx_options("cull.split_min", 1)
+        emit, comp, cnt = run_dev(ctx, cam, meshes, inst, pad_tail=True)
+        assert emit.tobytes() == want.tobytes(), f"split={split}"
+        assert cnt == wn and comp.tobytes() == wc.tobytes(), f"split={split}"
+    ctx_options("cull.split_min", None)
+
+
+def test_far_plane_on_a_cloud_behind_the_camera(ctx, ctx_options, oracle):
+    """Every instance behind the camera, uniform scale 0.85, so that most pass the side planes and the far test alone decides:
+    all three returns of is_visible are taken in one launch (emit_draws.wgsl:22-32)."""
+    cam_inf, meshes = synth.camera_uniform(eye=(0.0, 0.0, 0.0), pitch_deg=0.0), synth.mesh_infos()
+    n = 100_000
+    inst = synth.instances(n, seed=synth.SEED_BASE + 70, scale_range=(0.85, 0.85), extent=40.0, with_inverse=False)
+    rng = np.random.default_rng(70)
+    t = inst["transform"].reshape(n, 16)
+    t[:, 12] = rng.uniform(-30, 30, n).astype(np.float32)        # view x
+    t[:, 13] = rng.uniform(-30, 30, n).astype(np.float32)
+    t[:, 14] = rng.uniform(-100, 900, n).astype(np.float32)      # +z = behind an unrotated camera at the origin (RH view space)
+    for zfar in (20.0, 60.0):
+        cam = cam_inf.copy()
+        cam["zfar"] = np.float32(zfar)
+        want, want_inf = oracle.cull_emit(cam, meshes, inst, threads=8), oracle.cull_emit(cam_inf, meshes, inst, threads=8)
+        by_far = int(want_inf["instance_count"].sum()) - int(want["instance_count"].sum())
+        assert by_far > n // 50, by_far                            # the far test culls thousands ...
+        assert 0 < int(want["instance_count"].sum()) < n - by_far  # ... and the side planes and `visible` are taken too
+        wc, wn = oracle.compact(want)
+        for split in (False, True):
+            if split:
+                ctx_options("cull.split_min", 1)
+            emit, comp, cnt = run_dev(ctx, cam, meshes, inst)
+            assert emit.tobytes() == want.tobytes() and cnt == wn and comp[:cnt].tobytes() == wc[:wn].tobytes(), (zfar, split)
+        ctx_options("cull.split_min", None)
+
+
 def test_empty_input(ctx):
     import torch
     cam, meshes = synth.camera_uniform(), synth.mesh_infos()

@@ -1040,12 +1040,27 @@ static int launch_expand(VdCtx* ctx, const vd_u64* d_mask, unsigned n_words, uns
 }
 
 // Zero-fill out[count..n) so the unchanged multi_draw_indexed_indirect(buf, 0, N) consumer
-// (visibility.rs:188-192) sees instance_count = 0 in the tail.
+// (visibility.rs:188-192) sees instance_count = 0 in the tail.  The tail starts on a 4-byte boundary (count x 20 B): up to
+// three single dwords bring it to a 16-byte one, the body leaves as nontemporal 16-byte stores (the `dist small` cloud pads
+// 126 MB per step), the last few dwords singly again.  A count beyond n is the scan's error value (VD_SCAN_STUCK: no list was
+// written): then the WHOLE buffer is zeroed, so the consumer draws nothing instead of a mix of this frame's and the last
+// frame's commands.
 __global__ __launch_bounds__(kBlock) void pad_tail_kernel(VdDrawIndexedIndirect* __restrict__ out,
                                                           const unsigned* __restrict__ count, unsigned n) {
-    const size_t begin = (size_t)(*count) * 5u, end = (size_t)n * 5u;
+    const unsigned c = *count;
+    const size_t begin = (c > n ? (size_t)0 : (size_t)c) * 5u, end = (size_t)n * 5u;
     unsigned* o = reinterpret_cast<unsigned*>(out);
-    for (size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x; i < end; i += (size_t)gridDim.x * kBlock) o[i] = 0u;
+    if (begin >= end) return;
+    const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x, gsz = (size_t)gridDim.x * kBlock;
+    const size_t mis = (reinterpret_cast<uintptr_t>(o + begin) >> 2) & 3u;            // dwords past a 16-byte boundary
+    const size_t head = min(end - begin, (4u - mis) & 3u);
+    const size_t quads = (end - begin - head) >> 2;
+    const size_t tail_first = begin + head + quads * 4u;
+    if (gid < head) o[begin + gid] = 0u;
+    if (gid < end - tail_first) o[tail_first + gid] = 0u;
+    u32x4* q = reinterpret_cast<u32x4*>(o + begin + head);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (size_t i = gid; i < quads; i += gsz) __builtin_nontemporal_store(z, q + i);
 }
 
 // ------------------------------------------------------------------------------------------
