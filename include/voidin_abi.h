@@ -206,6 +206,8 @@ typedef enum VdOption {
                                      they would fit LDS (<= 5600 instances); default 1 (A/B)               */
     VD_OPT_BLAS_WIDE_PAYLOAD = 30,/* 1: vd_bvh_build moves the 8-byte payload (what meshes above 2^25 triangles use) at
                                      any size (tests); default 0                                                  */
+    VD_OPT_BLAS_FUSED_ROUNDS = 31,/* 0: every shuffle round of the builder's level-synchronous tier runs as two launches (rank tables
+                                     through memory: the round-5 form) instead of one where segments allow it; default 1 (A/B)     */
     VD_OPT_TRACE_SORT = 21,       /* 1: vd_trace* bin the rays first (sorted by origin cell + direction) and hand them
                                      out in that order; results are per ray, so only the order changes.  Default 0:
                                      measured slower on this part                                */
@@ -305,11 +307,16 @@ int vd_cull_emit_dev(VdCtx* ctx, const VdCameraUniform* camera /* host */,
  * `multi_draw_indexed_indirect(buf, 0, N)` consumer (visibility.rs:188-192) stays valid;
  * with pad_tail == 0 only out[0..count) is written (for multi_draw_indexed_indirect_count).
  * `out` must hold n_inst commands either way.
- * Error value of the count: the ordered scans behind the compaction wait for each other across
- * workgroups, and every such wait is bounded.  If one ever times out (a workgroup of the launch was lost)
- * the list is not written and the count becomes 0xffffffff - larger than any n_inst: vd_cull_compact
- * returns VD_ERR_HIP for it, callers of the *_dev forms see it in *d_out_count (pad_tail then pads
- * nothing).  The next call on the context starts from clean scan state by itself.         */
+ * When a launch fails: the ordered scans behind the compaction wait for each other across workgroups, and every
+ * such wait is bounded by the wall clock (two seconds).  If one times out (a workgroup of the launch was lost or
+ * stalled) no list is written, *count becomes 0 - with pad_tail the whole buffer is zeroed, so neither consumer
+ * draws anything, least of all a mix of this frame's and the last frame's commands - and the context remembers:
+ * vd_cull_compact returns VD_ERR_HIP for that very call; after a *_dev call the NEXT vd_cull_compact* /
+ * vd_compact_draws* call on the context returns VD_ERR_HIP once (and resets the scan state) instead of launching.
+ * One case cannot be turned into a count of 0: a launch that loses the workgroup that writes the count leaves the
+ * value its first workgroup pre-stored, 0xffffffff - larger than any n_inst.  vd_cull_compact returns VD_ERR_HIP
+ * for it as well; pad_tail zeroes the whole buffer for it; a caller that hands the count straight to
+ * multi_draw_indexed_indirect_count should clamp it to 0 when it exceeds n_inst.                              */
 int vd_cull_compact(VdCtx* ctx, const VdCameraUniform* camera,
                     const VdMeshInfo* meshes, uint32_t n_mesh,
                     const VdInstance* instances, uint32_t n_inst,

@@ -57,3 +57,40 @@ def test_two_ranks_report_the_second_metric_and_the_weak_run():
     assert rep["ranks"] == 2 and rep["tris_per_rank"] == 2 * 128 * 64 and rep["same_nodes_on_every_rank"] is True and rep["value"] > 0
     assert two["extra"]["weak_scaling"]["instances_total"] == 800000
     assert two["value_full"] > 0 and two["value_shard"] > 0
+
+
+def test_eight_ranks_default_command_finishes_in_time_and_carries_the_scaling_keys():
+    """The command the driver's 8-GPU tier runs - `bench.py --gpus 8 --steps K --warmup W` (here with --no-extra) at the DEFAULT
+    10 M instances - end to end on one GPU: the launcher, every rank's input generation, the C-ABI exchange (vd_dist_*, RCCL bound
+    through $VD_RCCL_LIB = the tests' double, tests/cpp/fake_rccl.cpp; real RCCL refuses eight ranks on one device), all four
+    gather modes, and rank 0's verification of the WHOLE gathered list against the oracle.  Wall clock < 120 s, so that an
+    8-rank launch on real hardware cannot time out on what surrounds the timed steps; the line must carry what a scaling curve
+    needs.  Timings through the double are not scaling numbers and are not asserted."""
+    import shutil
+    import tempfile
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_dist_ranks import _scratch_dir, build_fake
+    d = _scratch_dir()
+    try:
+        env = {"VD_RCCL_LIB": build_fake(), "VD_FAKE_RCCL_DIR": d, "VD_FAKE_RCCL_TIMEOUT_S": "120", "VOIDIN_RANKS_SHARE_GPUS": "1",
+               "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "4"}
+        t0 = time.time()
+        line = _bench("--gpus", "8", "--steps", "20", "--warmup", "5", "--no-extra", "--timeout", "300", env=env)
+        wall = time.time() - t0
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    assert wall < 120.0, f"{wall:.0f} s"
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["steps"] == 20 and line["warmup"] == 5
+    assert line["config"]["instances_total"] == 10_000_000 and line["config"]["instances_per_gpu"] == 1_250_000
+    assert line["config"]["verified_bit_exact_vs_oracle"] is True
+    assert line["config"]["rccl"]["version"] == 99901 and "libfake_rccl" in line["config"]["rccl"]["library"]      # the double, bound by the library itself
+    assert "C ABI vd_dist_*" in line["config"]["parallelism"] and "instance-shard x8" in line["config"]["parallelism"]
+    assert line["value"] > 0 and line["value_full"] > 0 and line["value_shard"] > 0
+    for k in ("cull_to_mask_ms", "mask_allgather_ms", "expand_all_shards_ms", "mask_bytes_per_rank"):
+        assert line["step_breakdown"][k] > 0, k
+    assert set(line["extra"]["gather_modes"]) >= {"full", "draws", "indices", "shard"}
+    assert line["scaling_ceiling"]["mask_allgather_ms_measured"] == line["step_breakdown"]["mask_allgather_ms"]
+    # the ordered list of the whole scene is the one-GPU list (same CRC as the N = 1 line of the same workload)
+    one = _bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline")
+    assert one["config"]["draw_list_crc32"] == line["config"]["draw_list_crc32"]

@@ -1,6 +1,6 @@
 """The ordered compaction scan (decoupled look-back, voidin_amd/csrc/vd_common.hpp) never waits forever: a workgroup that
-never publishes its total turns the count into the sentinel 0xffffffff -> VD_ERR_HIP, and the next call on the same
-context is clean.  The lost workgroup is simulated by vd_debug_scan_fault, a hook that exists only in the tuning build
+never publishes its total ends the launch with an error - VD_ERR_HIP from the host-pointer entry point; count 0, a zeroed
+padded buffer and a sticky fault for the device-pointer form - and the next call on the same context is clean.  The lost workgroup is simulated by vd_debug_scan_fault, a hook that exists only in the tuning build
 of the library (make -C voidin_amd/csrc tuning; -DVD_TUNING), so this test runs in a child process that loads that build."""
 import os
 import subprocess
@@ -45,6 +45,30 @@ CHILD = textwrap.dedent("""
         assert lib.vd_debug_scan_fault(ctx.h, -1) == 0
         got, n = ctx.cull_compact(cam, meshes, inst)                           # same context, next call: clean
         assert n == wn and got[:n].tobytes() == want[:wn].tobytes(), tile
+    # the device-pointer form (what a frame loop calls): count 0 and - with pad_tail - an all-zero buffer, so neither consumer of
+    # visibility.rs:188-192 draws anything; the NEXT call on the context says VD_ERR_HIP once, the one after is clean (ADVICE r5)
+    import torch
+    n = len(inst)
+    d_m, d_i = ctx.upload(meshes), ctx.upload(inst)
+    d_out, d_cnt = ctx.empty(n * 20), torch.full((4,), 7, dtype=torch.int32, device="cuda")
+    d_out.fill_(0xAB)
+    assert lib.vd_debug_scan_fault(ctx.h, 17) == 0
+    t0 = time.time()
+    ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, True)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 30.0
+    assert int(d_cnt[0].item()) == 0 and not bool(d_out[: n * 20].any())
+    assert lib.vd_debug_scan_fault(ctx.h, -1) == 0
+    try:
+        ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, True)
+    except RuntimeError as e:
+        assert "VD_ERR_HIP" in str(e) and "gave up" in str(e), str(e)
+    else:
+        raise AssertionError("the fault of the previous launch was not reported")
+    ctx.cull_compact_dev(cam, d_m, len(meshes), d_i, n, d_out, d_cnt, True)
+    torch.cuda.synchronize()
+    wp, wpn = ref.compact(ref.cull_emit(cam, meshes, inst), pad_tail=True)
+    assert int(d_cnt[0].item()) == wpn and d_out.cpu().numpy()[: n * 20].tobytes() == wp.tobytes()
     print("scan fault test OK")
 """)
 

@@ -819,3 +819,92 @@ def test_indexed_build_declines_when_every_area_ties(ctx, oracle, ctx_options, s
         dt = time.perf_counter() - t
         assert fields_equal(got, want)
         assert dt < 3.0, f"{dt:.1f} s: the build did not fall back to the plain chain"
+
+
+def _chain_scene(oracle, n_leaves=200):
+    """A TLAS that is one long chain - interior node k = {interior k - 1, leaf k}, spheres one unit apart along +x - in the
+    reference's node layout (leaves at 1..N, interior nodes behind them, node 0 = a copy of the root).  A ray from x = -5
+    along +x finds the chain as its NEAR child at every level and pushes the leaf: N - 1 pending entries when it reaches
+    sphere 0 - more than the 128 a lane holds (trace.hip), fewer than the oracle's 256."""
+    v, i = synth.uv_sphere(0.4, 2)
+    v = np.asarray(v, np.float32).reshape(-1, 3)
+    nodes, idx = oracle.bvh_build(v, i)
+    infos = np.zeros(1, dtype=abi.MESH_INFO)
+    infos[0]["min"], infos[0]["max"] = synth.mesh_bounds(v)
+    infos[0]["index_count"] = len(idx)
+    N = n_leaves
+    inst = np.zeros(N, dtype=abi.INSTANCE)
+    T = np.tile(np.eye(4, dtype=np.float32), (N, 1, 1))
+    T[:, 3, 0] = np.arange(N, dtype=np.float32)            # column-major storage: translation in elements 12..14
+    inst["transform"] = T.reshape(N, 16)
+    Ti = T.copy(); Ti[:, 3, 0] *= np.float32(-1)
+    inst["inv_transform"] = Ti.reshape(N, 16)
+    tl = np.zeros(2 * N, dtype=abi.TLAS_NODE)
+    mn, mx = infos[0]["min"], infos[0]["max"]
+    for k in range(N):
+        tl[1 + k]["min"] = mn + np.array([k, 0, 0], np.float32)
+        tl[1 + k]["max"] = mx + np.array([k, 0, 0], np.float32)
+        tl[1 + k]["left_right"], tl[1 + k]["instance_idx"] = 0, k
+    prev = 1
+    for k in range(1, N):
+        me = N + k
+        tl[me]["min"] = np.minimum(tl[prev]["min"], tl[1 + k]["min"])
+        tl[me]["max"] = np.maximum(tl[prev]["max"], tl[1 + k]["max"])
+        tl[me]["left_right"], tl[me]["instance_idx"] = prev | ((1 + k) << 16), 0xFFFFFFFF
+        prev = me
+    tl[0] = tl[prev]
+    return (tl, inst, infos, nodes, v, idx)
+
+
+@pytest.mark.parametrize("n_rays", [2_000, 420_000])       # one launch / a call large enough to fan out (>= one ray per lane of the grid)
+def test_rays_deeper_than_a_lanes_stack_are_walked_again(ctx, ctx_options, oracle, n_rays):
+    """The call is TOTAL: a ray that needs more than the 128 stack entries a lane holds used to end the call
+    with VD_ERR_STACK_OVERFLOW; now it is walked again with its stack in global memory and the record is the oracle's, bit for
+    bit - closest hit and occlusion, plain / indexed / prepared leaves, one launch and fanned out, deep rays mixed with cheap ones."""
+    import torch
+    scene = _chain_scene(oracle)
+    rng = np.random.default_rng(128)
+    rays = np.zeros(n_rays, dtype=abi.RAY)
+    rays["eye"] = (rng.random((n_rays, 3)).astype(np.float32) - np.float32(0.5)) * np.array([0.0, 0.6, 0.6], np.float32) + np.array([-5.0, 0, 0], np.float32)
+    rays["dir"] = np.array([1.0, 0.0, 0.0], np.float32)
+    far_side = rng.random(n_rays) < 0.5                      # from the far end the leaf is the near child: no depth at all
+    rays["eye"][far_side, 0] = np.float32(250.0)
+    rays["dir"][far_side] = np.array([-1.0, 0.0, 0.0], np.float32)
+    cheap = rng.random(n_rays) < (0.3 if n_rays < 10_000 else 0.97)   # the large call: most rays leave the scene at once
+    rays["dir"][cheap] = np.array([0.0, 1.0, 0.0], np.float32)
+    want, deepest = oracle.trace(scene, rays, threads=16)
+    assert 128 < deepest <= 256                              # deeper than a lane's stack, within the oracle's
+    assert want["hit"].sum() > n_rays // 100
+    ds = ctx.device_scene(scene)
+    d_rays, d_hits = ctx.upload(rays), ctx.empty(n_rays * 16)
+    d_any = torch.zeros(n_rays, dtype=torch.int32, device="cuda")
+    acc = ctx.trace_prepare(ds)
+    for fan in (1, 3):
+        ctx_options("trace.fan", fan)
+        for mode in ("plain", "indexed", "prepared"):
+            ctx_options("trace.auto_prepare", 0 if mode == "indexed" else None)
+            d_hits.zero_(); d_any.zero_()
+            if mode == "prepared":
+                ctx.trace_prepared_dev(acc, d_rays, n_rays, d_hits); ctx.trace_any_prepared_dev(acc, d_rays, n_rays, d_any)
+            else:
+                ctx.trace_dev(ds, d_rays, n_rays, d_hits); ctx.trace_any_dev(ds, d_rays, n_rays, d_any)
+            got = d_hits.cpu().numpy()[: n_rays * 16].view(abi.HIT)
+            assert got.tobytes() == np.ascontiguousarray(want).tobytes(), (fan, mode)
+            assert np.array_equal(d_any.cpu().numpy().astype(np.uint32), want["hit"]), (fan, mode)
+    acc.close()
+    # a call that overflows nowhere, right after: the bitmap was left clean
+    easy = rays[cheap | far_side]
+    w2, d2 = oracle.trace(scene, easy, threads=16)
+    assert d2 <= 64 and ctx.trace(scene, easy).tobytes() == np.ascontiguousarray(w2).tobytes()
+
+
+def test_a_fuzz_scene_that_used_to_overflow(ctx, oracle):
+    """profiles/r05_fuzz.log: seed 22, case 85 of tools/fuzz_trace.py - 1 500 instances, oracle's deepest stack 132 - ended
+    every one of its six walks with VD_ERR_STACK_OVERFLOW in round 5."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_trace
+    out = []
+    bad, deep = fuzz_trace.run(86, seed=22, ctx=ctx, log=out.append, only={85})
+    assert bad == 0, "\n".join(out[:10])
+    assert deep == 1

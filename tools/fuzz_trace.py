@@ -15,8 +15,9 @@ from voidin_amd import abi, synth  # noqa: E402
 from voidin_amd.runtime import Context, VoidinError  # noqa: E402
 
 
-def run(cases, seed, ctx=None, log=print, sides=(48, 160, 700)):
-    """-> (mismatches, walks that reported VD_ERR_STACK_OVERFLOW where the oracle's deepest stack is > 64)"""
+def run(cases, seed, ctx=None, log=print, sides=(48, 160, 700), only=None):
+    """-> (mismatches, cases whose rays needed the second pass: the oracle's deepest stack is > 64 there).  `only`: the cases
+    to trace (the others are generated, so that the random stream stays the campaign's, and skipped)."""
     rng = np.random.default_rng(seed)
     ctx = ctx or Context(0)
     bad = overflows = 0
@@ -64,7 +65,11 @@ def run(cases, seed, ctx=None, log=print, sides=(48, 160, 700)):
         rays["dir"][sel[k // 4: k // 2], rng.integers(0, 3, k // 2 - k // 4)] = np.float32(np.nan)
         rays["eye"][sel[k // 2:]] = inst["transform"][rng.integers(0, n_inst, k - k // 2)][:, 12:15]              # from instance centres
         scene = (tl, inst, infos, B, V, I)
+        if only is not None and case not in only:
+            continue
         want, want_stack = ref.trace(scene, rays, threads=16)
+        if want_stack > 64:
+            overflows += 1
         import torch
         ds = ctx.device_scene(scene)
         d_rays, d_hits = ctx.upload(rays), ctx.empty(len(rays) * 16)
@@ -80,12 +85,8 @@ def run(cases, seed, ctx=None, log=print, sides=(48, 160, 700)):
                     else:
                         ctx.trace_dev(ds, d_rays, len(rays), d_hits); ctx.trace_any_dev(ds, d_rays, len(rays), d_any)
                 except VoidinError as e:
-                    # the library's one 128-entry stack holds a ray's TLAS and BLAS entries together (the reference's two 24-entry stacks are
-                    # unchecked); the oracle reports the deepest use of either of its two 256-entry stacks
-                    if e.code == abi.VD_ERR_STACK_OVERFLOW and want_stack > 64:
-                        overflows += 1
-                        log(f"case {case}: {n_inst} instances, fan {fan} {mode}: stack overflow reported (oracle's deepest stack {want_stack})")
-                        continue
+                    # no status is acceptable: a ray that runs out of the 128 entries a lane holds is walked again with its stack in
+                    # global memory (trace.hip, launch_trace) - round 5 still reported VD_ERR_STACK_OVERFLOW for such scenes
                     bad += 1
                     log(f"case {case}: {n_inst} instances, {len(rays)} rays, fan {fan} {mode}: {e} (oracle's deepest stack {want_stack})")
                     continue
@@ -107,5 +108,5 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     bad, overflows = run(args.cases, args.seed, log=lambda m: print(m, flush=True))
-    print(f"{args.cases} cases x 6 walks, {bad} mismatches, {overflows} walks reported a stack overflow")
+    print(f"{args.cases} cases x 6 walks, {bad} mismatches; {overflows} cases with a ray deeper than 64 entries on the oracle's side")
     sys.exit(1 if bad else 0)

@@ -1326,12 +1326,14 @@ __device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_s
 template <typename P>
 __global__ __launch_bounds__(256) void a_bits_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                      typename P::T* __restrict__ pay, const f32x4* __restrict__ cent,
-                                                     unsigned* __restrict__ bits21, unsigned* __restrict__ item_cnt) {
+                                                     unsigned* __restrict__ bits21, unsigned* __restrict__ item_cnt,
+                                                     unsigned* __restrict__ cnt_zero) {
     __shared__ float s_pos[kCand + 3];
     __shared__ unsigned s_w[4];
     ItemCtx ic; SegHead hv; const SegHead* sg = &hv;
     if (!item_ctx(segs, item_seg, ctl, ic, hv)) return;
     VD_HEAD_VIEW(sg, segs, ic);
+    if (cnt_zero && threadIdx.x == 0) cnt_zero[blockIdx.x] = 0u;      // fused rounds (a_round_kernel): round 0 adds round 1's trues up in it
     // the 21 planes of the segment (blas.rs:142-146) from its centroid bounds; the segment's FIRST item also resets what the
     // level accumulates in the record - child keys, bin keys, the rounds' windows - and leaves the planes there.  (All of
     // that used to be a loop of the single-workgroup boundary kernel: 190 words x 1 859 segments through one CU, 100 us at
@@ -1780,6 +1782,242 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
             const bool mine = counts[j] && land[j] == blockIdx.x;
             own_cnt += (unsigned)__popcll(__ballot(mine));
             count_runs(counts[j] && !mine, land[j], cnt_next);
+        }
+        if (own_cnt && lane == 0u) __hip_atomic_fetch_add(cnt_next + blockIdx.x, own_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE launch per shuffle round (round 6; levels whose segments have <= 1024 items): a_ranks + a_apply in one kernel, without
+// the rank -> position tables in HBM.  What a_apply asks the tables is a SELECT on the far side of the segment - a false
+// left of the pivot goes to the F-th true from the right, a true right of it to the (T+1)-th false from the left - and the
+// askers of one item have consecutive ranks, so their partners sit in a few consecutive items of the other side.  A
+// workgroup therefore (1) scans the segment's item counts in LDS (it loads them anyway for its own prefix), (2) finds the
+// rank ranges its elements ask for and the items that hold them, (3) reads THOSE items' payloads - a wave per partner item,
+// sixteen coalesced rows, ballots, popcount prefixes - and writes the positions of the trues / falses with the wanted ranks
+// into two LDS tables, (4) goes on as a_apply does with LDS reads in place of the two gathers.  No a_ranks launch, no
+// second read of the own payload, no table round trip through HBM; the price is one more dependent trip to memory and three
+// more barriers per workgroup.  The counts of round r + 2 are zeroed here (a_ranks did that): three count arrays rotate.
+// Same arithmetic on the same predicates: the arrangement every round leaves is the one the two-launch form leaves.
+constexpr int kRoundTab = kItem + 8;
+template <typename P, int mode>
+__global__ __launch_bounds__(256) void a_round_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
+                                                      const typename P::T* __restrict__ src, typename P::T* __restrict__ dst, const RoundK rk,
+                                                      const unsigned* __restrict__ cnt_cur, unsigned char* __restrict__ is_u_flag,
+                                                      const unsigned* __restrict__ bits21, unsigned* __restrict__ cnt_next,
+                                                      unsigned* __restrict__ cnt_zero) {
+    static_assert(kItem == 1024, "a_round_kernel: 16 rows of 64 positions per item, 4 counts per lane");
+    __shared__ unsigned s_w[4], s_wsum[4], s_rng[8];
+    __shared__ unsigned s_incl[1024];                      // inclusive scan of the segment's item counts (trues per item, window positions only)
+    __shared__ unsigned s_tpos[kRoundTab], s_fpos[kRoundTab];
+    ItemCtx ic; SegHead hv; const SegHead* sg = &hv;
+    if (!item_ctx(segs, item_seg, ctl, ic, hv)) return;
+    VD_HEAD_VIEW(sg, segs, ic);
+    if (cnt_zero && threadIdx.x == 0) cnt_zero[blockIdx.x] = 0u;      // the round after next adds its trues up in it
+    const int c = rk.c;
+    const Window win = round_window(sg, rk);
+    const unsigned copy_from = mode == 2 ? 0u : win.band;
+    if (ic.rel0 + ic.n_here <= copy_from) return;         // frozen before the previous round: both buffers agree
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned own_cnt = 0;                                  // elements counted into this very item (wave-uniform)
+    const unsigned sh_next = rk.sh_next, axis_next = rk.axis_next;
+    unsigned long long masks[kPer]; typename P::T vals[kPer];
+    item_load<P>(sg, ic, src, vals);
+    // the segment's item counts, four CONSECUTIVE ones per lane (the scan below wants them in order)
+    const unsigned ni = sg->n_items, mine = blockIdx.x - sg->item_first;
+    unsigned cv[4];
+    {
+        const unsigned* __restrict__ cn = cnt_cur + sg->item_first;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const unsigned i = 4u * threadIdx.x + (unsigned)k; cv[k] = cn[i < ni ? i : 0u]; }
+    }
+    unsigned nb[kPer];
+    if (mode == 2 && P::kRefresh) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) nb[j] = bits21[P::pos(vals[j])];
+    }
+    // the band the previous round froze: straight copy, so that `dst` holds the whole arrangement
+    if (ic.rel0 < win.act && copy_from < win.act) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane, xa = ic.rel0 + xr;
+            bool pn = false;
+            if (xr < ic.n_here && xa >= copy_from && xa < win.act) {
+                typename P::T v = vals[j];
+                if (mode == 2) {
+                    if (P::kRefresh) v = P::make(P::pos(v), nb[j], axis_next);
+                    pn = (P::word(v) >> sh_next) & 1u;
+                }
+                dst[sg->start + xa] = v;
+            }
+            if (mode == 2) own_cnt += (unsigned)__popcll(__ballot(pn));
+        }
+    }
+    if (ic.rel0 + ic.n_here <= win.act) {
+        if (mode == 2 && own_cnt && lane == 0u) __hip_atomic_fetch_add(cnt_next + blockIdx.x, own_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    item_masks<P, false>(sg, ic, src, rk, win.act, masks, vals);
+    unsigned t = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
+    if (lane == 0u) s_w[wave] = t;
+    // ---- (1) scan of the item counts: lane-local, wave (shuffles), workgroup (s_wsum) ----
+    unsigned a[4];
+    {
+        unsigned acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc += (4u * threadIdx.x + (unsigned)k < ni) ? cv[k] : 0u; a[k] = acc; }
+    }
+    unsigned incl = a[3];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned v = __shfl_up(incl, off); if (lane >= (unsigned)off) incl += v; }
+    if (lane == 63u) s_wsum[wave] = incl;
+    if (threadIdx.x == 0) { s_rng[0] = 0xffffffffu; s_rng[1] = 0u; s_rng[2] = 0xffffffffu; s_rng[3] = 0u; s_rng[4] = 1u; s_rng[5] = 0u; s_rng[6] = 1u; s_rng[7] = 0u; }
+    __syncthreads();                                                                        // ---- barrier A
+    unsigned woff = 0, ttot = 0;
+#pragma unroll
+    for (unsigned w = 0; w < 4u; ++w) { const unsigned v = s_wsum[w]; if (w < wave) woff += v; ttot += v; }
+    const unsigned before4 = woff + incl - a[3];           // trues of the items before this lane's four
+    {
+        const u32x4 o = {before4 + a[0], before4 + a[1], before4 + a[2], before4 + a[3]};
+        *reinterpret_cast<u32x4*>(&s_incl[4u * threadIdx.x]) = o;
+    }
+    unsigned run = 0;
+    for (unsigned w = 0; w < wave; ++w) run += s_w[w];      // trues of this item's earlier waves
+    // ---- (2) what this item's elements ask for (the trues before the item come out of the scan: after barrier B) ----
+    const unsigned n = sg->count - win.act, s = sg->start + win.act, ftot = n - ttot;
+    __syncthreads();                                                                        // ---- barrier B: s_incl complete
+    const unsigned run0 = mine ? s_incl[mine - 1u] : 0u;
+    run += run0;
+    bool counts[kPer]; unsigned land[kPer];
+    bool in[kPer], pp[kPer], need_t[kPer], need_f[kPer];
+    unsigned xx[kPer], FF[kPer], TT[kPer], tp[kPer], fp[kPer];
+    unsigned q_lo = 0xffffffffu, q_hi = 0u, T_lo = 0xffffffffu, T_hi = 0u;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
+        in[j] = xr < ic.n_here && ic.rel0 + xr >= win.act;
+        xx[j] = ic.rel0 + xr - win.act;
+        pp[j] = (masks[j] >> lane) & 1ull;
+        const unsigned tl = run + vd_mbcnt(masks[j]);
+        FF[j] = xx[j] - tl; TT[j] = ttot - tl - (pp[j] ? 1u : 0u);
+        // who asks (a_apply believes a table entry in exactly these places): the F-th true from the right decides `left` AT ttot,
+        // gives the fetch index of the two positions left of / at ttot (the `u` test) and the landing place of a false the front
+        // pointer examines; the (T+1)-th false from the left the same on the other side
+        need_t[j] = in[j] && FF[j] != 0u && FF[j] <= ttot && xx[j] <= ttot && (!pp[j] || xx[j] + 1u >= ttot);
+        need_f[j] = in[j] && TT[j] + 1u <= ftot && xx[j] >= ttot && (pp[j] || xx[j] <= ttot + 1u);
+        if (need_t[j]) { const unsigned q = ttot - FF[j]; q_lo = min(q_lo, q); q_hi = max(q_hi, q); }      // left rank (0-based) of that true
+        if (need_f[j]) { T_lo = min(T_lo, TT[j]); T_hi = max(T_hi, TT[j]); }
+        run += (unsigned)__popcll(masks[j]);
+    }
+    {
+        const unsigned ql = (unsigned)wave_min_i((int)(q_lo ^ 0x80000000u)) ^ 0x80000000u, qh = (unsigned)wave_max_i((int)(q_hi ^ 0x80000000u)) ^ 0x80000000u;
+        const unsigned tl_ = (unsigned)wave_min_i((int)(T_lo ^ 0x80000000u)) ^ 0x80000000u, th = (unsigned)wave_max_i((int)(T_hi ^ 0x80000000u)) ^ 0x80000000u;
+        if (lane == 0u) {
+            if (ql != 0xffffffffu) { atomicMin(&s_rng[0], ql); atomicMax(&s_rng[1], qh); }
+            if (tl_ != 0xffffffffu) { atomicMin(&s_rng[2], tl_); atomicMax(&s_rng[3], th); }
+        }
+    }
+    __syncthreads();                                                                        // ---- barrier C: the wanted rank ranges
+    q_lo = s_rng[0]; q_hi = s_rng[1]; T_lo = s_rng[2]; T_hi = s_rng[3];
+    const bool want_t = q_lo != 0xffffffffu, want_f = T_lo != 0xffffffffu;
+    // which items hold those ranks: item k holds the trues with left ranks [incl(k - 1), incl(k)) and the falses with left ranks
+    // [wpos(k) - incl(k - 1), wpos(k + 1) - incl(k)), wpos(k) = window positions before item k
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned i = 4u * threadIdx.x + (unsigned)k;
+            if (i < ni) {
+                const unsigned hi_t = before4 + a[k], lo_t = k ? before4 + a[k - 1] : before4;
+                const unsigned p0 = i * (unsigned)kItem, p1 = min(sg->count, p0 + (unsigned)kItem);
+                const unsigned w0 = p0 > win.act ? p0 - win.act : 0u, w1 = p1 > win.act ? p1 - win.act : 0u;
+                const unsigned lo_f = w0 - lo_t, hi_f = w1 - hi_t;
+                if (want_t) { if (lo_t <= q_lo && q_lo < hi_t) s_rng[4] = i; if (lo_t <= q_hi && q_hi < hi_t) s_rng[5] = i; }
+                if (want_f) { if (lo_f <= T_lo && T_lo < hi_f) s_rng[6] = i; if (lo_f <= T_hi && T_hi < hi_f) s_rng[7] = i; }
+            }
+        }
+    }
+    __syncthreads();                                                                        // ---- barrier D: the partner items
+    // ---- (3) a wave per partner item: its payload in sixteen rows, ranks from ballots, positions into the LDS tables ----
+    {
+        const unsigned jt0 = s_rng[4], jt1 = s_rng[5], jf0 = s_rng[6], jf1 = s_rng[7];
+        const unsigned nt = want_t && jt1 >= jt0 ? jt1 - jt0 + 1u : 0u, nf = want_f && jf1 >= jf0 ? jf1 - jf0 + 1u : 0u;
+        const unsigned sh = rk.c >= 0 ? rk.sh : P::shift(sg->best);
+        for (unsigned k = wave; k < nt + nf; k += 4u) {
+            const bool tk = k < nt;
+            const unsigned j = tk ? jt0 + k : jf0 + (k - nt);
+            const unsigned before_t = j ? s_incl[j - 1u] : 0u;
+            if (tk && s_incl[j] == before_t) continue;                 // no true in it (wave-uniform)
+            const unsigned p0 = j * (unsigned)kItem, nh = min((unsigned)kItem, sg->count - p0);
+            const typename P::T* __restrict__ base = src + sg->start + p0;
+            typename P::T pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const unsigned x = (unsigned)r * 64u + lane; pv[r] = base[x < nh ? x : 0u]; }
+            unsigned rank = tk ? before_t : (p0 > win.act ? p0 - win.act : 0u) - before_t;      // left rank of the row's first true / false
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned x = (unsigned)r * 64u + lane;
+                const bool inw = x < nh && p0 + x >= win.act;
+                const bool bit = (P::word(pv[r]) >> sh) & 1u;
+                const unsigned long long m = __ballot(inw && (tk ? bit : !bit));
+                const unsigned mine_r = rank + vd_mbcnt(m);
+                if ((m >> lane) & 1ull) {
+                    if (tk) { if (mine_r >= q_lo && mine_r <= q_hi) s_tpos[mine_r - q_lo] = p0 + x - win.act; }
+                    else { if (mine_r >= T_lo && mine_r <= T_hi) s_fpos[mine_r - T_lo] = p0 + x - win.act; }
+                }
+                rank += (unsigned)__popcll(m);
+            }
+        }
+    }
+    __syncthreads();                                                                        // ---- barrier E: the tables
+    // ---- (4) a_apply from here on, the two gathers out of LDS ----
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        tp[j] = need_t[j] ? s_tpos[ttot - FF[j] - q_lo] : 0u;
+        fp[j] = need_f[j] ? s_fpos[TT[j] - T_lo] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        counts[j] = false; land[j] = 0u;
+        if (in[j]) {
+            const unsigned x = xx[j];
+            const bool p = pp[j];
+            const long long tF = FF[j] == 0u ? (long long)n : (need_t[j] ? (long long)tp[j] : -1ll);
+            const unsigned fj = need_f[j] ? fp[j] : n;
+            const bool left = x < ttot || (x == ttot && (long long)x < tF);
+            const bool amb = x + 1u - ttot <= 2u;
+            const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
+            const bool is_u = amb && fetch == n - 1u;
+            unsigned dest;
+            if (is_u) dest = ttot - (p ? 1u : 0u);
+            else if (left) dest = p ? x : (unsigned)tF - 1u;
+            else dest = p ? fj : x - 1u;
+            typename P::T v = vals[j];
+            const unsigned upos = P::pos(v);
+            if (mode == 2) {
+                if (P::kRefresh) v = P::make(upos, nb[j], axis_next);
+                counts[j] = (P::word(v) >> sh_next) & 1u;
+            } else if (mode == 1) {
+                counts[j] = ((P::word(v) >> sh_next) & 1u) && (is_u || dest >= ttot);   // left of the pivot = frozen for the next round
+            }
+            land[j] = sg->item_first + (win.act + dest) / (unsigned)kItem;
+            dst[s + dest] = v;
+            if (is_u && c >= 0) {
+                Seg& w = segs[ic.seg];
+                const u32x2 urec = {upos, bits21[upos]};               // the record keeps all 21 bits: the cost evaluation needs them
+                w.u_pay[c] = urec; w.u_p[c] = p ? 1u : 0u; w.ttot[c] = win.act + ttot;
+                w.act[rk.i_next] = win.act + ttot - (p ? 1u : 0u);   // this trial's pivot: where the next round starts
+                is_u_flag[upos] = 1;
+            }
+        }
+    }
+    if (mode != 0) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const bool mine_c = counts[j] && land[j] == blockIdx.x;
+            own_cnt += (unsigned)__popcll(__ballot(mine_c));
+            count_runs(counts[j] && !mine_c, land[j], cnt_next);
         }
         if (own_cnt && lane == 0u) __hip_atomic_fetch_add(cnt_next + blockIdx.x, own_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -2685,8 +2923,31 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
         const unsigned items_ub = (unsigned)(std::min<size_t>(T, active_bound) / kItem) + n_seg_now + 1;
         PT* src = reinterpret_cast<PT*>(P.pay0); PT* dst = reinterpret_cast<PT*>(P.pay1);
         unsigned* const cnt[2] = {P.item_cnt, P.item_cnt1};      // round c counts in cnt[c & 1]
-        hipLaunchKernelGGL((a_bits_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.cent, P.bits21, cnt[0]);
-        for (int c = 0; c <= kCand; ++c) {
+        // One launch per round (a_round_kernel) at the levels whose segments have <= 1024 items; three count arrays rotate there
+        // (item_pre, which only a_scan writes, is the third): round c reads cnt3[c % 3], adds round c + 1's trues up in
+        // cnt3[(c + 1) % 3] and zeroes cnt3[(c + 2) % 3].  VD_OPT_BLAS_FUSED_ROUNDS = 0: the two launches per round everywhere (A/B).
+        const bool fused = scan_free && ctx->option(VD_OPT_BLAS_FUSED_ROUNDS, 0) != 0;      // opt-in until measured
+        unsigned* const cnt3[3] = {P.item_cnt, P.item_cnt1, P.item_pre};
+        hipLaunchKernelGGL((a_bits_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.cent, P.bits21, cnt[0],
+                           fused ? cnt3[1] : (unsigned*)nullptr);
+        for (int c = 0; fused && c <= kCand; ++c) {
+            const int cc = c < kCand ? c : -1;
+            if (c == kCand) {
+                hipLaunchKernelGGL((a_bin_kernel<PayT>), dim3((items_ub + kBinItems - 1) / kBinItems), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.boxes,
+                                   P.is_u, P.bits21);
+                hipLaunchKernelGGL(a_eval_kernel, dim3(n_seg_now), dim3(64), 0, st, seg_cur, P.ctl, cur.boxes);
+                hipLaunchKernelGGL((a_count_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, cnt3[c % 3], P.bits21, 1);
+            }
+            const int mode = c + 1 >= kCand ? 0 : ((c + 1) % 7 == 0 ? 2 : 1);
+            unsigned* const cnt_next = mode ? cnt3[(c + 1) % 3] : nullptr;
+            const RoundK rk = make_round<PayT>(cc);
+            auto round = mode == 0 ? a_round_kernel<PayT, 0> : mode == 1 ? a_round_kernel<PayT, 1> : a_round_kernel<PayT, 2>;
+            hipLaunchKernelGGL(round, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, rk, cnt3[c % 3], P.is_u, P.bits21, cnt_next,
+                               cnt3[(c + 2) % 3]);
+            n_launch += 1u;
+            PT* t = src; src = dst; dst = t;
+        }
+        for (int c = 0; !fused && c <= kCand; ++c) {
             const int cc = c < kCand ? c : -1;       // -1: final re-shuffle with each segment's best plane
             if (c == kCand) {
                 hipLaunchKernelGGL((a_bin_kernel<PayT>), dim3((items_ub + kBinItems - 1) / kBinItems), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.boxes,

@@ -46,8 +46,17 @@ int vd_ensure_host(VdCtx* ctx, size_t need) {
     return VD_OK;
 }
 
+int vd_scan_check_fault(VdCtx* ctx) {
+    if (!ctx->host_pinned || ctx->host_pinned[kScanFaultWord] == 0u) return VD_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->host_pinned[kScanFaultWord] = 0u;
+    if (ctx->scan_state) (void)hipMemsetAsync(ctx->scan_state, 0, ctx->scan_state_bytes, ctx->stream);      // whatever state the launch left: start over
+    VD_FAIL(ctx, VD_ERR_HIP, "an earlier compaction launch on this context gave up waiting for a workgroup (bounded look-back scan): its "
+                             "count was 0 and no list was written; the scan state has been reset");
+}
+
 int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer) {
-    const size_t need = (16 + (size_t)n_tiles * 8 + 15) & ~(size_t)15;
+    const size_t need = (32 + (size_t)n_tiles * 8 + 15) & ~(size_t)15;
     const bool periodic = (++ctx->scan_launches & ((1ull << 28) - 1)) == 0;   // epoch field is 30 bits: never let it lap
     if (need > ctx->scan_state_bytes || !ctx->scan_state || periodic) {
         int rc = vd_ensure(ctx, &ctx->scan_state, &ctx->scan_state_bytes, need);
@@ -55,7 +64,7 @@ int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, u
         VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->scan_state, 0, ctx->scan_state_bytes, ctx->stream));
     }
     *ticket = reinterpret_cast<unsigned long long*>(ctx->scan_state);
-    *states = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->scan_state) + 16);
+    *states = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->scan_state) + 32);      // [2] = the stuck word (vd_common.hpp)
     if (start_timer) vd_time_begin(ctx);   // vd_last_gpu_ms brackets the scan kernel itself
     return VD_OK;
 }
@@ -84,6 +93,12 @@ int vd_ctx_create(int device, VdCtx** out_ctx) {
         return VD_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    memset(ctx->host_pinned, 0, 64 * sizeof(uint32_t));
+    {   // the scan kernels raise host_pinned[kScanFaultWord] themselves (system-scope store): they need its device address
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, ctx->host_pinned, 0) != hipSuccess || !dp) { vd_ctx_destroy(ctx); return VD_ERR_HIP; }
+        ctx->fault_dev = reinterpret_cast<unsigned*>(dp) + kScanFaultWord;
+    }
     for (int o = 0; o < VD_OPT_COUNT_; ++o) ctx->opt[o] = -1;
     *out_ctx = ctx;
     return VD_OK;
@@ -96,6 +111,8 @@ int vd_ctx_destroy(VdCtx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scan_state) (void)hipFree(ctx->scan_state);
     if (ctx->expand_state) (void)hipFree(ctx->expand_state);
+    if (ctx->trace_ovf) (void)hipFree(ctx->trace_ovf);
+    if (ctx->trace_deep) (void)hipFree(ctx->trace_deep);
     if (ctx->refit_state) (void)hipFree(ctx->refit_state);
     if (ctx->stage_in) (void)hipFree(ctx->stage_in);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);

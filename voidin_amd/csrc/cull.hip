@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlock, 3)
 void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, unsigned n_mesh,
                          const VdInstance* __restrict__ inst, unsigned n_inst, VdDrawIndexedIndirect* __restrict__ out,
                          unsigned* __restrict__ out_count, vd_u64* tile_state, vd_u64* ticket_counter,
-                         unsigned n_tiles, unsigned first_instance) {
+                         unsigned n_tiles, unsigned first_instance, unsigned* fault_host) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // dynamic LDS: per-wave slabs, then per-round records (mesh id | visible << 31), then scalars
     unsigned* s_rec = reinterpret_cast<unsigned*>(smem + kWavesPerBlock * kSlabBytes);   // [ROUNDS][kBlock]
@@ -247,7 +247,7 @@ void cull_compact_kernel(CullCamera cam, const VdMeshInfo* __restrict__ meshes, 
         const unsigned excl = vd_lookback(tile_state, epoch, tile, tile_total);
         if (lane == 0) {
             s_misc[1] = excl;
-            if (tile == n_tiles - 1u) *out_count = excl == VD_SCAN_STUCK ? VD_SCAN_STUCK : excl + tile_total;
+            if (tile == n_tiles - 1u) *out_count = vd_scan_final_count(tile_state, epoch, excl, tile_total, fault_host);
         }
     }
     __syncthreads();
@@ -1072,7 +1072,7 @@ constexpr int kCompactTile = kBlock * kCompactPerThread;
 __global__ __launch_bounds__(kBlock) void compact_draws_kernel(const VdDrawIndexedIndirect* __restrict__ in, unsigned n,
                                                                VdDrawIndexedIndirect* __restrict__ out,
                                                                unsigned* __restrict__ out_count, vd_u64* tile_state,
-                                                               vd_u64* ticket_counter, unsigned n_tiles) {
+                                                               vd_u64* ticket_counter, unsigned n_tiles, unsigned* fault_host) {
     __shared__ unsigned s_ticket, s_epoch, s_wave_total[kWavesPerBlock], s_tile_excl;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_ticket = vd_take_ticket(ticket_counter, n_tiles, &s_epoch);
@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(kBlock) void compact_draws_kernel(const VdDrawIndex
         const unsigned excl = vd_lookback(tile_state, epoch, tile, tile_total);
         if (lane == 0) {
             s_tile_excl = excl;
-            if (tile == n_tiles - 1u) *out_count = excl == VD_SCAN_STUCK ? VD_SCAN_STUCK : excl + tile_total;
+            if (tile == n_tiles - 1u) *out_count = vd_scan_final_count(tile_state, epoch, excl, tile_total, fault_host);
         }
     }
     __syncthreads();
@@ -1291,7 +1291,8 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
     if (!d_instances || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_cull_compact: null instances/out");
     int variant = ctx->cull_variant;
     vd_u64* ticket; vd_u64* states;
-    int rc = VD_OK;
+    int rc = vd_scan_check_fault(ctx);       // an EARLIER launch's scan gave up: said once, here
+    if (rc) return rc;
     if ((variant <= 0) && n_inst >= ctx->split_min) {
         // Split form (default for large inputs): pass 1 streams the instances and writes only one bit
         // + a compact mesh id per instance (reads run at ~6.4 TB/s when no 20-byte commands are stored
@@ -1320,7 +1321,7 @@ int vd_cull_compact_shard_dev(VdCtx* ctx, const VdCameraUniform* camera, const V
         if (rc) return rc;                                                                                       \
         hipLaunchKernelGGL((cull_compact_kernel<R>), dim3(n_tiles), dim3(kBlock), (compact_lds_bytes<R>()),      \
                            ctx->stream, make_cam(camera), d_meshes, n_mesh, d_instances, n_inst, d_out,          \
-                           d_out_count, states, ticket, n_tiles, first_instance);                                \
+                           d_out_count, states, ticket, n_tiles, first_instance, vd_scan_fault_word(ctx));       \
     } while (0)
     // fused form: tile size grows with n so that ticket + two barriers + look-back amortise while
     // small inputs still spread over the chip (a 100 k-instance scene in 1024-instance tiles is 98
@@ -1473,10 +1474,12 @@ int vd_compact_draws_dev(VdCtx* ctx, const VdDrawIndexedIndirect* d_in, uint32_t
     if (!d_in || !d_out) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_compact_draws: null in/out");
     const unsigned n_tiles = (n + kCompactTile - 1) / kCompactTile;
     vd_u64* ticket; vd_u64* states;
-    int rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);
+    int rc = vd_scan_check_fault(ctx);
+    if (rc) return rc;
+    rc = vd_scan_scratch(ctx, n_tiles, &ticket, &states, true);
     if (rc) return rc;
     hipLaunchKernelGGL(compact_draws_kernel, dim3(n_tiles), dim3(kBlock), 0, ctx->stream, d_in, n, d_out, d_out_count,
-                       states, ticket, n_tiles);
+                       states, ticket, n_tiles, vd_scan_fault_word(ctx));
     vd_time_end(ctx);
     VD_HIP_CHECK(ctx, hipGetLastError());
     return VD_OK;
@@ -1554,10 +1557,13 @@ int vd_cull_compact(VdCtx* ctx, const VdCameraUniform* camera, const VdMeshInfo*
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *out_count = ctx->host_pinned[0];
-    if (*out_count > n_inst) {        // VD_SCAN_STUCK: a cross-workgroup wait of the scan timed out (vd_common.hpp) - no list was written
+    // a cross-workgroup wait of the scan timed out (vd_common.hpp): the fault word is up and the count is 0 - or the launch lost its
+    // LAST workgroup and the count still holds the value the first one pre-stored, VD_SCAN_STUCK.  No list was written either way.
+    if (*out_count > n_inst || ctx->host_pinned[kScanFaultWord] != 0u) {
         *out_count = 0;
+        ctx->host_pinned[kScanFaultWord] = 0u;
         if (ctx->scan_state) (void)hipMemsetAsync(ctx->scan_state, 0, ctx->scan_state_bytes, ctx->stream);   // whatever state the launch left: start over
-        VD_FAIL(ctx, VD_ERR_HIP, "vd_cull_compact: the compaction scan gave up waiting for a workgroup (count sentinel 0xffffffff)");
+        VD_FAIL(ctx, VD_ERR_HIP, "vd_cull_compact: the compaction scan gave up waiting for a workgroup");
     }
     const size_t n_copy = pad_tail ? n_inst : *out_count;
     if (n_copy) {

@@ -6,7 +6,9 @@
 // One lane per ray at a time, persistent waves that refill (see trace_body); the arithmetic order is the WGSL
 // source order with no FMA, so hit distances are reproduced to the bit on the oracle's evaluation model (tolerance
 // in tests: 1e-5).  The reference's 24-entry stack is unchecked (shaders/utils/stack.wgsl:1-20); here one 128-entry
-// stack serves the TLAS and the BLAS walk of a ray and overflow is reported, not ignored.  Leaves of more than 3
+// stack serves the TLAS and the BLAS walk of a ray, and a ray that needs more is walked AGAIN, from its start, by a second
+// pass whose stack goes on in a slab of global memory (launch_trace: the call is total - VD_ERR_STACK_OVERFLOW is left for
+// scenes whose trees are deeper than the slab the context may allocate).  Leaves of more than 3
 // triangles do not occur (BvhBuilder stops at <= 3: blas.rs:108) and are not representable in a stack entry.
 #include "vd_common.hpp"
 
@@ -79,6 +81,9 @@ struct Scene {
     const float4* tpair;        // child pairs of the TLAS, 4 x float4 per node, at the LEFT child's index
     const float4* mrec;         // mesh records, 8 x float4 per mesh
     unsigned yield;             // waiting lanes at which a wave leaves the stepping loop (VD_OPT_TRACE_YIELD)
+    unsigned* ovf_bits = nullptr;   // first pass: bit r is set when ray r ran out of its 128 entries (the second pass walks those again)
+    unsigned* deep = nullptr;       // second pass (DEEP): entries 128.. of a lane's stack, [wave][entry][lane]
+    unsigned deep_cap = 0;          // ... and how many there are per lane
 };
 
 // Where a wave's rays come from.  `order` (nullptr = identity) lists the ray ids in the order they are handed out (the
@@ -153,7 +158,8 @@ constexpr int kWgWaves = 6;             // waves per workgroup of the chunked fo
 // CHUNKS = false (default): idle lanes draw single rays from one global counter, one wave per workgroup - the round-2
 // form, kept apart so that it carries none of the chunk machinery (inside multi-wave workgroups with the chunk state live
 // the closest-hit walk spilled registers and lost 10 %: 38.5 -> 34.5 Mrays/s, same-session A/B against the round-2 library).
-template <bool ANY, bool PREP, bool CHUNKS, bool FAN = false>
+// DEEP: the second pass over the rays whose stack overflowed (launch_trace) - same walk, entries 128.. in s.deep.
+template <bool ANY, bool PREP, bool CHUNKS, bool FAN = false, bool DEEP = false>
 __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restrict__ rays, const RaySource& src, VdHit* __restrict__ out,
                                            unsigned* __restrict__ out_any, unsigned* __restrict__ overflow) {
     const unsigned lane = threadIdx.x & 63u;
@@ -176,6 +182,7 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
     __shared__ unsigned s_stack[CHUNKS ? kWgWaves : 1][kLdsStack][64];
     const unsigned wv = CHUNKS ? (threadIdx.x >> 6) : 0u;     // (indexed, not through a pointer: a 64-bit pointer was spilled and reloaded at every push)
     unsigned stack[2 * kStack - kLdsStack];  // BLAS entries sit above the TLAS entries of the same ray
+    const size_t deep_base = DEEP ? (size_t)blockIdx.x * s.deep_cap * 64u + lane : 0u;       // one wave per workgroup in the DEEP kernel
     Ray world, ray;                        // `ray` is the active one (object space inside an instance)
     VdHit res;
     unsigned ray_id = 0;
@@ -199,7 +206,9 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
         if (((st & kInBlas) != 0u) && head == blas_base) { st &= ~kInBlas; ray = world; }
         if (head == 0u) { st |= kDone; return; }
         --head;
-        const unsigned w = head < (unsigned)kLdsStack ? s_stack[wv][head][lane] : stack[head - (unsigned)kLdsStack];
+        unsigned w;
+        if (DEEP && head >= 2u * (unsigned)kStack) w = s.deep[deep_base + (size_t)(head - 2u * (unsigned)kStack) * 64u];
+        else w = head < (unsigned)kLdsStack ? s_stack[wv][head][lane] : stack[head - (unsigned)kLdsStack];
         if (((st & kInBlas) != 0u)) cn = make_uint2(w & 0x3fffffffu, w >> 30);
         else cn = (w & 0xffffu) ? make_uint2(w, 0xffffffffu) : make_uint2(0u, w >> 16);
     };
@@ -488,11 +497,21 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
             // the TLAS loop on `<`
             const bool blas_now = (st & kInBlas) != 0u;
             if (max_dist < res.dist || (blas_now && max_dist == res.dist)) {
-                if (head + 1u > 2u * (unsigned)kStack) { st |= kOvf; st |= kDone; continue; }
+                if (head + 1u > 2u * (unsigned)kStack) {
+                    if (!DEEP) {          // out of entries: this ray is walked again by the second pass (its record is rewritten there)
+                        if (s.ovf_bits) {
+                            const unsigned rid = (FAN && (ray_id & 0x80000000u)) ? src.fan.jobs[ray_id & 0x7fffffffu].ray_id : ray_id;
+                            atomicOr(s.ovf_bits + (rid >> 5), 1u << (rid & 31u));
+                        }
+                        st |= kOvf; st |= kDone; continue;
+                    }
+                    if (head - 2u * (unsigned)kStack >= s.deep_cap) { st |= kOvf; st |= kDone; continue; }
+                }
                 if (blas_now && far.y > 3u) st |= kBadLeaf;   // not representable in a stack entry
                 const unsigned w_blas = far.x | (far.y << 30), w_tlas = far.x != 0u ? far.x : (far.y << 16);
                 const unsigned w = blas_now ? w_blas : w_tlas;
-                if (head < (unsigned)kLdsStack) s_stack[wv][head][lane] = w; else stack[head - (unsigned)kLdsStack] = w;
+                if (DEEP && head >= 2u * (unsigned)kStack) s.deep[deep_base + (size_t)(head - 2u * (unsigned)kStack) * 64u] = w;
+                else if (head < (unsigned)kLdsStack) s_stack[wv][head][lane] = w; else stack[head - (unsigned)kLdsStack] = w;
                 ++head;
             }
             cn = near;
@@ -550,7 +569,8 @@ __device__ __forceinline__ void trace_body(const Scene& s, const VdRay* __restri
 // Entry points.  The single-ray form takes the scene's buffers as plain kernel arguments (one wave per workgroup, the
 // persistent grid = 24 waves per CU); the chunked form takes the scene / supply structs.
 struct SceneArgs { const VdTlasNode* tlas; const VdInstance* inst; const VdMeshInfo* meshes; const VdBvhNode* bvh;
-                   const float* verts; const unsigned* indices; unsigned n_meshes, yield; const float4* irec; const float4* tpair; const float4* mrec; };
+                   const float* verts; const unsigned* indices; unsigned n_meshes, yield; const float4* irec; const float4* tpair; const float4* mrec;
+                   unsigned* ovf_bits; };
 #ifndef VD_FAN_WPS
 #define VD_FAN_WPS 5
 #endif
@@ -560,7 +580,7 @@ __global__ __launch_bounds__(64, FAN ? VD_FAN_WPS : 6)   // second argument (HIP
 void trace_single_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsigned n_rays, VdHit* __restrict__ out, unsigned* __restrict__ out_any,
                          unsigned* __restrict__ overflow, unsigned* next_ray, const unsigned* __restrict__ gate, Fan fan) {
     if (gate && *gate == 0u) return;          // the call de-indexed the leaves itself and that went well: the other kernel runs
-    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, nullptr, a.irec, a.tpair, a.mrec, a.yield};
+    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, nullptr, a.irec, a.tpair, a.mrec, a.yield, a.ovf_bits};
     const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray, fan};
     trace_body<ANY, false, false, FAN>(s, rays, src, out, out_any, overflow);
 }
@@ -570,9 +590,28 @@ void trace_single_prep_kernel(SceneArgs a, const VdRay* __restrict__ rays, unsig
                               unsigned* __restrict__ overflow, unsigned* next_ray, const float* __restrict__ tris,
                               const unsigned* __restrict__ gate, Fan fan) {
     if (gate && *gate != 0u) return;          // the call's own de-indexing met an index range it cannot use: the indexed kernel runs
-    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, tris, a.irec, a.tpair, a.mrec, a.yield};
+    const Scene s{a.tlas, a.inst, a.meshes, a.bvh, a.verts, a.indices, a.n_meshes, tris, a.irec, a.tpair, a.mrec, a.yield, a.ovf_bits};
     const RaySource src{nullptr, n_rays, 1u, n_rays, next_ray, fan};
     trace_body<ANY, true, false, FAN>(s, rays, src, out, out_any, overflow);
+}
+// The second pass: the rays listed in `list` (their ids, *n_list of them), one wave per workgroup, the stack beyond 128
+// entries in s.deep.  Rare by construction - a handful of rays of a deep scene - so it is one plain launch.
+template <bool ANY, bool PREP>
+__global__ __launch_bounds__(64, 4)
+void trace_deep_kernel(Scene s, const VdRay* __restrict__ rays, const unsigned* __restrict__ list, const unsigned* __restrict__ n_list,
+                       VdHit* __restrict__ out, unsigned* __restrict__ out_any, unsigned* __restrict__ overflow, unsigned* next_ray) {
+    const unsigned n = *n_list;
+    const RaySource src{list, n, 1u, n, next_ray};
+    trace_body<ANY, PREP, false, false, true>(s, rays, src, out, out_any, overflow);
+}
+// bitmap of the first pass -> list of ray ids (any order: a ray's record depends on the ray alone)
+__global__ __launch_bounds__(256) void ovf_list_kernel(const unsigned* __restrict__ bits, unsigned n_words, unsigned* __restrict__ list, unsigned* __restrict__ count) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_words) return;
+    unsigned w = bits[i];
+    if (w == 0u) return;
+    unsigned at = atomicAdd(count, (unsigned)__popc(w));
+    while (w) { const unsigned b = (unsigned)__builtin_ctz(w); list[at++] = i * 32u + b; w &= w - 1u; }
 }
 template <bool ANY, bool PREP>
 __global__ __launch_bounds__(64 * kWgWaves, 6)
@@ -1208,6 +1247,17 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     const size_t fan_bytes = phases > 1u ? 256 + best_bytes + (size_t)fan_cap * sizeof(FanJob) : 0;
     int rc = vd_ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, sort_at + fan_bytes);
     if (rc) return rc;
+    // one bit per ray: "ran out of its 128 stack entries" (second pass below).  All zero between calls: zeroed when (re)allocated
+    // and again after a call that set any, so a call that overflows nowhere pays nothing for it.
+    const unsigned ovf_words = (n_rays + 31u) / 32u;
+    {
+        const void* before = ctx->trace_ovf;
+        rc = vd_ensure(ctx, &ctx->trace_ovf, &ctx->trace_ovf_bytes, (size_t)ovf_words * 4u + 4u);
+        if (rc) return rc;
+        if (ctx->trace_ovf != before || ctx->trace_ovf_dirty) VD_HIP_CHECK(ctx, hipMemsetAsync(ctx->trace_ovf, 0, ctx->trace_ovf_bytes, ctx->stream));
+        ctx->trace_ovf_dirty = true;       // until this call has ended cleanly
+    }
+    unsigned* d_ovf = reinterpret_cast<unsigned*>(ctx->trace_ovf);
     // Binning is OFF by default: measured on the stress scene (tools/ab_trace.py, profiles/r03_ab_trace.log) rays handed
     // out in sorted order are SLOWER (32.0 against 35.7 Mrays/s): the walk is bound by the slowest of a wave's 64 fetches,
     // not by the L1 hit rate, and sorting puts the expensive rays of the dense screen centre side by side in time.
@@ -1246,14 +1296,14 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
                            sc->n_vertices, t, d_flag + 2);
         d_tris = t; gate = d_flag + 2;        // non-zero: some mesh's index range cannot be de-indexed - the indexed kernel takes the call
     }
-    Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, d_tris, d_rec, d_pair, d_mrec, yield};
+    Scene s{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, d_tris, d_rec, d_pair, d_mrec, yield, d_ovf};
     {
         // Default: single rays from one global counter (chunk = 1), one wave per workgroup - the finest balance.  Chunks of
         // consecutive rays per workgroup (a CU-local window of the ray order) lose more to imbalance than they gain in
         // locality: 64 rays per chunk 32.6, 256 rays 16.9 Mrays/s against 35.2 in the same kernel (same log).
         unsigned chunk = (unsigned)ctx->option(VD_OPT_TRACE_CHUNK, 1);
         if (chunk <= 1u && !order) {
-            const SceneArgs a{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, yield, d_rec, d_pair, d_mrec};
+            const SceneArgs a{sc->tlas_nodes, sc->instances, sc->meshes, sc->bvh_nodes, sc->vertices, sc->indices, sc->n_meshes, yield, d_rec, d_pair, d_mrec, d_ovf};
             // fan-out: launch 0 hands out the rays; launch p >= 1 the jobs appended before it started (fan_snapshot_kernel);
             // every launch but the last may append; fan_resolve_kernel writes the records of the rays that were fanned out
             for (unsigned ph = 0; ph < phases; ++ph) {
@@ -1287,6 +1337,7 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     VD_HIP_CHECK(ctx, hipGetLastError());
     VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (phases > 1u) VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned + 1, fan_ctl, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned + 2, d_flag + 2, 4, hipMemcpyDeviceToHost, ctx->stream));      // the gate: which of the two kernels walked
     VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (phases > 1u) {
         ctx->fan_tlas = sc->tlas_nodes; ctx->fan_nodes = sc->n_tlas_nodes; ctx->fan_inst = sc->n_instances;
@@ -1294,7 +1345,47 @@ int launch_trace(VdCtx* ctx, const VdTraceScene* sc, const float* d_tris, const 
     }
     if (ctx->host_pinned[0] & 4u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: a TLAS leaf's instance, its mesh's root or the root's children lie outside the scene's buffers");
     if (ctx->host_pinned[0] & 2u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: BVH leaf with more than 3 triangles (BvhBuilder never makes one: blas.rs:108)");
-    if (ctx->host_pinned[0]) VD_FAIL(ctx, VD_ERR_STACK_OVERFLOW, "vd_trace: traversal stack (128 entries per ray) exceeded");
+    if (ctx->host_pinned[0] & 1u) {
+        // Some rays needed more than the 128 entries a lane holds (the reference's own 24-entry stack is unchecked,
+        // shaders/utils/stack.wgsl:1-20: it has no answer there at all).  They are walked again, from their start, with the entries
+        // beyond 128 in a slab of global memory - same visits, same arithmetic, so the records are the ones an unbounded stack gives
+        // (tests/test_gpu_tlas_trace.py holds them against the oracle's 256-entry walk).  Entries per lane grow 1 Ki -> 4 Ki -> ...
+        // until nothing overflows; the slab is waves x 64 lanes x entries x 4 B under a 256 MB budget (fewer waves as it deepens),
+        // and a stack cannot hold more entries than the scene has nodes.
+        const bool prep_walked = d_tris && (!gate || ctx->host_pinned[2] == 0u);
+        const size_t node_bound = (size_t)sc->n_tlas_nodes + (size_t)sc->n_bvh_nodes + 2u;
+        const size_t list_bytes = ((size_t)n_rays * 4u + 255) & ~(size_t)255;
+        const size_t budget = (size_t)256 << 20;
+        for (size_t cap = 1024;; cap *= 4) {
+            const size_t per_wave = cap * 64u * 4u;
+            if (per_wave > ((size_t)2 << 30)) VD_FAIL(ctx, VD_ERR_STACK_OVERFLOW, "vd_trace: a ray's traversal stack needs more than 8 Mi entries");
+            const unsigned waves_d = (unsigned)std::max<size_t>(1, std::min<size_t>(waves, budget / per_wave));
+            rc = vd_ensure(ctx, &ctx->trace_deep, &ctx->trace_deep_bytes, 256 + list_bytes + (size_t)waves_d * per_wave);
+            if (rc) return rc;
+            unsigned* ctl = reinterpret_cast<unsigned*>(ctx->trace_deep);                 // [0] listed rays, [1] supply counter
+            unsigned* list = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctl) + 256);
+            VD_HIP_CHECK(ctx, hipMemsetAsync(ctl, 0, 256, ctx->stream));
+            VD_HIP_CHECK(ctx, hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(ovf_list_kernel, dim3((ovf_words + 255u) / 256u), dim3(256), 0, ctx->stream, d_ovf, ovf_words, list, ctl);
+            Scene sd = s;
+            sd.ovf_bits = nullptr;
+            sd.deep = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(list) + list_bytes);
+            sd.deep_cap = (unsigned)cap;
+#define VD_TRACE_D(A, P) hipLaunchKernelGGL((trace_deep_kernel<A, P>), dim3(waves_d), dim3(64), 0, ctx->stream, sd, d_rays, list, ctl, d_out, d_any, d_flag, ctl + 1)
+            if (d_any) { if (prep_walked) VD_TRACE_D(true, true); else VD_TRACE_D(true, false); }
+            else { if (prep_walked) VD_TRACE_D(false, true); else VD_TRACE_D(false, false); }
+#undef VD_TRACE_D
+            vd_time_end(ctx);                                                              // vd_last_gpu_ms covers the second pass too
+            VD_HIP_CHECK(ctx, hipGetLastError());
+            VD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_pinned, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+            VD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->host_pinned[0] & 6u) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_trace: the scene's buffers are inconsistent (bad leaf or entry met by the second pass)");
+            if (!(ctx->host_pinned[0] & 1u)) break;
+            if (cap >= node_bound) VD_FAIL(ctx, VD_ERR_STACK_OVERFLOW, "vd_trace: traversal stack deeper than the scene has nodes (cyclic node arrays?)");
+        }
+        VD_HIP_CHECK(ctx, hipMemsetAsync(d_ovf, 0, (size_t)ovf_words * 4u, ctx->stream));
+    }
+    ctx->trace_ovf_dirty = false;
     return VD_OK;
 }
 

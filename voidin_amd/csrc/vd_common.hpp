@@ -33,6 +33,9 @@ struct VdCtx {
     void* scratch = nullptr;     size_t scratch_bytes = 0;     // general purpose
     void* scan_state = nullptr;  size_t scan_state_bytes = 0;  // look-back granules + ticket word (epoch-tagged)
     void* expand_state = nullptr; size_t expand_state_bytes = 0;  // mask_scan_kernel: done counter + chunk offsets
+    void* trace_ovf = nullptr;   size_t trace_ovf_bytes = 0;      // traversal: one bit per ray of the call = "its 128-entry stack overflowed"
+    bool trace_ovf_dirty = false;                                 // a call left early (error) and may have left bits set
+    void* trace_deep = nullptr;  size_t trace_deep_bytes = 0;     // traversal, second pass over those rays: their list + stack entries beyond 128 (allocated when first needed)
     void* refit_state = nullptr; size_t refit_state_bytes = 0;    // TLAS refit: epoch-tagged {parent, sibling} links + arrival words
     unsigned refit_epoch = 0;                                     // tag of the last refit launch (0 = the arena is freshly zeroed)
     const void* fan_tlas = nullptr; unsigned fan_idle_calls = 0;  // traversal fan-out: top level of the last call that tried it, calls left to run without it
@@ -45,6 +48,7 @@ struct VdCtx {
     void* stage_out = nullptr;   size_t stage_out_bytes = 0;
     void* stage_aux = nullptr;   size_t stage_aux_bytes = 0;
     uint32_t* host_pinned = nullptr;                           // 64 u32 of pinned host memory
+    unsigned* fault_dev = nullptr;                             // device address of host_pinned[kScanFaultWord] (vd_scan_check_fault)
     void* host_stage = nullptr;  size_t host_stage_bytes = 0;  // grow-only pinned staging (BLAS top tree)
     void* lvl_pinned = nullptr; hipEvent_t ev_lvl[2] = {nullptr, nullptr};   // BLAS level loop: control words of the last two levels (pinned) + their events
     hipStream_t aux_stream = nullptr;                          // copies that overlap a kernel on `stream`
@@ -94,6 +98,11 @@ int vd_tlas_build_from_boxes(VdCtx* ctx, const float* d_boxes, uint32_t n, VdTla
 // Look-back scan state for n_tiles tiles: *ticket = 64-bit {epoch | ticket} word, *states = granules.
 // Zeroed once when (re)allocated; the epoch tags make per-launch clearing unnecessary.
 int vd_scan_scratch(VdCtx* ctx, unsigned n_tiles, unsigned long long** ticket, unsigned long long** states, bool start_timer);
+// Has a scan of an earlier launch on this context given up (fault word in pinned host memory)?  Reports it ONCE: VD_ERR_HIP
+// with a message, after draining the stream and zeroing the scan state; VD_OK otherwise.  Called at the entry of every vd_*
+// that launches a look-back scan, so a renderer that only uses the *_dev forms hears about it on its next frame.
+int vd_scan_check_fault(VdCtx* ctx);
+static inline unsigned* vd_scan_fault_word(VdCtx* ctx) { return ctx->fault_dev; }
 
 static inline void vd_time_begin(VdCtx* ctx) {
     ctx->timed_mid = false;
@@ -167,14 +176,21 @@ typedef unsigned long long vd_u64;
 // recorded in a HIP graph replays correctly (tests/test_gpu_frame_loop.py).  Tickets come from an
 // atomic counter, so every predecessor of a running tile is itself running or finished: no
 // residency assumption.
-// Every wait is BOUNDED: a tile whose predecessor does not show up within kScanSpinLimit polls (seconds; an
-// ordinary wait is microseconds) publishes VD_TILE_POISON and returns VD_SCAN_STUCK, every later tile runs
-// into the poison and does the same at once, and the last tile writes VD_SCAN_STUCK to the count - an error
-// code (VD_ERR_HIP on the host-pointer entry points, which also zero the scan state before they return), not a
-// stream that never finishes.  The launch after it draws its tickets under the next epoch and is clean.
+// Every wait is BOUNDED, by the wall clock: a tile whose predecessor does not show up within kScanTimeoutTicks of the
+// constant 100 MHz counter (two seconds; an ordinary wait is microseconds) - ONE deadline for both of its waiting loops -
+// publishes VD_TILE_POISON and returns VD_SCAN_STUCK, and every later tile that runs into the poison does the same at once.
+// Giving up is STICKY for the launch: the tile also stores the launch's epoch + 1 into the arena's stuck word, and the last
+// tile looks at that word after its own look-back - a tile that had read the quitter's AGGREGATE before it was poisoned and
+// then completed normally would otherwise hide the failure behind its INCLUSIVE.  What the last tile then does is
+// the kernel's business (cull.hip: count = 0, no list, the fault word in pinned host memory raised - the next vd_* call on the
+// context reports VD_ERR_HIP and zeroes the scan state); a launch that lost its LAST tile keeps the count the first tile
+// pre-stored, VD_SCAN_STUCK.
+// Arena layout (vd_scan_scratch): u64[0] ticket word, u64[1] tuning hook (vd_debug_scan_fault), u64[2] stuck word,
+// u64[3] spare, granules from byte 32: the stuck word of a granule array is tile_state[-2].
 enum : unsigned { VD_TILE_AGGREGATE = 1u, VD_TILE_INCLUSIVE = 2u, VD_TILE_POISON = 3u };
 constexpr unsigned VD_SCAN_STUCK = 0xffffffffu;
-constexpr unsigned kScanSpinLimit = 1u << 20;
+constexpr unsigned long long kScanTimeoutTicks = 200000000ull;     // wall_clock64(): 100 MHz on gfx950 -> 2 s
+constexpr int kScanFaultWord = 63;                                 // VdCtx::host_pinned[63]: raised by a launch whose scan gave up
 
 __device__ __forceinline__ vd_u64 vd_tile_pack(unsigned epoch, unsigned status, unsigned value) {
     return ((vd_u64)(epoch & 0x3fffffffu) << 34) | ((vd_u64)status << 32) | value;
@@ -190,6 +206,10 @@ __device__ __forceinline__ unsigned vd_take_ticket(vd_u64* ticket_word, unsigned
     return ticket;
 }
 
+__device__ __forceinline__ bool vd_scan_gave_up(vd_u64* tile_state, unsigned epoch) {      // has any tile of this launch given up?
+    return __hip_atomic_load(tile_state - 2, VD_RLX_AGENT) == (vd_u64)(epoch & 0x3fffffffu) + 1ull;
+}
+
 // Called by ONE full wave of the workgroup. Returns the exclusive prefix of tile `t`
 // (sum of `total` over tiles < t) in every lane, after publishing this tile's state - or VD_SCAN_STUCK.
 // `first` marks the first tile of a segment (segmented scan): its prefix restarts at 0.
@@ -201,6 +221,7 @@ __device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned epo
         return 0u;
     }
     if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_AGGREGATE, total), VD_RLX_AGENT);
+    const unsigned long long deadline = wall_clock64() + kScanTimeoutTicks;      // one deadline for both loops below: they expire together
     unsigned exclusive = 0u;
     int look = (int)t - 1;
     bool stuck = false;
@@ -210,7 +231,7 @@ __device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned epo
             vd_u64 s0 = __hip_atomic_load(&tile_state[look], VD_RLX_AGENT);
             unsigned spins = 0;
             while ((unsigned)(s0 >> 34) != ep || ((unsigned)(s0 >> 32) & 3u) == 0u) {
-                if (++spins > kScanSpinLimit) { stuck = true; break; }
+                if ((++spins & 63u) == 0u && wall_clock64() > deadline) { stuck = true; break; }
                 __builtin_amdgcn_s_sleep(8);
                 s0 = __hip_atomic_load(&tile_state[look], VD_RLX_AGENT);
             }
@@ -225,7 +246,7 @@ __device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned epo
             s = __hip_atomic_load(&tile_state[idx], VD_RLX_AGENT);
             unsigned spins = 0;
             while ((unsigned)(s >> 34) != ep || ((unsigned)(s >> 32) & 3u) == 0u) {   // not written in this launch yet
-                if (++spins > kScanSpinLimit) { mine_stuck = true; break; }
+                if ((++spins & 63u) == 0u && wall_clock64() > deadline) { mine_stuck = true; break; }
                 __builtin_amdgcn_s_sleep(1);
                 s = __hip_atomic_load(&tile_state[idx], VD_RLX_AGENT);
             }
@@ -244,10 +265,21 @@ __device__ __forceinline__ unsigned vd_lookback(vd_u64* tile_state, unsigned epo
         look -= 64;
     }
     if (stuck) {
-        if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_POISON, 0u), VD_RLX_AGENT);
+        if (lane == 0) {
+            __hip_atomic_store(tile_state - 2, (vd_u64)ep + 1ull, VD_RLX_AGENT);      // sticky for the launch: the last tile reads it
+            __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_POISON, 0u), VD_RLX_AGENT);
+        }
         return VD_SCAN_STUCK;
     }
     if (lane == 0) __hip_atomic_store(&tile_state[t], vd_tile_pack(ep, VD_TILE_INCLUSIVE, exclusive + total), VD_RLX_AGENT);
     return exclusive;
+}
+
+// What the LAST tile of a launch stores as the count (one lane): the total - or, when some tile of the launch gave up, 0
+// (no list was written: nothing to draw) while the fault word in pinned host memory is raised for the host side.
+__device__ __forceinline__ unsigned vd_scan_final_count(vd_u64* tile_state, unsigned epoch, unsigned excl, unsigned tile_total, unsigned* fault_host) {
+    if (excl != VD_SCAN_STUCK && !vd_scan_gave_up(tile_state, epoch)) return excl + tile_total;
+    __hip_atomic_store(fault_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return 0u;
 }
 #endif  // __HIPCC__
