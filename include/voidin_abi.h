@@ -206,8 +206,6 @@ typedef enum VdOption {
                                      they would fit LDS (<= 5600 instances); default 1 (A/B)               */
     VD_OPT_BLAS_WIDE_PAYLOAD = 30,/* 1: vd_bvh_build moves the 8-byte payload (what meshes above 2^25 triangles use) at
                                      any size (tests); default 0                                                  */
-    VD_OPT_BLAS_FUSED_ROUNDS = 31,/* 0: every shuffle round of the builder's level-synchronous tier runs as two launches (rank tables
-                                     through memory: the round-5 form) instead of one where segments allow it; default 1 (A/B)     */
     VD_OPT_TRACE_SORT = 21,       /* 1: vd_trace* bin the rays first (sorted by origin cell + direction) and hand them
                                      out in that order; results are per ray, so only the order changes.  Default 0:
                                      measured slower on this part                                */

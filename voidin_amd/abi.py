@@ -61,8 +61,8 @@ VD_DIST_ID_BYTES = 128
 # never by the library
 OPTIONS = {"cull.split_min": 1, "cull.variant": 2, "tlas.index": 10, "tlas.index_min": 11, "tlas.phase2": 12, "tlas.refresh": 13,
            "tlas.groups": 14, "tlas.spin_limit": 15, "tlas.spec": 16, "tlas.profile": 17, "tlas.chain_lds": 18,
-           "blas.wide_payload": 30, "blas.fused_rounds": 31, "trace.sort": 21, "trace.sort_min": 22, "trace.chunk": 23, "trace.yield": 24, "trace.waves": 25, "trace.auto_prepare": 27, "trace.tight_tlas": 28, "trace.fan": 29, "trace.fan_slots": 26}
-OPTION_ENV = {"VD_BLAS_FUSED_ROUNDS": "blas.fused_rounds", "VD_SPLIT_MIN": "cull.split_min", "VD_CULL_VARIANT": "cull.variant", "VD_TLAS_INDEX": "tlas.index",
+           "blas.wide_payload": 30, "trace.sort": 21, "trace.sort_min": 22, "trace.chunk": 23, "trace.yield": 24, "trace.waves": 25, "trace.auto_prepare": 27, "trace.tight_tlas": 28, "trace.fan": 29, "trace.fan_slots": 26}
+OPTION_ENV = {"VD_SPLIT_MIN": "cull.split_min", "VD_CULL_VARIANT": "cull.variant", "VD_TLAS_INDEX": "tlas.index",
               "VD_TLAS_INDEX_MIN": "tlas.index_min", "VD_TLAS_PHASE2": "tlas.phase2", "VD_TLAS_REFRESH": "tlas.refresh",
               "VD_TLAS_GROUPS": "tlas.groups", "VD_TLAS_SPIN_LIMIT": "tlas.spin_limit", "VD_TLAS_SPEC": "tlas.spec",
               "VD_TLAS_PROFILE": "tlas.profile", "VD_TLAS_CHAIN_LDS": "tlas.chain_lds", "VD_TRACE_SORT": "trace.sort",

@@ -523,6 +523,9 @@ struct WaveQueues {                      // entry = node | start << 10 | count <
     float r_pos;
     unsigned h16, t16, h32, t32;
     unsigned n_small, root_left, bad;
+#ifdef VD_TUNING
+    unsigned cls[48];   // wave-cycles by node size class and step (blas_small_kernel: cls_prof)
+#endif
 #ifdef VD_PROF_SEL
     unsigned prof[8];   // 0 root node done, 1 wave loop done, 2 lists drained, 3 renumber scan done, 4 group batches, 5 listed nodes, 6 wide nodes
 #endif
@@ -646,9 +649,20 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                        const unsigned* __restrict__ ids32, ArrSet set0, ArrSet set1,
                        TmpNode* __restrict__ subnodes, unsigned short* __restrict__ submap,
                        unsigned* __restrict__ sub_interior, unsigned* __restrict__ final_ids, unsigned* __restrict__ err,
-                       unsigned* __restrict__ dbg_cycles, const unsigned* __restrict__ order) {
+                       unsigned* __restrict__ dbg_cycles, const unsigned* __restrict__ order, unsigned long long* __restrict__ cls_prof) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    // -DVD_TUNING only (vd_debug_blas_small_classes -> profiles/r06_blas_small_classes.log): wave-cycles by node size class
+    // (0: <= 32, the lane-group batches; 1: 33..64; 2: 65..128; 3: 129..256; 4: 257..512) and step (0 setup: centroid bounds,
+    // planes, predicate bits; 1 the 21 trials; 2 cost evaluation; 3 the final shuffle; 4 children + hand-over; 5 nodes; 6: batches
+    // for class 0), cls_prof[class * 8 + step]; row 5: [40] all waves' lifetimes, [41] idle polling, [42] load, [43] drain + renumber
+#ifdef VD_TUNING
+#define VD_CLS_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define VD_CLS_ADD(slot, cyc) do { if (vd_lane() == 0u) atomicAdd(&Q.cls[slot], (unsigned)(cyc)); } while (0)      /* in LDS; one flush per workgroup */
+#else
+#define VD_CLS_T(var) do { } while (0)
+#define VD_CLS_ADD(slot, cyc) do { } while (0)
+#endif
     const unsigned tid = threadIdx.x, lane = vd_lane();
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds& L = *reinterpret_cast<WaveLds*>(smem);
@@ -701,12 +715,16 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
     if (tid == 0) {
         Q.pool = 0; Q.n_small = 0; Q.root_left = kNone; Q.bad = 0; Q.head = 0; Q.tail = 0; Q.pending = 0; Q.s_head = 0;
         Q.s_pending = 0; Q.h16 = 0; Q.t16 = 0; Q.h32 = 0; Q.t32 = 0;
+#ifdef VD_TUNING
+        for (int q = 0; q < 48; ++q) Q.cls[q] = 0u;
+#endif
 #ifdef VD_PROF_SEL
         for (int q = 0; q < 8; ++q) Q.prof[q] = 0;
 #endif
         if (N > (unsigned)kLaneMax) Q.pending = 1; else { Q.small[0] = root_ent; Q.n_small = 1; Q.s_pending = 1; }
     }
     __syncthreads();
+    VD_CLS_T(t_loaded);
     // ---------------- nodes of <= 32 prims: several at a time per wave, one per lane group ----------------
     // A wave takes eight nodes of <= 8 prims, four of 9..16 or two of 17..32 and gives each a group of 8 / 16 / 32
     // lanes: one position per lane, the arrangement kept in registers across the trials and moved through the LDS
@@ -740,6 +758,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
         const unsigned first = W.g_first, count = W.g_count & 255u, cls = W.g_count >> 8;
         vd_wave_lds_sync();
         if (count == 0u) return false;
+        VD_CLS_T(tg0);
         VD_MARK("setup_begin");
 #ifdef VD_PROF_SEL
         if (lane == 0) { atomicAdd(&Q.prof[4], 1u); atomicAdd(&Q.prof[5], count); }
@@ -781,6 +800,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 }
             }
             VD_MARK("setup_end");
+            VD_CLS_T(tg1);
             // one trial (blas.rs:168-182 in closed form, as the wave-wide register path): moves el / pb
             auto trial = [&](int c, bool record) {
                 VD_MARK("trial_begin");
@@ -815,6 +835,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             };
             for (int c = 0; c < kCand; ++c) trial(c, true);                        // blas.rs:144-147
             vd_wave_lds_sync();
+            VD_CLS_T(tg2);
             VD_MARK("eval_begin");
             // evaluate (blas.rs:149-161): left = examined trues = {e : p_c(e) and e != u_c}, right = the rest (incl. u_c)
             if (valid) {
@@ -880,7 +901,9 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             const unsigned tb = W.g_tt[grp][best];
             const unsigned Lst = (tb & 127u) - (tb >> 7);                            // stale optimal_pivot (blas.rs:159,165)
             VD_MARK("eval_end");
+            VD_CLS_T(tg3);
             trial(best, false);                                                     // blas.rs:164
+            VD_CLS_T(tg4);
             VD_MARK("finish_begin");
             if (valid) { L.perm[0][s + gl] = (unsigned short)el; L.perm[1][s + gl] = (unsigned short)el; }
             if (valid) {
@@ -921,6 +944,10 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 }
             }
         VD_MARK("finish_end");
+#ifdef VD_TUNING
+        { VD_CLS_T(tg5); VD_CLS_ADD(0, tg1 - tg0); VD_CLS_ADD(1, tg2 - tg1); VD_CLS_ADD(2, tg3 - tg2); VD_CLS_ADD(3, tg4 - tg3); VD_CLS_ADD(4, tg5 - tg4);
+          VD_CLS_ADD(5, count); VD_CLS_ADD(6, 1); }
+#endif
         return true;
     };
 
@@ -957,6 +984,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             next_ent = 0u;
             const unsigned node_id = ent & 1023u, s = (ent >> 10) & 1023u, n = ent >> 20;
             const bool is_root = ent == root_ent;
+            VD_CLS_T(tw0);
             int cur = 0;
             int kmn[3] = {kBig, kBig, kBig}, kmx[3] = {-kBig - 1, -kBig - 1, -kBig - 1};
             for (unsigned x = lane; x < n; x += 64u) {
@@ -969,6 +997,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             for (int k = 0; k < 3; ++k) { cbmin[k] = box_lo(wave_min_i(kmn[k])); cbmax[k] = box_hi(wave_max_i(kmx[k])); }
             if (lane < (unsigned)kCand) W.pos[lane] = cand_pos(cbmin, cbmax, (int)lane);
             vd_wave_lds_sync();
+            VD_CLS_T(tw1);
             if (n <= 64u) {
                 // One position per lane: the arrangement (element id + the element's 21 predicate bits) stays in registers
                 // across the 21 trials and moves through the LDS crossbar (ds_permute / ds_bpermute), the rank ->
@@ -1028,6 +1057,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 }
             }
             vd_wave_lds_sync();
+            VD_CLS_T(tw2);
             vd_u64 key = ~0ull;
             if (n > (unsigned)VD_BINEVAL_MIN) {
                 // evaluate (blas.rs:149-161) from binned statistics, as phase A does: the cost of a trial depends on the
@@ -1130,6 +1160,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             }
             const int best = (int)(unsigned)key;
             const unsigned Lst = W.ttot[best] - W.u_p[best];             // stale optimal_pivot (blas.rs:159,165)
+            VD_CLS_T(tw3);
             {
                 unsigned tt, ue, up;                                     // blas.rs:164
                 if (is_root && root_by_block) {
@@ -1139,6 +1170,7 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
                 } else wave_shuffle_any(L, cur, s, n, best / 7, W.pos[best], 0u, 0u, tt, ue, up);
                 cur ^= 1;                                                // 22 flips: back in buffer 0
             }
+            VD_CLS_T(tw4);
             int k12[12];                                                 // children boxes (blas.rs:115-123)
 #pragma unroll
             for (int i = 0; i < 12; ++i) k12[i] = (i % 6) < 3 ? kBig : -kBig - 1;
@@ -1188,8 +1220,14 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
             }
             vd_wave_lds_sync();
             next_ent = W.next_ent;
+#ifdef VD_TUNING
+            { VD_CLS_T(tw5); const unsigned cls = n <= 64u ? 1u : (n <= 128u ? 2u : (n <= 256u ? 3u : 4u)), b8 = cls * 8u;
+              VD_CLS_ADD(b8 + 0u, tw1 - tw0); VD_CLS_ADD(b8 + 1u, tw2 - tw1); VD_CLS_ADD(b8 + 2u, tw3 - tw2); VD_CLS_ADD(b8 + 3u, tw4 - tw3);
+              VD_CLS_ADD(b8 + 4u, tw5 - tw4); VD_CLS_ADD(b8 + 5u, 1); if (is_root && root_by_block) VD_CLS_ADD(b8 + 6u, tw5 - tw0); }
+#endif
         }
     }
+    VD_CLS_T(t_loop_end);
     __syncthreads();
 
 #ifdef VD_PROF_SEL
@@ -1254,7 +1292,15 @@ void blas_small_kernel(const SmallRoot* __restrict__ roots, const unsigned* __re
         if (dbg_cycles) { dbg_cycles[2 * root_i] = (unsigned)(__builtin_amdgcn_s_memtime() - t_begin); dbg_cycles[2 * root_i + 1] = N; }
 #endif
     }
+#ifdef VD_TUNING
+    { VD_CLS_T(t_end); VD_CLS_ADD(40, t_end - t_begin); VD_CLS_ADD(42, t_loaded - t_begin); VD_CLS_ADD(43, t_end - t_loop_end); VD_CLS_ADD(44, 1); }
+    __syncthreads();
+    // 64 replicas of the 64 counters (workgroup -> replica by its index): same-address global atomics are serialised chip-wide
+    if (tid < 48u && Q.cls[tid] != 0u) atomicAdd(cls_prof + 64u * (blockIdx.x & 63u) + tid, (unsigned long long)Q.cls[tid]);
+#endif
 }
+#undef VD_CLS_T
+#undef VD_CLS_ADD
 
 // =============================================================================================
 // Phase A: level-synchronous emulation for segments larger than kSmallMax.
@@ -1326,14 +1372,12 @@ __device__ __forceinline__ bool item_ctx(const Seg* segs, const unsigned* item_s
 template <typename P>
 __global__ __launch_bounds__(256) void a_bits_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
                                                      typename P::T* __restrict__ pay, const f32x4* __restrict__ cent,
-                                                     unsigned* __restrict__ bits21, unsigned* __restrict__ item_cnt,
-                                                     unsigned* __restrict__ cnt_zero) {
+                                                     unsigned* __restrict__ bits21, unsigned* __restrict__ item_cnt) {
     __shared__ float s_pos[kCand + 3];
     __shared__ unsigned s_w[4];
     ItemCtx ic; SegHead hv; const SegHead* sg = &hv;
     if (!item_ctx(segs, item_seg, ctl, ic, hv)) return;
     VD_HEAD_VIEW(sg, segs, ic);
-    if (cnt_zero && threadIdx.x == 0) cnt_zero[blockIdx.x] = 0u;      // fused rounds (a_round_kernel): round 0 adds round 1's trues up in it
     // the 21 planes of the segment (blas.rs:142-146) from its centroid bounds; the segment's FIRST item also resets what the
     // level accumulates in the record - child keys, bin keys, the rounds' windows - and leaves the planes there.  (All of
     // that used to be a loop of the single-workgroup boundary kernel: 190 words x 1 859 segments through one CU, 100 us at
@@ -1782,242 +1826,6 @@ __global__ __launch_bounds__(256) void a_apply_kernel(Seg* segs, const unsigned*
             const bool mine = counts[j] && land[j] == blockIdx.x;
             own_cnt += (unsigned)__popcll(__ballot(mine));
             count_runs(counts[j] && !mine, land[j], cnt_next);
-        }
-        if (own_cnt && lane == 0u) __hip_atomic_fetch_add(cnt_next + blockIdx.x, own_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// ONE launch per shuffle round (round 6; levels whose segments have <= 1024 items): a_ranks + a_apply in one kernel, without
-// the rank -> position tables in HBM.  What a_apply asks the tables is a SELECT on the far side of the segment - a false
-// left of the pivot goes to the F-th true from the right, a true right of it to the (T+1)-th false from the left - and the
-// askers of one item have consecutive ranks, so their partners sit in a few consecutive items of the other side.  A
-// workgroup therefore (1) scans the segment's item counts in LDS (it loads them anyway for its own prefix), (2) finds the
-// rank ranges its elements ask for and the items that hold them, (3) reads THOSE items' payloads - a wave per partner item,
-// sixteen coalesced rows, ballots, popcount prefixes - and writes the positions of the trues / falses with the wanted ranks
-// into two LDS tables, (4) goes on as a_apply does with LDS reads in place of the two gathers.  No a_ranks launch, no
-// second read of the own payload, no table round trip through HBM; the price is one more dependent trip to memory and three
-// more barriers per workgroup.  The counts of round r + 2 are zeroed here (a_ranks did that): three count arrays rotate.
-// Same arithmetic on the same predicates: the arrangement every round leaves is the one the two-launch form leaves.
-constexpr int kRoundTab = kItem + 8;
-template <typename P, int mode>
-__global__ __launch_bounds__(256) void a_round_kernel(Seg* segs, const unsigned* item_seg, const LevelCtl* ctl,
-                                                      const typename P::T* __restrict__ src, typename P::T* __restrict__ dst, const RoundK rk,
-                                                      const unsigned* __restrict__ cnt_cur, unsigned char* __restrict__ is_u_flag,
-                                                      const unsigned* __restrict__ bits21, unsigned* __restrict__ cnt_next,
-                                                      unsigned* __restrict__ cnt_zero) {
-    static_assert(kItem == 1024, "a_round_kernel: 16 rows of 64 positions per item, 4 counts per lane");
-    __shared__ unsigned s_w[4], s_wsum[4], s_rng[8];
-    __shared__ unsigned s_incl[1024];                      // inclusive scan of the segment's item counts (trues per item, window positions only)
-    __shared__ unsigned s_tpos[kRoundTab], s_fpos[kRoundTab];
-    ItemCtx ic; SegHead hv; const SegHead* sg = &hv;
-    if (!item_ctx(segs, item_seg, ctl, ic, hv)) return;
-    VD_HEAD_VIEW(sg, segs, ic);
-    if (cnt_zero && threadIdx.x == 0) cnt_zero[blockIdx.x] = 0u;      // the round after next adds its trues up in it
-    const int c = rk.c;
-    const Window win = round_window(sg, rk);
-    const unsigned copy_from = mode == 2 ? 0u : win.band;
-    if (ic.rel0 + ic.n_here <= copy_from) return;         // frozen before the previous round: both buffers agree
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    unsigned own_cnt = 0;                                  // elements counted into this very item (wave-uniform)
-    const unsigned sh_next = rk.sh_next, axis_next = rk.axis_next;
-    unsigned long long masks[kPer]; typename P::T vals[kPer];
-    item_load<P>(sg, ic, src, vals);
-    // the segment's item counts, four CONSECUTIVE ones per lane (the scan below wants them in order)
-    const unsigned ni = sg->n_items, mine = blockIdx.x - sg->item_first;
-    unsigned cv[4];
-    {
-        const unsigned* __restrict__ cn = cnt_cur + sg->item_first;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const unsigned i = 4u * threadIdx.x + (unsigned)k; cv[k] = cn[i < ni ? i : 0u]; }
-    }
-    unsigned nb[kPer];
-    if (mode == 2 && P::kRefresh) {
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) nb[j] = bits21[P::pos(vals[j])];
-    }
-    // the band the previous round froze: straight copy, so that `dst` holds the whole arrangement
-    if (ic.rel0 < win.act && copy_from < win.act) {
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane, xa = ic.rel0 + xr;
-            bool pn = false;
-            if (xr < ic.n_here && xa >= copy_from && xa < win.act) {
-                typename P::T v = vals[j];
-                if (mode == 2) {
-                    if (P::kRefresh) v = P::make(P::pos(v), nb[j], axis_next);
-                    pn = (P::word(v) >> sh_next) & 1u;
-                }
-                dst[sg->start + xa] = v;
-            }
-            if (mode == 2) own_cnt += (unsigned)__popcll(__ballot(pn));
-        }
-    }
-    if (ic.rel0 + ic.n_here <= win.act) {
-        if (mode == 2 && own_cnt && lane == 0u) __hip_atomic_fetch_add(cnt_next + blockIdx.x, own_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    item_masks<P, false>(sg, ic, src, rk, win.act, masks, vals);
-    unsigned t = 0;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) t += (unsigned)__popcll(masks[j]);
-    if (lane == 0u) s_w[wave] = t;
-    // ---- (1) scan of the item counts: lane-local, wave (shuffles), workgroup (s_wsum) ----
-    unsigned a[4];
-    {
-        unsigned acc = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { acc += (4u * threadIdx.x + (unsigned)k < ni) ? cv[k] : 0u; a[k] = acc; }
-    }
-    unsigned incl = a[3];
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const unsigned v = __shfl_up(incl, off); if (lane >= (unsigned)off) incl += v; }
-    if (lane == 63u) s_wsum[wave] = incl;
-    if (threadIdx.x == 0) { s_rng[0] = 0xffffffffu; s_rng[1] = 0u; s_rng[2] = 0xffffffffu; s_rng[3] = 0u; s_rng[4] = 1u; s_rng[5] = 0u; s_rng[6] = 1u; s_rng[7] = 0u; }
-    __syncthreads();                                                                        // ---- barrier A
-    unsigned woff = 0, ttot = 0;
-#pragma unroll
-    for (unsigned w = 0; w < 4u; ++w) { const unsigned v = s_wsum[w]; if (w < wave) woff += v; ttot += v; }
-    const unsigned before4 = woff + incl - a[3];           // trues of the items before this lane's four
-    {
-        const u32x4 o = {before4 + a[0], before4 + a[1], before4 + a[2], before4 + a[3]};
-        *reinterpret_cast<u32x4*>(&s_incl[4u * threadIdx.x]) = o;
-    }
-    unsigned run = 0;
-    for (unsigned w = 0; w < wave; ++w) run += s_w[w];      // trues of this item's earlier waves
-    // ---- (2) what this item's elements ask for (the trues before the item come out of the scan: after barrier B) ----
-    const unsigned n = sg->count - win.act, s = sg->start + win.act, ftot = n - ttot;
-    __syncthreads();                                                                        // ---- barrier B: s_incl complete
-    const unsigned run0 = mine ? s_incl[mine - 1u] : 0u;
-    run += run0;
-    bool counts[kPer]; unsigned land[kPer];
-    bool in[kPer], pp[kPer], need_t[kPer], need_f[kPer];
-    unsigned xx[kPer], FF[kPer], TT[kPer], tp[kPer], fp[kPer];
-    unsigned q_lo = 0xffffffffu, q_hi = 0u, T_lo = 0xffffffffu, T_hi = 0u;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const unsigned xr = wave * (unsigned)(kItem / 4) + j * 64u + lane;
-        in[j] = xr < ic.n_here && ic.rel0 + xr >= win.act;
-        xx[j] = ic.rel0 + xr - win.act;
-        pp[j] = (masks[j] >> lane) & 1ull;
-        const unsigned tl = run + vd_mbcnt(masks[j]);
-        FF[j] = xx[j] - tl; TT[j] = ttot - tl - (pp[j] ? 1u : 0u);
-        // who asks (a_apply believes a table entry in exactly these places): the F-th true from the right decides `left` AT ttot,
-        // gives the fetch index of the two positions left of / at ttot (the `u` test) and the landing place of a false the front
-        // pointer examines; the (T+1)-th false from the left the same on the other side
-        need_t[j] = in[j] && FF[j] != 0u && FF[j] <= ttot && xx[j] <= ttot && (!pp[j] || xx[j] + 1u >= ttot);
-        need_f[j] = in[j] && TT[j] + 1u <= ftot && xx[j] >= ttot && (pp[j] || xx[j] <= ttot + 1u);
-        if (need_t[j]) { const unsigned q = ttot - FF[j]; q_lo = min(q_lo, q); q_hi = max(q_hi, q); }      // left rank (0-based) of that true
-        if (need_f[j]) { T_lo = min(T_lo, TT[j]); T_hi = max(T_hi, TT[j]); }
-        run += (unsigned)__popcll(masks[j]);
-    }
-    {
-        const unsigned ql = (unsigned)wave_min_i((int)(q_lo ^ 0x80000000u)) ^ 0x80000000u, qh = (unsigned)wave_max_i((int)(q_hi ^ 0x80000000u)) ^ 0x80000000u;
-        const unsigned tl_ = (unsigned)wave_min_i((int)(T_lo ^ 0x80000000u)) ^ 0x80000000u, th = (unsigned)wave_max_i((int)(T_hi ^ 0x80000000u)) ^ 0x80000000u;
-        if (lane == 0u) {
-            if (ql != 0xffffffffu) { atomicMin(&s_rng[0], ql); atomicMax(&s_rng[1], qh); }
-            if (tl_ != 0xffffffffu) { atomicMin(&s_rng[2], tl_); atomicMax(&s_rng[3], th); }
-        }
-    }
-    __syncthreads();                                                                        // ---- barrier C: the wanted rank ranges
-    q_lo = s_rng[0]; q_hi = s_rng[1]; T_lo = s_rng[2]; T_hi = s_rng[3];
-    const bool want_t = q_lo != 0xffffffffu, want_f = T_lo != 0xffffffffu;
-    // which items hold those ranks: item k holds the trues with left ranks [incl(k - 1), incl(k)) and the falses with left ranks
-    // [wpos(k) - incl(k - 1), wpos(k + 1) - incl(k)), wpos(k) = window positions before item k
-    {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned i = 4u * threadIdx.x + (unsigned)k;
-            if (i < ni) {
-                const unsigned hi_t = before4 + a[k], lo_t = k ? before4 + a[k - 1] : before4;
-                const unsigned p0 = i * (unsigned)kItem, p1 = min(sg->count, p0 + (unsigned)kItem);
-                const unsigned w0 = p0 > win.act ? p0 - win.act : 0u, w1 = p1 > win.act ? p1 - win.act : 0u;
-                const unsigned lo_f = w0 - lo_t, hi_f = w1 - hi_t;
-                if (want_t) { if (lo_t <= q_lo && q_lo < hi_t) s_rng[4] = i; if (lo_t <= q_hi && q_hi < hi_t) s_rng[5] = i; }
-                if (want_f) { if (lo_f <= T_lo && T_lo < hi_f) s_rng[6] = i; if (lo_f <= T_hi && T_hi < hi_f) s_rng[7] = i; }
-            }
-        }
-    }
-    __syncthreads();                                                                        // ---- barrier D: the partner items
-    // ---- (3) a wave per partner item: its payload in sixteen rows, ranks from ballots, positions into the LDS tables ----
-    {
-        const unsigned jt0 = s_rng[4], jt1 = s_rng[5], jf0 = s_rng[6], jf1 = s_rng[7];
-        const unsigned nt = want_t && jt1 >= jt0 ? jt1 - jt0 + 1u : 0u, nf = want_f && jf1 >= jf0 ? jf1 - jf0 + 1u : 0u;
-        const unsigned sh = rk.c >= 0 ? rk.sh : P::shift(sg->best);
-        for (unsigned k = wave; k < nt + nf; k += 4u) {
-            const bool tk = k < nt;
-            const unsigned j = tk ? jt0 + k : jf0 + (k - nt);
-            const unsigned before_t = j ? s_incl[j - 1u] : 0u;
-            if (tk && s_incl[j] == before_t) continue;                 // no true in it (wave-uniform)
-            const unsigned p0 = j * (unsigned)kItem, nh = min((unsigned)kItem, sg->count - p0);
-            const typename P::T* __restrict__ base = src + sg->start + p0;
-            typename P::T pv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const unsigned x = (unsigned)r * 64u + lane; pv[r] = base[x < nh ? x : 0u]; }
-            unsigned rank = tk ? before_t : (p0 > win.act ? p0 - win.act : 0u) - before_t;      // left rank of the row's first true / false
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned x = (unsigned)r * 64u + lane;
-                const bool inw = x < nh && p0 + x >= win.act;
-                const bool bit = (P::word(pv[r]) >> sh) & 1u;
-                const unsigned long long m = __ballot(inw && (tk ? bit : !bit));
-                const unsigned mine_r = rank + vd_mbcnt(m);
-                if ((m >> lane) & 1ull) {
-                    if (tk) { if (mine_r >= q_lo && mine_r <= q_hi) s_tpos[mine_r - q_lo] = p0 + x - win.act; }
-                    else { if (mine_r >= T_lo && mine_r <= T_hi) s_fpos[mine_r - T_lo] = p0 + x - win.act; }
-                }
-                rank += (unsigned)__popcll(m);
-            }
-        }
-    }
-    __syncthreads();                                                                        // ---- barrier E: the tables
-    // ---- (4) a_apply from here on, the two gathers out of LDS ----
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        tp[j] = need_t[j] ? s_tpos[ttot - FF[j] - q_lo] : 0u;
-        fp[j] = need_f[j] ? s_fpos[TT[j] - T_lo] : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        counts[j] = false; land[j] = 0u;
-        if (in[j]) {
-            const unsigned x = xx[j];
-            const bool p = pp[j];
-            const long long tF = FF[j] == 0u ? (long long)n : (need_t[j] ? (long long)tp[j] : -1ll);
-            const unsigned fj = need_f[j] ? fp[j] : n;
-            const bool left = x < ttot || (x == ttot && (long long)x < tF);
-            const bool amb = x + 1u - ttot <= 2u;
-            const unsigned fetch = left ? x + n - (unsigned)tF : (n - 1u - x) + fj + 1u;
-            const bool is_u = amb && fetch == n - 1u;
-            unsigned dest;
-            if (is_u) dest = ttot - (p ? 1u : 0u);
-            else if (left) dest = p ? x : (unsigned)tF - 1u;
-            else dest = p ? fj : x - 1u;
-            typename P::T v = vals[j];
-            const unsigned upos = P::pos(v);
-            if (mode == 2) {
-                if (P::kRefresh) v = P::make(upos, nb[j], axis_next);
-                counts[j] = (P::word(v) >> sh_next) & 1u;
-            } else if (mode == 1) {
-                counts[j] = ((P::word(v) >> sh_next) & 1u) && (is_u || dest >= ttot);   // left of the pivot = frozen for the next round
-            }
-            land[j] = sg->item_first + (win.act + dest) / (unsigned)kItem;
-            dst[s + dest] = v;
-            if (is_u && c >= 0) {
-                Seg& w = segs[ic.seg];
-                const u32x2 urec = {upos, bits21[upos]};               // the record keeps all 21 bits: the cost evaluation needs them
-                w.u_pay[c] = urec; w.u_p[c] = p ? 1u : 0u; w.ttot[c] = win.act + ttot;
-                w.act[rk.i_next] = win.act + ttot - (p ? 1u : 0u);   // this trial's pivot: where the next round starts
-                is_u_flag[upos] = 1;
-            }
-        }
-    }
-    if (mode != 0) {
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            const bool mine_c = counts[j] && land[j] == blockIdx.x;
-            own_cnt += (unsigned)__popcll(__ballot(mine_c));
-            count_runs(counts[j] && !mine_c, land[j], cnt_next);
         }
         if (own_cnt && lane == 0u) __hip_atomic_fetch_add(cnt_next + blockIdx.x, own_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -2834,7 +2642,7 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
                    unsigned *falsepos, *truepos, *final_ids, *stack, *idx_copy;
                    unsigned char* is_u; Seg *seg0, *seg1; MidRoot* mid; unsigned *item_seg, *item_cnt, *item_cnt1, *item_pre; TopNode* top; SmallRoot* small;
                    unsigned* sub_interior; TmpNode* subnodes; unsigned short* submap; LevelCtl* ctl; int* root_keys; TopOut* tout; unsigned* root_pair;
-                   MeshDesc* meshes; unsigned* bad_mesh; } p;
+                   MeshDesc* meshes; unsigned* bad_mesh; unsigned long long* cls_prof; } p;
         // payload ping-pong: 4 bytes per triangle up to 2^25 triangles, 8 beyond (allocated for the width in use)
         const size_t pay_words = wide_pay ? T : (T + 1) / 2;
         p.pay0 = a.take<u32x2>(pay_words); p.pay1 = a.take<u32x2>(pay_words);
@@ -2849,6 +2657,7 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
         p.subnodes = a.take<TmpNode>(2 * T + 2); p.submap = a.take<unsigned short>(2 * T + 2); p.ctl = a.take<LevelCtl>(1); p.root_keys = a.take<int>(16 * (size_t)K);
         p.tout = a.take<TopOut>(top_cap); p.root_pair = a.take<unsigned>(small_cap);
         p.meshes = a.take<MeshDesc>(K); p.bad_mesh = a.take<unsigned>(1);
+        p.cls_prof = a.take<unsigned long long>(64 * 64);  // written by the -DVD_TUNING build only: 64 replicas of 64 counters
         return p;
     };
     (void)layout(probe, false);
@@ -2889,6 +2698,9 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
         VD_HIP_CHECK(ctx, hipMemsetAsync(P.bad_mesh, 0xff, 4, st));
         VD_HIP_CHECK(ctx, hipMemsetAsync(P.is_u, 0, T, st));
     }
+#ifdef VD_TUNING
+    VD_HIP_CHECK(ctx, hipMemsetAsync(P.cls_prof, 0, 64 * 64 * sizeof(unsigned long long), st));
+#endif
     hipLaunchKernelGGL(blas_precompute_kernel, dim3(n_chunks), dim3(256), 0, st, P.meshes, K, P.idx_copy, P.cent, P.boxes, P.root_keys, &P.ctl->err, P.bad_mesh);
     const ArrSet sets[2] = {ArrSet{P.cent, P.boxes}, ArrSet{P.cent1, P.boxes1}};
     hipLaunchKernelGGL(c_root_kernel, dim3((K + 63u) / 64u), dim3(64), 0, st, P.top, P.root_keys, P.meshes, K, P.small, P.ctl, P.seg0, P.mid);
@@ -2923,31 +2735,8 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
         const unsigned items_ub = (unsigned)(std::min<size_t>(T, active_bound) / kItem) + n_seg_now + 1;
         PT* src = reinterpret_cast<PT*>(P.pay0); PT* dst = reinterpret_cast<PT*>(P.pay1);
         unsigned* const cnt[2] = {P.item_cnt, P.item_cnt1};      // round c counts in cnt[c & 1]
-        // One launch per round (a_round_kernel) at the levels whose segments have <= 1024 items; three count arrays rotate there
-        // (item_pre, which only a_scan writes, is the third): round c reads cnt3[c % 3], adds round c + 1's trues up in
-        // cnt3[(c + 1) % 3] and zeroes cnt3[(c + 2) % 3].  VD_OPT_BLAS_FUSED_ROUNDS = 0: the two launches per round everywhere (A/B).
-        const bool fused = scan_free && ctx->option(VD_OPT_BLAS_FUSED_ROUNDS, 0) != 0;      // opt-in until measured
-        unsigned* const cnt3[3] = {P.item_cnt, P.item_cnt1, P.item_pre};
-        hipLaunchKernelGGL((a_bits_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.cent, P.bits21, cnt[0],
-                           fused ? cnt3[1] : (unsigned*)nullptr);
-        for (int c = 0; fused && c <= kCand; ++c) {
-            const int cc = c < kCand ? c : -1;
-            if (c == kCand) {
-                hipLaunchKernelGGL((a_bin_kernel<PayT>), dim3((items_ub + kBinItems - 1) / kBinItems), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.boxes,
-                                   P.is_u, P.bits21);
-                hipLaunchKernelGGL(a_eval_kernel, dim3(n_seg_now), dim3(64), 0, st, seg_cur, P.ctl, cur.boxes);
-                hipLaunchKernelGGL((a_count_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cc, cnt3[c % 3], P.bits21, 1);
-            }
-            const int mode = c + 1 >= kCand ? 0 : ((c + 1) % 7 == 0 ? 2 : 1);
-            unsigned* const cnt_next = mode ? cnt3[(c + 1) % 3] : nullptr;
-            const RoundK rk = make_round<PayT>(cc);
-            auto round = mode == 0 ? a_round_kernel<PayT, 0> : mode == 1 ? a_round_kernel<PayT, 1> : a_round_kernel<PayT, 2>;
-            hipLaunchKernelGGL(round, dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, dst, rk, cnt3[c % 3], P.is_u, P.bits21, cnt_next,
-                               cnt3[(c + 2) % 3]);
-            n_launch += 1u;
-            PT* t = src; src = dst; dst = t;
-        }
-        for (int c = 0; !fused && c <= kCand; ++c) {
+        hipLaunchKernelGGL((a_bits_kernel<PayT>), dim3(items_ub), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.cent, P.bits21, cnt[0]);
+        for (int c = 0; c <= kCand; ++c) {
             const int cc = c < kCand ? c : -1;       // -1: final re-shuffle with each segment's best plane
             if (c == kCand) {
                 hipLaunchKernelGGL((a_bin_kernel<PayT>), dim3((items_ub + kBinItems - 1) / kBinItems), dim3(256), 0, st, seg_cur, P.item_seg, P.ctl, src, cur.boxes,
@@ -3072,8 +2861,8 @@ int bvh_build_batch_impl(VdCtx* ctx, BuildMesh* hm, uint32_t K, VdBvhNode* d_pac
     if (n_small) {
         hipLaunchKernelGGL(b_order_kernel, dim3(1), dim3(1024), 0, st, P.small, &P.ctl->n_small, P.root_pair);   // root_pair is free until phase C
         hipLaunchKernelGGL(blas_small_kernel, dim3(n_small), dim3(64 * kSubWaves), sizeof(WaveLds) + sizeof(WaveQueues), st, P.small, &P.ctl->n_small, P.ids32,
-                           sets[0], sets[1], P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err, P.stack, P.root_pair);
-        ctx->dbg_ptr = P.stack; ctx->dbg_count = 2 * n_small;
+                           sets[0], sets[1], P.subnodes, P.submap, P.sub_interior, P.final_ids, &P.ctl->err, P.stack, P.root_pair, P.cls_prof);
+        ctx->dbg_ptr = P.stack; ctx->dbg_count = 2 * n_small; ctx->dbg_ptr2 = P.cls_prof;
     }
     // ---- phase C: DFS numbering of the top tree on the host ----
     // The top tree is final before phase B starts (the stream was synchronised after the last level / the mid tier), so
@@ -3210,6 +2999,15 @@ int vd_debug_blas_cycles(VdCtx* ctx, uint32_t* out, uint32_t cap) {
     const uint32_t n = ctx->dbg_count < cap ? ctx->dbg_count : cap;
     if (hipMemcpy(out, ctx->dbg_ptr, 4 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return (int)n;
+}
+// ... and the 64 wave-cycle counters of its phase B by node size class and step (blas_small_kernel, cls_prof)
+int vd_debug_blas_small_classes(VdCtx* ctx, uint64_t* out64) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx || !ctx->dbg_ptr2 || !out64) return VD_ERR_INVALID_ARG;
+    static uint64_t rep[64 * 64];
+    if (hipMemcpy(rep, ctx->dbg_ptr2, sizeof(rep), hipMemcpyDeviceToHost) != hipSuccess) return VD_ERR_HIP;
+    for (int k = 0; k < 64; ++k) { out64[k] = 0; for (int r = 0; r < 64; ++r) out64[k] += rep[64 * r + k]; }
+    return VD_OK;
 }
 #endif
 

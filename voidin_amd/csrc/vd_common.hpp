@@ -43,7 +43,7 @@ struct VdCtx {
     void fan_forget(const void* tlas) { if (tlas == fan_tlas) { fan_tlas = nullptr; fan_idle_calls = 0; } }   // the top level at this address was rebuilt / refitted / released
     unsigned refit_n = 0;                                         // instance count the arena's layout was last used with
     unsigned long long scan_launches = 0;
-    void* dbg_ptr = nullptr; unsigned dbg_count = 0;   // tuning hooks
+    void* dbg_ptr = nullptr; unsigned dbg_count = 0; void* dbg_ptr2 = nullptr;   // tuning hooks
     void* stage_in = nullptr;    size_t stage_in_bytes = 0;    // host-pointer API staging
     void* stage_out = nullptr;   size_t stage_out_bytes = 0;
     void* stage_aux = nullptr;   size_t stage_aux_bytes = 0;
