@@ -11,8 +11,8 @@
  *     across the boundary (the reference panics — crates/bvh/src/blas.rs:114-116 — we do not);
  *   - `*_dev` variants take DEVICE pointers (hipMalloc'd on the ctx's device) and enqueue
  *     on the ctx's stream without synchronising (exceptions, stated at their declarations:
- *     vd_bvh_build_dev, vd_dist_step_draws_dev and the traversal entry points that report a
- *     stack overflow read a word back and block); the plain variants take HOST pointers,
+ *     vd_bvh_build_dev, vd_dist_step_draws_dev and the traversal entry points - which read
+ *     a status word back - block); the plain variants take HOST pointers,
  *     stage through ctx-owned device buffers and return after the result is in host memory;
  *   - the caller owns every in/out buffer; device scratch belongs to the VdCtx;
  *   - a VdCtx is thread-compatible, not thread-safe (the reference's `World` is
@@ -158,7 +158,9 @@ typedef enum VdStatus {
                                     (tlas.rs:71)                                         */
     VD_ERR_NO_DEVICE = -5,       /* no gfx950 device / extension built for another arch  */
     VD_ERR_STACK_OVERFLOW = -6,  /* traversal stack exceeded (reference has no check:
-                                    shaders/utils/stack.wgsl:1-20)                       */
+                                    shaders/utils/stack.wgsl:1-20).  vd_trace*: only for a
+                                    stack of more than 8 Mi entries (see there);
+                                    vd_traverse_iter / vd_traverse: beyond 128           */
     VD_ERR_OOM = -7,
     VD_ERR_COMM = -8             /* RCCL: library not found, communicator or collective failed;
                                     text in vd_last_error                                  */
@@ -477,8 +479,13 @@ typedef struct VdTraceScene {
 
 /* Replaces `traverse_tlas(ray)` (shaders/utils/bvh.wgsl:89-123) for a batch of rays.
  * out[i].dist matches the WGSL result within 1e-5 relative; a ray has 128 stack entries
- * for its TLAS + BLAS walk, pushing far children only (reference: 24 per walk, unchecked);
- * overflow is reported as VD_ERR_STACK_OVERFLOW.  BLAS leaves hold at most 3 triangles
+ * for its TLAS + BLAS walk in registers / LDS, pushing far children only (reference: 24 per
+ * walk, unchecked).  The call is TOTAL: a ray that needs more is walked again, from its start,
+ * by a second pass whose stack goes on in global memory (grow-only scratch of the context,
+ * allocated when first needed: 1 Ki entries per lane, then 4 Ki, ... under a 256 MB budget) -
+ * same visits, same arithmetic, same record as an unbounded stack gives; calls without such a
+ * ray pay nothing.  VD_ERR_STACK_OVERFLOW is left for a stack deeper than 8 Mi entries or than
+ * the scene has nodes (cyclic node arrays).  BLAS leaves hold at most 3 triangles
  * (what BvhBuilder makes, blas.rs:108); anything else is VD_ERR_INVALID_ARG, and so is a TLAS
  * leaf a ray ENTERS whose instance index, whose mesh's BLAS root or whose root's children lie
  * outside the scene's buffers (unreachable slots of the TLAS array may hold anything).  Every
