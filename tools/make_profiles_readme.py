@@ -139,9 +139,9 @@ def round_section(tag):
 
 NOTES = {
     "pytest_gpu.log": "tail of `python -m pytest tests -q -m gpu --durations=8` on the GPU box",
-    "tlas_time.log": "`tools/tlas_time.py`: TLAS build ms at 32768 / 65536 for VD_TLAS_PHASE2 / VD_TLAS_REFRESH variants, bit-exactness vs oracle",
+    "tlas_time.log": "(round 2, `tools/tlas_time.py`, since removed): TLAS build ms at 32768 / 65536 for VD_TLAS_PHASE2 / VD_TLAS_REFRESH variants, bit-exactness vs oracle",
     "tlas_index_profile.log": "`VD_TLAS_PROFILE=1 tools/tlas_time.py`: in-kernel cycle counts of the indexed TLAS build per query stage (4-wave form)",
-    "blas_levels.log": "`tools/gpu_prof_gaps.sh`: per-level span / busy time of phase A of one 8.4 M-triangle build, launch gaps",
+    "blas_levels.log": "(rounds 2-3, `tools/gpu_prof_gaps.sh`, since removed): per-level span / busy time of phase A of one 8.4 M-triangle build, launch gaps",
     "expand_pipe_experiment.log": "measured and NOT kept: persistent register-prefetch form of the 80 M-instance expansion",
     "blas_item_sweep.log": "phase A item size sweep (`-DVD_ITEM`), 8.4 M triangles",
     "blas_big_tier_experiment.log": "measured and NOT kept: an LDS tier for 2049..8192-prim segments (in-kernel cycles per phase)",
@@ -168,12 +168,14 @@ NOTES = {
     "ab_cull_small.log": "`tools/ab_cull.py --variants 0,1,2,4,8` at 1 k .. 1 M instances: tile size of the fused single-launch cull (the automatic choice is variant 0)",
     "ab_trace_fan_wps.log": "the fan-out's kernels compiled for 4 / 5 / 6 waves per SIMD (spills against occupancy) on the stress scene",
     "ab_trace_sibling_pruning.log": "VERDICT r4 item 6, measured and NOT kept: sibling jobs of the fan-out publish hits early and read the shared bound at every instance entry (bit-identical, 126 vs 128 Mrays/s)",
-    "fuzz.log": "round 5 fuzz campaign: 7 200 + 2 700 (after the sparse rank tables; up to 250 k triangles) + 9 600 (final tree) random meshes, 900 + 800 random cull scenes (both forms), 600 + 600 random TLAS scenes, 750 + 600 random trace scenes x 6 walks against the oracle, byte for byte: 0 mismatches",
+    "fuzz.log": "fuzz campaign of the round with fresh seeds (round 6: `tools/fuzz_*.py --seed 6xx`; the fixed-seed slices run inside `pytest -m gpu`).  Round 5's file: 7 200 + 2 700 (after the sparse rank tables; up to 250 k triangles) + 9 600 (final tree) random meshes, 900 + 800 random cull scenes (both forms), 600 + 600 random TLAS scenes, 750 + 600 random trace scenes x 6 walks against the oracle, byte for byte: 0 mismatches",
     "blas_sizes.log": "BLAS build time by mesh size, 131 k .. 32.8 M triangles, one mesh per build",
     "stress.log": "the race / repeat stress tools at the round's final tree: every run of the cull, expansion, refit, BLAS build (incl. a 3 000-mesh batch), TLAS build and traversal compared with the first, bit for bit",
     "blas_issue_cost.log": "what bounds the two kernels of a phase-A round: sparse rank tables (kept), pads of 200 scalar / vector instructions and of dependent loads, empty-grid probes (4.9 us to start a round's 32 768 waves), "
                            "item sizes, wave-uniform short forms, per-item records, host-side round constants (kept), phase B beside the last levels - each with its same-box numbers",
     "blas_mid_ab.log": "VERDICT r4 item 2 (ii), measured and NOT kept: the BLAS mid tier at 4096 / 8192 triangles against 2048",
+    "blas_small_classes.log": "`tools/blas_small_classes.py` (round 6, VERDICT r5 item 4): phase B's wave-cycles by node size class (<= 32, 33..64, 65..128, 129..256, 257..512) and step (setup, 21 trials, evaluation, final shuffle, children) from s_memtime brackets in the tuning build",
+    "pytest_gpu_mid.log": "tail of `pytest -m gpu` in the middle of round 6 (before the one-launch round was measured and removed): 277 passed",
     "blas_bin_stream.log": "`a_bin_kernel` streaming in pos0 order instead of gathering through the final arrangement, then with its loads pipelined across items: same-box A/B, kernel stats, `a_boundary` cycle stamps",
 }
 
