@@ -81,3 +81,20 @@ def test_option_ids_of_the_python_mirror_are_the_headers():
     mirror = {"VD_OPT_" + k.replace(".", "_").upper(): v for k, v in abi.OPTIONS.items()}
     assert mirror == header, (sorted(set(header) ^ set(mirror)), {k: (header.get(k), mirror.get(k)) for k in header if header.get(k) != mirror.get(k)})
     assert set(abi.OPTION_ENV.values()) <= set(abi.OPTIONS)
+
+
+def test_the_boundary_header_is_plain_c():
+    """The drop-in boundary is a C ABI (the Rust side binds it through `extern "C"`, a C host includes it): the header must
+    parse as C11 on its own - no C++ constructs, no missing includes - with the struct sizes the wire contract fixes."""
+    import subprocess
+    import tempfile
+    src = ('#include "voidin_abi.h"\n'
+           "_Static_assert(sizeof(VdInstance) == 144 && sizeof(VdMeshInfo) == 48 && sizeof(VdDrawIndexedIndirect) == 20, \"wire structs\");\n"
+           "_Static_assert(sizeof(VdCameraUniform) == 320 && sizeof(VdBvhNode) == 32 && sizeof(VdTlasNode) == 32, \"wire structs\");\n"
+           "int main(void) { return vd_version() == 0; }\n")
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "abi_is_c.c")
+        open(p, "w").write(src)
+        r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), p],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]

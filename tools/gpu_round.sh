@@ -62,3 +62,12 @@ make -C voidin_amd/csrc tuning > /dev/null 2>&1
   AB_FAN=1,3 AB_COUNTERS=1 VOIDIN_HIP_LIB=$PWD/voidin_amd/csrc/libvoidin_hip_tuning.so python3 tools/ab_trace.py --reps 2 2>&1 | grep -v amdgpu.ids | head -20 | cut -c1-700; } > $O/${R}_ab_trace.log 2>&1
 tail -5 $O/${R}_ab_trace.log | cut -c1-200
 ls -la $O
+echo "== fuzz campaign with fresh seeds (the fixed-seed slices run inside pytest -m gpu: tests/test_gpu_fuzz.py)"
+RN=${R#r}; RN=$((10#$RN))
+{ echo "# round $RN fuzz campaign at the round's final tree, one MI355X: random inputs through the C ABI against the oracle, byte for byte (tools/fuzz_*.py)";
+  for sd in $((RN * 100 + 11)) $((RN * 100 + 12)); do echo "## fuzz_blas.py --cases 2400 --max-tris 12000 --seed $sd"; timeout 900 python3 tools/fuzz_blas.py --cases 2400 --max-tris 12000 --seed $sd 2>&1 | grep -v amdgpu.ids | tail -4; done;
+  echo "## fuzz_blas.py --cases 300 --max-tris 250000 --seed $((RN * 100 + 31)) (up to seven levels of phase A)"; timeout 900 python3 tools/fuzz_blas.py --cases 300 --max-tris 250000 --seed $((RN * 100 + 31)) 2>&1 | grep -v amdgpu.ids | tail -4;
+  for sd in $((RN * 100 + 61)) $((RN * 100 + 62)); do echo "## fuzz_cull.py --cases 400 --seed $sd (fused and split form; every second case under a finite / negative / NaN far plane)"; timeout 600 python3 tools/fuzz_cull.py --cases 400 --seed $sd 2>&1 | grep -v amdgpu.ids | tail -4; done;
+  for sd in $((RN * 100 + 71)); do echo "## fuzz_tlas.py --cases 400 --seed $sd (indexed build forced from 65 clusters)"; timeout 600 python3 tools/fuzz_tlas.py --cases 400 --seed $sd 2>&1 | grep -v amdgpu.ids | tail -4; done;
+  for sd in $((RN * 100 + 81)) $((RN * 100 + 82)); do echo "## fuzz_trace.py --cases 250 --seed $sd (6 walks per scene; no status is accepted: deep rays take the second pass)"; timeout 900 python3 tools/fuzz_trace.py --cases 250 --seed $sd 2>&1 | grep -v amdgpu.ids | tail -4; done; } > $O/${R}_fuzz.log 2>&1
+tail -3 $O/${R}_fuzz.log
