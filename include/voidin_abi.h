@@ -273,9 +273,14 @@ int vd_release_external_buffer(VdCtx* ctx, VdExternalBuffer* handle);
  * for a binary semaphore).  The fd is consumed on success.  vd_release_external_semaphore synchronises the stream
  * first (queued waits / signals refer to the semaphore).
  * What this image can test: argument validation and the error path of a descriptor that is not a semaphore
- * (tests/test_gpu_tlas_trace.py).  A functional round trip needs a Vulkan device and loader on the box - the image
- * has neither - so none is claimed; the calls are hipImportExternalSemaphore / hip{Wait,Signal}ExternalSemaphoresAsync /
- * hipDestroyExternalSemaphore and nothing else.                                                                       */
+ * (tests/test_gpu_tlas_trace.py), and - round 6 - an import of a REAL kernel sync object (what a Vulkan binary semaphore
+ * exported as an opaque fd is on amdgpu; tests/cpp/external_semaphore_test.cpp makes one with DRM_IOCTL_SYNCOBJ_CREATE):
+ * the HIP runtime of this image answers hipImportExternalSemaphore with "operation not supported" (binary) and
+ * "invalid argument" (timeline), so VD_ERR_HIP is what these calls return on this platform today and no functional
+ * round trip is claimed (profiles/r06_external_semaphore_probe.log; the test runs the signal and the wait round trip
+ * on a runtime that accepts the import).  The calls are hipImportExternalSemaphore /
+ * hip{Wait,Signal}ExternalSemaphoresAsync / hipDestroyExternalSemaphore and nothing else.  Until a runtime implements
+ * them, order the frame through the host without blocking the render thread: INTEGRATION.md 5.                       */
 typedef struct VdExternalSemaphore VdExternalSemaphore;
 int vd_import_external_semaphore(VdCtx* ctx, int opaque_fd, int is_timeline, VdExternalSemaphore** out_handle);
 int vd_wait_external_semaphore_async(VdCtx* ctx, VdExternalSemaphore* handle, uint64_t value);

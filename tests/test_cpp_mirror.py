@@ -25,7 +25,7 @@ def test_mirror_header_compiles_and_links():
     assert os.path.exists(EXE)
 
 
-def _build_cpp(name):
+def _build_cpp(name, extra=()):
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
     exe = os.path.join(ROOT, "tests", "cpp", name)
     newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "voidin.hpp")),
@@ -33,7 +33,7 @@ def _build_cpp(name):
     if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), src,
                "-L", os.path.join(ROOT, "voidin_amd", "csrc"), "-lvoidin_hip", f"-Wl,-rpath,{os.path.join(ROOT, 'voidin_amd', 'csrc')}",
-               "-o", exe]
+               "-o", exe, *extra]
         subprocess.run(cmd, check=True, capture_output=True, timeout=900)
     return exe
 
@@ -122,6 +122,24 @@ def test_external_buffer_import_round_trip():
     if "SKIP" in out.stdout:
         pytest.skip(out.stdout.strip())
     assert "external_buffer_test OK" in out.stdout
+
+
+def test_external_semaphore_test_compiles():
+    _build_cpp("external_semaphore_test", extra=["-lpthread"])
+
+
+@pytest.mark.gpu
+def test_external_semaphore_round_trip():
+    """SURVEY.md §8f N1, the frame's ordering without a CPU wait: a DRM sync object (what a Vulkan binary semaphore exported by
+    vkGetSemaphoreFdKHR is on this platform; the image has no Vulkan loader to make one) goes through
+    vd_import_external_semaphore; vd_signal_external_semaphore_async behind real work signals it (seen from the host through the
+    kernel's own wait ioctl), and a second context's stream queued behind vd_wait_external_semaphore_async is held until then."""
+    exe = _build_cpp("external_semaphore_test", extra=["-lpthread"])
+    out = subprocess.run(["timeout", "120", exe], capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stdout + out.stderr
+    if "SKIP" in out.stdout:
+        pytest.skip(out.stdout.strip())
+    assert "external_semaphore_test OK" in out.stdout
 
 
 def test_dist_world1_test_compiles():
