@@ -1397,7 +1397,7 @@ int tlas_build_impl(VdCtx* ctx, const VdInstance* d_inst, uint32_t n, const VdMe
     // LDS; above that the scans are spread over several workgroups.  Per-context options (vd_ctx_set_option):
     // VD_OPT_TLAS_INDEX = 0 switches it off (A/B), VD_OPT_TLAS_INDEX_MIN / _PHASE2 / _REFRESH tune it.
     const int env_index = (int)ctx->option(VD_OPT_TLAS_INDEX, 1);
-    const unsigned ix_min = (unsigned)ctx->option(VD_OPT_TLAS_INDEX_MIN, 6800);    // below: the chain is faster (from LDS up to 5600 instances; tools/tlas_index_min_ab.py)
+    const unsigned ix_min = (unsigned)ctx->option(VD_OPT_TLAS_INDEX_MIN, 6800);    // below: the chain is faster (from LDS up to 5600 instances; A/B in profiles/NOTEBOOK_r01_r04.md, the script is in the history)
     unsigned phase2 = (unsigned)ctx->option(VD_OPT_TLAS_PHASE2, 4096);     // 2048 until the final scans moved into LDS (round 4): 184.6 -> 182.7 ms at 32 768, 41.1 -> 39.2 at 8192
     const unsigned refresh = (unsigned)ctx->option(VD_OPT_TLAS_REFRESH, 512);      // re-swept in round 4: 256: 183.4 ms at 32 768, 512: 182.4, 1024: 183.1, 2048: 185.5
     if (phase2 < 64u) phase2 = 64u;
