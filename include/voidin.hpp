@@ -102,6 +102,20 @@ class ExternalSemaphore {
     VdExternalSemaphore* handle_ = nullptr;
 };
 
+// The ordering that works on a runtime without external-semaphore import (voidin_abi.h, "Ordering that WORKS on this
+// platform"): a frame word in memory both APIs see, and a host function for the way back.
+class FrameWord {
+   public:
+    FrameWord(const Gpu& gpu, uint32_t* device_word) : gpu_(gpu), word_(device_word) {}
+    void wait_async(uint32_t frame) const { gpu_.check(vd_wait_value32_async(gpu_.ctx(), word_, frame)); }       // holds the stream until *word >= frame
+    void write_async(uint32_t frame) const { gpu_.check(vd_write_value32_async(gpu_.ctx(), word_, frame)); }
+    void then_on_host(VdHostFn callback, void* user) const { gpu_.check(vd_host_callback_async(gpu_.ctx(), callback, user)); }
+
+   private:
+    const Gpu& gpu_;
+    uint32_t* word_;
+};
+
 // ---- crates/bvh ---------------------------------------------------------------------------
 enum class DistKind { Hit, Miss };   // enum Dist { Hit(f32), Miss } (crates/bvh/src/intersection.rs:22-26)
 struct Dist {

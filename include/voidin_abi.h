@@ -287,6 +287,26 @@ int vd_wait_external_semaphore_async(VdCtx* ctx, VdExternalSemaphore* handle, ui
 int vd_signal_external_semaphore_async(VdCtx* ctx, VdExternalSemaphore* handle, uint64_t value);
 int vd_release_external_semaphore(VdCtx* ctx, VdExternalSemaphore* handle);
 
+/* Ordering that WORKS on this platform (NEW, round 6): a word of shared memory and the host.
+ * The external-semaphore import above is refused by this image's HIP runtime (profiles/r06_external_semaphore_probe.log),
+ * so the frame's two hand-overs have a second form:
+ *   renderer -> HIP, GPU side only: the renderer's upload submit ends by writing the frame number f into a 32-bit word of a
+ *     buffer both APIs see (vkCmdFillBuffer into an allocation imported with vd_import_external_buffer - the draw buffer's
+ *     own tail will do); vd_wait_value32_async(ctx, d_word, f) holds the context's stream until *d_word >= f (unsigned,
+ *     hipStreamWaitValue32 / GTE), then the cull runs.  No host thread waits, none is woken.
+ *   HIP -> renderer: Vulkan cannot wait on a memory word; vd_host_callback_async(ctx, callback, user) runs callback(user) on a thread
+ *     of the HIP runtime once the stream reaches it (hipLaunchHostFunc) - it calls vkSignalSemaphore on a timeline semaphore
+ *     the frame's queue.submit waits for.  The callback must not call into HIP or this library.
+ *   vd_write_value32_async(ctx, d_word, v) is the stream-side store (hipStreamWriteValue32): a second HIP context, or a
+ *     test, stands in for the renderer's queue with it.
+ * Enqueue-only, like the per-frame entry points; d_word must be 4-byte aligned device-accessible memory of the context's
+ * device (ordinary allocations and imported external buffers both work here: tests/cpp/frame_ordering_test.cpp).  Stream
+ * memory operations are not captured into HIP graphs: keep them outside a captured frame.                              */
+typedef void (*VdHostFn)(void* user);
+int vd_wait_value32_async(VdCtx* ctx, const uint32_t* d_word, uint32_t value);
+int vd_write_value32_async(VdCtx* ctx, uint32_t* d_word, uint32_t value);
+int vd_host_callback_async(VdCtx* ctx, VdHostFn callback, void* user);
+
 /* ------------------------------------------------------------------------------------ */
 /* Cull + emit                                                      */
 /* ------------------------------------------------------------------------------------ */

@@ -142,6 +142,24 @@ def test_external_semaphore_round_trip():
     assert "external_semaphore_test OK" in out.stdout
 
 
+def test_frame_ordering_test_compiles():
+    _build_cpp("frame_ordering_test", extra=["-lpthread"])
+
+
+@pytest.mark.gpu
+def test_frame_ordering_through_a_shared_word_and_a_host_callback():
+    """SURVEY.md §8f N1, the ordering that works on this platform: vd_wait_value32_async holds the cull's stream on a word of the
+    buffer imported with vd_import_external_buffer until another queue (here a second context, writing through the exporter's own
+    mapping) stores the frame number; vd_host_callback_async reports the frame's completion without a host wait.  Three frames,
+    the list read back through the exporter's mapping."""
+    exe = _build_cpp("frame_ordering_test", extra=["-lpthread"])
+    out = subprocess.run(["timeout", "120", exe], capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stdout + out.stderr
+    if "SKIP" in out.stdout:
+        pytest.skip(out.stdout.strip())
+    assert "frame_ordering_test OK" in out.stdout
+
+
 def test_dist_world1_test_compiles():
     _build_cpp("dist_world1_test")
 

@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TYPES = {"int": "i32", "float": "f32", "uint32_t": "u32", "uint64_t": "u64", "int32_t": "i32", "void": "core::ffi::c_void", "char": "core::ffi::c_char",
          "VdInstance": "Instance", "VdMeshInfo": "MeshInfo", "VdDrawIndexedIndirect": "DrawIndexedIndirect", "VdCameraUniform": "CameraUniform",
-         "VdBvhNode": "BvhNode", "VdTlasNode": "TlasNode"}
+         "VdBvhNode": "BvhNode", "VdTlasNode": "TlasNode", "VdHostFn": "VdHostFn"}
 
 
 def rust_type(c):

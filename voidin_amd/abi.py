@@ -162,6 +162,9 @@ PROTOTYPES = {
     "vd_wait_external_semaphore_async": (_I, [_P, _P, C.c_uint64]),
     "vd_signal_external_semaphore_async": (_I, [_P, _P, C.c_uint64]),
     "vd_release_external_semaphore": (_I, [_P, _P]),
+    "vd_wait_value32_async": (_I, [_P, _P, _U]),
+    "vd_write_value32_async": (_I, [_P, _P, _U]),
+    "vd_host_callback_async": (_I, [_P, C.CFUNCTYPE(None, C.c_void_p), _P]),
     "vd_trace_any_dev": (_I, [_P, C.POINTER(TraceScene), _P, _U, _P]),
     "vd_trace_prepare_dev": (_I, [_P, C.POINTER(TraceScene), C.POINTER(_P)]),
     "vd_trace_release": (_I, [_P, _P]),

@@ -251,6 +251,31 @@ int vd_release_external_semaphore(VdCtx* ctx, VdExternalSemaphore* handle) {
     return VD_OK;
 }
 
+// Ordering through a shared word and through the host (include/voidin_abi.h, "Ordering that WORKS on this platform").
+int vd_wait_value32_async(VdCtx* ctx, const uint32_t* d_word, uint32_t value) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!d_word || (reinterpret_cast<uintptr_t>(d_word) & 3u)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_wait_value32_async: null or misaligned word");
+    VD_HIP_CHECK(ctx, hipStreamWaitValue32(ctx->stream, const_cast<uint32_t*>(d_word), value, hipStreamWaitValueGte, 0xffffffffu));
+    return VD_OK;
+}
+
+int vd_write_value32_async(VdCtx* ctx, uint32_t* d_word, uint32_t value) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!d_word || (reinterpret_cast<uintptr_t>(d_word) & 3u)) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_write_value32_async: null or misaligned word");
+    VD_HIP_CHECK(ctx, hipStreamWriteValue32(ctx->stream, d_word, value, 0));
+    return VD_OK;
+}
+
+int vd_host_callback_async(VdCtx* ctx, VdHostFn fn, void* user) {
+    VdDeviceGuard vd_guard_(ctx);
+    if (!ctx) return VD_ERR_INVALID_ARG;
+    if (!fn) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_host_callback_async: null function");
+    VD_HIP_CHECK(ctx, hipLaunchHostFunc(ctx->stream, fn, user));
+    return VD_OK;
+}
+
 int vd_ctx_set_option(VdCtx* ctx, int option, int64_t value) {
     if (!ctx) return VD_ERR_INVALID_ARG;
     if (option <= 0 || option >= VD_OPT_COUNT_) VD_FAIL(ctx, VD_ERR_INVALID_ARG, "vd_ctx_set_option: unknown option");

@@ -143,6 +143,17 @@ class Context:
         self._chk(self.lib.vd_compute_update_dev(self.h, abi.ptr(d_indices), n_indices, abi.ptr(d_instances), n_instances,
                                                  float(time), float(dt), int(fix_inverse)))
 
+    # -- ordering through a shared word / the host (voidin_abi.h: "Ordering that WORKS on this platform") ------
+    def wait_value32(self, d_word_ptr: int, value: int):
+        self._chk(self.lib.vd_wait_value32_async(self.h, d_word_ptr, value))
+
+    def write_value32(self, d_word_ptr: int, value: int):
+        self._chk(self.lib.vd_write_value32_async(self.h, d_word_ptr, value))
+
+    def host_callback(self, fn, user=None):
+        """fn: a ctypes CFUNCTYPE(None, c_void_p) object the CALLER keeps alive until it has run."""
+        self._chk(self.lib.vd_host_callback_async(self.h, fn, user))
+
     # -- cull / emit (host arrays) ----------------------------------------------------------
     def cull_emit(self, camera, meshes, instances) -> np.ndarray:
         cam = np.ascontiguousarray(camera, dtype=abi.CAMERA)
