@@ -301,7 +301,9 @@ int vd_release_external_semaphore(VdCtx* ctx, VdExternalSemaphore* handle);
  *     test, stands in for the renderer's queue with it.
  * Enqueue-only, like the per-frame entry points; d_word must be 4-byte aligned device-accessible memory of the context's
  * device (ordinary allocations and imported external buffers both work here: tests/cpp/frame_ordering_test.cpp).  Stream
- * memory operations are not captured into HIP graphs: keep them outside a captured frame.                              */
+ * memory operations are not captured into HIP graphs: keep them outside a captured frame.  A wait nobody ever satisfies
+ * holds the stream for good (vd_ctx_synchronize and everything that synchronises would not return): the protocol on the
+ * word - monotone frame numbers, written once per frame by the other queue - is the caller's.                          */
 typedef void (*VdHostFn)(void* user);
 int vd_wait_value32_async(VdCtx* ctx, const uint32_t* d_word, uint32_t value);
 int vd_write_value32_async(VdCtx* ctx, uint32_t* d_word, uint32_t value);
