@@ -856,13 +856,45 @@ def _chain_scene(oracle, n_leaves=200):
     return (tl, inst, infos, nodes, v, idx)
 
 
+def _chain_blas_scene(oracle, n_tris=190):
+    """ONE instance whose BLAS is a hand-made chain in the reference's node layout (node 0 the root, node 1 unused, child pairs
+    behind): every interior node splits off the FARTHEST triangle as a one-triangle leaf and keeps the rest.  A ray from
+    x = -1 along +x takes the rest as its near child at every level and pushes the leaf (bvh.wgsl:56-74 pushes the far child
+    while nothing is hit): n - 3 pending BLAS entries before the first triangle test."""
+    n = n_tris
+    tri = np.zeros((n, 3, 3), np.float32)
+    tri[:, :, 0] = np.arange(n, dtype=np.float32)[:, None]
+    tri[:, 0, 1:] = [-0.5, -0.5]; tri[:, 1, 1:] = [0.0, 0.6]; tri[:, 2, 1:] = [0.5, -0.5]
+    verts, idx = tri.reshape(-1, 3).copy(), np.arange(3 * n, dtype=np.uint32)
+    levels = n - 3
+    nodes = np.zeros(2 + 2 * levels, dtype=abi.BVH_NODE)
+    box = lambda a, b: (tri[a:b].reshape(-1, 3).min(axis=0), tri[a:b].reshape(-1, 3).max(axis=0))
+    cur, hi = 0, n
+    for j in range(levels):
+        pair = 2 + 2 * j
+        nodes[cur]["min"], nodes[cur]["max"] = box(0, hi)
+        nodes[cur]["left_first"], nodes[cur]["count"] = pair, 0
+        nodes[pair + 1]["min"], nodes[pair + 1]["max"] = box(hi - 1, hi)
+        nodes[pair + 1]["left_first"], nodes[pair + 1]["count"] = hi - 1, 1
+        cur, hi = pair, hi - 1
+    nodes[cur]["min"], nodes[cur]["max"] = box(0, hi)
+    nodes[cur]["left_first"], nodes[cur]["count"] = 0, hi
+    infos = np.zeros(1, dtype=abi.MESH_INFO)
+    infos[0]["min"], infos[0]["max"] = synth.mesh_bounds(verts)
+    infos[0]["index_count"] = len(idx)
+    inst = np.zeros(1, dtype=abi.INSTANCE)
+    inst["transform"] = inst["inv_transform"] = np.eye(4, dtype=np.float32).reshape(16)
+    return (oracle.tlas_build(inst, infos), inst, infos, nodes, verts, idx)
+
+
+@pytest.mark.parametrize("kind", ["tlas chain", "blas chain"])
 @pytest.mark.parametrize("n_rays", [2_000, 420_000])       # one launch / a call large enough to fan out (>= one ray per lane of the grid)
-def test_rays_deeper_than_a_lanes_stack_are_walked_again(ctx, ctx_options, oracle, n_rays):
+def test_rays_deeper_than_a_lanes_stack_are_walked_again(ctx, ctx_options, oracle, n_rays, kind):
     """The call is TOTAL: a ray that needs more than the 128 stack entries a lane holds used to end the call
     with VD_ERR_STACK_OVERFLOW; now it is walked again with its stack in global memory and the record is the oracle's, bit for
     bit - closest hit and occlusion, plain / indexed / prepared leaves, one launch and fanned out, deep rays mixed with cheap ones."""
     import torch
-    scene = _chain_scene(oracle)
+    scene = _chain_scene(oracle) if kind == "tlas chain" else _chain_blas_scene(oracle)      # depth on the TLAS side / inside one instance
     rng = np.random.default_rng(128)
     rays = np.zeros(n_rays, dtype=abi.RAY)
     rays["eye"] = (rng.random((n_rays, 3)).astype(np.float32) - np.float32(0.5)) * np.array([0.0, 0.6, 0.6], np.float32) + np.array([-5.0, 0, 0], np.float32)
