@@ -175,7 +175,7 @@ NOTES = {
                            "item sizes, wave-uniform short forms, per-item records, host-side round constants (kept), phase B beside the last levels - each with its same-box numbers",
     "blas_mid_ab.log": "VERDICT r4 item 2 (ii), measured and NOT kept: the BLAS mid tier at 4096 / 8192 triangles against 2048",
     "blas_small_classes.log": "`tools/blas_small_classes.py` (round 6, VERDICT r5 item 4): phase B's wave-cycles by node size class (<= 32, 33..64, 65..128, 129..256, 257..512) and step (setup, 21 trials, evaluation, final shuffle, children) from s_memtime brackets in the tuning build",
-    "pytest_gpu_final.log": "tail of `pytest -m gpu` at round 6's final tree: 277 passed, 3 skipped (the third skip: the external-semaphore round trip, whose import this HIP runtime refuses)",
+    "pytest_gpu_final.log": "tail of `pytest -m gpu` at round 6's final tree: 281 passed, 3 skipped (the third skip: the external-semaphore round trip, whose import this HIP runtime refuses)",
     "suite_repeat.log": "the gpu suite four times in a row on one box + smoke(): no flaky test",
     "external_semaphore_probe.log": "what this HIP runtime accepts for the HIP -> wgpu ordering: import of a real DRM sync object (refused), stream value waits on ordinary / signal / fd-imported memory, host functions",
     "blas_bin_stream.log": "`a_bin_kernel` streaming in pos0 order instead of gathering through the final arrangement, then with its loads pipelined across items: same-box A/B, kernel stats, `a_boundary` cycle stamps",
