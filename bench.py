@@ -850,6 +850,36 @@ def single_gpu_extras(args, ctx, dev, cam, meshes, d_m, inst, d_i, d_out, d_cnt,
         t_frame = pipelined(frame, reps=30)
         extra["dynamic_frame"] = {"instances": n, "moving": int(d_mov.numel()), "tlas_instances": n_tl,
                                   "ms_per_frame": round(t_frame * 1e3, 4), "fps_equivalent": round(1.0 / t_frame, 1)}
+        # The same frame on TWO streams: the refit (a latency-bound climb over 65 k nodes on a few CUs) does not depend on the cull
+        # (HBM-bound, all CUs) - both only read what compute_update wrote - so a second context on its own stream runs it beside the
+        # cull; events order update -> {refit | cull} -> next update.  Same bytes out (checked against the one-stream frame).
+        from voidin_amd.runtime import Context
+        ctx2 = Context(dev.index, use_torch_stream=False)
+        s1, s2 = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+        ctx2.set_stream(s2.cuda_stream)
+        ev_upd, ev_ref = torch.cuda.Event(), torch.cuda.Event()
+
+        def frame2():
+            ctx.compute_update_dev(d_mov, d_mov.numel(), d_dyn, n, 1.0, 0.016, True)
+            ev_upd.record(s1)
+            s2.wait_event(ev_upd)
+            ctx2.tlas_refit_dev(d_dyn, n_tl, d_m, n_mesh, d_t2)
+            ev_ref.record(s2)
+            ctx.cull_compact_dev(cam, d_m, n_mesh, d_dyn, n, d_out, d_cnt, False, first)
+            s1.wait_event(ev_ref)                                 # the next frame's update must not overtake the refit's reads
+        # one frame of each form from the same state: same top level, same survivor count
+        d_dyn.copy_(d_i); ctx.tlas_build_dev(d_dyn, n_tl, d_m, n_mesh, d_t2); torch.cuda.synchronize()
+        frame(); torch.cuda.synchronize()
+        a_t, a_c = d_t2.clone(), int(d_cnt[0].item())
+        d_dyn.copy_(d_i); ctx.tlas_build_dev(d_dyn, n_tl, d_m, n_mesh, d_t2); torch.cuda.synchronize()
+        frame2(); torch.cuda.synchronize()
+        d_dyn2_ok = bool(torch.equal(a_t, d_t2) and a_c == int(d_cnt[0].item()))
+        del a_t
+        t_frame2 = pipelined(frame2, reps=30)
+        extra["dynamic_frame"]["two_streams"] = {"ms_per_frame": round(t_frame2 * 1e3, 4), "fps_equivalent": round(1.0 / t_frame2, 1),
+                                                 "same_tlas_and_count_as_one_stream": d_dyn2_ok,
+                                                 "note": "refit on a second context / stream beside the cull (events: update -> {refit | cull} -> next update)"}
+        ctx2.close()
         del d_dyn, d_mov, d_t2
         ctx.cull_compact_dev(cam, d_m, n_mesh, d_i, n, d_out, d_cnt, False, first)   # leave d_out / the id table as the later legs expect
     # BASELINE config 5 names a 64k-instance refit: beyond the reference's 16-bit child ids (tlas.rs:71), so in
